@@ -1,0 +1,216 @@
+/*
+ * uniir_hip.h -- C ABI of libuniir_hip.so, the MI355X (gfx950) hot path of the UniIR
+ * contrastive-train / embed / brute-force-retrieve pipeline.
+ *
+ * Boundary contract: plain pointers and sizes only, no torch types.  Every
+ * entry point is asynchronous on the caller's hipStream_t (passed as void*), never allocates device
+ * memory, never synchronises the host (the two top-k helpers that return host-visible counts say so),
+ * returns 0 (UNIIR_OK) or a negative UNIIR_E* code and never throws.  All pointers are DEVICE pointers
+ * unless the parameter name ends in _host.  bf16 / fp16 tensors are passed as const void*.
+ *
+ * Each group names the reference code it replaces (paths relative to the UniIR tree):
+ *   [ENC]   openai/CLIP VisionTransformer / Transformer forward+backward as called from
+ *           src/models/uniir_clip/clip_scorefusion/clip_sf.py:43-47 (encode_text / encode_image)
+ *   [FUSE]  clip_sf.py:53-63 (mask * emb fuse), :88-97 (row select + F.normalize)
+ *   [NCE]   clip_sf.py:133-144 (similarity * exp(logit_scale), CrossEntropy, argmax accuracy)
+ *   [OPT]   clip_scorefusion/train.py:52-61,195-199 (two-group AdamW) + uniir_clip/engine.py:41-46
+ *   [TOPK]  src/common/mbeir_retriever.py:76,85-103 (normalize_L2 + IDMap,Flat IP index),
+ *           :188-232 (search_index: normalize queries, exact top-k by inner product)
+ */
+#ifndef UNIIR_HIP_H
+#define UNIIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNIIR_OK 0
+#define UNIIR_EINVAL (-1)       /* null pointer / negative size / bad enum */
+#define UNIIR_ESHAPE (-2)       /* shape not supported by the kernels (see each function) */
+#define UNIIR_EALIGN (-3)       /* pointer or leading dimension not 16-byte aligned */
+#define UNIIR_ELAUNCH (-4)      /* HIP launch failed */
+#define UNIIR_EUNSUPPORTED (-5)
+
+const char* uniir_strerror(int code);
+/* ABI version; bumped on any signature change. */
+int uniir_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * [ENC] building block 1: 16-bit MFMA GEMM with fused epilogues.
+ *   C[M,N] = alpha * op(A)[M,K] . op(B)[K,N]  (+ epilogue)
+ * a_tmaj = 0: A stored [M][lda] (K contiguous);  1: A stored [K][lda] (M contiguous)
+ * b_tmaj = 0: B stored [N][ldb] (K contiguous; torch Linear weight layout);  1: B stored [K][ldb]
+ * Requirements: K-contiguous operands need K % 8 == 0, M/N-contiguous ones need that extent % 8 == 0,
+ * N % 8 == 0, all base pointers and leading dimensions multiples of 8 elements (16 B).
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    UNIIR_EPI_BF16 = 0,          /* C(bf16) = v + bias?                                          */
+    UNIIR_EPI_BIAS_ACT = 1,      /* f = bf16(v + bias) -> C ; act(f) -> C2 (both bf16)           */
+    UNIIR_EPI_RESID_F32 = 2,     /* C(f32) = v + bias? + resid(f32, ldc) ; C2(bf16 copy) optional */
+    UNIIR_EPI_DACT = 3,          /* C(bf16) = v * act'(aux[m][n])   (aux bf16, ldaux)             */
+    UNIIR_EPI_F32 = 4,           /* C(f32) = v  (beta = 0)                                        */
+    UNIIR_EPI_ATOMIC_F32 = 5     /* C(f32) += v via atomics; enables split-K (wgrad accumulate)  */
+};
+enum { UNIIR_ACT_QUICKGELU = 0, UNIIR_ACT_GELU_ERF = 1, UNIIR_ACT_RELU = 2 };
+enum { UNIIR_DT_BF16 = 0, UNIIR_DT_F16 = 1 };
+
+typedef struct {
+    const void* A;
+    const void* B;
+    void* C;
+    void* C2;            /* optional second output */
+    const float* bias;   /* [N] or NULL */
+    const float* resid;  /* [M][ldc] f32 or NULL */
+    const void* aux;     /* [M][ldaux] bf16 or NULL */
+    int32_t M, N, K;
+    int64_t lda, ldb, ldc, ldaux;
+    int32_t a_tmaj, b_tmaj;
+    int32_t epilogue, act, dtype;
+    int32_t k_splits;    /* >= 1; > 1 only with UNIIR_EPI_ATOMIC_F32 */
+    float alpha;
+} uniir_gemm_desc;
+
+int uniir_gemm(const uniir_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * [ENC] building block 2: LayerNorm over the last dim (fp32 statistics, CLIP eps 1e-5).
+ * x is the fp32 residual stream [rows][x_stride]; y is bf16 [rows][width] (GEMM operand) and/or f32.
+ * bwd: dx_f32 = (dres ? dres : 0) + LN'(dy); also writes a bf16 copy when dx_bf16 != NULL;
+ * dgamma/dbeta are ACCUMULATED (+=) in fp32 (zero them once per optimizer step).
+ * dy may be bf16 (dy_is_f32 = 0) or fp32.
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta,
+                        void* y_bf16, float* y_f32, int32_t rows, int32_t width, float eps, void* stream);
+int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float* gamma, const void* dy,
+                        int32_t dy_is_f32, const float* dres, float* dx_f32, int64_t dx_stride,
+                        void* dx_bf16, float* dgamma, float* dbeta, int32_t rows, int32_t width,
+                        float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * [ENC] building block 3: fused multi-head attention, head_dim 64, seq <= 512.
+ * qkv bf16 [batch*seq][3*heads*64] as produced by nn.MultiheadAttention.in_proj ([q | k | v] per row);
+ * out bf16 [batch*seq][heads*64]; lse f32 [batch][heads][seq] (natural log-sum-exp of scaled scores).
+ * causal = 1 applies CLIP's build_attention_mask (key <= query).
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32_t batch, int32_t seq,
+                        int32_t heads, int32_t causal, void* stream);
+int uniir_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                        void* dqkv, int32_t batch, int32_t seq, int32_t heads, int32_t causal,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * [ENC] small fused pieces of the towers.
+ * ---------------------------------------------------------------------------------------------- */
+/* images f32 NCHW [n][3][res][res] -> patches bf16 [n*grid*grid][kpad], k = c*P*P + py*P + px (the
+ * Conv2d weight's own flattening), zero-padded to kpad (multiple of 64). */
+int uniir_patchify(const float* images, void* patches, int32_t n, int32_t res, int32_t patch,
+                   int32_t kpad, void* stream);
+/* x[n][1+g][w] (f32) = concat(class_emb, patch_out[n][g][w] (bf16)) + pos_emb[1+g][w] */
+int uniir_vit_assemble(const void* patch_out, const float* class_emb, const float* pos_emb, float* x,
+                       int32_t n, int32_t tokens, int32_t width, void* stream);
+/* backward of the above: dpatch bf16 [n*g][w] = dx[:,1:,:]; dclass += sum_n dx[:,0,:]; dpos += sum_n dx */
+int uniir_vit_assemble_bwd(const float* dx, void* dpatch_out, float* dclass, float* dpos, int32_t n,
+                           int32_t tokens, int32_t width, void* stream);
+/* x[n][ctx][w] (f32) = token_emb[text[n][t]] + pos_emb[t]; also eot[n] = argmax_t text[n][t] (first max) */
+int uniir_text_embed(const int32_t* text, const float* token_emb, const float* pos_emb, float* x,
+                     int32_t* eot, int32_t n, int32_t ctx, int32_t width, int32_t vocab, void* stream);
+int uniir_text_embed_bwd(const int32_t* text, const float* dx, float* dtoken_emb, float* dpos,
+                         int32_t n, int32_t ctx, int32_t width, int32_t vocab, void* stream);
+/* out[i][:] = x[(i*seq + idx[i])][:] (idx NULL -> 0, the class token): rows for ln_post / ln_final */
+int uniir_gather_rows(const float* x, const int32_t* idx, float* out, int32_t n, int32_t seq,
+                      int32_t width, void* stream);
+/* dx[(i*seq + idx[i])][:] += dout[i][:] ; all other rows of dx must have been zeroed by the caller */
+int uniir_scatter_rows(const float* dout, const int32_t* idx, float* dx, int32_t n, int32_t seq,
+                       int32_t width, void* stream);
+/* act / colsum / casts */
+int uniir_act_fwd(const void* f_bf16, void* g_bf16, int64_t count, int32_t act, void* stream);
+/* out[n] += sum_m x[m][n]  (x bf16 [rows][ld]) */
+int uniir_colsum_bf16(const void* x, int64_t ld, float* out, int32_t rows, int32_t cols, void* stream);
+int uniir_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);
+int uniir_cast_bf16_to_f32(const void* src, float* dst, int64_t count, void* stream);
+/* dst bf16 [rows][ld_dst] (zero padded) = src f32 [rows][cols] */
+int uniir_cast_pad_rows(const float* src, void* dst, int32_t rows, int32_t cols, int32_t ld_dst,
+                        void* stream);
+/* dst f32 [rows][cols] += src f32 [rows][ld_src][:cols]  (un-pad a wgrad result) */
+int uniir_unpad_add(const float* src, float* dst, int32_t rows, int32_t cols, int32_t ld_src,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * [FUSE] emb = txt_emb * txt_mask[:,None] + img_emb * img_mask[:,None]  (clip_sf.py:61-63), then
+ * q = normalize(emb[idx_q]), p = normalize(emb[idx_p])  (clip_sf.py:88-97; F.normalize eps 1e-12).
+ * Masks are int64 like the collator's (mbeir_dataset.py:427-434).  All fp32.
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_fuse_embeddings(const float* txt_emb, const float* img_emb, const int64_t* txt_mask,
+                          const int64_t* img_mask, float* emb, int32_t n, int32_t dim, void* stream);
+int uniir_select_normalize(const float* emb, const int32_t* idx, float* out, float* inv_norm,
+                           int32_t rows, int32_t dim, void* stream);
+/* demb[idx[i]] += (dout[i] - out[i] * <out[i], dout[i]>) * inv_norm[i]  (demb zeroed by the caller) */
+int uniir_select_normalize_bwd(const float* out, const float* inv_norm, const float* dout,
+                               const int32_t* idx, float* demb, int32_t rows, int32_t dim, void* stream);
+/* dtxt = demb * txt_mask, dimg = demb * img_mask */
+int uniir_fuse_embeddings_bwd(const float* demb, const int64_t* txt_mask, const int64_t* img_mask,
+                              float* dtxt, float* dimg, int32_t n, int32_t dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * [NCE] in-batch InfoNCE, fp32 end to end (f32 MFMA 16x16x4: exact fp32 fma chains).
+ *   score[i][j] = <q[i], all_p[j]> * scale            (scale = exp(logit_scale), device scalar)
+ *   loss = mean_i( logsumexp_j score[i][:] - score[i][t_i] ),  t_i = target_offset + i
+ *   acc  = mean_i( argmax_j score[i][:] == t_i )      (first max on ties, torch.max semantics)
+ * score may be NULL only in uniir_infonce_bwd (it is required by fwd as the stash for bwd).
+ * bwd: with g = dloss (device scalar), G = (softmax(score) - onehot) * g / b,
+ *   dq = scale * G . all_p,  d_all_p = scale * G^T . q,  dscale = sum(G * score) / scale.
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_infonce_fwd(const float* q, const float* all_p, const float* scale, int32_t b, int32_t B,
+                      int32_t dim, int32_t target_offset, float* score, float* row_lse, float* loss,
+                      float* acc, void* stream);
+int uniir_infonce_bwd(const float* q, const float* all_p, const float* scale, const float* score,
+                      const float* row_lse, const float* dloss, int32_t b, int32_t B, int32_t dim,
+                      int32_t target_offset, float* gbuf, float* dq, float* d_all_p, float* dscale,
+                      void* stream);
+/* generic strided fp32 MFMA GEMM used by the two above (exported for tests):
+ * C[m][n] (ldc) = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]  */
+int uniir_sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * [OPT] fused AdamW over one flat fp32 parameter group (torch.optim.AdamW semantics, no amsgrad):
+ *   p *= 1 - lr*wd ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * grad_scale multiplies g first (1/accumulation_steps or 1/world); also refreshes the bf16 shadow.
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                     void* param_bf16, int64_t count, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int32_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * [TOPK] exact brute-force inner-product top-k over an fp16 pool (FAISS "IDMap,Flat" + normalize_L2).
+ *   uniir_pool_inv_norms: inv[i] = 1/sqrt(sum_j x[i][j]^2) in the oracle's summation order
+ *                         (sequential fp32, no fma), 0 for an all-zero row (FAISS leaves it untouched).
+ *   uniir_topk_coarse:    MFMA fp16 scan, per query the best kc candidates of pool rows [row_begin,
+ *                         row_begin+rows) by approximate score; kc >= k, kc <= 64.
+ *   uniir_topk_rescore:   exact fp32 re-score of a shortlist in the oracle's summation order, sort by
+ *                         (score desc, id asc), keep k.  exact_ws: nq*ncand floats of scratch.
+ * Layouts: pool fp16 [n][dim] (dim % 64 == 0), queries fp16 [nq][dim] as stored by the embedder
+ * (un-normalised), ids int64 [n].  Outputs: cand_idx int32 [nq][kc] pool-row indices (-1 = empty),
+ * out_scores f32 [nq][k] descending, out_ids int64 [nq][k] (-1 padded like FAISS).
+ * workspace: uniir_topk_workspace_bytes(nq, kc) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_pool_inv_norms(const void* x_f16, int64_t n, int32_t dim, float* inv_norm, void* stream);
+int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t rows);
+int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_norm, int64_t rows, int32_t dim,
+                      const void* queries_f16, int32_t nq, int32_t kc, int32_t* cand_idx,
+                      float* cand_score, void* workspace, int64_t workspace_bytes, void* stream);
+int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids,
+                       int64_t rows, int32_t dim, const void* queries_f16, const float* query_inv_norm,
+                       int32_t nq, const int32_t* cand_idx, int32_t ncand, int32_t k, float* exact_ws,
+                       float* out_scores, int64_t* out_ids, void* stream);
+/* k-way merge of per-shard results (score desc, id asc): in [nshard][nq][k] -> out [nq][k] */
+int uniir_topk_merge(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k,
+                     float* out_scores, int64_t* out_ids, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIIR_HIP_H */

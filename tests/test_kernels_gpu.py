@@ -1,0 +1,250 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain PyTorch fp32 references
+of the same op.  bf16 kernels: tolerance stated per test (inputs are bf16-rounded before the reference runs,
+so the only differences are accumulation order and the bf16 rounding of outputs)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from uniir_amd import ops
+    return ops
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (200, 136, 72), (1000, 768, 1024)])
+def test_gemm_nt_bf16(M, N, K):
+    ops = _ops()
+    torch.manual_seed(0)
+    x, w = bf(torch.randn(M, K, device=DEV)), bf(torch.randn(N, K, device=DEV))
+    bias = torch.randn(N, device=DEV)
+    y = ops.linear_fwd(x, w, bias)
+    ref = x.float() @ w.float().t() + bias
+    assert rel_err(y, ref) < 4e-3, rel_err(y, ref)
+    # asymmetric check (transposition detector): first row / first col
+    assert torch.allclose(y[0].float(), ref[0], rtol=2e-2, atol=2e-1)
+    assert torch.allclose(y[:, 0].float(), ref[:, 0], rtol=2e-2, atol=2e-1)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (264, 320, 136), (1000, 1024, 768)])
+def test_gemm_dgrad_nn(M, N, K):
+    ops = _ops()
+    torch.manual_seed(1)
+    dy, w = bf(torch.randn(M, N, device=DEV)), bf(torch.randn(N, K, device=DEV))
+    dx = ops.linear_dgrad(dy, w)
+    ref = dy.float() @ w.float()
+    assert rel_err(dx, ref) < 4e-3, rel_err(dx, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 136, 200), (5000, 768, 1024), (263, 384, 64)])
+def test_gemm_wgrad_tn_splitk(M, N, K):
+    ops = _ops()
+    torch.manual_seed(2)
+    Mp = (M + 7) // 8 * 8  # rows are the contraction dim here: no alignment requirement, but keep tail odd
+    dy, x = bf(torch.randn(M, N, device=DEV)), bf(torch.randn(M, K, device=DEV))
+    dw = torch.ones(N, K, device=DEV)
+    ops.linear_wgrad(dy, x, dw)
+    ref = dy.float().t() @ x.float() + 1.0
+    assert rel_err(dw, ref) < 1e-3, rel_err(dw, ref)
+
+
+def test_gemm_epilogues():
+    ops = _ops()
+    torch.manual_seed(3)
+    M, N, K = 300, 256, 128
+    x, w = bf(torch.randn(M, K, device=DEV)), bf(torch.randn(N, K, device=DEV) * 0.1)
+    bias = torch.randn(N, device=DEV)
+    # bias + QuickGELU: C = f, C2 = act(f)
+    g = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    f = ops.linear_fwd(x, w, bias, epilogue=ops.EPI_BIAS_ACT, C2=g)
+    fref = x.float() @ w.float().t() + bias
+    assert rel_err(f, fref) < 4e-3
+    gref = f.float() * torch.sigmoid(1.702 * f.float())
+    assert rel_err(g, gref) < 4e-3
+    # residual fp32
+    res = torch.randn(M, N, device=DEV)
+    y = ops.linear_fwd(x, w, bias, epilogue=ops.EPI_RESID_F32, resid=res)
+    assert y.dtype == torch.float32
+    assert rel_err(y, fref + res) < 1e-5 + 4e-3
+    assert (y - (fref + res)).abs().max() < 2e-3
+    # dgrad * act'(f)
+    dy = bf(torch.randn(M, N, device=DEV))
+    w2 = bf(torch.randn(N, K, device=DEV) * 0.1)
+    aux = bf(torch.randn(M, K, device=DEV))
+    dx = ops.linear_dgrad(dy, w2, aux=aux)
+    a = aux.float()
+    s = torch.sigmoid(1.702 * a)
+    dref = (dy.float() @ w2.float()) * (s * (1 + 1.702 * a * (1 - s)))
+    assert rel_err(dx, dref) < 5e-3, rel_err(dx, dref)
+
+
+@pytest.mark.parametrize("rows,width", [(7, 512), (1000, 768), (513, 1024)])
+def test_layernorm_fwd_bwd(rows, width):
+    ops = _ops()
+    torch.manual_seed(4)
+    x = torch.randn(rows, width, device=DEV) * 2 + 0.5
+    gamma, beta = torch.randn(width, device=DEV), torch.randn(width, device=DEV)
+    y32 = torch.empty(rows, width, device=DEV)
+    y16 = torch.empty(rows, width, device=DEV, dtype=torch.bfloat16)
+    ops.layernorm_fwd(x, gamma, beta, 1e-5, out_bf16=y16, out_f32=y32)
+    ref = torch.nn.functional.layer_norm(x, (width,), gamma, beta, 1e-5)
+    assert (y32 - ref).abs().max() < 2e-5
+    assert rel_err(y16, ref) < 4e-3
+    dy = torch.randn(rows, width, device=DEV)
+    dres = torch.randn(rows, width, device=DEV)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (width,), gr, br, 1e-5).backward(dy)
+    dgamma, dbeta = torch.zeros(width, device=DEV), torch.zeros(width, device=DEV)
+    dxb = torch.empty(rows, width, device=DEV, dtype=torch.bfloat16)
+    dx = ops.layernorm_bwd(x, gamma, dy, dgamma, dbeta, 1e-5, dres=dres, dx_bf16=dxb)
+    assert (dx - (xr.grad + dres)).abs().max() < 1e-4
+    assert rel_err(dgamma, gr.grad) < 1e-5
+    assert rel_err(dbeta, br.grad) < 1e-5
+    assert rel_err(dxb, dx) < 4e-3
+    # bf16 dy path
+    dgamma.zero_(); dbeta.zero_()
+    dyb = bf(dy)
+    xr.grad = None; gr.grad = None; br.grad = None
+    torch.nn.functional.layer_norm(xr, (width,), gr, br, 1e-5).backward(dyb.float())
+    dx = ops.layernorm_bwd(x, gamma, dyb, dgamma, dbeta, 1e-5)
+    assert (dx - xr.grad).abs().max() < 1e-4
+    assert rel_err(dgamma, gr.grad) < 1e-5
+
+
+def _attn_ref(qkv, batch, seq, heads, causal):
+    W = heads * 64
+    q, k, v = qkv.float().view(batch, seq, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        m = torch.full((seq, seq), float("-inf"), device=qkv.device).triu_(1)
+        s = s + m
+    p = torch.softmax(s, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(batch * seq, W)
+    lse = torch.logsumexp(s, -1)
+    return o, lse
+
+
+@pytest.mark.parametrize("batch,seq,heads,causal", [(3, 257, 4, 0), (5, 77, 3, 1), (4, 50, 2, 0), (2, 33, 1, 1), (2, 16, 1, 0)])
+def test_attention_fwd_bwd(batch, seq, heads, causal):
+    ops = _ops()
+    torch.manual_seed(5)
+    W = heads * 64
+    qkv = bf(torch.randn(batch * seq, 3 * W, device=DEV))
+    out, lse = ops.attention_fwd(qkv, batch, seq, heads, causal)
+    qr = qkv.float().requires_grad_(True)
+    oref, lref = _attn_ref(qr, batch, seq, heads, causal)
+    assert rel_err(out, oref) < 8e-3, rel_err(out, oref)
+    assert (lse - lref).abs().max() < 2e-3
+    do = bf(torch.randn(batch * seq, W, device=DEV))
+    oref.backward(do.float())
+    dqkv = ops.attention_bwd(qkv, out, do, lse, batch, seq, heads, causal)
+    g = qr.grad.view(batch * seq, 3, W)
+    d = dqkv.float().view(batch * seq, 3, W)
+    for i, name in enumerate("qkv"):
+        e = rel_err(d[:, i], g[:, i])
+        assert e < 1.5e-2, (name, e)
+
+
+def test_attention_softmax_spike():
+    """one key dominating at a late tile forces the running-max rescale path (online softmax)."""
+    ops = _ops()
+    torch.manual_seed(6)
+    batch, seq, heads = 1, 257, 1
+    qkv = torch.randn(batch * seq, 192, device=DEV)
+    qkv[:, :64] *= 0.1
+    qkv[200, 64:128] = qkv[5, :64] * 400.0  # key 200 spikes against query 5
+    qkv = bf(qkv)
+    out, lse = ops.attention_fwd(qkv, batch, seq, heads, 0)
+    oref, lref = _attn_ref(qkv, batch, seq, heads, 0)
+    assert rel_err(out, oref) < 8e-3
+    assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("b,B,E,toff", [(4, 4, 8, 0), (32, 32, 512, 0), (48, 192, 768, 96), (512, 4096, 768, 1024)])
+def test_infonce_fwd_bwd(b, B, E, toff):
+    ops = _ops()
+    torch.manual_seed(7)
+    q = torch.nn.functional.normalize(torch.randn(b, E, device=DEV), dim=-1)
+    ap = torch.nn.functional.normalize(torch.randn(B, E, device=DEV), dim=-1)
+    scale = torch.tensor([1.0 / 0.07], device=DEV)
+    score = torch.empty(b, B, device=DEV)
+    stats = torch.empty(3 * b, device=DEV)
+    loss, acc = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+    ops.call("uniir_infonce_fwd", q, ap, scale, b, B, E, toff, score, stats, loss, acc)
+    qr, pr, sr = q.clone().requires_grad_(True), ap.clone().requires_grad_(True), scale.clone().requires_grad_(True)
+    sref = (qr @ pr.t()) * sr
+    tgt = toff + torch.arange(b, device=DEV)
+    lref = torch.nn.functional.cross_entropy(sref, tgt)
+    aref = (sref.argmax(1) == tgt).float().mean()
+    assert (score - sref).abs().max() < 1e-3  # north-star tolerance on fp32 logits
+    assert abs(loss.item() - lref.item()) < 1e-5 * max(1.0, abs(lref.item()))
+    assert acc.item() == aref.item()
+    lref.backward()
+    gbuf = torch.empty(b * B + b, device=DEV)
+    dq, dp, ds = torch.empty(b, E, device=DEV), torch.empty(B, E, device=DEV), torch.empty(1, device=DEV)
+    dl = torch.ones(1, device=DEV)
+    ops.call("uniir_infonce_bwd", q, ap, scale, score, stats, dl, b, B, E, toff, gbuf, dq, dp, ds)
+    assert rel_err(dq, qr.grad) < 1e-4
+    assert rel_err(dp, pr.grad) < 1e-4
+    assert abs(ds.item() - sr.grad.item()) < 1e-4 * max(1.0, abs(sr.grad.item()))
+
+
+def test_elementwise_misc():
+    ops = _ops()
+    torch.manual_seed(8)
+    # patchify vs unfold
+    n, res, P = 3, 224, 14
+    img = torch.randn(n, 3, res, res, device=DEV)
+    kpad = 640
+    patches = torch.empty(n * 256, kpad, device=DEV, dtype=torch.bfloat16)
+    ops.call("uniir_patchify", img, patches, n, res, P, kpad)
+    ref = torch.nn.functional.unfold(img, P, stride=P).transpose(1, 2).reshape(n * 256, 588)
+    assert torch.equal(patches[:, :588].float(), bf(ref).float())
+    assert (patches[:, 588:] == 0).all()
+    # colsum
+    x = bf(torch.randn(1000, 776, device=DEV))
+    out = torch.ones(776, device=DEV)
+    ops.call("uniir_colsum_bf16", x, 776, out, 1000, 776)
+    assert rel_err(out, x.float().sum(0) + 1) < 1e-5
+    # text embed + eot
+    text = torch.zeros(5, 77, dtype=torch.int32, device=DEV)
+    for i in range(5):
+        L = 3 + 7 * i
+        text[i, 0] = 49406
+        text[i, 1:1 + L] = torch.randint(1, 49405, (L,), device=DEV, dtype=torch.int32)
+        text[i, 1 + L] = 49407
+    tok, pos = torch.randn(49408, 64, device=DEV), torch.randn(77, 64, device=DEV)
+    xo = torch.empty(5, 77, 64, device=DEV)
+    eot = torch.empty(5, dtype=torch.int32, device=DEV)
+    ops.call("uniir_text_embed", text, tok, pos, xo, eot, 5, 77, 64, 49408)
+    assert torch.equal(xo, tok[text.long()] + pos)
+    assert torch.equal(eot.long(), text.argmax(-1))
+    # adamw vs torch
+    p = torch.randn(1003, device=DEV)
+    g = torch.randn(1003, device=DEV)
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pb = torch.empty(1003, device=DEV, dtype=torch.bfloat16)
+    pp = torch.zeros(1008, device=DEV)[:1003]
+    pp.copy_(p)
+    for step in range(1, 4):
+        pt.grad = g.clone()
+        opt.step()
+        ops.call("uniir_adamw_step", pp, g, m, v, pb, 1003, 1e-3, 0.9, 0.98, 1e-6, 0.2, step, 1.0)
+    assert (pp - pt.detach()).abs().max() < 1e-6
+    assert torch.equal(pb.float(), bf(pp).float())

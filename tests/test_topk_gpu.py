@@ -1,0 +1,76 @@
+"""GPU parity of the brute-force top-k against a torch fp32 restatement of FAISS IDMap,Flat IP semantics
+(normalize rows, exact inner product, top-k descending).  Ids must be identical wherever the reference's own
+score gap exceeds fp32 noise; planted neighbours make that explicit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref(pool, ids, queries, k):
+    p = torch.nn.functional.normalize(pool.double(), dim=-1)
+    q = torch.nn.functional.normalize(queries.double(), dim=-1)
+    s = q @ p.t()
+    v, i = torch.topk(s, min(k, pool.shape[0]), dim=-1)
+    return v, ids[i]
+
+
+@pytest.mark.parametrize("n,nq,d,k", [(1000, 7, 64, 10), (5000, 130, 512, 10), (70000, 33, 768, 10), (20000, 300, 768, 50), (5, 3, 64, 10)])
+def test_topk_matches_reference(n, nq, d, k):
+    from uniir_amd import retrieval
+    torch.manual_seed(0)
+    pool = torch.randn(n, d, device=DEV).half()
+    queries = torch.randn(nq, d, device=DEV).half()
+    if n > 100:
+        # planted neighbours: query j ~ pool row 10*j+3
+        for j in range(min(nq, 20)):
+            queries[j] = (pool[10 * j + 3].float() * 2.0 + 0.05 * torch.randn(d, device=DEV)).half()
+        pool[17] = 0  # zero row must score 0 and not break anything
+    ids = (torch.randperm(n, device=DEV) * 7 + 1000).long()
+    shard = retrieval.PoolShard(pool, ids)
+    s, i = retrieval.search_shard(shard, queries, k)
+    v, ri = _ref(pool, ids, queries, k)
+    kk = v.shape[1]
+    assert (s[:, :kk].double() - v).abs().max() < 2e-6
+    # ids identical except where the double-precision reference itself has a near-tie (< 1e-6 gap)
+    gap_ok = torch.ones_like(ri, dtype=torch.bool)
+    gap_ok[:, 1:] &= (v[:, :-1] - v[:, 1:]) > 1e-6
+    gap_ok[:, :-1] &= (v[:, :-1] - v[:, 1:]) > 1e-6
+    mism = (i[:, :kk] != ri) & gap_ok
+    assert not mism.any(), mism.nonzero()[:5]
+    if kk < k:
+        assert (i[:, kk:] == -1).all()
+    # descending
+    assert (s[:, :kk - 1] >= s[:, 1:kk]).all()
+
+
+def test_topk_sharded_equals_unsharded():
+    from uniir_amd import retrieval
+    torch.manual_seed(1)
+    n, nq, d, k = 40000, 64, 768, 10
+    pool = torch.randn(n, d, device=DEV).half()
+    queries = torch.randn(nq, d, device=DEV).half()
+    ids = torch.arange(n, device=DEV) + 5
+    full = retrieval.search_shard(retrieval.PoolShard(pool, ids), queries, k)
+    parts = []
+    bounds = [0, 13000, 13000 + 9001, n]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        parts.append(retrieval.search_shard(retrieval.PoolShard(pool[a:b], ids[a:b]), queries, k))
+    ms, mi = retrieval.merge_shards(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(mi, full[1])
+    assert torch.equal(ms, full[0])
+
+
+def test_topk_duplicates_tiebreak():
+    from uniir_amd import retrieval
+    torch.manual_seed(2)
+    n, d, k = 3000, 64, 10
+    pool = torch.randn(n, d, device=DEV).half()
+    pool[100:106] = pool[50]  # 6 exact duplicates of row 50
+    ids = torch.arange(n, device=DEV).flip(0).contiguous()  # descending ids: tie-break must use ids, not rows
+    q = pool[50:51].clone()
+    s, i = retrieval.search_shard(retrieval.PoolShard(pool, ids), q, k)
+    dup_ids = sorted(ids[[50, 100, 101, 102, 103, 104, 105]].tolist())
+    assert i[0, :7].tolist() == dup_ids
+    assert (s[0, :7] == s[0, 0]).all()

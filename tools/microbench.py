@@ -1,0 +1,75 @@
+"""Per-kernel timing on the GPU box (dev tool): prints TF/s and GB/s per kernel; not part of the shipped path."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from uniir_amd import ops, retrieval
+
+dev = "cuda"
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    items = int(os.environ.get("MB_ITEMS", "256"))
+    R = items * 257
+    print(f"rows={R}")
+    for (N, K, name) in [(3072, 1024, "qkv"), (1024, 1024, "out"), (4096, 1024, "fc"), (1024, 4096, "proj")]:
+        x = torch.randn(R, K, device=dev).bfloat16()
+        w = torch.randn(N, K, device=dev).bfloat16()
+        y = torch.empty(R, N, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.linear_fwd(x, w, out=y))
+        print(f"gemm fwd NT {name}: {t*1e3:.3f} ms  {2*R*N*K/t/1e12:.1f} TF/s")
+        dy = torch.randn(R, N, device=dev).bfloat16()
+        dx = torch.empty(R, K, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.linear_dgrad(dy, w, out=dx))
+        print(f"gemm dgrad NN {name}: {t*1e3:.3f} ms  {2*R*N*K/t/1e12:.1f} TF/s")
+        dw = torch.zeros(N, K, device=dev)
+        t = timeit(lambda: ops.linear_wgrad(dy, x, dw))
+        print(f"gemm wgrad TN {name}: {t*1e3:.3f} ms  {2*R*N*K/t/1e12:.1f} TF/s")
+        del x, w, y, dy, dx, dw
+    # attention
+    for (T, H, causal, b) in [(257, 16, 0, items), (77, 12, 1, items)]:
+        qkv = torch.randn(b * T, 3 * H * 64, device=dev).bfloat16()
+        out, lse = ops.attention_fwd(qkv, b, T, H, causal)
+        t = timeit(lambda: ops.attention_fwd(qkv, b, T, H, causal, out=out, lse=lse))
+        fl = 4 * b * H * T * T * 64
+        print(f"attn fwd T={T}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TF/s (dense count)")
+        do = torch.randn_like(out)
+        dqkv = torch.empty_like(qkv)
+        t = timeit(lambda: ops.attention_bwd(qkv, out, do, lse, b, T, H, causal, dqkv=dqkv))
+        print(f"attn bwd T={T}: {t*1e3:.3f} ms  {2.5*fl/t/1e12:.1f} TF/s (2.5x fwd count)")
+    # layernorm
+    x = torch.randn(R, 1024, device=dev)
+    g, bb = torch.ones(1024, device=dev), torch.zeros(1024, device=dev)
+    y = torch.empty(R, 1024, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda: ops.layernorm_fwd(x, g, bb, out_bf16=y))
+    print(f"ln fwd: {t*1e3:.3f} ms  {R*1024*6/t/1e9:.0f} GB/s")
+    dy = torch.randn(R, 1024, device=dev).bfloat16()
+    dx = torch.empty(R, 1024, device=dev)
+    dg, db = torch.zeros(1024, device=dev), torch.zeros(1024, device=dev)
+    t = timeit(lambda: ops.layernorm_bwd(x, g, dy, dg, db, dx=dx))
+    print(f"ln bwd: {t*1e3:.3f} ms  {R*1024*10/t/1e9:.0f} GB/s")
+    # top-k
+    n = int(os.environ.get("MB_POOL", "700000"))
+    pool = torch.randn(n, 768, device=dev).half()
+    ids = torch.arange(n, device=dev)
+    shard = retrieval.PoolShard(pool, ids)
+    for nq in (16, 64, 128, 1024):
+        q = torch.randn(nq, 768, device=dev).half()
+        t = timeit(lambda: retrieval.search_shard(shard, q, 10), iters=5, warm=2)
+        print(f"topk nq={nq} n={n}: {t*1e3:.3f} ms  pool {n*768*2/t/1e9:.0f} GB/s  {2*nq*n*768/t/1e12:.1f} TF/s  {nq*n/t/1e6:.0f} Mscores/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""ctypes binding of libuniir_hip.so (C ABI declared in include/uniir_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this module raises,
+and every wrapper raises RuntimeError(uniir_strerror(code)) on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuniir_hip.so")
+
+c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p),
+        ("bias", c_void_p), ("resid", c_void_p), ("aux", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ldaux", c_i64),
+        ("a_tmaj", c_int), ("b_tmaj", c_int),
+        ("epilogue", c_int), ("act", c_int), ("dtype", c_int),
+        ("k_splits", c_int), ("alpha", c_float),
+    ]
+
+
+# name -> (restype, argtypes); P = device pointer, S = stream
+P, S = c_void_p, c_void_p
+SIGNATURES = {
+    "uniir_strerror": (C.c_char_p, [c_int]),
+    "uniir_abi_version": (c_int, []),
+    "uniir_gemm": (c_int, [C.POINTER(GemmDesc), S]),
+    "uniir_layernorm_fwd": (c_int, [P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
+    "uniir_layernorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, c_int, c_int, c_float, S]),
+    "uniir_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_patchify": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_vit_assemble": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
+    "uniir_vit_assemble_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
+    "uniir_text_embed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_text_embed_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_gather_rows": (c_int, [P, P, P, c_int, c_int, c_int, S]),
+    "uniir_scatter_rows": (c_int, [P, P, P, c_int, c_int, c_int, S]),
+    "uniir_act_fwd": (c_int, [P, P, c_i64, c_int, S]),
+    "uniir_colsum_bf16": (c_int, [P, c_i64, P, c_int, c_int, S]),
+    "uniir_cast_f32_to_bf16": (c_int, [P, P, c_i64, S]),
+    "uniir_cast_bf16_to_f32": (c_int, [P, P, c_i64, S]),
+    "uniir_cast_pad_rows": (c_int, [P, P, c_int, c_int, c_int, S]),
+    "uniir_unpad_add": (c_int, [P, P, c_int, c_int, c_int, S]),
+    "uniir_fuse_embeddings": (c_int, [P, P, P, P, P, c_int, c_int, S]),
+    "uniir_select_normalize": (c_int, [P, P, P, P, c_int, c_int, S]),
+    "uniir_select_normalize_bwd": (c_int, [P, P, P, P, P, c_int, c_int, S]),
+    "uniir_fuse_embeddings_bwd": (c_int, [P, P, P, P, P, c_int, c_int, S]),
+    "uniir_infonce_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, S]),
+    "uniir_infonce_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, S]),
+    "uniir_sgemm": (c_int, [P, c_i64, c_i64, P, c_i64, c_i64, P, c_i64, c_int, c_int, c_int, c_float, S]),
+    "uniir_adamw_step": (c_int, [P, P, P, P, P, c_i64, c_float, c_float, c_float, c_float, c_float, c_int,
+                                 c_float, S]),
+    "uniir_pool_inv_norms": (c_int, [P, c_i64, c_int, P, S]),
+    "uniir_topk_workspace_bytes": (c_i64, [c_int, c_int, c_i64]),
+    "uniir_topk_coarse": (c_int, [P, P, c_i64, c_int, P, c_int, c_int, P, P, P, c_i64, S]),
+    "uniir_topk_rescore": (c_int, [P, P, P, c_i64, c_int, P, P, c_int, P, c_int, c_int, P, P, P, S]),
+    "uniir_topk_merge": (c_int, [P, P, c_int, c_int, c_int, P, P, S]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise (never fall back) when it or one of its symbols is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C uniir_amd/csrc). uniir_amd has no CPU/torch fallback for its HIP path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().uniir_strerror(int(code)).decode()
+        raise RuntimeError(f"uniir_hip {what} failed: {msg} (code {code})")

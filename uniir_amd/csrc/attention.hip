@@ -1,0 +1,354 @@
+// Fused multi-head attention forward / backward for the CLIP towers (head_dim 64; seq 257 / 77 / 50).
+// Replaces nn.MultiheadAttention's softmax(QK^T/sqrt(64) [+ causal mask])V inside openai/CLIP
+// ResidualAttentionBlock.attention (model.py), reached from clip_sf.py:43-47.
+//
+// One workgroup (4 waves) per (item, head); the whole K/V (fwd) or Q/dO then K/V (bwd) of that head sits
+// in LDS ([row][64] bf16, 128-B rows, 16-B chunk index XOR (row & 7): conflict-free both for the
+// ds_read_b128 fragment reads and for the ds_read_b64_tr_b16 transposing reads).
+//
+// Everything is computed "transposed" so that softmax statistics are lane-local:
+//   S^T = K Q^T   -> lane holds S[q = lane&15][key = 4*(lane>>4) + r]   (v_mfma_f32_16x16x32_bf16)
+//   O^T = V^T P^T -> A operand = V^T via transposing LDS reads, B operand = P^T straight from the S^T
+//                    accumulators (k-slots permuted consistently on both operands).
+#include "common.h"
+#include "../../include/uniir_hip.h"
+
+#define ATT_D 64
+#define SCALE_LOG2E 0.18033688011112042f  // (1/sqrt(64)) * log2(e)
+#define ATT_SCALE 0.125f
+#define LN2F 0.6931471805599453f
+#define LOG2EF 1.4426950408889634f
+
+DEVINL int swz_off(int row, int col) {  // byte offset of element (row, col) in a swizzled [rows][64] bf16 tile
+    return row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1));
+}
+
+// stage rows [0, Tp) of a [T][64] bf16 head slice (row stride `ld` elements) into swizzled LDS, zero padded
+DEVINL void stage_head(char* lds, const unsigned short* __restrict__ src, long ld, int T, int Tp, int tid) {
+    for (int c = tid; c < Tp * 8; c += 256) {
+        const int row = c >> 3, kc = c & 7;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (row < T) v = *reinterpret_cast<const u32x4_t*>(src + (long)row * ld + kc * 8);
+        *reinterpret_cast<u32x4_t*>(lds + row * 128 + ((kc ^ (row & 7)) << 4)) = v;
+    }
+}
+// b128 fragment: 8 consecutive d (k-step s) of row r0 + (lane&15)
+DEVINL bf16x8_t frag_rows(const char* lds, int r0, int s, int lane) {
+    const int row = r0 + (lane & 15), kc = s * 4 + (lane >> 4);
+    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lds + row * 128 + ((kc ^ (row & 7)) << 4)));
+}
+// same fragment straight from global (rows >= T read as zero)
+DEVINL bf16x8_t frag_rows_global(const unsigned short* __restrict__ src, long ld, int r0, int s, int lane, int T) {
+    const int row = r0 + (lane & 15);
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (row < T) v = *reinterpret_cast<const u32x4_t*>(src + (long)row * ld + s * 32 + (lane >> 4) * 8);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// transposed fragment for column tile dt (16 cols) over the 32-row block starting at rb:
+// lane (i = col = lane&15, g = lane>>4) gets rows {rb+4g+0..3, rb+16+4g+0..3} of column 16*dt + (lane&15)
+DEVINL bf16x8_t frag_cols_tr(const char* lds, int rb, int dt, int lane) {
+    const int t = lane & 15, g = lane >> 4;
+    const int row = rb + 4 * g + (t >> 2), col = 16 * dt + 4 * (t & 3);
+    const s16x4_t lo = lds_read_tr16(lds + swz_off(row, col));
+    const s16x4_t hi = lds_read_tr16(lds + swz_off(row + 16, col));
+    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+    const u32x4_t r = {l2[0], l2[1], h2[0], h2[1]};
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+DEVINL bf16x8_t pack8(const f32x4_t a, const f32x4_t b) {
+    const u32x4_t r = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
+                       pack_bf16x2(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+DEVINL f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+DEVINL float group_max(float v) {  // across the 4 lane groups (same lane&15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+DEVINL float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const unsigned short* __restrict__ qkv,
+                                                       unsigned short* __restrict__ out,
+                                                       float* __restrict__ lse, int T, int H, int causal) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int Tp = (T + 31) & ~31;
+    char* ldsK = lds;
+    char* ldsV = lds + Tp * 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = blockIdx.x / H, h = blockIdx.x % H;
+    const long W = (long)H * ATT_D, ld = 3 * W;
+    const unsigned short* qbase = qkv + (long)m * T * ld + h * ATT_D;
+    stage_head(ldsK, qbase + W, ld, T, Tp, tid);
+    stage_head(ldsV, qbase + 2 * W, ld, T, Tp, tid);
+    __syncthreads();
+    const int nqt = (T + 15) >> 4;
+    const int qi = lane & 15, g = lane >> 4;
+    for (int qt = w; qt < nqt; qt += 4) {
+        const int q0 = qt * 16, q = q0 + qi;
+        bf16x8_t qf[2];
+        qf[0] = frag_rows_global(qbase, ld, q0, 0, lane, T);
+        qf[1] = frag_rows_global(qbase, ld, q0, 1, lane, T);
+        f32x4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        float m_run = -1e30f, l_run = 0.f;
+        const int kmax = causal ? min(T, q0 + 16) : T;
+        const int nkb = (kmax + 31) >> 5;
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x4_t st[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                st[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    st[kt] = mfma16(frag_rows(ldsK, kb * 32 + kt * 16, s, lane), qf[s], st[kt]);
+            }
+            float mx = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb * 32 + kt * 16 + 4 * g + r;
+                    float v = st[kt][r] * SCALE_LOG2E;
+                    if (key >= T || (causal && key > q)) v = -1e30f;
+                    st[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = group_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f(m_run - m_new);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = (st[kt][r] <= -1e29f) ? 0.f : exp2f(st[kt][r] - m_new);
+                    st[kt][r] = p;
+                    sum += p;
+                }
+            sum = group_sum(sum);
+            l_run = l_run * alpha + sum;
+            m_run = m_new;
+            const bf16x8_t pf = pack8(st[0], st[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[dt] = o[dt] * alpha;
+                o[dt] = mfma16(frag_cols_tr(ldsV, kb * 32, dt, lane), pf, o[dt]);
+            }
+        }
+        if (q < T) {
+            const float inv = 1.0f / l_run;
+            unsigned short* orow = out + ((long)m * T + q) * W + h * ATT_D;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4_t v = o[dt] * inv;
+                u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2_t*>(orow + 16 * dt + 4 * g) = pk;
+            }
+            if (g == 0) lse[((long)m * H + h) * T + q] = m_run * LN2F + __logf(l_run);
+        }
+    }
+}
+
+// Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
+// Phase 2 (per 16-query tile): dQ^T += K^T dS^T with S^T = K Q^T oriented [key][q].
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const unsigned short* __restrict__ qkv,
+                                                       const unsigned short* __restrict__ out,
+                                                       const unsigned short* __restrict__ dout,
+                                                       const float* __restrict__ lse,
+                                                       unsigned short* __restrict__ dqkv, int T, int H,
+                                                       int causal) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int Tp = (T + 31) & ~31;
+    char* bufA = lds;               // Q, later K
+    char* bufB = lds + Tp * 128;    // dO, later V
+    float* lse2 = reinterpret_cast<float*>(lds + 2 * Tp * 128);
+    float* Dq = lse2 + Tp;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = blockIdx.x / H, h = blockIdx.x % H;
+    const long W = (long)H * ATT_D, ld = 3 * W;
+    const unsigned short* qbase = qkv + (long)m * T * ld + h * ATT_D;
+    const unsigned short* obase = out + (long)m * T * W + h * ATT_D;
+    const unsigned short* dobase = dout + (long)m * T * W + h * ATT_D;
+    unsigned short* dqbase = dqkv + (long)m * T * ld + h * ATT_D;
+
+    for (int r = tid; r < Tp; r += 256) {
+        float d = 0.f, l = 0.f;
+        if (r < T) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const u32x4_t a = *reinterpret_cast<const u32x4_t*>(obase + (long)r * W + c * 8);
+                const u32x4_t b = *reinterpret_cast<const u32x4_t*>(dobase + (long)r * W + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    d += __uint_as_float(a[e] << 16) * __uint_as_float(b[e] << 16);
+                    d += __uint_as_float(a[e] & 0xffff0000u) * __uint_as_float(b[e] & 0xffff0000u);
+                }
+            }
+            l = lse[((long)m * H + h) * T + r] * LOG2EF;
+        }
+        Dq[r] = d;
+        lse2[r] = l;
+    }
+    stage_head(bufA, qbase, ld, T, Tp, tid);
+    stage_head(bufB, dobase, W, T, Tp, tid);
+    __syncthreads();
+
+    const int li = lane & 15, g = lane >> 4;
+    const int ntile = (T + 15) >> 4;
+    const int nblk = Tp >> 5;
+    // ---------------- phase 1: dK, dV ----------------
+    for (int kt = w; kt < ntile; kt += 4) {
+        const int k0 = kt * 16, key = k0 + li;
+        bf16x8_t kf[2], vf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            kf[s] = frag_rows_global(qbase + W, ld, k0, s, lane, T);
+            vf[s] = frag_rows_global(qbase + 2 * W, ld, k0, s, lane, T);
+        }
+        f32x4_t dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        const int qb0 = causal ? (k0 >> 5) : 0;
+        for (int qb = qb0; qb < nblk; ++qb) {
+            f32x4_t pt[2], dst[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    sa = mfma16(frag_rows(bufA, qb * 32 + qt * 16, s, lane), kf[s], sa);
+                    dp = mfma16(frag_rows(bufB, qb * 32 + qt * 16, s, lane), vf[s], dp);
+                }
+                // NOTE operand order: A rows = queries, B cols = keys -> acc[r] = S[q = 4g + r][key = li]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qb * 32 + qt * 16 + 4 * g + r;
+                    float p = exp2f(sa[r] * SCALE_LOG2E - lse2[q]);
+                    if (causal && key > q) p = 0.f;
+                    pt[qt][r] = p;
+                    dst[qt][r] = p * (dp[r] - Dq[q]);
+                }
+            }
+            const bf16x8_t pf = pack8(pt[0], pt[1]), dsf = pack8(dst[0], dst[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = mfma16(frag_cols_tr(bufB, qb * 32, dt, lane), pf, dv[dt]);
+                dk[dt] = mfma16(frag_cols_tr(bufA, qb * 32, dt, lane), dsf, dk[dt]);
+            }
+        }
+        if (key < T) {
+            unsigned short* krow = dqbase + (long)key * ld + W;
+            unsigned short* vrow = dqbase + (long)key * ld + 2 * W;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4_t a = dk[dt] * ATT_SCALE;
+                u32x2_t pk = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+                *reinterpret_cast<u32x2_t*>(krow + 16 * dt + 4 * g) = pk;
+                u32x2_t pv = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
+                *reinterpret_cast<u32x2_t*>(vrow + 16 * dt + 4 * g) = pv;
+            }
+        }
+    }
+    __syncthreads();
+    stage_head(bufA, qbase + W, ld, T, Tp, tid);
+    stage_head(bufB, qbase + 2 * W, ld, T, Tp, tid);
+    __syncthreads();
+    // ---------------- phase 2: dQ ----------------
+    for (int qt = w; qt < ntile; qt += 4) {
+        const int q0 = qt * 16, q = q0 + li;
+        bf16x8_t qf[2], dof[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[s] = frag_rows_global(qbase, ld, q0, s, lane, T);
+            dof[s] = frag_rows_global(dobase, W, q0, s, lane, T);
+        }
+        const float my_lse = lse2[q0 + li], my_D = Dq[q0 + li];
+        f32x4_t dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int kmax = causal ? min(T, q0 + 16) : T;
+        const int nkb = (kmax + 31) >> 5;
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x4_t dst[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    sa = mfma16(frag_rows(bufA, kb * 32 + kt * 16, s, lane), qf[s], sa);
+                    dp = mfma16(frag_rows(bufB, kb * 32 + kt * 16, s, lane), dof[s], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb * 32 + kt * 16 + 4 * g + r;
+                    float p = exp2f(sa[r] * SCALE_LOG2E - my_lse);
+                    if (key >= T || (causal && key > q)) p = 0.f;
+                    dst[kt][r] = p * (dp[r] - my_D);
+                }
+            }
+            const bf16x8_t dsf = pack8(dst[0], dst[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(frag_cols_tr(bufA, kb * 32, dt, lane), dsf, dq[dt]);
+        }
+        if (q < T) {
+            unsigned short* qrow = dqbase + (long)q * ld;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4_t a = dq[dt] * ATT_SCALE;
+                u32x2_t pk = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+                *reinterpret_cast<u32x2_t*>(qrow + 16 * dt + 4 * g) = pk;
+            }
+        }
+    }
+}
+
+extern "C" int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32_t batch, int32_t seq,
+                                   int32_t heads, int32_t causal, void* stream) {
+    if (!qkv || !out || !lse || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (seq < 1 || seq > 512) return UNIIR_ESHAPE;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return UNIIR_EALIGN;
+    const int Tp = (seq + 31) & ~31;
+    const int sm = 2 * Tp * 128;
+    static int attr = 0;
+    if (sm > attr) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
+        attr = 2 * 512 * 128;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(batch * heads), dim3(256), sm, (hipStream_t)stream,
+                       (const unsigned short*)qkv, (unsigned short*)out, lse, seq, heads, causal);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+extern "C" int uniir_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                                   void* dqkv, int32_t batch, int32_t seq, int32_t heads, int32_t causal,
+                                   void* stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (seq < 1 || seq > 512) return UNIIR_ESHAPE;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15))
+        return UNIIR_EALIGN;
+    const int Tp = (seq + 31) & ~31;
+    const int sm = 2 * Tp * 128 + 2 * Tp * 4;
+    static int attr = 0;
+    if (sm > attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * 512 * 128 + 2 * 512 * 4);
+        attr = 2 * 512 * 128 + 2 * 512 * 4;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * heads), dim3(256), sm, (hipStream_t)stream,
+                       (const unsigned short*)qkv, (const unsigned short*)out, (const unsigned short*)dout, lse,
+                       (unsigned short*)dqkv, seq, heads, causal);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}

@@ -1,0 +1,68 @@
+// Shared device helpers for the gfx950 kernels of uniir_amd (wave64, MFMA 16x16x32, LDS tr-reads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef unsigned short bf16_t;   // raw bf16 bits
+typedef unsigned short f16_t;    // raw fp16 bits (only moved around / fed to MFMA)
+
+#define UNIIR_OK 0
+#define UNIIR_EINVAL (-1)
+#define UNIIR_ESHAPE (-2)
+#define UNIIR_EALIGN (-3)
+#define UNIIR_ELAUNCH (-4)
+#define UNIIR_EUNSUPPORTED (-5)
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even, NaN kept quiet
+DEVINL bf16_t f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+DEVINL unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+DEVINL float f16_to_f32(f16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+DEVINL f16_t f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+
+DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVINL float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// LDS transposing read: the 16 lanes of a group each give the address of 4 contiguous
+// 16-bit elements (8 B, 8-B aligned); together a 4x16 block M (lane t -> row t>>2, cols 4*(t&3)..+3).
+// Lane t receives column t: {M[0][t], M[1][t], M[2][t], M[3][t]}.
+DEVINL s16x4_t lds_read_tr16(const void* lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4_t __attribute__((address_space(3)))*)(lds_addr));
+}
+
+DEVINL int xcd_remap(int bid, int nwg) {
+    // bijective XCD-aware remap (8 XCDs): blocks that land on one XCD get a contiguous chunk of tiles
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+#define HIP_LAUNCH_CHECK()                                         \
+    do {                                                           \
+        hipError_t e__ = hipGetLastError();                        \
+        if (e__ != hipSuccess) return UNIIR_ELAUNCH;               \
+    } while (0)

@@ -1,0 +1,558 @@
+// HBM-bound glue kernels of the CLIP towers, the fuse/normalise step and the optimizer.
+// Reference semantics (UniIR tree): clip_sf.py:53-63 (mask fuse), :88-97 (select + F.normalize),
+// clip_scorefusion/train.py:195-199 (AdamW), openai/CLIP model.py (conv1 patch embed, class/positional
+// embeddings, token embedding, EOT pooling) as called from clip_sf.py:43-47.
+#include "common.h"
+#include "../../include/uniir_hip.h"
+
+static inline int grid_for(long work, int per_block, int cap = 8192) {
+    long g = (work + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// patchify: images f32 [n][3][res][res] -> bf16 [n*g*g][kpad], k = c*P*P + py*P + px
+// one thread produces 8 consecutive k (16 B store); reads are P-contiguous runs of a pixel row.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img,
+                                                       unsigned short* __restrict__ out, int n, int res,
+                                                       int P, int kpad) {
+    const int g = res / P, kreal = 3 * P * P, chunks = kpad >> 3;
+    const long total = (long)n * g * g * chunks;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int ch = (int)(t % chunks);
+        const long row = t / chunks;
+        const int gx = (int)(row % g), gy = (int)((row / g) % g);
+        const long im = row / ((long)g * g);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e;
+            float val = 0.f;
+            if (k < kreal) {
+                const int c = k / (P * P), rem = k - c * P * P, py = rem / P, px = rem - py * P;
+                val = img[((im * 3 + c) * res + (gy * P + py)) * (long)res + gx * P + px];
+            }
+            v[e] = val;
+        }
+        u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                     pack_bf16x2(v[6], v[7])};
+        *reinterpret_cast<u32x4_t*>(out + row * kpad + ch * 8) = o;
+    }
+}
+
+extern "C" int uniir_patchify(const float* images, void* patches, int32_t n, int32_t res, int32_t patch,
+                              int32_t kpad, void* stream) {
+    if (!images || !patches || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    if (patch <= 0 || res % patch || kpad % 8 || kpad < 3 * patch * patch) return UNIIR_ESHAPE;
+    const int g = res / patch;
+    const long total = (long)n * g * g * (kpad / 8);
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       images, (unsigned short*)patches, n, res, patch, kpad);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// vit assemble: x[n][T][w] = (t == 0 ? class_emb : patch_out[n][t-1]) + pos[t]
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const unsigned short* __restrict__ po,
+                                                           const float* __restrict__ cls,
+                                                           const float* __restrict__ pos,
+                                                           float* __restrict__ x, int n, int T, int w) {
+    const int wc = w >> 2;
+    const long total = (long)n * T * wc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % wc);
+        const long row = i / wc;
+        const int t = (int)(row % T);
+        const long im = row / T;
+        f32x4_t v;
+        if (t == 0) {
+            v = *reinterpret_cast<const f32x4_t*>(cls + 4 * c);
+        } else {
+            const u32x2_t pk =
+                *reinterpret_cast<const u32x2_t*>(po + (im * (T - 1) + (t - 1)) * (long)w + 4 * c);
+            v = f32x4_t{__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                        __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+        }
+        v += *reinterpret_cast<const f32x4_t*>(pos + (long)t * w + 4 * c);
+        *reinterpret_cast<f32x4_t*>(x + row * w + 4 * c) = v;
+    }
+}
+
+extern "C" int uniir_vit_assemble(const void* patch_out, const float* class_emb, const float* pos_emb,
+                                  float* x, int32_t n, int32_t tokens, int32_t width, void* stream) {
+    if (!patch_out || !class_emb || !pos_emb || !x || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    if (width % 4 || tokens < 2) return UNIIR_ESHAPE;
+    const long total = (long)n * tokens * (width / 4);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned short*)patch_out, class_emb, pos_emb, x, n, tokens,
+                       width);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// backward: dpatch = bf16(dx[:,1:,:]); dpos[t] += sum_n dx[n][t]; dclass += sum_n dx[n][0]
+// grid = (T, w/256-ish): each block owns one token position t and reduces over n.
+__global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __restrict__ dx,
+                                                               unsigned short* __restrict__ dpo,
+                                                               float* __restrict__ dcls,
+                                                               float* __restrict__ dpos, int n, int T,
+                                                               int w) {
+    const int t = blockIdx.x;
+    for (int col = blockIdx.y * 256 + threadIdx.x; col < w; col += gridDim.y * 256) {
+        float s = 0.f;
+        for (int im = 0; im < n; ++im) {
+            const float v = dx[((long)im * T + t) * w + col];
+            s += v;
+            if (t > 0) dpo[((long)im * (T - 1) + (t - 1)) * w + col] = f32_to_bf16(v);
+        }
+        dpos[(long)t * w + col] += s;
+        if (t == 0) dcls[col] += s;
+    }
+}
+
+extern "C" int uniir_vit_assemble_bwd(const float* dx, void* dpatch_out, float* dclass, float* dpos,
+                                      int32_t n, int32_t tokens, int32_t width, void* stream) {
+    if (!dx || !dpatch_out || !dclass || !dpos || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(tokens, (width + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, dx, (unsigned short*)dpatch_out, dclass, dpos, n, tokens, width);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// text embed: x[n][t][:] = tok[text[n][t]] + pos[t]; eot[n] = first argmax_t text[n][t]
+__global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ text,
+                                                         const float* __restrict__ tok,
+                                                         const float* __restrict__ pos,
+                                                         float* __restrict__ x, int n, int ctx, int w,
+                                                         int vocab) {
+    const int wc = w >> 2;
+    const long total = (long)n * ctx * wc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % wc);
+        const long row = i / wc;
+        const int t = (int)(row % ctx);
+        int id = text[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(tok + (long)id * w + 4 * c);
+        v += *reinterpret_cast<const f32x4_t*>(pos + (long)t * w + 4 * c);
+        *reinterpret_cast<f32x4_t*>(x + row * w + 4 * c) = v;
+    }
+}
+__global__ void text_eot_kernel(const int* __restrict__ text, int* __restrict__ eot, int n, int ctx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int best = text[(long)i * ctx], bi = 0;
+    for (int t = 1; t < ctx; ++t) {
+        const int v = text[(long)i * ctx + t];
+        if (v > best) { best = v; bi = t; }
+    }
+    eot[i] = bi;
+}
+
+extern "C" int uniir_text_embed(const int32_t* text, const float* token_emb, const float* pos_emb, float* x,
+                                int32_t* eot, int32_t n, int32_t ctx, int32_t width, int32_t vocab,
+                                void* stream) {
+    if (!text || !token_emb || !pos_emb || !x || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    if (width % 4) return UNIIR_ESHAPE;
+    const long total = (long)n * ctx * (width / 4);
+    hipLaunchKernelGGL(text_embed_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       text, token_emb, pos_emb, x, n, ctx, width, vocab);
+    if (eot)
+        hipLaunchKernelGGL(text_eot_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, text, eot,
+                           n, ctx);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// backward: dtok[text[n][t]] += dx[n][t] (atomics: ids repeat); dpos[t] += sum_n dx[n][t]
+__global__ __launch_bounds__(256) void text_embed_bwd_tok_kernel(const int* __restrict__ text,
+                                                                 const float* __restrict__ dx,
+                                                                 float* __restrict__ dtok, int n, int ctx,
+                                                                 int w, int vocab) {
+    const long total = (long)n * ctx * w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int col = (int)(i % w);
+        const long row = i / w;
+        int id = text[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        unsafeAtomicAdd(dtok + (long)id * w + col, dx[i]);
+    }
+}
+__global__ __launch_bounds__(256) void text_embed_bwd_pos_kernel(const float* __restrict__ dx,
+                                                                 float* __restrict__ dpos, int n, int ctx,
+                                                                 int w) {
+    const int t = blockIdx.x;
+    for (int col = blockIdx.y * 256 + threadIdx.x; col < w; col += gridDim.y * 256) {
+        float s = 0.f;
+        for (int im = 0; im < n; ++im) s += dx[((long)im * ctx + t) * w + col];
+        dpos[(long)t * w + col] += s;
+    }
+}
+
+extern "C" int uniir_text_embed_bwd(const int32_t* text, const float* dx, float* dtoken_emb, float* dpos,
+                                    int32_t n, int32_t ctx, int32_t width, int32_t vocab, void* stream) {
+    if (!text || !dx || !dtoken_emb || !dpos || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    const long total = (long)n * ctx * width;
+    hipLaunchKernelGGL(text_embed_bwd_tok_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, text, dx, dtoken_emb, n, ctx, width, vocab);
+    hipLaunchKernelGGL(text_embed_bwd_pos_kernel, dim3(ctx, (width + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, dx, dpos, n, ctx, width);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x,
+                                                          const int* __restrict__ idx,
+                                                          float* __restrict__ out, int n, int seq, int w,
+                                                          int scatter_add) {
+    const int wc = w >> 2;
+    const long total = (long)n * wc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % wc);
+        const long r = i / wc;
+        const long src = r * seq + (idx ? idx[r] : 0);
+        if (!scatter_add) {
+            *reinterpret_cast<f32x4_t*>(out + r * w + 4 * c) = *reinterpret_cast<const f32x4_t*>(x + src * w + 4 * c);
+        } else {  // here "x" is dout [n][w] and "out" is dx [n*seq][w]
+            f32x4_t* d = reinterpret_cast<f32x4_t*>(out + src * w + 4 * c);
+            *d = *d + *reinterpret_cast<const f32x4_t*>(x + r * w + 4 * c);
+        }
+    }
+}
+extern "C" int uniir_gather_rows(const float* x, const int32_t* idx, float* out, int32_t n, int32_t seq,
+                                 int32_t width, void* stream) {
+    if (!x || !out || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    if (width % 4) return UNIIR_ESHAPE;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * (width / 4), 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, idx, out, n, seq, width, 0);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+extern "C" int uniir_scatter_rows(const float* dout, const int32_t* idx, float* dx, int32_t n, int32_t seq,
+                                  int32_t width, void* stream) {
+    if (!dout || !dx || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    if (width % 4) return UNIIR_ESHAPE;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * (width / 4), 256)), dim3(256), 0,
+                       (hipStream_t)stream, dout, idx, dx, n, seq, width, 1);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+DEVINL float act_fwd_e(float x, int act) {
+    if (act == UNIIR_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+    if (act == UNIIR_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    return fmaxf(x, 0.0f);
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(const u32x4_t* __restrict__ f, u32x4_t* __restrict__ g,
+                                                      long nvec, int act) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const u32x4_t a = f[i];
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = act_fwd_e(__uint_as_float(a[e] << 16), act);
+            const float hi = act_fwd_e(__uint_as_float(a[e] & 0xffff0000u), act);
+            o[e] = pack_bf16x2(lo, hi);
+        }
+        g[i] = o;
+    }
+}
+extern "C" int uniir_act_fwd(const void* f_bf16, void* g_bf16, int64_t count, int32_t act, void* stream) {
+    if (!f_bf16 || !g_bf16 || count < 0) return UNIIR_EINVAL;
+    if (count == 0) return UNIIR_OK;
+    if (count % 8) return UNIIR_ESHAPE;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(count / 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4_t*)f_bf16, (u32x4_t*)g_bf16, (long)(count / 8), act);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// colsum: out[c] += sum_r x[r][c].  Block = 256 threads covers 64 column-chunks of 8 (512 cols) x 4 row lanes.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ x, long ld,
+                                                          float* __restrict__ out, int rows, int cols,
+                                                          int rows_per_block) {
+    __shared__ float red[4][512];
+    const int cchunk = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + cchunk * 8;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < cols) {
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const u32x4_t a = *reinterpret_cast<const u32x4_t*>(x + (long)r * ld + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += __uint_as_float(a[e] << 16);
+                acc[2 * e + 1] += __uint_as_float(a[e] & 0xffff0000u);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cchunk * 8 + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int gc = blockIdx.x * 512 + c;
+        if (gc < cols) unsafeAtomicAdd(out + gc, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    }
+}
+extern "C" int uniir_colsum_bf16(const void* x, int64_t ld, float* out, int32_t rows, int32_t cols,
+                                 void* stream) {
+    if (!x || !out || rows < 0 || cols <= 0) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    if (cols % 8 || ld % 8) return UNIIR_ESHAPE;
+    const int gx = (cols + 511) / 512;
+    int gy = 2048 / gx;
+    if (gy < 1) gy = 1;
+    int rpb = (rows + gy - 1) / gy;
+    if (rpb < 64) rpb = 64;
+    gy = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, (long)ld, out, rows, cols, rpb);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ s,
+                                                            unsigned short* __restrict__ d, long n) {
+    const long nv = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(s + 4 * i);
+        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2_t*>(d + 4 * i) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) d[(nv << 2) + threadIdx.x] = f32_to_bf16(s[(nv << 2) + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const unsigned short* __restrict__ s,
+                                                            float* __restrict__ d, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) d[i] = bf16_to_f32(s[i]);
+}
+extern "C" int uniir_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream) {
+    if (!src || !dst || count < 0) return UNIIR_EINVAL;
+    if (count == 0) return UNIIR_OK;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return UNIIR_EALIGN;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(count / 4 + 1, 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, src, (unsigned short*)dst, (long)count);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+extern "C" int uniir_cast_bf16_to_f32(const void* src, float* dst, int64_t count, void* stream) {
+    if (!src || !dst || count < 0) return UNIIR_EINVAL;
+    if (count == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(count, 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned short*)src, dst, (long)count);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+__global__ __launch_bounds__(256) void cast_pad_rows_kernel(const float* __restrict__ s,
+                                                            unsigned short* __restrict__ d, int rows, int cols,
+                                                            int ld) {
+    const long total = (long)rows * ld;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % ld);
+        const long r = i / ld;
+        d[i] = c < cols ? f32_to_bf16(s[r * cols + c]) : (unsigned short)0;
+    }
+}
+extern "C" int uniir_cast_pad_rows(const float* src, void* dst, int32_t rows, int32_t cols, int32_t ld_dst,
+                                   void* stream) {
+    if (!src || !dst || rows < 0 || cols <= 0 || ld_dst < cols) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(cast_pad_rows_kernel, dim3(grid_for((long)rows * ld_dst, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, (unsigned short*)dst, rows, cols, ld_dst);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+__global__ __launch_bounds__(256) void unpad_add_kernel(const float* __restrict__ s, float* __restrict__ d,
+                                                        int rows, int cols, int ld) {
+    const long total = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cols);
+        const long r = i / cols;
+        d[i] += s[r * ld + c];
+    }
+}
+extern "C" int uniir_unpad_add(const float* src, float* dst, int32_t rows, int32_t cols, int32_t ld_src,
+                               void* stream) {
+    if (!src || !dst || rows < 0 || cols <= 0 || ld_src < cols) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(unpad_add_kernel, dim3(grid_for((long)rows * cols, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, rows, cols, ld_src);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fuse: emb = txt * tmask + img * imask   (clip_sf.py:61-63)
+__global__ __launch_bounds__(256) void fuse_kernel(const float* __restrict__ t, const float* __restrict__ im,
+                                                   const long long* __restrict__ tm,
+                                                   const long long* __restrict__ imk, float* __restrict__ e,
+                                                   int n, int dim) {
+    const long total = (long)n * dim;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / dim;
+        // same association as the reference: fuse_embeddings(txt_emb, img_emb) = img_emb' + txt_emb'
+        // with img_emb' := txt*mask (first arg) -> (txt*tm) + (img*im); fp32 add is commutative.
+        e[i] = t[i] * (float)tm[r] + im[i] * (float)imk[r];
+    }
+}
+extern "C" int uniir_fuse_embeddings(const float* txt_emb, const float* img_emb, const int64_t* txt_mask,
+                                     const int64_t* img_mask, float* emb, int32_t n, int32_t dim,
+                                     void* stream) {
+    if (!txt_emb || !img_emb || !txt_mask || !img_mask || !emb || n < 0 || dim <= 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(fuse_kernel, dim3(grid_for((long)n * dim, 256)), dim3(256), 0, (hipStream_t)stream,
+                       txt_emb, img_emb, (const long long*)txt_mask, (const long long*)img_mask, emb, n, dim);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(const float* __restrict__ de,
+                                                       const long long* __restrict__ tm,
+                                                       const long long* __restrict__ imk,
+                                                       float* __restrict__ dt, float* __restrict__ di, int n,
+                                                       int dim) {
+    const long total = (long)n * dim;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / dim;
+        const float g = de[i];
+        dt[i] = g * (float)tm[r];
+        di[i] = g * (float)imk[r];
+    }
+}
+extern "C" int uniir_fuse_embeddings_bwd(const float* demb, const int64_t* txt_mask, const int64_t* img_mask,
+                                         float* dtxt, float* dimg, int32_t n, int32_t dim, void* stream) {
+    if (!demb || !txt_mask || !img_mask || !dtxt || !dimg || n < 0 || dim <= 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(fuse_bwd_kernel, dim3(grid_for((long)n * dim, 256)), dim3(256), 0, (hipStream_t)stream,
+                       demb, (const long long*)txt_mask, (const long long*)img_mask, dtxt, dimg, n, dim);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// select + normalize: out[i] = emb[idx[i]] / max(||emb[idx[i]]||_2, 1e-12)   (F.normalize, clip_sf.py:96-97)
+// one wave per row.
+__global__ __launch_bounds__(256) void select_norm_kernel(const float* __restrict__ emb,
+                                                          const int* __restrict__ idx,
+                                                          float* __restrict__ out, float* __restrict__ inv,
+                                                          int rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* src = emb + (long)(idx ? idx[r] : r) * dim;
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 64) { const float v = src[c]; s += v * v; }
+    s = wave_sum(s);
+    const float nrm = fmaxf(sqrtf(s), 1e-12f);
+    const float iv = 1.0f / nrm;
+    for (int c = lane; c < dim; c += 64) out[(long)r * dim + c] = src[c] / nrm;
+    if (lane == 0 && inv) inv[r] = iv;
+}
+extern "C" int uniir_select_normalize(const float* emb, const int32_t* idx, float* out, float* inv_norm,
+                                      int32_t rows, int32_t dim, void* stream) {
+    if (!emb || !out || rows < 0 || dim <= 0) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(select_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, emb, idx,
+                       out, inv_norm, rows, dim);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+// bwd of y = x/||x||: dx = (dy - y <y,dy>) / ||x||; scattered (+=) to demb[idx[i]] with atomics (an item may
+// be selected more than once, e.g. as hard negative of several queries).
+__global__ __launch_bounds__(256) void select_norm_bwd_kernel(const float* __restrict__ y,
+                                                              const float* __restrict__ inv,
+                                                              const float* __restrict__ dy,
+                                                              const int* __restrict__ idx,
+                                                              float* __restrict__ demb, int rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* yr = y + (long)r * dim;
+    const float* dr = dy + (long)r * dim;
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 64) s += yr[c] * dr[c];
+    s = wave_sum(s);
+    const float iv = inv[r];
+    float* dst = demb + (long)(idx ? idx[r] : r) * dim;
+    for (int c = lane; c < dim; c += 64) unsafeAtomicAdd(dst + c, (dr[c] - yr[c] * s) * iv);
+}
+extern "C" int uniir_select_normalize_bwd(const float* out, const float* inv_norm, const float* dout,
+                                          const int32_t* idx, float* demb, int32_t rows, int32_t dim,
+                                          void* stream) {
+    if (!out || !inv_norm || !dout || !demb || rows < 0 || dim <= 0) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(select_norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, out,
+                       inv_norm, dout, idx, demb, rows, dim);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused AdamW (torch.optim.AdamW single-tensor semantics) + bf16 shadow refresh. 16-24 B/param of traffic.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    unsigned short* __restrict__ pb, long n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2s,
+                                                    float gscale) {
+    const long nv = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        f32x4_t pp = *reinterpret_cast<f32x4_t*>(p + 4 * i);
+        const f32x4_t gg = *reinterpret_cast<const f32x4_t*>(g + 4 * i) * gscale;
+        f32x4_t mm = *reinterpret_cast<f32x4_t*>(m + 4 * i);
+        f32x4_t vv = *reinterpret_cast<f32x4_t*>(v + 4 * i);
+        pp = pp * (1.0f - lr * wd);
+        mm = mm * b1 + gg * (1.0f - b1);
+        vv = vv * b2 + gg * gg * (1.0f - b2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float denom = sqrtf(vv[e]) / bc2s + eps;
+            pp[e] -= (lr / bc1) * (mm[e] / denom);
+        }
+        *reinterpret_cast<f32x4_t*>(p + 4 * i) = pp;
+        *reinterpret_cast<f32x4_t*>(m + 4 * i) = mm;
+        *reinterpret_cast<f32x4_t*>(v + 4 * i) = vv;
+        if (pb) {
+            u32x2_t o = {pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3])};
+            *reinterpret_cast<u32x2_t*>(pb + 4 * i) = o;
+        }
+    }
+    // tail (count % 4)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (nv << 2) + threadIdx.x;
+        float pp = p[i] * (1.0f - lr * wd);
+        const float gg = g[i] * gscale;
+        const float mm = m[i] * b1 + gg * (1.0f - b1);
+        const float vv = v[i] * b2 + gg * gg * (1.0f - b2);
+        pp -= (lr / bc1) * (mm / (sqrtf(vv) / bc2s + eps));
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (pb) pb[i] = f32_to_bf16(pp);
+    }
+}
+extern "C" int uniir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                void* param_bf16, int64_t count, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int32_t step, float grad_scale, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || count < 0 || step < 1) return UNIIR_EINVAL;
+    if (count == 0) return UNIIR_OK;
+    if (((uintptr_t)param & 15) || ((uintptr_t)grad & 15) || ((uintptr_t)exp_avg & 15) ||
+        ((uintptr_t)exp_avg_sq & 15) || ((uintptr_t)param_bf16 & 7))
+        return UNIIR_EALIGN;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(count / 4 + 1, 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (unsigned short*)param_bf16,
+                       (long)count, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}

@@ -1,0 +1,175 @@
+// uniir_gemm: 16-bit MFMA GEMM with fused epilogues (see include/uniir_hip.h, gemm_core.h).
+// Replaces the cuBLAS calls behind nn.Linear / nn.MultiheadAttention.in_proj / Conv2d-as-GEMM of the
+// CLIP towers (openai/CLIP model.py as called from clip_sf.py:43-47) and their autograd backward.
+#include "gemm_core.h"
+#include "../../include/uniir_hip.h"
+
+struct GemmKArgs {
+    const unsigned short* A;
+    const unsigned short* B;
+    void* C;
+    void* C2;
+    const float* bias;
+    const float* resid;
+    const unsigned short* aux;
+    int M, N, K;
+    long lda, ldb, ldc, ldaux;
+    int epilogue, act, k_splits, tiles_m, tiles_n;
+    float alpha;
+};
+
+DEVINL float act_fwd(float x, int act) {
+    if (act == UNIIR_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+    if (act == UNIIR_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    return fmaxf(x, 0.0f);
+}
+DEVINL float act_bwd(float x, int act) {
+    if (act == UNIIR_ACT_QUICKGELU) {
+        const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+        return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+    if (act == UNIIR_ACT_GELU_ERF) {
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    }
+    return x > 0.0f ? 1.0f : 0.0f;
+}
+
+template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int nwg = gridDim.x;
+    int id = xcd_remap(blockIdx.x, nwg);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = id / tiles;
+    id -= split * tiles;
+    const int mt = id / p.tiles_n, nt = id - mt * p.tiles_n;
+    const int m0 = mt * GEMM_BM, n0 = nt * GEMM_BN;
+    // split-K range, aligned to BK
+    int kbeg = 0, kend = p.K;
+    if (p.k_splits > 1) {
+        const int ksteps = (p.K + GEMM_BK - 1) / GEMM_BK;
+        const int per = (ksteps + p.k_splits - 1) / p.k_splits;
+        kbeg = split * per * GEMM_BK;
+        kend = min(p.K, (split + 1) * per * GEMM_BK);
+        if (kbeg >= kend) return;
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    gemm_mainloop<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    const int epi = p.epilogue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
+            if (n >= p.N) continue;
+            f32x4_t v = acc[i][j] * p.alpha;
+            if (p.bias) {
+                const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+                v += b;
+            }
+            const long off = (long)m * p.ldc + n;
+            if (epi == UNIIR_EPI_BF16) {
+                u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+            } else if (epi == UNIIR_EPI_BIAS_ACT) {
+                u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+                float g[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = act_fwd(bf16_to_f32(f32_to_bf16(v[r])), p.act);
+                u32x2_t o2 = {pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
+                *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o2;
+            } else if (epi == UNIIR_EPI_RESID_F32) {
+                if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
+                *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
+                if (p.C2) {
+                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o;
+                }
+            } else if (epi == UNIIR_EPI_DACT) {
+                const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + (long)m * p.ldaux + n);
+                const float f0 = __uint_as_float(a[0] << 16), f1 = __uint_as_float(a[0] & 0xffff0000u);
+                const float f2 = __uint_as_float(a[1] << 16), f3 = __uint_as_float(a[1] & 0xffff0000u);
+                u32x2_t o = {pack_bf16x2(v[0] * act_bwd(f0, p.act), v[1] * act_bwd(f1, p.act)),
+                             pack_bf16x2(v[2] * act_bwd(f2, p.act), v[3] * act_bwd(f3, p.act))};
+                *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+            } else if (epi == UNIIR_EPI_F32) {
+                *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
+            } else {  // UNIIR_EPI_ATOMIC_F32
+                float* c = (float*)p.C + off;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, v[r]);
+            }
+        }
+    }
+}
+
+template <typename Elem>
+static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t st) {
+    const int grid = a.tiles_m * a.tiles_n * a.k_splits;
+    dim3 g(grid), b(256);
+    const size_t sm = GEMM_LDS_BYTES;
+#define LAUNCH(AT, BT)                                                                            \
+    do {                                                                                          \
+        static bool attr_set = false;                                                             \
+        if (!attr_set) {                                                                          \
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<Elem, AT, BT>,                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);             \
+            attr_set = true;                                                                      \
+        }                                                                                         \
+        hipLaunchKernelGGL((gemm_kernel<Elem, AT, BT>), g, b, sm, st, a);                         \
+    } while (0)
+    if (!a_tmaj && !b_tmaj) LAUNCH(false, false);
+    else if (!a_tmaj && b_tmaj) LAUNCH(false, true);
+    else if (a_tmaj && !b_tmaj) LAUNCH(true, false);
+    else LAUNCH(true, true);
+#undef LAUNCH
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
+    if (!d || !d->A || !d->B || !d->C) return UNIIR_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->k_splits < 1) return UNIIR_EINVAL;
+    if (d->epilogue < 0 || d->epilogue > UNIIR_EPI_ATOMIC_F32) return UNIIR_EINVAL;
+    if (d->k_splits > 1 && d->epilogue != UNIIR_EPI_ATOMIC_F32) return UNIIR_EINVAL;
+    if (d->epilogue == UNIIR_EPI_BIAS_ACT && !d->C2) return UNIIR_EINVAL;
+    if (d->epilogue == UNIIR_EPI_DACT && !d->aux) return UNIIR_EINVAL;
+    if (d->N % 8) return UNIIR_ESHAPE;
+    if (!d->a_tmaj && (d->K % 8)) return UNIIR_ESHAPE;
+    if (!d->b_tmaj && (d->K % 8)) return UNIIR_ESHAPE;
+    if (d->a_tmaj && (d->M % 8)) return UNIIR_ESHAPE;
+    if ((d->lda % 8) || (d->ldb % 8) || (d->ldc % 4)) return UNIIR_EALIGN;
+    if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15) || ((uintptr_t)d->C & 15)) return UNIIR_EALIGN;
+    if (d->aux && ((d->ldaux % 4) || ((uintptr_t)d->aux & 7))) return UNIIR_EALIGN;
+    if (d->bias && ((uintptr_t)d->bias & 15)) return UNIIR_EALIGN;
+    GemmKArgs a;
+    a.A = (const unsigned short*)d->A;
+    a.B = (const unsigned short*)d->B;
+    a.C = d->C;
+    a.C2 = d->C2;
+    a.bias = d->bias;
+    a.resid = d->resid;
+    a.aux = (const unsigned short*)d->aux;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldaux = d->ldaux;
+    a.epilogue = d->epilogue; a.act = d->act; a.k_splits = d->k_splits;
+    a.tiles_m = (d->M + GEMM_BM - 1) / GEMM_BM;
+    a.tiles_n = (d->N + GEMM_BN - 1) / GEMM_BN;
+    a.alpha = d->alpha;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == UNIIR_DT_BF16) return launch_gemm<ElemBF16>(a, d->a_tmaj, d->b_tmaj, st);
+    if (d->dtype == UNIIR_DT_F16) return launch_gemm<ElemF16>(a, d->a_tmaj, d->b_tmaj, st);
+    return UNIIR_EINVAL;
+}

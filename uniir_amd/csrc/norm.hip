@@ -1,0 +1,193 @@
+// LayerNorm forward / backward for the CLIP towers (openai/CLIP model.py LayerNorm subclass: computes in
+// fp32, eps 1e-5; used as ln_pre/ln_1/ln_2/ln_post/ln_final, reached from clip_sf.py:43-47).
+// HBM-bound: one wave per row, float4 loads, the whole row lives in registers (width <= 2048).
+#include "common.h"
+#include "../../include/uniir_hip.h"
+
+#define LN_MAXC 8  // float4 chunks per lane -> width <= 64*4*8 = 2048
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long x_stride,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     unsigned short* __restrict__ y_bf16,
+                                                     float* __restrict__ y_f32, int rows, int width,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nchunk = width >> 2;
+    const float inv_w = 1.0f / (float)width;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        const float* xr = x + row * x_stride;
+        f32x4_t v[LN_MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                v[i] = *reinterpret_cast<const f32x4_t*>(xr + 4 * c);
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
+        }
+        const float mean = wave_sum(s) * inv_w;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                const f32x4_t d = v[i] - mean;
+                q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_w + eps);
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                const f32x4_t g = *reinterpret_cast<const f32x4_t*>(gamma + 4 * c);
+                const f32x4_t b = *reinterpret_cast<const f32x4_t*>(beta + 4 * c);
+                const f32x4_t o = (v[i] - mean) * rstd * g + b;
+                if (y_bf16) {
+                    u32x2_t pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    *reinterpret_cast<u32x2_t*>(y_bf16 + row * width + 4 * c) = pk;
+                }
+                if (y_f32) *reinterpret_cast<f32x4_t*>(y_f32 + row * width + 4 * c) = o;
+            }
+        }
+    }
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy * gamma;  dgamma += dy*xhat; dbeta += dy
+template <bool DY_F32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, long x_stride,
+                                                     const float* __restrict__ gamma,
+                                                     const void* __restrict__ dy_,
+                                                     const float* __restrict__ dres,
+                                                     float* __restrict__ dx, long dx_stride,
+                                                     unsigned short* __restrict__ dx_bf16,
+                                                     float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows, int width,
+                                                     float eps) {
+    __shared__ float red[4][64 * 4 * LN_MAXC];  // per wave staging for the column reduction (8 KB/wave)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nchunk = width >> 2;
+    const float inv_w = 1.0f / (float)width;
+    f32x4_t ag[LN_MAXC], ab[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        ag[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        ab[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long row = (long)blockIdx.x * 4 + w; row < rows; row += (long)gridDim.x * 4) {
+        const float* xr = x + row * x_stride;
+        f32x4_t v[LN_MAXC], d[LN_MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                v[i] = *reinterpret_cast<const f32x4_t*>(xr + 4 * c);
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                if (DY_F32) {
+                    d[i] = *reinterpret_cast<const f32x4_t*>((const float*)dy_ + row * width + 4 * c);
+                } else {
+                    const u32x2_t pk =
+                        *reinterpret_cast<const u32x2_t*>((const unsigned short*)dy_ + row * width + 4 * c);
+                    d[i] = f32x4_t{__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                                   __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+                }
+            }
+        }
+        const float mean = wave_sum(s) * inv_w;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                v[i] = v[i] - mean;
+                q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_w + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                v[i] = v[i] * rstd;  // xhat
+                const f32x4_t g = d[i] * *reinterpret_cast<const f32x4_t*>(gamma + 4 * c);
+                ag[i] += d[i] * v[i];
+                ab[i] += d[i];
+                d[i] = g;
+                s1 += (g[0] + g[1]) + (g[2] + g[3]);
+                s2 += (g[0] * v[i][0] + g[1] * v[i][1]) + (g[2] * v[i][2] + g[3] * v[i][3]);
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_w, c2 = wave_sum(s2) * inv_w;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                f32x4_t o = (d[i] - c1 - v[i] * c2) * rstd;
+                if (dres) o += *reinterpret_cast<const f32x4_t*>(dres + row * dx_stride + 4 * c);
+                *reinterpret_cast<f32x4_t*>(dx + row * dx_stride + 4 * c) = o;
+                if (dx_bf16) {
+                    u32x2_t pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    *reinterpret_cast<u32x2_t*>(dx_bf16 + row * width + 4 * c) = pk;
+                }
+            }
+        }
+    }
+    // block reduction of the per-wave column partials, then one atomic per column per block
+    float* mine = &red[w][0];
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) *reinterpret_cast<f32x4_t*>(mine + 4 * c) = pass ? ab[i] : ag[i];
+        }
+        __syncthreads();
+        float* dst = pass ? dbeta : dgamma;
+        for (int col = threadIdx.x; col < width; col += 256) {
+            const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+            unsafeAtomicAdd(dst + col, t);
+        }
+        __syncthreads();
+    }
+}
+
+static inline int ln_grid(int rows) {
+    int g = (rows + 3) / 4;
+    return g > 2048 ? 2048 : (g < 1 ? 1 : g);
+}
+
+extern "C" int uniir_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta,
+                                   void* y_bf16, float* y_f32, int32_t rows, int32_t width, float eps,
+                                   void* stream) {
+    if (!x || !gamma || !beta || (!y_bf16 && !y_f32) || rows < 0) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    if (width % 4 || width > 64 * 4 * LN_MAXC || width <= 0 || x_stride % 4) return UNIIR_ESHAPE;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, (long)x_stride,
+                       gamma, beta, (unsigned short*)y_bf16, y_f32, rows, width, eps);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+extern "C" int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float* gamma, const void* dy,
+                                   int32_t dy_is_f32, const float* dres, float* dx_f32, int64_t dx_stride,
+                                   void* dx_bf16, float* dgamma, float* dbeta, int32_t rows, int32_t width,
+                                   float eps, void* stream) {
+    if (!x || !gamma || !dy || !dx_f32 || !dgamma || !dbeta || rows < 0) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    if (width % 4 || width > 64 * 4 * LN_MAXC || width <= 0 || x_stride % 4 || dx_stride % 4) return UNIIR_ESHAPE;
+    int g = ln_grid(rows);
+    if (g > 1024) g = 1024;
+    if (dy_is_f32)
+        hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (long)x_stride,
+                           gamma, dy, dres, dx_f32, (long)dx_stride, (unsigned short*)dx_bf16, dgamma, dbeta,
+                           rows, width, eps);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (long)x_stride,
+                           gamma, dy, dres, dx_f32, (long)dx_stride, (unsigned short*)dx_bf16, dgamma, dbeta,
+                           rows, width, eps);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}

@@ -1,0 +1,390 @@
+// Exact brute-force inner-product top-k over an fp16 candidate pool: the MI355X replacement of
+// faiss.normalize_L2 + index_factory("IDMap,Flat", METRIC_INNER_PRODUCT) + index.search
+// (UniIR src/common/mbeir_retriever.py:76,85-103,188-232).
+//
+//   coarse : fp16 MFMA scan (gemm_core.h main loop, fp32 accumulate) of a [128 queries] x [pool slice] panel
+//            with a threshold-select epilogue: a score enters the per-query candidate buffer only when it
+//            beats the current kc-th best, so after the first tiles almost nothing is appended.
+//   rescore: the shortlist is re-scored in fp32 in the oracle's exact summation order (sequential, no fma;
+//            oracle/topk_oracle.c) and sorted by (score desc, id asc) -> bit-exact distances, identical ids.
+#include "gemm_core.h"
+#include "../../include/uniir_hip.h"
+
+#define TK_QT 128        // queries per block tile (GEMM M)
+#define TK_CAP 256       // candidate buffer entries per (block, query)
+#define TK_MAXKC 64
+
+struct TkEntry { float score; int idx; };
+
+// inv_norm[i] = 1/sqrt(sum_j x_j^2), sequential fp32 without fma (matches oracle); 0 for zero rows
+__global__ __launch_bounds__(256) void inv_norm_kernel(const unsigned short* __restrict__ x, long n, int dim,
+                                                       float* __restrict__ inv) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned short* r = x + i * dim;
+    float s = 0.f;
+    for (int c = 0; c < dim; c += 8) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(r + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = f16_to_f32((unsigned short)(v[e] & 0xffffu));
+            const float hi = f16_to_f32((unsigned short)(v[e] >> 16));
+            s = __fadd_rn(s, __fmul_rn(lo, lo));
+            s = __fadd_rn(s, __fmul_rn(hi, hi));
+        }
+    }
+    inv[i] = s > 0.f ? __fdiv_rn(1.0f, __fsqrt_rn(s)) : 0.f;
+}
+
+extern "C" int uniir_pool_inv_norms(const void* x_f16, int64_t n, int32_t dim, float* inv_norm, void* stream) {
+    if (!x_f16 || !inv_norm || n < 0 || dim <= 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    if (dim % 8) return UNIIR_ESHAPE;
+    if ((uintptr_t)x_f16 & 15) return UNIIR_EALIGN;
+    hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x_f16, (long)n, dim, inv_norm);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+DEVINL bool better(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
+
+// One wave selects the best `kc` of buf[0..cnt) (cnt <= TK_CAP) by (score desc, idx asc).  Lane j ends up
+// holding the j-th best in (*my_s, *my_i); returns the new count and the kc-th score through tau_out
+// (-inf when fewer than kc entries exist).  Does not write memory.
+DEVINL int wave_select(const TkEntry* buf, int cnt, int kc, int lane, float* tau_out, float* my_s, int* my_i) {
+    float s[TK_CAP / 64];
+    int ix[TK_CAP / 64];
+#pragma unroll
+    for (int e = 0; e < TK_CAP / 64; ++e) {
+        const int p = lane + 64 * e;
+        if (p < cnt) { s[e] = buf[p].score; ix[e] = buf[p].idx; } else { s[e] = -INFINITY; ix[e] = 0x7fffffff; }
+    }
+    const int keep = cnt < kc ? cnt : kc;
+    float last = -INFINITY, ms = -INFINITY;
+    int mi = -1;
+    for (int j = 0; j < keep; ++j) {
+        float bs = s[0]; int bi = ix[0]; int be = 0;
+#pragma unroll
+        for (int e = 1; e < TK_CAP / 64; ++e)
+            if (better(s[e], ix[e], bs, bi)) { bs = s[e]; bi = ix[e]; be = e; }
+        float ws = bs; int wi = bi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(ws, o, 64);
+            const int oi = __shfl_xor(wi, o, 64);
+            if (better(os, oi, ws, wi)) { ws = os; wi = oi; }
+        }
+        if (wi == bi && bi != 0x7fffffff) {  // this lane owns the winner (idx is unique within a buffer)
+#pragma unroll
+            for (int e = 0; e < TK_CAP / 64; ++e)
+                if (e == be) { s[e] = -INFINITY; ix[e] = 0x7fffffff; }
+        }
+        if (lane == j) { ms = ws; mi = wi; }
+        last = ws;
+    }
+    *tau_out = (keep == kc) ? last : -INFINITY;
+    *my_s = ms;
+    *my_i = mi;
+    return keep;
+}
+
+// grid = (nslices, nqtiles). Block scans pool rows [slice*rows_per_slice, ...) for queries [qt*128, +128).
+__global__ __launch_bounds__(256, 2) void topk_coarse_kernel(const unsigned short* __restrict__ pool,
+                                                             const float* __restrict__ pinv, long rows, int dim,
+                                                             const unsigned short* __restrict__ queries, int nq,
+                                                             int kc, long rows_per_slice,
+                                                             TkEntry* __restrict__ bufs,      // [blocks][128][CAP]
+                                                             TkEntry* __restrict__ partial) { // [nslices][nq][kc]
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* tau = reinterpret_cast<float*>(lds + GEMM_LDS_BYTES);          // [128]
+    int* cnt = reinterpret_cast<int*>(lds + GEMM_LDS_BYTES + 512);        // [128]
+    int* flag = reinterpret_cast<int*>(lds + GEMM_LDS_BYTES + 1024);      // [1]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int slice = blockIdx.x, qt = blockIdx.y;
+    const int q0 = qt * TK_QT;
+    const long r_begin = (long)slice * rows_per_slice;
+    const long r_end = min(rows, r_begin + rows_per_slice);
+    TkEntry* mybuf = bufs + ((long)blockIdx.y * gridDim.x + blockIdx.x) * TK_QT * TK_CAP;
+    if (tid < TK_QT) { tau[tid] = -INFINITY; cnt[tid] = 0; }
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    for (long n0 = r_begin; n0 < r_end; n0 += GEMM_BN) {
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // B operand = pool rows [n0, n0+128) limited to r_end (rows beyond read as zero)
+        gemm_mainloop<ElemF16, false, false>(queries, dim, nq, pool + n0 * dim, dim, (int)min((long)GEMM_BN, r_end - n0),
+                                             q0, 0, 0, dim, lds, acc);
+        // threshold-select epilogue
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = wm + i * 16 + (lane & 15);
+            const float t = tau[ml];
+            const bool qok = (q0 + ml) < nq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nl = wn + j * 16 + 4 * (lane >> 4);
+                const long n = n0 + nl;
+                f32x4_t iv = {0.f, 0.f, 0.f, 0.f};
+                if (n + 3 < r_end) iv = *reinterpret_cast<const f32x4_t*>(pinv + n);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) iv[r] = (n + r < r_end) ? pinv[n + r] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = acc[i][j][r] * iv[r];
+                    if (qok && (n + r < r_end) && sc > t) {
+                        const int pos = atomicAdd(&cnt[ml], 1);
+                        if (pos < TK_CAP) { mybuf[ml * TK_CAP + pos].score = sc; mybuf[ml * TK_CAP + pos].idx = (int)(n + r); }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < TK_QT && cnt[tid] >= TK_CAP - GEMM_BN) flag[0] = 1;
+        __syncthreads();
+        if (flag[0]) {
+            __threadfence_block();
+            for (int ql = w; ql < TK_QT; ql += 4) {
+                int c = cnt[ql];
+                if (c > TK_CAP) c = TK_CAP;
+                if (c > kc) {
+                    float t, ms;
+                    int mi;
+                    const int keep = wave_select(mybuf + ql * TK_CAP, c, kc, lane, &t, &ms, &mi);
+                    if (lane < keep) { mybuf[ql * TK_CAP + lane].score = ms; mybuf[ql * TK_CAP + lane].idx = mi; }
+                    if (lane == 0) { cnt[ql] = keep; tau[ql] = t; }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) flag[0] = 0;
+            __syncthreads();
+        }
+    }
+    // final selection -> partial[slice][q][kc]
+    __syncthreads();
+    for (int ql = w; ql < TK_QT; ql += 4) {
+        const int q = q0 + ql;
+        if (q >= nq) continue;
+        int c = cnt[ql];
+        if (c > TK_CAP) c = TK_CAP;
+        float t, ms;
+        int mi;
+        const int keep = wave_select(mybuf + ql * TK_CAP, c, kc, lane, &t, &ms, &mi);
+        TkEntry* dst = partial + ((long)slice * nq + q) * kc;
+        if (lane < kc) {
+            TkEntry e;
+            if (lane < keep) { e.score = ms; e.idx = mi; } else { e.score = -INFINITY; e.idx = -1; }
+            dst[lane] = e;
+        }
+    }
+}
+
+// merge the per-slice partial lists: one block per query, iterative selection of kc best.
+__global__ __launch_bounds__(256) void topk_merge_partial_kernel(const TkEntry* __restrict__ partial, int nslices,
+                                                                 int nq, int kc, int* __restrict__ cand_idx,
+                                                                 float* __restrict__ cand_score) {
+    __shared__ float ss[4];
+    __shared__ int si[4];
+    __shared__ float wsel;
+    __shared__ int isel;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int total = nslices * kc;
+    float last_s = INFINITY;
+    int last_i = -1;
+    for (int j = 0; j < kc; ++j) {
+        // best entry strictly after (last_s, last_i) in (score desc, idx asc) order
+        float bs = -INFINITY; int bi = 0x7fffffff;
+        for (int e = tid; e < total; e += 256) {
+            const int sl = e / kc, p = e - sl * kc;
+            const TkEntry en = partial[((long)sl * nq + q) * kc + p];
+            if (en.idx < 0) continue;
+            const bool after = (en.score < last_s) || (en.score == last_s && en.idx > last_i);
+            if (after && better(en.score, en.idx, bs, bi)) { bs = en.score; bi = en.idx; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(os, oi, bs, bi)) { bs = os; bi = oi; }
+        }
+        if (lane == 0) { ss[w] = bs; si[w] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float fs = ss[0]; int fi = si[0];
+            for (int k = 1; k < 4; ++k) if (better(ss[k], si[k], fs, fi)) { fs = ss[k]; fi = si[k]; }
+            wsel = fs; isel = fi;
+            cand_idx[(long)q * kc + j] = (fi == 0x7fffffff) ? -1 : fi;
+            if (cand_score) cand_score[(long)q * kc + j] = fs;
+        }
+        __syncthreads();
+        last_s = wsel; last_i = isel;
+        if (last_i == 0x7fffffff) { last_s = -INFINITY; }
+        __syncthreads();
+    }
+}
+
+static void coarse_plan(int nq, long rows, int* nqt, int* nslices, long* rows_per_slice) {
+    *nqt = (nq + TK_QT - 1) / TK_QT;
+    long tiles = (rows + GEMM_BN - 1) / GEMM_BN;
+    long want = (1024 + *nqt - 1) / *nqt;       // aim at ~1024 workgroups in flight
+    if (want < 1) want = 1;
+    if (want > tiles) want = tiles;
+    long tps = (tiles + want - 1) / want;       // candidate tiles per slice
+    if (tps < 1) tps = 1;
+    *rows_per_slice = tps * GEMM_BN;
+    *nslices = (int)((rows + *rows_per_slice - 1) / *rows_per_slice);
+}
+
+extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t rows) {
+    if (nq <= 0 || kc <= 0 || rows <= 0) return 0;
+    int nqt, nsl; long rps;
+    coarse_plan(nq, rows, &nqt, &nsl, &rps);
+    return (int64_t)nqt * nsl * TK_QT * TK_CAP * (int64_t)sizeof(TkEntry) + (int64_t)nsl * nq * kc * (int64_t)sizeof(TkEntry) + 256;
+}
+
+extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_norm, int64_t rows, int32_t dim,
+                                 const void* queries_f16, int32_t nq, int32_t kc, int32_t* cand_idx,
+                                 float* cand_score, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!pool_f16 || !pool_inv_norm || !queries_f16 || !cand_idx || !workspace) return UNIIR_EINVAL;
+    if (rows <= 0 || nq <= 0 || kc <= 0) return UNIIR_EINVAL;
+    if (kc > TK_MAXKC || dim % 64 || dim <= 0 || rows > 0x7fffffffL) return UNIIR_ESHAPE;
+    if (((uintptr_t)pool_f16 & 15) || ((uintptr_t)queries_f16 & 15) || ((uintptr_t)pool_inv_norm & 15) ||
+        ((uintptr_t)workspace & 15))
+        return UNIIR_EALIGN;
+    if (workspace_bytes < uniir_topk_workspace_bytes(nq, kc, rows)) return UNIIR_EINVAL;
+    int nqt, nsl; long rps;
+    coarse_plan(nq, rows, &nqt, &nsl, &rps);
+    TkEntry* bufs = (TkEntry*)workspace;
+    TkEntry* partial = bufs + (long)nqt * nsl * TK_QT * TK_CAP;
+    const size_t sm = GEMM_LDS_BYTES + 1024 + 64;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)topk_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        attr = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(topk_coarse_kernel, dim3(nsl, nqt), dim3(256), sm, st, (const unsigned short*)pool_f16,
+                       pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, kc, rps, bufs, partial);
+    hipLaunchKernelGGL(topk_merge_partial_kernel, dim3(nq), dim3(256), 0, st, partial, nsl, nq, kc, cand_idx,
+                       cand_score);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// exact re-score: one thread per (query, candidate); then one thread per query sorts its shortlist.
+__global__ __launch_bounds__(256) void rescore_kernel(const unsigned short* __restrict__ pool,
+                                                      const float* __restrict__ pinv,
+                                                      const unsigned short* __restrict__ queries,
+                                                      const float* __restrict__ qinv, int nq, int dim,
+                                                      const int* __restrict__ cand_idx, int ncand,
+                                                      float* __restrict__ exact) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)nq * ncand) return;
+    const int q = (int)(t / ncand);
+    const int ci = cand_idx[t];
+    if (ci < 0) { exact[t] = -INFINITY; return; }
+    const unsigned short* qr = queries + (long)q * dim;
+    const unsigned short* cr = pool + (long)ci * dim;
+    const float iq = qinv[q], ic = pinv[ci];
+    float s = 0.f;
+    for (int c = 0; c < dim; c += 8) {
+        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(qr + c);
+        const u32x4_t b = *reinterpret_cast<const u32x4_t*>(cr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float qa = f16_to_f32((unsigned short)(a[e] & 0xffffu)), ca = f16_to_f32((unsigned short)(b[e] & 0xffffu));
+            float qb = f16_to_f32((unsigned short)(a[e] >> 16)), cb = f16_to_f32((unsigned short)(b[e] >> 16));
+            // FAISS renorm: x[i] *= inv_nr (skipped for all-zero rows, where inv == 0 and x == 0 anyway)
+            if (iq != 0.f) { qa = __fmul_rn(qa, iq); qb = __fmul_rn(qb, iq); }
+            if (ic != 0.f) { ca = __fmul_rn(ca, ic); cb = __fmul_rn(cb, ic); }
+            s = __fadd_rn(s, __fmul_rn(qa, ca));
+            s = __fadd_rn(s, __fmul_rn(qb, cb));
+        }
+    }
+    exact[t] = s;
+}
+__global__ __launch_bounds__(256) void final_sort_kernel(const float* __restrict__ exact,
+                                                         const int* __restrict__ cand_idx,
+                                                         const long long* __restrict__ ids, int nq, int ncand,
+                                                         int k, float* __restrict__ out_s,
+                                                         long long* __restrict__ out_i) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float* es = exact + (long)q * ncand;
+    const int* ci = cand_idx + (long)q * ncand;
+    float last_s = INFINITY;
+    long long last_id = -1;
+    for (int j = 0; j < k; ++j) {
+        float bs = -INFINITY; long long bid = 0x7fffffffffffffffLL; bool found = false;
+        for (int c = 0; c < ncand; ++c) {
+            if (ci[c] < 0) continue;
+            const float s = es[c];
+            const long long id = ids ? ids[ci[c]] : (long long)ci[c];
+            const bool after = (s < last_s) || (s == last_s && id > last_id);
+            if (!after) continue;
+            if (!found || s > bs || (s == bs && id < bid)) { bs = s; bid = id; found = true; }
+        }
+        if (found) { out_s[(long)q * k + j] = bs; out_i[(long)q * k + j] = bid; last_s = bs; last_id = bid; }
+        else {  // FAISS pads missing results with -inf distance / id -1 for inner product
+            out_s[(long)q * k + j] = -INFINITY; out_i[(long)q * k + j] = -1; last_s = -INFINITY; last_id = 0x7fffffffffffffffLL;
+        }
+    }
+}
+
+extern "C" int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids,
+                                  int64_t rows, int32_t dim, const void* queries_f16, const float* query_inv_norm,
+                                  int32_t nq, const int32_t* cand_idx, int32_t ncand, int32_t k, float* exact_ws,
+                                  float* out_scores, int64_t* out_ids, void* stream) {
+    if (!pool_f16 || !pool_inv_norm || !queries_f16 || !query_inv_norm || !cand_idx || !exact_ws || !out_scores ||
+        !out_ids)
+        return UNIIR_EINVAL;
+    if (rows <= 0 || nq <= 0 || ncand <= 0 || k <= 0) return UNIIR_EINVAL;
+    if (dim % 8) return UNIIR_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const long pairs = (long)nq * ncand;
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned short*)pool_f16, pool_inv_norm, (const unsigned short*)queries_f16,
+                       query_inv_norm, nq, dim, cand_idx, ncand, exact_ws);
+    hipLaunchKernelGGL(final_sort_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, exact_ws, cand_idx,
+                       (const long long*)pool_ids, nq, ncand, k, out_scores, (long long*)out_ids);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// k-way merge of per-shard final results (score desc, id asc); ids are unique across shards.
+__global__ __launch_bounds__(256) void merge_shards_kernel(const float* __restrict__ s, const long long* __restrict__ ids,
+                                                           int nshard, int nq, int k, float* __restrict__ os,
+                                                           long long* __restrict__ oi) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    float last_s = INFINITY; long long last_id = -1;
+    for (int j = 0; j < k; ++j) {
+        float bs = -INFINITY; long long bid = 0x7fffffffffffffffLL; bool found = false;
+        for (int sh = 0; sh < nshard; ++sh)
+            for (int c = 0; c < k; ++c) {
+                const long o = ((long)sh * nq + q) * k + c;
+                const long long id = ids[o];
+                if (id < 0) continue;
+                const float v = s[o];
+                const bool after = (v < last_s) || (v == last_s && id > last_id);
+                if (!after) continue;
+                if (!found || v > bs || (v == bs && id < bid)) { bs = v; bid = id; found = true; }
+            }
+        if (found) { os[(long)q * k + j] = bs; oi[(long)q * k + j] = bid; last_s = bs; last_id = bid; }
+        else { os[(long)q * k + j] = -INFINITY; oi[(long)q * k + j] = -1; last_s = -INFINITY; last_id = 0x7fffffffffffffffLL; }
+    }
+}
+extern "C" int uniir_topk_merge(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k,
+                                float* out_scores, int64_t* out_ids, void* stream) {
+    if (!scores || !ids || !out_scores || !out_ids || nshard <= 0 || nq <= 0 || k <= 0) return UNIIR_EINVAL;
+    hipLaunchKernelGGL(merge_shards_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores,
+                       (const long long*)ids, nshard, nq, k, out_scores, (long long*)out_ids);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}

@@ -1,0 +1,124 @@
+"""Tensor-level wrappers over the C ABI (include/uniir_hip.h).  PyTorch is only the device-memory / stream
+plumbing here: every function passes raw device pointers + the current HIP stream to libuniir_hip.so.
+There is no torch fallback: a CPU tensor raises."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+EPI_BF16, EPI_BIAS_ACT, EPI_RESID_F32, EPI_DACT, EPI_F32, EPI_ATOMIC_F32 = range(6)
+ACT_QUICKGELU, ACT_GELU_ERF, ACT_RELU = range(3)
+DT_BF16, DT_F16 = 0, 1
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("uniir_amd ops need device tensors (no CPU fallback on the product path)")
+    return C.c_void_p(t.data_ptr())
+
+
+def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epilogue=EPI_BF16, bias=None,
+         resid=None, aux=None, ldaux=0, C2=None, act=ACT_QUICKGELU, k_splits=1, alpha=1.0, dtype=DT_BF16):
+    d = GemmDesc()
+    d.A, d.B, d.C, d.C2 = A.data_ptr(), B.data_ptr(), C_out.data_ptr(), (C2.data_ptr() if C2 is not None else None)
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.aux = aux.data_ptr() if aux is not None else None
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldaux = lda, ldb, ldc, ldaux
+    d.a_tmaj, d.b_tmaj = int(a_tmaj), int(b_tmaj)
+    d.epilogue, d.act, d.dtype, d.k_splits, d.alpha = epilogue, act, dtype, k_splits, alpha
+    check(_lib.load().uniir_gemm(C.byref(d), _stream()), "gemm")
+    return C_out
+
+
+def linear_fwd(x, w, bias=None, *, out=None, epilogue=EPI_BF16, resid=None, C2=None, act=ACT_QUICKGELU):
+    """y[M,N] = x[M,K] @ w[N,K]^T (+bias ...).  x, w bf16 contiguous."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device,
+                          dtype=torch.float32 if epilogue in (EPI_RESID_F32, EPI_F32) else torch.bfloat16)
+    return gemm(x, w, out, M, N, K, K, K, N, epilogue=epilogue, bias=bias, resid=resid, C2=C2, act=act)
+
+
+def linear_dgrad(dy, w, *, out=None, aux=None, act=ACT_QUICKGELU):
+    """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * act'(aux))."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty(M, K, device=dy.device, dtype=torch.bfloat16)
+    return gemm(dy, w, out, M, K, N, N, K, K, b_tmaj=True, epilogue=EPI_DACT if aux is not None else EPI_BF16,
+                aux=aux, ldaux=K, act=act)
+
+
+def wgrad_splits(rows, tiles):
+    """split-K factor for dW: aim at >= 1024 workgroups, each with >= 8 K steps of 64."""
+    s = max(1, min((1024 + tiles - 1) // tiles, max(1, rows // 512)))
+    return s
+
+
+def linear_wgrad(dy, x, dw):
+    """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]."""
+    M, N = dy.shape
+    K = x.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    return gemm(dy, x, dw, N, K, M, N, K, K, a_tmaj=True, b_tmaj=True, epilogue=EPI_ATOMIC_F32,
+                k_splits=wgrad_splits(M, tiles))
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, *, out_bf16=None, out_f32=None, rows=None, width=None, x_stride=None):
+    width = width or x.shape[-1]
+    rows = rows if rows is not None else x.numel() // width
+    x_stride = x_stride or width
+    if out_bf16 is None and out_f32 is None:
+        out_bf16 = torch.empty(rows, width, device=x.device, dtype=torch.bfloat16)
+    check(_lib.load().uniir_layernorm_fwd(_p(x), x_stride, _p(gamma), _p(beta), _p(out_bf16), _p(out_f32), rows,
+                                          width, eps, _stream()), "layernorm_fwd")
+    return out_bf16 if out_bf16 is not None else out_f32
+
+
+def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5, *, dres=None, dx=None, dx_bf16=None, rows=None,
+                  width=None, x_stride=None, dx_stride=None):
+    width = width or x.shape[-1]
+    rows = rows if rows is not None else x.numel() // width
+    x_stride = x_stride or width
+    dx_stride = dx_stride or width
+    if dx is None:
+        dx = torch.empty(rows, width, device=x.device, dtype=torch.float32)
+    check(_lib.load().uniir_layernorm_bwd(_p(x), x_stride, _p(gamma), _p(dy), int(dy.dtype == torch.float32),
+                                          _p(dres), _p(dx), dx_stride, _p(dx_bf16), _p(dgamma), _p(dbeta), rows,
+                                          width, eps, _stream()), "layernorm_bwd")
+    return dx
+
+
+def attention_fwd(qkv, batch, seq, heads, causal, *, out=None, lse=None):
+    if out is None:
+        out = torch.empty(batch * seq, heads * 64, device=qkv.device, dtype=torch.bfloat16)
+    if lse is None:
+        lse = torch.empty(batch, heads, seq, device=qkv.device, dtype=torch.float32)
+    check(_lib.load().uniir_attention_fwd(_p(qkv), _p(out), _p(lse), batch, seq, heads, int(causal), _stream()),
+          "attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, batch, seq, heads, causal, *, dqkv=None):
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    check(_lib.load().uniir_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), batch, seq, heads,
+                                          int(causal), _stream()), "attention_bwd")
+    return dqkv
+
+
+def call(name, *args):
+    """Generic checked call: tensors are converted to device pointers, the stream is appended."""
+    conv = [(_p(a) if isinstance(a, torch.Tensor) else a) for a in args]
+    check(getattr(_lib.load(), name)(*conv, _stream()), name)
