@@ -1,0 +1,277 @@
+"""CPU ORACLE (test infrastructure, NOT the product path) -- plain PyTorch fp32 restatement of the hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; it is the checker,
+never the thing measured or shipped.
+
+What is restated, and from where (paths relative to the UniIR reference tree):
+  * CLIP towers: openai/CLIP `clip/model.py` (git HEAD, un-vendored and unpinned in the reference:
+    src/models/uniir_env.yml:23).  Call sites: src/models/uniir_clip/clip_scorefusion/clip_sf.py:25-26,44,47,66.
+    The published algorithm is restated below (VisionTransformer.forward, CLIP.encode_text,
+    ResidualAttentionBlock, QuickGELU, LayerNorm-in-fp32, build_attention_mask).  PARITY PINNING: the reference
+    holds no test of the encoders; this restatement is pinned against an independent implementation of the same
+    architecture (transformers.CLIPModel, tests/golden/make_golden.py -> tests/golden/g5_*.npz).
+  * encode_multimodal_input / fuse:    clip_sf.py:53-63
+  * in-batch contrastive loss:         clip_sf.py:68-147 (incl. the hard-negative branch :105-131)
+    pinned against the reference class itself, imported with a stub `clip` module (tests/golden g1/g2/g3/g4).
+  * optimizer groups + AdamW + cosine: clip_scorefusion/train.py:52-61,195-199,281-284; uniir_clip/engine.py:19-50
+    pinned by g10 (the reference's own train_one_epoch run on CPU).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+CLIP_CONFIGS = {
+    # geometry of the published checkpoints
+    "ViT-B/32": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
+                     context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
+                     transformer_layers=12),
+    "ViT-B/16": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=16,
+                     context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
+                     transformer_layers=12),
+    "ViT-L/14": dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024, vision_patch_size=14,
+                     context_length=77, vocab_size=49408, transformer_width=768, transformer_heads=12,
+                     transformer_layers=12),
+}
+
+
+def tiny_config(**kw):
+    cfg = dict(embed_dim=64, image_resolution=64, vision_layers=2, vision_width=128, vision_patch_size=16,
+               context_length=77, vocab_size=512, transformer_width=64, transformer_heads=1, transformer_layers=2)
+    cfg.update(kw)
+    return cfg
+
+
+# ------------------------------------------------------------------------------------------------------------
+# parameter construction (names = the checkpoint keys of SURVEY.md section 3.2, without the "clip_model." prefix)
+# ------------------------------------------------------------------------------------------------------------
+def init_state_dict(cfg, seed=0, dtype=torch.float32):
+    """Random init following upstream CLIP.initialize_parameters / VisionTransformer.__init__ std choices."""
+    g = torch.Generator().manual_seed(seed)
+
+    def randn(*shape, std=1.0):
+        return (torch.randn(*shape, generator=g) * std).to(dtype)
+
+    sd = OrderedDict()
+    vw, tw, E = cfg["vision_width"], cfg["transformer_width"], cfg["embed_dim"]
+    P = cfg["vision_patch_size"]
+    grid = cfg["image_resolution"] // P
+    scale = vw ** -0.5
+    fan_in = 3 * P * P
+    sd["visual.conv1.weight"] = randn(vw, 3, P, P, std=(1.0 / fan_in) ** 0.5)
+    sd["visual.class_embedding"] = randn(vw, std=scale)
+    sd["visual.positional_embedding"] = randn(grid * grid + 1, vw, std=scale)
+    sd["visual.ln_pre.weight"] = torch.ones(vw, dtype=dtype)
+    sd["visual.ln_pre.bias"] = torch.zeros(vw, dtype=dtype)
+
+    def blocks(prefix, width, layers):
+        proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
+        attn_std = width ** -0.5
+        fc_std = (2 * width) ** -0.5
+        for i in range(layers):
+            p = f"{prefix}.resblocks.{i}"
+            sd[f"{p}.attn.in_proj_weight"] = randn(3 * width, width, std=attn_std)
+            sd[f"{p}.attn.in_proj_bias"] = randn(3 * width, std=0.01)
+            sd[f"{p}.attn.out_proj.weight"] = randn(width, width, std=proj_std)
+            sd[f"{p}.attn.out_proj.bias"] = randn(width, std=0.01)
+            sd[f"{p}.ln_1.weight"] = 1.0 + randn(width, std=0.02)
+            sd[f"{p}.ln_1.bias"] = randn(width, std=0.02)
+            sd[f"{p}.mlp.c_fc.weight"] = randn(4 * width, width, std=fc_std)
+            sd[f"{p}.mlp.c_fc.bias"] = randn(4 * width, std=0.01)
+            sd[f"{p}.mlp.c_proj.weight"] = randn(width, 4 * width, std=proj_std)
+            sd[f"{p}.mlp.c_proj.bias"] = randn(width, std=0.01)
+            sd[f"{p}.ln_2.weight"] = 1.0 + randn(width, std=0.02)
+            sd[f"{p}.ln_2.bias"] = randn(width, std=0.02)
+
+    blocks("visual.transformer", vw, cfg["vision_layers"])
+    sd["visual.ln_post.weight"] = torch.ones(vw, dtype=dtype)
+    sd["visual.ln_post.bias"] = torch.zeros(vw, dtype=dtype)
+    sd["visual.proj"] = randn(vw, E, std=scale)
+    blocks("transformer", tw, cfg["transformer_layers"])
+    sd["token_embedding.weight"] = randn(cfg["vocab_size"], tw, std=0.02)
+    sd["positional_embedding"] = randn(cfg["context_length"], tw, std=0.01)
+    sd["ln_final.weight"] = torch.ones(tw, dtype=dtype)
+    sd["ln_final.bias"] = torch.zeros(tw, dtype=dtype)
+    sd["text_projection"] = randn(tw, E, std=tw ** -0.5)
+    sd["logit_scale"] = torch.tensor(math.log(1 / 0.07), dtype=dtype)
+    return sd
+
+
+# ------------------------------------------------------------------------------------------------------------
+# towers
+# ------------------------------------------------------------------------------------------------------------
+def layer_norm(x, w, b, eps=1e-5):
+    # upstream LayerNorm subclass: compute in fp32, cast back
+    return F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps).to(x.dtype)
+
+
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def attention(x, sd, p, heads, attn_mask=None):
+    """nn.MultiheadAttention(x, x, x, need_weights=False, attn_mask=mask) on [N, L, W] (batch first here)."""
+    N, L, W = x.shape
+    hd = W // heads
+    qkv = x @ sd[f"{p}.attn.in_proj_weight"].t() + sd[f"{p}.attn.in_proj_bias"]
+    q, k, v = qkv.split(W, dim=-1)
+    q = q.view(N, L, heads, hd).transpose(1, 2)
+    k = k.view(N, L, heads, hd).transpose(1, 2)
+    v = v.view(N, L, heads, hd).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if attn_mask is not None:
+        s = s + attn_mask
+    a = torch.softmax(s, dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(N, L, W)
+    return o @ sd[f"{p}.attn.out_proj.weight"].t() + sd[f"{p}.attn.out_proj.bias"]
+
+
+def resblock(x, sd, p, heads, attn_mask=None):
+    x = x + attention(layer_norm(x, sd[f"{p}.ln_1.weight"], sd[f"{p}.ln_1.bias"]), sd, p, heads, attn_mask)
+    h = layer_norm(x, sd[f"{p}.ln_2.weight"], sd[f"{p}.ln_2.bias"])
+    h = quick_gelu(h @ sd[f"{p}.mlp.c_fc.weight"].t() + sd[f"{p}.mlp.c_fc.bias"])
+    return x + (h @ sd[f"{p}.mlp.c_proj.weight"].t() + sd[f"{p}.mlp.c_proj.bias"])
+
+
+def encode_image(sd, image, cfg, return_tokens=False):
+    """VisionTransformer.forward: conv1 -> [cls; patches] + pos -> ln_pre -> blocks -> ln_post(x[:,0]) @ proj."""
+    vw, P = cfg["vision_width"], cfg["vision_patch_size"]
+    x = F.conv2d(image, sd["visual.conv1.weight"], stride=P)          # [N, W, g, g]
+    x = x.reshape(x.shape[0], vw, -1).permute(0, 2, 1)                # [N, g*g, W]
+    cls = sd["visual.class_embedding"].to(x.dtype) + torch.zeros(x.shape[0], 1, vw, dtype=x.dtype)
+    x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]
+    x = layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"])
+    heads = vw // 64
+    for i in range(cfg["vision_layers"]):
+        x = resblock(x, sd, f"visual.transformer.resblocks.{i}", heads)
+    if return_tokens:
+        return x
+    x = layer_norm(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"])
+    return x @ sd["visual.proj"]
+
+
+def build_attention_mask(L):
+    return torch.full((L, L), float("-inf")).triu_(1)
+
+
+def encode_text(sd, text, cfg):
+    """CLIP.encode_text: token_embedding + pos -> causal blocks -> ln_final -> row at argmax(text) @ text_projection."""
+    x = sd["token_embedding.weight"][text.long()] + sd["positional_embedding"]
+    mask = build_attention_mask(cfg["context_length"]).to(x.dtype)
+    for i in range(cfg["transformer_layers"]):
+        x = resblock(x, sd, f"transformer.resblocks.{i}", cfg["transformer_heads"], mask)
+    x = layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"])
+    x = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]
+    return x @ sd["text_projection"]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# UniIR-owned logic
+# ------------------------------------------------------------------------------------------------------------
+def encode_multimodal_input(sd, cfg, txt, img, txt_mask, img_mask):
+    """clip_sf.py:53-63: text_emb * txt_mask[:,None] + image_emb * img_mask[:,None] (both towers always run)."""
+    txt_emb = encode_text(sd, txt, cfg) * txt_mask.unsqueeze(-1)
+    img_emb = encode_image(sd, img, cfg) * img_mask.unsqueeze(-1)
+    return img_emb + txt_emb  # fuse_embeddings(txt_emb, img_emb) = img_emb(arg) + txt_emb(arg): a commutative add
+
+
+def inbatch_contrastive_loss(embeddings, index_mapping, logit_scale_exp, *, gather=None, rank=0,
+                             in_batch_neg_num=0):
+    """clip_sf.py:88-147.  `gather`: None (gather_embeddings False) or a callable p_embeds -> all_p_embeds
+    (rank-major concat of every rank's p_embeds, differentiable)."""
+    q = embeddings[torch.tensor(index_mapping["query"]).flatten()]
+    p = embeddings[torch.tensor(index_mapping["pos_cand"]).flatten()]
+    bs = q.size(0)
+    q = F.normalize(q, dim=-1)
+    p = F.normalize(p, dim=-1)
+    if "neg_cand_list" in index_mapping:  # hard-negative branch, clip_sf.py:105-131
+        n = F.normalize(embeddings[torch.tensor(index_mapping["neg_cand_list"])], dim=-1)
+        nneg = min(bs - 1, in_batch_neg_num)
+        mask = torch.eye(bs) == 0
+        inb = p.unsqueeze(1).expand(-1, bs, -1)[mask].reshape(bs, bs - 1, -1)[:, :nneg, :]
+        aug = torch.cat([n, inb], dim=1)
+        pos = (q * p).sum(-1) * logit_scale_exp
+        neg = (q.unsqueeze(1) * aug).sum(-1) * logit_scale_exp
+        logits = torch.cat([pos.unsqueeze(-1), neg], 1)
+        loss = torch.mean(-1.0 * F.log_softmax(logits, dim=1)[:, 0])
+        acc = (logits.max(1)[1] == 0).sum() / bs
+        return {"loss": loss, "accuracy": acc, "score": logits}
+    if gather is not None:
+        all_p = gather(p)
+        score = torch.matmul(q, all_p.t()) * logit_scale_exp
+        target = rank * bs + torch.arange(bs)
+    else:
+        score = torch.matmul(q, p.t()) * logit_scale_exp
+        target = torch.arange(bs)
+    loss = F.cross_entropy(score, target)
+    acc = (score.max(1)[1] == target).sum() / bs
+    return {"loss": loss, "accuracy": acc, "score": score}
+
+
+def weight_decay_groups(named_parameters):
+    """train.py:195-197: wd 0 for p.ndim < 2 or a name containing bn / ln / bias / logit_scale; wd 0.2 otherwise."""
+    no_decay, decay = [], []
+    for n, p in named_parameters:
+        if not p.requires_grad:
+            continue
+        if p.ndim < 2 or any(s in n for s in ["bn", "ln", "bias", "logit_scale"]):
+            no_decay.append((n, p))
+        else:
+            decay.append((n, p))
+    return no_decay, decay
+
+
+def cosine_lr(base_lr, step, t_total):
+    """closed form of CosineAnnealingLR(T_max=t_total, eta_min=0) after `step` scheduler.step() calls."""
+    return base_lr * (1 + math.cos(math.pi * step / t_total)) / 2
+
+
+class OracleCLIP(torch.nn.Module):
+    """nn.Module wrapper (parameters named like the checkpoint) so that autograd / torch.optim can drive the oracle
+    and so that the reference's CLIPScoreFusion can be exercised with it through a stub `clip` module."""
+
+    def __init__(self, cfg, sd=None, seed=0):
+        super().__init__()
+        self.cfg = cfg
+        sd = sd if sd is not None else init_state_dict(cfg, seed)
+        self._names = list(sd.keys())
+        for k, v in sd.items():
+            self.register_parameter(k.replace(".", "__"), torch.nn.Parameter(v.clone().float()))
+
+    def sd(self):
+        return {k: getattr(self, k.replace(".", "__")) for k in self._names}
+
+    @property
+    def logit_scale(self):
+        return getattr(self, "logit_scale".replace(".", "__"))
+
+    def encode_image(self, image):
+        return encode_image(self.sd(), image, self.cfg)
+
+    def encode_text(self, text):
+        return encode_text(self.sd(), text, self.cfg)
+
+
+def synthetic_batch(cfg, pairs, seed=2023, device="cpu"):
+    """SURVEY.md section 8(d) synthetic inputs: images randn, token rows [SOT, r_1..r_L, EOT, 0...], masks all 1,
+    index_mapping as the collator builds it (mbeir_dataset.py:483-498: item 2i = query, 2i+1 = pos cand)."""
+    g = torch.Generator().manual_seed(seed)
+    M = 2 * pairs
+    res, ctx, vocab = cfg["image_resolution"], cfg["context_length"], cfg["vocab_size"]
+    img = torch.randn(M, 3, res, res, generator=g)
+    txt = torch.zeros(M, ctx, dtype=torch.int32)
+    sot, eot = vocab - 2, vocab - 1
+    for i in range(M):
+        L = int(torch.randint(5, min(61, ctx - 2), (1,), generator=g))
+        txt[i, 0] = sot
+        txt[i, 1:1 + L] = torch.randint(1, sot, (L,), generator=g, dtype=torch.int32)
+        txt[i, 1 + L] = eot
+    batch = {
+        "txt_batched": txt.to(device),
+        "image_batched": img.to(device),
+        "txt_mask_batched": torch.ones(M, dtype=torch.int64, device=device),
+        "image_mask_batched": torch.ones(M, dtype=torch.int64, device=device),
+        "index_mapping": {"query": [[2 * i] for i in range(pairs)], "pos_cand": [[2 * i + 1] for i in range(pairs)]},
+    }
+    return batch

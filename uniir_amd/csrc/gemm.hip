@@ -35,6 +35,60 @@ DEVINL float act_bwd(float x, int act) {
     return x > 0.0f ? 1.0f : 0.0f;
 }
 
+template <int EPI>
+DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[4][4], int m0, int n0) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
+            if (m < p.M && n < p.N) {
+                f32x4_t v = acc[i][j] * p.alpha;
+                if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+                const long off = (long)m * p.ldc + n;
+                if (EPI == UNIIR_EPI_BF16) {
+                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+                } else if (EPI == UNIIR_EPI_BIAS_ACT) {
+                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+                    const float g0 = act_fwd(__uint_as_float(o[0] << 16), p.act);
+                    const float g1 = act_fwd(__uint_as_float(o[0] & 0xffff0000u), p.act);
+                    const float g2 = act_fwd(__uint_as_float(o[1] << 16), p.act);
+                    const float g3 = act_fwd(__uint_as_float(o[1] & 0xffff0000u), p.act);
+                    u32x2_t o2 = {pack_bf16x2(g0, g1), pack_bf16x2(g2, g3)};
+                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o2;
+                } else if (EPI == UNIIR_EPI_RESID_F32) {
+                    if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
+                    *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
+                    if (p.C2) {
+                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o;
+                    }
+                } else if (EPI == UNIIR_EPI_DACT) {
+                    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + (long)m * p.ldaux + n);
+                    const float f0 = __uint_as_float(a[0] << 16), f1 = __uint_as_float(a[0] & 0xffff0000u);
+                    const float f2 = __uint_as_float(a[1] << 16), f3 = __uint_as_float(a[1] & 0xffff0000u);
+                    u32x2_t o = {pack_bf16x2(v[0] * act_bwd(f0, p.act), v[1] * act_bwd(f1, p.act)),
+                                 pack_bf16x2(v[2] * act_bwd(f2, p.act), v[3] * act_bwd(f3, p.act))};
+                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+                } else if (EPI == UNIIR_EPI_F32) {
+                    *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
+                } else {  // UNIIR_EPI_ATOMIC_F32
+                    float* c = (float*)p.C + off;
+                    unsafeAtomicAdd(c + 0, v[0]);
+                    unsafeAtomicAdd(c + 1, v[1]);
+                    unsafeAtomicAdd(c + 2, v[2]);
+                    unsafeAtomicAdd(c + 3, v[3]);
+                }
+            }
+        }
+    }
+}
+
 template <typename Elem, bool A_TMAJ, bool B_TMAJ>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -62,56 +116,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
 
     gemm_mainloop<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
 
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
-    const int epi = p.epilogue;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
-            if (n >= p.N) continue;
-            f32x4_t v = acc[i][j] * p.alpha;
-            if (p.bias) {
-                const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bias + n);
-                v += b;
-            }
-            const long off = (long)m * p.ldc + n;
-            if (epi == UNIIR_EPI_BF16) {
-                u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
-            } else if (epi == UNIIR_EPI_BIAS_ACT) {
-                u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
-                float g[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = act_fwd(bf16_to_f32(f32_to_bf16(v[r])), p.act);
-                u32x2_t o2 = {pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
-                *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o2;
-            } else if (epi == UNIIR_EPI_RESID_F32) {
-                if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
-                *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
-                if (p.C2) {
-                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o;
-                }
-            } else if (epi == UNIIR_EPI_DACT) {
-                const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + (long)m * p.ldaux + n);
-                const float f0 = __uint_as_float(a[0] << 16), f1 = __uint_as_float(a[0] & 0xffff0000u);
-                const float f2 = __uint_as_float(a[1] << 16), f3 = __uint_as_float(a[1] & 0xffff0000u);
-                u32x2_t o = {pack_bf16x2(v[0] * act_bwd(f0, p.act), v[1] * act_bwd(f1, p.act)),
-                             pack_bf16x2(v[2] * act_bwd(f2, p.act), v[3] * act_bwd(f3, p.act))};
-                *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
-            } else if (epi == UNIIR_EPI_F32) {
-                *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
-            } else {  // UNIIR_EPI_ATOMIC_F32
-                float* c = (float*)p.C + off;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, v[r]);
-            }
-        }
+    switch (p.epilogue) {
+        case UNIIR_EPI_BF16: gemm_epilogue<UNIIR_EPI_BF16>(p, acc, m0, n0); break;
+        case UNIIR_EPI_BIAS_ACT: gemm_epilogue<UNIIR_EPI_BIAS_ACT>(p, acc, m0, n0); break;
+        case UNIIR_EPI_RESID_F32: gemm_epilogue<UNIIR_EPI_RESID_F32>(p, acc, m0, n0); break;
+        case UNIIR_EPI_DACT: gemm_epilogue<UNIIR_EPI_DACT>(p, acc, m0, n0); break;
+        case UNIIR_EPI_F32: gemm_epilogue<UNIIR_EPI_F32>(p, acc, m0, n0); break;
+        default: gemm_epilogue<UNIIR_EPI_ATOMIC_F32>(p, acc, m0, n0); break;
     }
 }
 

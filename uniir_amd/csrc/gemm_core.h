@@ -36,32 +36,38 @@ struct ElemF16 {
 template <bool TMAJ>
 struct OperandStage {
     u32x4_t r[4];
+    unsigned okmask;
     // base: element pointer to operand origin; ld: leading dimension in elements.
     // mn0: first row (KMAJ) / column (TMAJ) of this block's panel; mn_total: operand extent in that dim.
     DEVINL void load(const unsigned short* __restrict__ base, long ld, int mn0, int mn_total, int k0,
                      int kend, int tid) {
+        // branch-free: always load from a clamped (valid) address, then select zero for out-of-range chunks
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 256 * i;
-            u32x4_t v = {0u, 0u, 0u, 0u};
+            bool ok;
+            long off;
             if (!TMAJ) {
                 const int row = c >> 3, kc = c & 7;
                 const int gm = mn0 + row, gk = k0 + kc * 8;
-                if (gm < mn_total && gk < kend)
-                    v = *reinterpret_cast<const u32x4_t*>(base + (long)gm * ld + gk);
+                ok = (gm < mn_total) && (gk < kend);
+                off = (long)min(gm, mn_total - 1) * ld + min(gk, kend - 8);
             } else {
                 const int krow = c >> 4, mc = c & 15;
                 const int gk = k0 + krow, gm = mn0 + mc * 8;
-                if (gk < kend && gm < mn_total)
-                    v = *reinterpret_cast<const u32x4_t*>(base + (long)gk * ld + gm);
+                ok = (gk < kend) && (gm < mn_total);
+                off = (long)min(gk, kend - 1) * ld + min(gm, mn_total - 8);
             }
-            r[i] = v;
+            // the zero-select is deferred to store() so the wait for the load lands after the MFMAs
+            r[i] = *reinterpret_cast<const u32x4_t*>(base + off);
+            okmask = (i == 0 ? 0u : okmask) | ((ok ? 1u : 0u) << i);
         }
     }
-    DEVINL void store(char* lds, int tid) const {
+    DEVINL void store(char* lds, int tid) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 256 * i;
+            if (!((okmask >> i) & 1u)) r[i] = u32x4_t{0u, 0u, 0u, 0u};
             int off;
             if (!TMAJ) {
                 const int row = c >> 3, kc = c & 7;
