@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native UniIR hot path (contract: see the task statement).
+
+A "step" is one in-batch contrastive train step (forward + backward + gradient all-reduce + AdamW) of CLIP_SF
+ViT-L/14 on synthetic 224x224 images + 77-token texts (BASELINE.json configs[1]).  Per-GPU work is fixed
+(weak scaling): --pairs query+candidate pairs per rank, global batch = pairs * n_gpus (4096 at 8 GPUs with the
+default 512).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "uniir_amd", "src"))
+
+FLOP_PER_PAIR = {"ViT-L/14": 1.052e12, "ViT-B/32": 88.7e9}
+MFMA_PEAK_BF16 = 2.5e15
+HBM_PEAK = 8.0e12
+
+
+def synth_batch(cfg, pairs, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    M = 2 * pairs
+    res, ctx, vocab = cfg["image_resolution"], cfg["context_length"], cfg["vocab_size"]
+    txt = torch.zeros(M, ctx, dtype=torch.int32)
+    L = torch.randint(5, 61, (M,), generator=g)
+    body = torch.randint(1, vocab - 2, (M, ctx), generator=g, dtype=torch.int32)
+    pos = torch.arange(ctx).unsqueeze(0)
+    txt = torch.where((pos >= 1) & (pos <= L.unsqueeze(1)), body, txt)
+    txt[:, 0] = vocab - 2
+    txt[torch.arange(M), L + 1] = vocab - 1
+    gd = torch.Generator(device=device).manual_seed(seed)
+    img = torch.randn(M, 3, res, res, generator=gd, device=device)
+    return {
+        "txt_batched": txt.to(device),
+        "image_batched": img,
+        "txt_mask_batched": torch.ones(M, dtype=torch.int64, device=device),
+        "image_mask_batched": torch.ones(M, dtype=torch.int64, device=device),
+        "index_mapping": {"query": [[2 * i] for i in range(pairs)], "pos_cand": [[2 * i + 1] for i in range(pairs)]},
+    }
+
+
+def cpu_baseline(model_name, budget_s=25.0):
+    """The oracle (CPU restatement of the reference path, oracle/clip_oracle.py) timed on the host cores on a
+    bounded sample of the same workload: same architecture, same synthetic inputs, b=2 pairs per step."""
+    from oracle import clip_oracle as O
+    torch.manual_seed(0)
+    cfg = O.CLIP_CONFIGS[model_name]
+    threads = torch.get_num_threads()
+    model = O.OracleCLIP(cfg, seed=0)
+    nd, d = O.weight_decay_groups(model.named_parameters())
+    opt = torch.optim.AdamW([{"params": [p for _, p in nd], "weight_decay": 0.0},
+                             {"params": [p for _, p in d], "weight_decay": 0.2}], lr=1e-5, betas=(0.9, 0.98), eps=1e-6)
+    pairs = 2
+    batch = O.synthetic_batch(cfg, pairs, seed=2023)
+    steps, t_used = 0, 0.0
+    t_all0 = time.time()
+    while True:
+        t0 = time.time()
+        emb = O.encode_multimodal_input(model.sd(), cfg, batch["txt_batched"], batch["image_batched"],
+                                        batch["txt_mask_batched"], batch["image_mask_batched"])
+        out = O.inbatch_contrastive_loss(emb, batch["index_mapping"], model.logit_scale.exp())
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        dt = time.time() - t0
+        if steps > 0 or dt > budget_s / 2:   # first step is warm-up unless it already eats the budget
+            t_used += dt
+            steps_timed = steps if steps > 0 else 1
+        steps += 1
+        if time.time() - t_all0 > budget_s or steps >= 4:
+            break
+    timed = max(1, steps - 1) if steps > 1 else 1
+    return {"value": pairs * timed / t_used, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/clip_oracle.py CLIP_SF {model_name} fp32 fwd+bwd+AdamW, {pairs} pairs/step, "
+                      f"{timed} timed step(s) on {threads} host threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("UNIIR_BENCH_PAIRS", "512")))
+    ap.add_argument("--model", default="ViT-L/14")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-retrieval", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from types import SimpleNamespace
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd import ops
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    from uniir_amd.trainer import NativeTrainer
+
+    cfg = CLIP_CONFIGS[args.model]
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=True), data_config=SimpleNamespace(in_batch_neg_num=0))
+    torch.manual_seed(2023 + rank)
+    model = CLIPScoreFusion(model_name=args.model, device=dev, config=config)
+    model.float()
+    trainer = NativeTrainer(model, lr=1e-5, t_total=10000)
+    batch = synth_batch(cfg, args.pairs, 2023 + rank, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = trainer.train_step(batch)
+    barrier()
+    ops.GEMM_TIMING = [] if rank == 0 else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.train_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    timing = ops.GEMM_TIMING
+    ops.GEMM_TIMING = None
+    loss = float(out["loss"])
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    global_pairs = args.pairs * world
+    value = global_pairs * args.steps / dt
+
+    result = None
+    if rank == 0:
+        gflop = sum(f for f, _, _ in timing)
+        gtime = sum(e0.elapsed_time(e1) for _, e0, e1 in timing) * 1e-3
+        roof = {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT/NN/TN MFMA GEMMs of the towers)",
+                "achieved": round(gflop / gtime / 1e12, 2) if gtime > 0 else None, "peak": MFMA_PEAK_BF16 / 1e12,
+                "unit": "TFLOP/s", "frac": round(gflop / gtime / MFMA_PEAK_BF16, 4) if gtime > 0 else None,
+                "traffic": None,
+                "launches": len(timing), "gemm_time_share": round(gtime / dt, 3),
+                "end_to_end_frac": round(value * FLOP_PER_PAIR[args.model] / (world * MFMA_PEAK_BF16), 4)}
+        result = {
+            "metric": "query+cand pairs/sec in-batch contrastive (CLIP_SF-L)", "value": round(value, 2),
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"CLIP_SF {args.model} in-batch contrastive train step (fwd+bwd+allreduce+AdamW), "
+                                   f"{args.pairs} pairs/GPU, global batch {global_pairs}, 224x224 images + 77-token text",
+                       "pairs_per_gpu": args.pairs, "global_batch": global_pairs, "parallelism": f"dp{world}",
+                       "final_loss": round(loss, 4)},
+            "roofline": roof,
+        }
+    del trainer, model, batch, out
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_retrieval:
+        result["retrieval"] = bench_retrieval(dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.model)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_retrieval(dev, n=700_000, d=768, k=10):
+    """Secondary metric: brute-force top-10 over one GPU's 700k x 768 fp16 shard of the 5.6M pool (configs[3])."""
+    from uniir_amd import retrieval
+    g = torch.Generator(device=dev).manual_seed(2023)
+    pool = torch.randn(n, d, generator=g, device=dev).half()
+    shard = retrieval.PoolShard(pool, torch.arange(n, device=dev))
+    out = {}
+    for nq in (64, 1024):
+        q = torch.randn(nq, d, generator=g, device=dev).half()
+        retrieval.search_shard(shard, q, k)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 5
+        e0.record()
+        for _ in range(iters):
+            retrieval.search_shard(shard, q, k)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / iters
+        out[f"q{nq}"] = {"M_candidates_per_s": round(n / t / 1e6, 1), "M_scores_per_s": round(nq * n / t / 1e6, 1),
+                         "ms": round(t * 1e3, 3),
+                         "hbm": {"achieved": round(n * d * 2 / t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                 "frac": round(n * d * 2 / t / HBM_PEAK, 4)}}
+    out["workload"] = f"top-{k} of {n} x {d} fp16 candidates (one GPU shard of the 5.6M pool), exact re-score"
+    return out
+
+
+if __name__ == "__main__":
+    main()

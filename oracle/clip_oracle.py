@@ -242,9 +242,7 @@ class OracleCLIP(torch.nn.Module):
     def sd(self):
         return {k: getattr(self, k.replace(".", "__")) for k in self._names}
 
-    @property
-    def logit_scale(self):
-        return getattr(self, "logit_scale".replace(".", "__"))
+    # `logit_scale` has no dot in its key, so the registered parameter is reachable as self.logit_scale directly
 
     def encode_image(self, image):
         return encode_image(self.sd(), image, self.cfg)

@@ -1,0 +1,391 @@
+"""MI355X-native CLIP towers behind the openai/CLIP module surface that UniIR's clip_sf.py uses
+(`clip.load()` -> model with .encode_image / .encode_text / .logit_scale, state-dict keys of the published
+checkpoints: SURVEY.md section 3.2; reference call sites src/models/uniir_clip/clip_scorefusion/clip_sf.py:25-26,
+44,47,66).
+
+The arithmetic is entirely in libuniir_hip.so (include/uniir_hip.h): bf16 MFMA GEMMs with fused epilogues,
+fp32 LayerNorm, fused attention, fp32 residual stream.  This file is host plumbing only: parameter bookkeeping
+(one flat fp32 master buffer + flat grad buffer + bf16 shadow), the per-layer launch sequence of forward and
+backward, and the activation stash.  There is no torch fallback.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import ops
+
+ALIGN = 64  # elements; every parameter starts on a 256-B boundary of the flat buffers
+
+CLIP_CONFIGS = {
+    "ViT-B/32": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
+                     context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
+                     transformer_layers=12),
+    "ViT-B/16": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=16,
+                     context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
+                     transformer_layers=12),
+    "ViT-L/14": dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024, vision_patch_size=14,
+                     context_length=77, vocab_size=49408, transformer_width=768, transformer_heads=12,
+                     transformer_layers=12),
+}
+
+
+def _is_no_decay(name, p):
+    # UniIR clip_scorefusion/train.py:195: p.ndim < 2 or name contains bn / ln / bias / logit_scale
+    return p.ndim < 2 or any(s in name for s in ["bn", "ln", "bias", "logit_scale"])
+
+
+class _P(nn.Module):
+    """bare parameter holder so that state-dict keys match upstream module paths"""
+
+    def __init__(self, **params):
+        super().__init__()
+        for k, v in params.items():
+            self.register_parameter(k, nn.Parameter(v))
+
+
+def _resblocks(width, layers, gen):
+    proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
+    attn_std = width ** -0.5
+    fc_std = (2 * width) ** -0.5
+
+    def rn(*shape, std):
+        return torch.randn(*shape, generator=gen) * std
+
+    blocks = nn.ModuleList()
+    for _ in range(layers):
+        blk = nn.Module()
+        blk.attn = _P(in_proj_weight=rn(3 * width, width, std=attn_std), in_proj_bias=torch.zeros(3 * width))
+        blk.attn.out_proj = _P(weight=rn(width, width, std=proj_std), bias=torch.zeros(width))
+        blk.ln_1 = _P(weight=torch.ones(width), bias=torch.zeros(width))
+        blk.mlp = nn.Module()
+        blk.mlp.c_fc = _P(weight=rn(4 * width, width, std=fc_std), bias=torch.zeros(4 * width))
+        blk.mlp.c_proj = _P(weight=rn(width, 4 * width, std=proj_std), bias=torch.zeros(width))
+        blk.ln_2 = _P(weight=torch.ones(width), bias=torch.zeros(width))
+        blocks.append(blk)
+    t = nn.Module()
+    t.resblocks = blocks
+    return t
+
+
+class CLIP(nn.Module):
+    """Same attribute / key layout as upstream clip.model.CLIP (visual.*, transformer.*, token_embedding.weight, ...)."""
+
+    def __init__(self, cfg, seed=0):
+        super().__init__()
+        self.cfg = dict(cfg)
+        g = torch.Generator().manual_seed(seed)
+        vw, tw, E, P = cfg["vision_width"], cfg["transformer_width"], cfg["embed_dim"], cfg["vision_patch_size"]
+        grid = cfg["image_resolution"] // P
+        scale = vw ** -0.5
+        self.visual = nn.Module()
+        self.visual.conv1 = _P(weight=torch.randn(vw, 3, P, P, generator=g) * (1.0 / (3 * P * P)) ** 0.5)
+        self.visual.register_parameter("class_embedding", nn.Parameter(torch.randn(vw, generator=g) * scale))
+        self.visual.register_parameter("positional_embedding",
+                                       nn.Parameter(torch.randn(grid * grid + 1, vw, generator=g) * scale))
+        self.visual.ln_pre = _P(weight=torch.ones(vw), bias=torch.zeros(vw))
+        self.visual.transformer = _resblocks(vw, cfg["vision_layers"], g)
+        self.visual.ln_post = _P(weight=torch.ones(vw), bias=torch.zeros(vw))
+        self.visual.register_parameter("proj", nn.Parameter(torch.randn(vw, E, generator=g) * scale))
+        self.transformer = _resblocks(tw, cfg["transformer_layers"], g)
+        self.token_embedding = _P(weight=torch.randn(cfg["vocab_size"], tw, generator=g) * 0.02)
+        self.positional_embedding = nn.Parameter(torch.randn(cfg["context_length"], tw, generator=g) * 0.01)
+        self.ln_final = _P(weight=torch.ones(tw), bias=torch.zeros(tw))
+        self.text_projection = nn.Parameter(torch.randn(tw, E, generator=g) * tw ** -0.5)
+        self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
+        # flat storage (built lazily on the device)
+        self._flat = None
+        self.kpad = (3 * P * P + 63) // 64 * 64
+
+    # ---- flat parameter / gradient / bf16-shadow storage -----------------------------------------------------
+    def _ensure_flat(self):
+        params = list(self.named_parameters())
+        dev = self.logit_scale.device
+        if dev.type != "cuda":
+            raise RuntimeError("uniir_amd CLIP runs on an MI355X only (no CPU path); move the model to cuda")
+        fl = self._flat
+        if fl is not None and fl["dev"] == dev and all(p.data_ptr() == fl["p32"].data_ptr() + 4 * fl["off"][n]
+                                                        for n, p in params):
+            return fl
+        order = [(n, p) for n, p in params if _is_no_decay(n, p)] + [(n, p) for n, p in params if not _is_no_decay(n, p)]
+        n_nodecay = sum(1 for n, p in params if _is_no_decay(n, p))
+        off, cur, split = {}, 0, 0
+        for i, (n, p) in enumerate(order):
+            if i == n_nodecay:
+                split = cur
+            off[n] = cur
+            cur += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        if n_nodecay == len(order):
+            split = cur
+        p32 = torch.zeros(cur, device=dev, dtype=torch.float32)
+        g32 = torch.zeros(cur, device=dev, dtype=torch.float32)
+        for n, p in order:
+            view = p32[off[n]:off[n] + p.numel()].view(p.shape)
+            view.copy_(p.data.float())
+            p.data = view
+            p.grad = g32[off[n]:off[n] + p.numel()].view(p.shape)
+        w16 = torch.empty(cur, device=dev, dtype=torch.bfloat16)
+        self._flat = fl = dict(dev=dev, p32=p32, g32=g32, w16=w16, off=off, total=cur, split=split, version=-1,
+                               shapes={n: p.shape for n, p in order})
+        self._conv16 = torch.zeros(self.cfg["vision_width"], self.kpad, device=dev, dtype=torch.bfloat16)
+        self._dconv = torch.zeros(self.cfg["vision_width"], self.kpad, device=dev, dtype=torch.float32)
+        self.refresh_shadow()
+        return fl
+
+    def refresh_shadow(self):
+        """bf16 copies of the master weights (called after every optimizer step; the fused AdamW does it itself)."""
+        fl = self._flat
+        ops.call("uniir_cast_f32_to_bf16", fl["p32"], fl["w16"], fl["total"])
+        self._refresh_conv()
+        fl["version"] = self._param_version()
+
+    def _refresh_conv(self):
+        vw, P = self.cfg["vision_width"], self.cfg["vision_patch_size"]
+        ops.call("uniir_cast_pad_rows", self.visual.conv1.weight.data, self._conv16, vw, 3 * P * P, self.kpad)
+
+    def _param_version(self):
+        return sum(p._version for _, p in self.named_parameters())
+
+    def _sync_shadow(self):
+        fl = self._ensure_flat()
+        if fl["version"] != self._param_version():
+            self.refresh_shadow()
+        return fl
+
+    def w16(self, name):
+        fl = self._flat
+        o = fl["off"][name]
+        return fl["w16"][o:o + math.prod(fl["shapes"][name])].view(fl["shapes"][name])
+
+    def grad_view(self, name):
+        fl = self._flat
+        o = fl["off"][name]
+        return fl["g32"][o:o + math.prod(fl["shapes"][name])].view(fl["shapes"][name])
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients live in one flat buffer; zeroing it is one memset (they are never set to None)."""
+        if self._flat is not None:
+            self._flat["g32"].zero_()
+            for n, p in self.named_parameters():
+                if p.grad is None or p.grad.data_ptr() != self.grad_view(n).data_ptr():
+                    p.grad = self.grad_view(n)
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    # ---- public encoder API (upstream names) ---------------------------------------------------------------------
+    @property
+    def dtype(self):
+        return torch.float32
+
+    def encode_image(self, image):
+        self._sync_shadow()
+        return _TowerFn.apply(self, "image", image.contiguous(), self._anchor_for(image.device))
+
+    def encode_text(self, text):
+        self._sync_shadow()
+        return _TowerFn.apply(self, "text", text.to(torch.int32).contiguous(), self._anchor_for(text.device))
+
+    def _anchor_for(self, dev):
+        # a leaf that requires grad, so autograd calls the tower backward (parameter grads are written straight
+        # into the flat gradient buffer, they do not travel through autograd)
+        return torch.zeros(1, device=dev, requires_grad=torch.is_grad_enabled())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# layer launch sequences
+# ------------------------------------------------------------------------------------------------------------
+class _Blk:
+    """names of one residual block's tensors inside the flat buffers"""
+
+    def __init__(self, model, prefix):
+        p = prefix
+        self.names = dict(wqkv=f"{p}.attn.in_proj_weight", bqkv=f"{p}.attn.in_proj_bias", wo=f"{p}.attn.out_proj.weight",
+                          bo=f"{p}.attn.out_proj.bias", ln1w=f"{p}.ln_1.weight", ln1b=f"{p}.ln_1.bias",
+                          wfc=f"{p}.mlp.c_fc.weight", bfc=f"{p}.mlp.c_fc.bias", wproj=f"{p}.mlp.c_proj.weight",
+                          bproj=f"{p}.mlp.c_proj.bias", ln2w=f"{p}.ln_2.weight", ln2b=f"{p}.ln_2.bias")
+        self.m = model
+
+    def w16(self, k):
+        return self.m.w16(self.names[k])
+
+    def p32(self, k):
+        fl = self.m._flat
+        n = self.names[k]
+        o = fl["off"][n]
+        return fl["p32"][o:o + math.prod(fl["shapes"][n])].view(fl["shapes"][n])
+
+    def g(self, k):
+        return self.m.grad_view(self.names[k])
+
+
+def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save):
+    R = M * T
+    dev = x.device
+    h = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
+    g = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
+    saved = []
+    for i in range(layers):
+        b = _Blk(model, f"{prefix}.resblocks.{i}")
+        ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), out_bf16=h, rows=R, width=W)
+        qkv = ops.linear_fwd(h, b.w16("wqkv"), b.p32("bqkv"))
+        ao, lse = ops.attention_fwd(qkv, M, T, heads, causal)
+        x2 = ops.linear_fwd(ao, b.w16("wo"), b.p32("bo"), epilogue=ops.EPI_RESID_F32, resid=x)
+        ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), out_bf16=h, rows=R, width=W)
+        f = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
+        ops.linear_fwd(h, b.w16("wfc"), b.p32("bfc"), out=f, epilogue=ops.EPI_BIAS_ACT, C2=g)
+        xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32, resid=x2)
+        if save:
+            saved.append((x, qkv, ao, lse, x2, f))
+        x = xn
+    return x, saved
+
+
+def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal):
+    """dx fp32 [R,W] and its bf16 copy dxb: gradient w.r.t. the tower output.  Returns d(tower input) (fp32)."""
+    R = M * T
+    dev = dx.device
+    h = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
+    g = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
+    dh = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
+    for i in reversed(range(layers)):
+        b = _Blk(model, f"{prefix}.resblocks.{i}")
+        x, qkv, ao, lse, x2, f = saved[i]
+        saved[i] = None
+        ops.call("uniir_act_fwd", f, g, f.numel(), ops.ACT_QUICKGELU)
+        ops.linear_wgrad(dxb, g, b.g("wproj"))
+        ops.call("uniir_colsum_bf16", dxb, W, b.g("bproj"), R, W)
+        ops.linear_dgrad(dxb, b.w16("wproj"), out=g, aux=f)                      # g := df
+        ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), out_bf16=h, rows=R, width=W)
+        ops.linear_wgrad(g, h, b.g("wfc"))
+        ops.call("uniir_colsum_bf16", g, 4 * W, b.g("bfc"), R, 4 * W)
+        ops.linear_dgrad(g, b.w16("wfc"), out=dh)                                # dh := d ln_2 out
+        dx2 = torch.empty(R, W, device=dev, dtype=torch.float32)
+        ops.layernorm_bwd(x2, b.p32("ln2w"), dh, b.g("ln2w"), b.g("ln2b"), dres=dx, dx=dx2, dx_bf16=dxb,
+                          rows=R, width=W)
+        del x2, f
+        ops.linear_wgrad(dxb, ao, b.g("wo"))
+        ops.call("uniir_colsum_bf16", dxb, W, b.g("bo"), R, W)
+        ops.linear_dgrad(dxb, b.w16("wo"), out=dh)                               # dh := d attn out
+        dqkv = ops.attention_bwd(qkv, ao, dh, lse, M, T, heads, causal)
+        del qkv, ao, lse
+        ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), out_bf16=h, rows=R, width=W)
+        ops.linear_wgrad(dqkv, h, b.g("wqkv"))
+        ops.call("uniir_colsum_bf16", dqkv, 3 * W, b.g("bqkv"), R, 3 * W)
+        ops.linear_dgrad(dqkv, b.w16("wqkv"), out=dh)                            # dh := d ln_1 out
+        del dqkv
+        ops.layernorm_bwd(x, b.p32("ln1w"), dh, b.g("ln1w"), b.g("ln1b"), dres=dx2, dx=dx, dx_bf16=dxb,
+                          rows=R, width=W)
+        del x, dx2
+    return dx
+
+
+class _TowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, which, inp, anchor):
+        cfg = model.cfg
+        need_grad = bool(ctx.needs_input_grad[3])
+        dev = inp.device
+        E = cfg["embed_dim"]
+        M = inp.shape[0]
+        ctx.model, ctx.which, ctx.M = model, which, M
+        if M == 0:
+            return torch.zeros(0, E, device=dev)
+        fl = model._flat
+
+        def p32(name):
+            o = fl["off"][name]
+            return fl["p32"][o:o + math.prod(fl["shapes"][name])].view(fl["shapes"][name])
+
+        if which == "image":
+            W, P, L = cfg["vision_width"], cfg["vision_patch_size"], cfg["vision_layers"]
+            res = cfg["image_resolution"]
+            G = (res // P) ** 2
+            T = G + 1
+            heads = W // 64
+            patches = torch.empty(M * G, model.kpad, device=dev, dtype=torch.bfloat16)
+            ops.call("uniir_patchify", inp.float(), patches, M, res, P, model.kpad)
+            po = ops.linear_fwd(patches, model._conv16)
+            x0 = torch.empty(M * T, W, device=dev, dtype=torch.float32)
+            ops.call("uniir_vit_assemble", po, p32("visual.class_embedding"), p32("visual.positional_embedding"), x0,
+                     M, T, W)
+            del po
+            x = torch.empty(M * T, W, device=dev, dtype=torch.float32)
+            ops.layernorm_fwd(x0, p32("visual.ln_pre.weight"), p32("visual.ln_pre.bias"), out_f32=x, rows=M * T, width=W)
+            x, saved = _tower_fwd(model, "visual.transformer", L, x, M, T, W, heads, False, need_grad)
+            rows = torch.empty(M, W, device=dev, dtype=torch.float32)
+            ops.call("uniir_gather_rows", x, None, rows, M, T, W)
+            pooled = ops.layernorm_fwd(rows, p32("visual.ln_post.weight"), p32("visual.ln_post.bias"), rows=M, width=W)
+            emb = torch.empty(M, E, device=dev, dtype=torch.float32)
+            ops.gemm(pooled, model.w16("visual.proj"), emb, M, E, W, W, E, E, b_tmaj=True, epilogue=ops.EPI_F32)
+            if need_grad:
+                ctx.stash = dict(patches=patches, x0=x0, saved=saved, rows=rows, pooled=pooled, T=T, W=W, L=L,
+                                 heads=heads, idx=None)
+            return emb
+        # text tower
+        W, L, ctxlen = cfg["transformer_width"], cfg["transformer_layers"], cfg["context_length"]
+        heads, T = cfg["transformer_heads"], ctxlen
+        x = torch.empty(M * T, W, device=dev, dtype=torch.float32)
+        eot = torch.empty(M, device=dev, dtype=torch.int32)
+        ops.call("uniir_text_embed", inp, p32("token_embedding.weight"), p32("positional_embedding"), x, eot, M, T, W,
+                 cfg["vocab_size"])
+        x, saved = _tower_fwd(model, "transformer", L, x, M, T, W, heads, True, need_grad)
+        rows = torch.empty(M, W, device=dev, dtype=torch.float32)
+        ops.call("uniir_gather_rows", x, eot, rows, M, T, W)
+        pooled = ops.layernorm_fwd(rows, p32("ln_final.weight"), p32("ln_final.bias"), rows=M, width=W)
+        emb = torch.empty(M, E, device=dev, dtype=torch.float32)
+        ops.gemm(pooled, model.w16("text_projection"), emb, M, E, W, W, E, E, b_tmaj=True, epilogue=ops.EPI_F32)
+        if need_grad:
+            ctx.stash = dict(text=inp, saved=saved, rows=rows, pooled=pooled, T=T, W=W, L=L, heads=heads, idx=eot)
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        model, which, M = ctx.model, ctx.which, ctx.M
+        if M == 0:
+            return None, None, None, None
+        st = ctx.stash
+        ctx.stash = None
+        cfg = model.cfg
+        fl = model._flat
+        dev = demb.device
+        E = cfg["embed_dim"]
+        T, W, L, heads = st["T"], st["W"], st["L"], st["heads"]
+        R = M * T
+
+        def p32(name):
+            o = fl["off"][name]
+            return fl["p32"][o:o + math.prod(fl["shapes"][name])].view(fl["shapes"][name])
+
+        image = which == "image"
+        proj_n = "visual.proj" if image else "text_projection"
+        lnw, lnb = (("visual.ln_post.weight", "visual.ln_post.bias") if image else ("ln_final.weight", "ln_final.bias"))
+        prefix = "visual.transformer" if image else "transformer"
+        demb16 = demb.contiguous().to(torch.bfloat16)
+        # dproj[W,E] += pooled^T @ demb ; dpooled[M,W] = demb @ proj^T
+        ops.gemm(st["pooled"], demb16, model.grad_view(proj_n), W, E, M, W, E, E, a_tmaj=True, b_tmaj=True,
+                 epilogue=ops.EPI_ATOMIC_F32)
+        dpooled = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
+        ops.gemm(demb16, model.w16(proj_n), dpooled, M, W, E, E, E, W)
+        drows = ops.layernorm_bwd(st["rows"], p32(lnw), dpooled, model.grad_view(lnw), model.grad_view(lnb), rows=M,
+                                  width=W)
+        dx = torch.zeros(R, W, device=dev, dtype=torch.float32)
+        ops.call("uniir_scatter_rows", drows, st["idx"], dx, M, T, W)
+        dxb = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
+        ops.call("uniir_cast_f32_to_bf16", dx, dxb, dx.numel())
+        dx = _tower_bwd(model, prefix, L, dx, dxb, st["saved"], M, T, W, heads, not image)
+        if image:
+            P = cfg["vision_patch_size"]
+            G = T - 1
+            dx0 = ops.layernorm_bwd(st["x0"], p32("visual.ln_pre.weight"), dx, model.grad_view("visual.ln_pre.weight"),
+                                    model.grad_view("visual.ln_pre.bias"), rows=R, width=W)
+            dpo = torch.empty(M * G, W, device=dev, dtype=torch.bfloat16)
+            ops.call("uniir_vit_assemble_bwd", dx0, dpo, model.grad_view("visual.class_embedding"),
+                     model.grad_view("visual.positional_embedding"), M, T, W)
+            model._dconv.zero_()
+            ops.linear_wgrad(dpo, st["patches"], model._dconv)
+            ops.call("uniir_unpad_add", model._dconv, model.grad_view("visual.conv1.weight"), W, 3 * P * P, model.kpad)
+        else:
+            ops.call("uniir_text_embed_bwd", st["text"], dx, model.grad_view("token_embedding.weight"),
+                     model.grad_view("positional_embedding"), M, T, W, cfg["vocab_size"])
+        return None, None, None, None

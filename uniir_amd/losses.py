@@ -1,0 +1,86 @@
+"""Autograd glue for the fuse / select+normalise / in-batch InfoNCE kernels (include/uniir_hip.h [FUSE], [NCE]).
+
+Mirrors UniIR src/models/uniir_clip/clip_scorefusion/clip_sf.py:53-63 (fuse), :88-97 (select + normalise),
+:99-103 (differentiable all-gather of p, backward = reduce-scatter SUM), :133-144 (scores, CE, accuracy).
+All arithmetic is in libuniir_hip.so; torch.distributed (RCCL) carries the one exchange step.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FuseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, txt_emb, img_emb, txt_mask, img_mask):
+        n, d = txt_emb.shape
+        emb = torch.empty(n, d, device=txt_emb.device, dtype=torch.float32)
+        tm, im = txt_mask.to(torch.int64).contiguous(), img_mask.to(torch.int64).contiguous()
+        ops.call("uniir_fuse_embeddings", txt_emb.contiguous(), img_emb.contiguous(), tm, im, emb, n, d)
+        ctx.save_for_backward(tm, im)
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        tm, im = ctx.saved_tensors
+        n, d = demb.shape
+        dt, di = torch.empty_like(demb), torch.empty_like(demb)
+        ops.call("uniir_fuse_embeddings_bwd", demb.contiguous(), tm, im, dt, di, n, d)
+        return dt, di, None, None
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class InBatchNCEFn(torch.autograd.Function):
+    """(emb [M,E] fp32, idx_q int32 [b], idx_p int32 [b], scale 0-dim) -> (loss, accuracy, score [b,B])"""
+
+    @staticmethod
+    def forward(ctx, emb, idx_q, idx_p, scale, gather):
+        dev = emb.device
+        b, E = idx_q.numel(), emb.shape[1]
+        emb = emb.contiguous()
+        q = torch.empty(b, E, device=dev)
+        p = torch.empty(b, E, device=dev)
+        qinv, pinv = torch.empty(b, device=dev), torch.empty(b, device=dev)
+        ops.call("uniir_select_normalize", emb, idx_q, q, qinv, b, E)
+        ops.call("uniir_select_normalize", emb, idx_p, p, pinv, b, E)
+        world, rank = 1, 0
+        if gather and _dist_on():
+            world, rank = dist.get_world_size(), dist.get_rank()
+            all_p = torch.empty(world * b, E, device=dev)
+            dist.all_gather_into_tensor(all_p, p)      # RCCL all-gather over xGMI, rank-major like torch.cat
+        else:
+            all_p = p
+        B = all_p.shape[0]
+        sc = scale.detach().reshape(1).float().contiguous()
+        score = torch.empty(b, B, device=dev)
+        stats = torch.empty(3 * b, device=dev)
+        loss, acc = torch.empty(1, device=dev), torch.empty(1, device=dev)
+        toff = rank * b if (gather and world > 1) else 0
+        ops.call("uniir_infonce_fwd", q, all_p, sc, b, B, E, toff, score, stats, loss, acc)
+        ctx.save_for_backward(q, p, all_p, qinv, pinv, idx_q, idx_p, sc, score, stats)
+        ctx.meta = (b, B, E, toff, world, emb.shape[0])
+        ctx.mark_non_differentiable(acc, score)
+        return loss.reshape(()), acc.reshape(()), score
+
+    @staticmethod
+    def backward(ctx, dloss, _dacc, _dscore):
+        q, p, all_p, qinv, pinv, idx_q, idx_p, sc, score, stats = ctx.saved_tensors
+        b, B, E, toff, world, M = ctx.meta
+        dev = q.device
+        gbuf = torch.empty(b * B + b, device=dev)
+        dq, dall = torch.empty(b, E, device=dev), torch.empty(B, E, device=dev)
+        dscale = torch.empty(1, device=dev)
+        dl = dloss.reshape(1).float().contiguous()
+        ops.call("uniir_infonce_bwd", q, all_p, sc, score, stats, dl, b, B, E, toff, gbuf, dq, dall, dscale)
+        if world > 1:
+            dp = torch.empty(b, E, device=dev)
+            dist.reduce_scatter_tensor(dp, dall, op=dist.ReduceOp.SUM)   # backward of the autograd all-gather
+        else:
+            dp = dall
+        demb = torch.zeros(M, E, device=dev)
+        ops.call("uniir_select_normalize_bwd", q, qinv, dq, idx_q, demb, b, E)
+        ops.call("uniir_select_normalize_bwd", p, pinv, dp, idx_p, demb, b, E)
+        return demb, None, None, dscale.reshape(()), None

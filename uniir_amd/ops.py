@@ -11,6 +11,7 @@ from ._lib import GemmDesc, check
 EPI_BF16, EPI_BIAS_ACT, EPI_RESID_F32, EPI_DACT, EPI_F32, EPI_ATOMIC_F32 = range(6)
 ACT_QUICKGELU, ACT_GELU_ERF, ACT_RELU = range(3)
 DT_BF16, DT_F16 = 0, 1
+GEMM_TIMING = None  # bench.py sets this to a list to collect (flops, start_event, end_event) per GEMM launch
 
 
 def _stream():
@@ -36,6 +37,13 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epi
     d.lda, d.ldb, d.ldc, d.ldaux = lda, ldb, ldc, ldaux
     d.a_tmaj, d.b_tmaj = int(a_tmaj), int(b_tmaj)
     d.epilogue, d.act, d.dtype, d.k_splits, d.alpha = epilogue, act, dtype, k_splits, alpha
+    if GEMM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().uniir_gemm(C.byref(d), _stream()), "gemm")
+        e1.record()
+        GEMM_TIMING.append((2.0 * M * N * K, e0, e1))
+        return C_out
     check(_lib.load().uniir_gemm(C.byref(d), _stream()), "gemm")
     return C_out
 

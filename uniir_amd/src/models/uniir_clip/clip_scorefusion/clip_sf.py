@@ -1,0 +1,79 @@
+"""Drop-in for UniIR src/models/uniir_clip/clip_scorefusion/clip_sf.py (class CLIPScoreFusion): same constructor,
+methods, batch dictionary and output dictionary; the towers and the loss run on libuniir_hip.so (MI355X).
+
+Reference lines mirrored: __init__ :14-30, get_tokenizer :35-41, encode_multimodal_input :53-63,
+get_logit_scale :65-66, compute_inbatch_contrastive_loss :68-147, forward :149-152, encode_mbeir_batch :154-168.
+Not built as a kernel: the hard-negative branch (:105-131) -- every shipped config has hard_neg_num 0
+(marked OUT); requesting it raises.
+"""
+import torch
+from torch import nn
+
+from uniir_amd import clip_front
+from uniir_amd.losses import FuseFn, InBatchNCEFn
+
+
+class CLIPScoreFusion(nn.Module):
+    def __init__(self, model_name="ViT-B/32", device="cuda", jit=False, download_root=None, config=None):
+        super().__init__()
+        self.clip_model, self.img_preprocess_fn = clip_front.load(model_name, device, jit, download_root=download_root)
+        self.tokenizer = clip_front.tokenize
+        self.loss_function = nn.CrossEntropyLoss()  # kept for attribute parity; the fused kernel computes the CE
+        if config is not None:
+            self.gather_embeddings = config.model.gather_embeddings
+            self.in_batch_neg_num = config.data_config.in_batch_neg_num
+
+    def get_img_preprocess_fn(self):
+        return self.img_preprocess_fn
+
+    def get_tokenizer(self):
+        def tokenizer_wrapper(txt):
+            return self.tokenizer(txt, context_length=77, truncate=True)
+
+        return tokenizer_wrapper
+
+    def encode_text(self, text_tensor):
+        return self.clip_model.encode_text(text_tensor)
+
+    def encode_image(self, image_tensor):
+        return self.clip_model.encode_image(image_tensor)
+
+    def fuse_embeddings(self, img_emb, txt_emb):
+        return img_emb + txt_emb
+
+    def encode_multimodal_input(self, txt_tensor, img_tensor, txt_mask, img_mask):
+        txt_emb = self.encode_text(txt_tensor)
+        img_emb = self.encode_image(img_tensor)
+        return FuseFn.apply(txt_emb, img_emb, txt_mask, img_mask)  # txt*mask + img*mask, [batch, embed_dim]
+
+    def get_logit_scale(self):
+        return self.clip_model.logit_scale.exp()
+
+    def compute_inbatch_contrastive_loss(self, batch):
+        index_mapping = batch["index_mapping"]
+        if "neg_cand_list" in index_mapping:
+            raise NotImplementedError(
+                "hard-negative branch (clip_sf.py:105-131) is outside the MI355X hot path: all shipped configs "
+                "train with hard_neg_num 0; see DESIGN.md 'out of scope'")
+        embeddings = self.encode_multimodal_input(batch["txt_batched"], batch["image_batched"],
+                                                  batch["txt_mask_batched"], batch["image_mask_batched"])
+        dev = embeddings.device
+        idx_q = torch.tensor(index_mapping["query"], dtype=torch.int32).flatten().to(dev, non_blocking=True)
+        idx_p = torch.tensor(index_mapping["pos_cand"], dtype=torch.int32).flatten().to(dev, non_blocking=True)
+        gather = bool(getattr(self, "gather_embeddings", False))
+        loss, accuracy, _score = InBatchNCEFn.apply(embeddings, idx_q, idx_p, self.get_logit_scale(), gather)
+        return {"loss": loss, "accuracy": accuracy}
+
+    def forward(self, batch, encode_mbeir_batch=False):
+        if encode_mbeir_batch:
+            return self.encode_mbeir_batch(batch)
+        return self.compute_inbatch_contrastive_loss(batch)
+
+    def encode_mbeir_batch(self, batch):
+        id_list = batch.get("did_list") or batch.get("qid_list")
+        assert id_list is not None, "id_list must be provided."
+        assert isinstance(id_list[0], int), "id_list must be hashed to int."
+        embeddings = self.encode_multimodal_input(batch["txt_batched"], batch["image_batched"],
+                                                  batch["txt_mask_batched"], batch["image_mask_batched"])
+        assert embeddings.size(0) == len(id_list), "embeddings and id_batched must have the same batch size."
+        return embeddings, id_list
