@@ -1,0 +1,75 @@
+"""The exchange steps of the hot path over torch.distributed (backend "nccl" = RCCL over xGMI on MI355X, "gloo" in
+the CPU tests).  Only collectives the path really has:
+  * all_gather_rows / reduce_scatter_rows: forward and backward of clip_sf.py:102-103
+    (torch.distributed.nn.all_gather of p_embeds; its autograd backward is a reduce-scatter SUM);
+  * allreduce_mean_: DDP's gradient averaging (clip_scorefusion/train.py:218) on one flat buffer;
+  * gather_topk: per-shard (score, id) lists to every rank for the k-way merge (FAISS shard=True semantics,
+    mbeir_retriever.py:98-100).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def all_gather_rows(p):
+    """[b, E] on every rank -> [W*b, E], rank-major (== torch.cat(all_gather(p), dim=0))."""
+    W = world()
+    if W == 1:
+        return p
+    out = torch.empty(W * p.shape[0], p.shape[1], device=p.device, dtype=p.dtype)
+    dist.all_gather_into_tensor(out, p.contiguous())
+    return out
+
+
+def reduce_scatter_rows(d_all, b):
+    """backward of all_gather_rows: rank r receives sum over ranks of d_all[r*b:(r+1)*b]."""
+    W = world()
+    if W == 1:
+        return d_all
+    out = torch.empty(b, d_all.shape[1], device=d_all.device, dtype=d_all.dtype)
+    if dist.get_backend() == "gloo":   # gloo has no reduce_scatter: all_reduce then slice (tests only)
+        tmp = d_all.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+        out.copy_(tmp[rank() * b:(rank() + 1) * b])
+    else:
+        dist.reduce_scatter_tensor(out, d_all.contiguous(), op=dist.ReduceOp.SUM)
+    return out
+
+
+def target_offset(b):
+    """clip_sf.py:135-136: sim_targets = rank * bs + arange(bs)."""
+    return rank() * b
+
+
+def allreduce_sum_(flat):
+    if world() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def gather_topk(scores, ids):
+    """[q, k] per rank -> [W, q, k] on every rank."""
+    W = world()
+    if W == 1:
+        return scores.unsqueeze(0), ids.unsqueeze(0)
+    s = torch.empty((W,) + tuple(scores.shape), device=scores.device, dtype=scores.dtype)
+    i = torch.empty((W,) + tuple(ids.shape), device=ids.device, dtype=ids.dtype)
+    dist.all_gather_into_tensor(s, scores.contiguous())
+    dist.all_gather_into_tensor(i, ids.contiguous())
+    return s, i
+
+
+def contiguous_shard(n, W=None, r=None):
+    """common/dist_utils.py:94-115 ContiguousDistributedSampler: rank r owns [r*ceil(n/W), min((r+1)*ceil(n/W), n))."""
+    W = world() if W is None else W
+    r = rank() if r is None else r
+    per = -(-n // W) if W > 0 else n
+    lo = min(r * per, n)
+    return lo, min(lo + per, n)

@@ -5,9 +5,8 @@ Mirrors UniIR src/models/uniir_clip/clip_scorefusion/clip_sf.py:53-63 (fuse), :8
 All arithmetic is in libuniir_hip.so; torch.distributed (RCCL) carries the one exchange step.
 """
 import torch
-import torch.distributed as dist
 
-from . import ops
+from . import comm, ops
 
 
 class FuseFn(torch.autograd.Function):
@@ -29,10 +28,6 @@ class FuseFn(torch.autograd.Function):
         return dt, di, None, None
 
 
-def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-
-
 class InBatchNCEFn(torch.autograd.Function):
     """(emb [M,E] fp32, idx_q int32 [b], idx_p int32 [b], scale 0-dim) -> (loss, accuracy, score [b,B])"""
 
@@ -46,19 +41,14 @@ class InBatchNCEFn(torch.autograd.Function):
         qinv, pinv = torch.empty(b, device=dev), torch.empty(b, device=dev)
         ops.call("uniir_select_normalize", emb, idx_q, q, qinv, b, E)
         ops.call("uniir_select_normalize", emb, idx_p, p, pinv, b, E)
-        world, rank = 1, 0
-        if gather and _dist_on():
-            world, rank = dist.get_world_size(), dist.get_rank()
-            all_p = torch.empty(world * b, E, device=dev)
-            dist.all_gather_into_tensor(all_p, p)      # RCCL all-gather over xGMI, rank-major like torch.cat
-        else:
-            all_p = p
+        world = comm.world() if gather else 1
+        all_p = comm.all_gather_rows(p) if world > 1 else p   # RCCL all-gather over xGMI, rank-major like torch.cat
         B = all_p.shape[0]
         sc = scale.detach().reshape(1).float().contiguous()
         score = torch.empty(b, B, device=dev)
         stats = torch.empty(3 * b, device=dev)
         loss, acc = torch.empty(1, device=dev), torch.empty(1, device=dev)
-        toff = rank * b if (gather and world > 1) else 0
+        toff = comm.target_offset(b) if world > 1 else 0
         ops.call("uniir_infonce_fwd", q, all_p, sc, b, B, E, toff, score, stats, loss, acc)
         ctx.save_for_backward(q, p, all_p, qinv, pinv, idx_q, idx_p, sc, score, stats)
         ctx.meta = (b, B, E, toff, world, emb.shape[0])
@@ -75,11 +65,7 @@ class InBatchNCEFn(torch.autograd.Function):
         dscale = torch.empty(1, device=dev)
         dl = dloss.reshape(1).float().contiguous()
         ops.call("uniir_infonce_bwd", q, all_p, sc, score, stats, dl, b, B, E, toff, gbuf, dq, dall, dscale)
-        if world > 1:
-            dp = torch.empty(b, E, device=dev)
-            dist.reduce_scatter_tensor(dp, dall, op=dist.ReduceOp.SUM)   # backward of the autograd all-gather
-        else:
-            dp = dall
+        dp = comm.reduce_scatter_rows(dall, b) if world > 1 else dall   # backward of the autograd all-gather
         demb = torch.zeros(M, E, device=dev)
         ops.call("uniir_select_normalize_bwd", q, qinv, dq, idx_q, demb, b, E)
         ops.call("uniir_select_normalize_bwd", p, pinv, dp, idx_p, demb, b, E)
