@@ -72,7 +72,7 @@ void oracle_inv_norms(const uint16_t* x_f16, int64_t n, int dim, float* inv) {
             const float v = half_to_float(x_f16[i * dim + j]);
             s = s + v * v;
         }
-        inv[i] = s > 0.0f ? 1.0f / sqrtf(s) : 0.0f;
+        inv[i] = s > 0.0f ? (float)(1.0 / (double)sqrtf(s)) : 0.0f; /* faiss fvec_renorm_L2: 1.0 / sqrtf(nr) */
     }
 }
 

@@ -44,8 +44,8 @@ def test_infonce_golden_reference_vectors():
     from uniir_amd import ops
     d = np.load(os.path.join(G, "g1_infonce_w1.npz"))
     for tag in ("a", "b"):
-        emb = torch.tensor(d[f"{tag}_img"] * d[f"{tag}_imask"][:, None] + d[f"{tag}_txt"] * d[f"{tag}_tmask"][:, None],
-                           device=DEV)
+        emb = torch.tensor((d[f"{tag}_img"] * d[f"{tag}_imask"][:, None].astype(np.float32)
+                            + d[f"{tag}_txt"] * d[f"{tag}_tmask"][:, None].astype(np.float32)).astype(np.float32), device=DEV)
         b, E = emb.shape[0] // 2, emb.shape[1]
         q, p = torch.empty(b, E, device=DEV), torch.empty(b, E, device=DEV)
         iq = torch.arange(0, 2 * b, 2, device=DEV, dtype=torch.int32)

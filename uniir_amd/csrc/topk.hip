@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const unsigned short* __r
             s = __fadd_rn(s, __fmul_rn(hi, hi));
         }
     }
-    inv[i] = s > 0.f ? __fdiv_rn(1.0f, __fsqrt_rn(s)) : 0.f;
+    // FAISS fvec_renorm_L2: inv_nr = 1.0 / sqrtf(nr) (double division of a correctly rounded float sqrt). The f32
+    // sqrt is taken through f64 (exactly the correctly rounded f32 result) so it cannot be lowered to v_rsq/v_sqrt.
+    inv[i] = s > 0.f ? (float)(1.0 / (double)(float)sqrt((double)s)) : 0.f;
 }
 
 extern "C" int uniir_pool_inv_norms(const void* x_f16, int64_t n, int32_t dim, float* inv_norm, void* stream) {
