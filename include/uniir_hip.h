@@ -70,6 +70,8 @@ typedef struct {
     int32_t epilogue, act, dtype;
     int32_t k_splits;    /* >= 1; > 1 only with UNIIR_EPI_ATOMIC_F32 */
     float alpha;
+    void* splitk_ws;          /* optional scratch for split-K: when it holds k_splits*M*N floats the splits write */
+    int64_t splitk_ws_bytes;  /* plain fp32 slabs that one reduce kernel adds into C (no atomics)               */
 } uniir_gemm_desc;
 
 int uniir_gemm(const uniir_gemm_desc* d, void* stream);

@@ -25,7 +25,7 @@ def bf(x):
     return x.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (200, 136, 72), (1000, 768, 1024)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (200, 136, 72), (1000, 768, 1024), (520, 392, 128), (256, 256, 64), (4100, 1024, 640)])
 def test_gemm_nt_bf16(M, N, K):
     ops = _ops()
     torch.manual_seed(0)
@@ -39,7 +39,7 @@ def test_gemm_nt_bf16(M, N, K):
     assert torch.allclose(y[:, 0].float(), ref[:, 0], rtol=2e-2, atol=2e-1)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (264, 320, 136), (1000, 1024, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (264, 320, 136), (1000, 1024, 768), (777, 192, 520), (2048, 3072, 1024)])
 def test_gemm_dgrad_nn(M, N, K):
     ops = _ops()
     torch.manual_seed(1)
@@ -49,7 +49,7 @@ def test_gemm_dgrad_nn(M, N, K):
     assert rel_err(dx, ref) < 4e-3, rel_err(dx, ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 136, 200), (5000, 768, 1024), (263, 384, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 136, 200), (5000, 768, 1024), (263, 384, 64), (4096, 392, 264), (8192, 768, 1024), (16384, 3072, 1024)])
 def test_gemm_wgrad_tn_splitk(M, N, K):
     ops = _ops()
     torch.manual_seed(2)

@@ -23,13 +23,30 @@ DEVINL int swz_off(int row, int col) {  // byte offset of element (row, col) in 
     return row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1));
 }
 
-// stage rows [0, Tp) of a [T][64] bf16 head slice (row stride `ld` elements) into swizzled LDS, zero padded
+#define ATT_THREADS 512
+#define ATT_WAVES (ATT_THREADS / 64)
+
+// stage rows [0, Tp) of a [T][64] bf16 head slice (row stride `ld` elements) into swizzled LDS, zero padded.
+// Loads are issued 4 deep from clamped (always valid) addresses; the zero-select happens at the LDS store.
 DEVINL void stage_head(char* lds, const unsigned short* __restrict__ src, long ld, int T, int Tp, int tid) {
-    for (int c = tid; c < Tp * 8; c += 256) {
-        const int row = c >> 3, kc = c & 7;
-        u32x4_t v = {0u, 0u, 0u, 0u};
-        if (row < T) v = *reinterpret_cast<const u32x4_t*>(src + (long)row * ld + kc * 8);
-        *reinterpret_cast<u32x4_t*>(lds + row * 128 + ((kc ^ (row & 7)) << 4)) = v;
+    const int total = Tp * 8;
+    for (int c0 = 0; c0 < total; c0 += 4 * ATT_THREADS) {
+        u32x4_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * ATT_THREADS + tid;
+            const int row = min(c >> 3, T - 1), kc = c & 7;
+            v[u] = *reinterpret_cast<const u32x4_t*>(src + (long)row * ld + kc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * ATT_THREADS + tid;
+            const int row = c >> 3, kc = c & 7;
+            if (c < total) {
+                const u32x4_t z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4_t*>(lds + row * 128 + ((kc ^ (row & 7)) << 4)) = (row < T) ? v[u] : z;
+            }
+        }
     }
 }
 // b128 fragment: 8 consecutive d (k-step s) of row r0 + (lane&15)
@@ -72,7 +89,7 @@ DEVINL float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const unsigned short* __restrict__ qkv,
                                                        unsigned short* __restrict__ out,
                                                        float* __restrict__ lse, int T, int H, int causal) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -88,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const unsigned short* __r
     __syncthreads();
     const int nqt = (T + 15) >> 4;
     const int qi = lane & 15, g = lane >> 4;
-    for (int qt = w; qt < nqt; qt += 4) {
+    for (int qt = w; qt < nqt; qt += ATT_WAVES) {
         const int q0 = qt * 16, q = q0 + qi;
         bf16x8_t qf[2];
         qf[0] = frag_rows_global(qbase, ld, q0, 0, lane, T);
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const unsigned short* __r
 
 // Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
 // Phase 2 (per 16-query tile): dQ^T += K^T dS^T with S^T = K Q^T oriented [key][q].
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                        const unsigned short* __restrict__ out,
                                                        const unsigned short* __restrict__ dout,
                                                        const float* __restrict__ lse,
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const unsigned short* __r
     const unsigned short* dobase = dout + (long)m * T * W + h * ATT_D;
     unsigned short* dqbase = dqkv + (long)m * T * ld + h * ATT_D;
 
-    for (int r = tid; r < Tp; r += 256) {
+    for (int r = tid; r < Tp; r += ATT_THREADS) {
         float d = 0.f, l = 0.f;
         if (r < T) {
 #pragma unroll
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const unsigned short* __r
     const int ntile = (T + 15) >> 4;
     const int nblk = Tp >> 5;
     // ---------------- phase 1: dK, dV ----------------
-    for (int kt = w; kt < ntile; kt += 4) {
+    for (int kt = w; kt < ntile; kt += ATT_WAVES) {
         const int k0 = kt * 16, key = k0 + li;
         bf16x8_t kf[2], vf[2];
 #pragma unroll
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const unsigned short* __r
     stage_head(bufB, qbase + 2 * W, ld, T, Tp, tid);
     __syncthreads();
     // ---------------- phase 2: dQ ----------------
-    for (int qt = w; qt < ntile; qt += 4) {
+    for (int qt = w; qt < ntile; qt += ATT_WAVES) {
         const int q0 = qt * 16, q = q0 + li;
         bf16x8_t qf[2], dof[2];
 #pragma unroll
@@ -324,7 +341,7 @@ extern "C" int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
         attr = 2 * 512 * 128;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(batch * heads), dim3(256), sm, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(batch * heads), dim3(ATT_THREADS), sm, (hipStream_t)stream,
                        (const unsigned short*)qkv, (unsigned short*)out, lse, seq, heads, causal);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
@@ -346,7 +363,7 @@ extern "C" int uniir_attention_bwd(const void* qkv, const void* out, const void*
                                   2 * 512 * 128 + 2 * 512 * 4);
         attr = 2 * 512 * 128 + 2 * 512 * 4;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * heads), dim3(256), sm, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * heads), dim3(ATT_THREADS), sm, (hipStream_t)stream,
                        (const unsigned short*)qkv, (const unsigned short*)out, (const unsigned short*)dout, lse,
                        (unsigned short*)dqkv, seq, heads, causal);
     HIP_LAUNCH_CHECK();

@@ -2,7 +2,9 @@
 // Replaces the cuBLAS calls behind nn.Linear / nn.MultiheadAttention.in_proj / Conv2d-as-GEMM of the
 // CLIP towers (openai/CLIP model.py as called from clip_sf.py:43-47) and their autograd backward.
 #include "gemm_core.h"
+#include "gemm_core256.h"
 #include "../../include/uniir_hip.h"
+#include <stdlib.h>
 
 struct GemmKArgs {
     const unsigned short* A;
@@ -16,6 +18,7 @@ struct GemmKArgs {
     long lda, ldb, ldc, ldaux;
     int epilogue, act, k_splits, tiles_m, tiles_n;
     float alpha;
+    float* slab;  // split-K slabs [k_splits][M][N] (plain stores) or nullptr (atomics)
 };
 
 DEVINL float act_fwd(float x, int act) {
@@ -35,15 +38,14 @@ DEVINL float act_bwd(float x, int act) {
     return x > 0.0f ? 1.0f : 0.0f;
 }
 
-template <int EPI>
-DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[4][4], int m0, int n0) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+template <int EPI, int MT, int NT>
+DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[MT][NT], int m0, int n0, int wm, int wn) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
         const int m = m0 + wm + i * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
             if (m < p.M && n < p.N) {
                 f32x4_t v = acc[i][j] * p.alpha;
@@ -89,6 +91,18 @@ DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[4][4], int m0
     }
 }
 
+template <int MT, int NT>
+DEVINL void gemm_epilogue_dispatch(const GemmKArgs& p, const f32x4_t (&acc)[MT][NT], int m0, int n0, int wm, int wn) {
+    switch (p.epilogue) {
+        case UNIIR_EPI_BF16: gemm_epilogue<UNIIR_EPI_BF16, MT, NT>(p, acc, m0, n0, wm, wn); break;
+        case UNIIR_EPI_BIAS_ACT: gemm_epilogue<UNIIR_EPI_BIAS_ACT, MT, NT>(p, acc, m0, n0, wm, wn); break;
+        case UNIIR_EPI_RESID_F32: gemm_epilogue<UNIIR_EPI_RESID_F32, MT, NT>(p, acc, m0, n0, wm, wn); break;
+        case UNIIR_EPI_DACT: gemm_epilogue<UNIIR_EPI_DACT, MT, NT>(p, acc, m0, n0, wm, wn); break;
+        case UNIIR_EPI_F32: gemm_epilogue<UNIIR_EPI_F32, MT, NT>(p, acc, m0, n0, wm, wn); break;
+        default: gemm_epilogue<UNIIR_EPI_ATOMIC_F32, MT, NT>(p, acc, m0, n0, wm, wn); break;
+    }
+}
+
 template <typename Elem, bool A_TMAJ, bool B_TMAJ>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -116,18 +130,93 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
 
     gemm_mainloop<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
 
-    switch (p.epilogue) {
-        case UNIIR_EPI_BF16: gemm_epilogue<UNIIR_EPI_BF16>(p, acc, m0, n0); break;
-        case UNIIR_EPI_BIAS_ACT: gemm_epilogue<UNIIR_EPI_BIAS_ACT>(p, acc, m0, n0); break;
-        case UNIIR_EPI_RESID_F32: gemm_epilogue<UNIIR_EPI_RESID_F32>(p, acc, m0, n0); break;
-        case UNIIR_EPI_DACT: gemm_epilogue<UNIIR_EPI_DACT>(p, acc, m0, n0); break;
-        case UNIIR_EPI_F32: gemm_epilogue<UNIIR_EPI_F32>(p, acc, m0, n0); break;
-        default: gemm_epilogue<UNIIR_EPI_ATOMIC_F32>(p, acc, m0, n0); break;
+    const int w = threadIdx.x >> 6;
+    if (p.slab) {
+        GemmKArgs q = p;
+        q.C = p.slab + (long)split * p.M * p.N;
+        q.ldc = p.N;
+        q.bias = nullptr;
+        gemm_epilogue<UNIIR_EPI_F32, 4, 4>(q, acc, m0, n0, (w >> 1) * 64, (w & 1) * 64);
+        return;
     }
+    gemm_epilogue_dispatch<4, 4>(p, acc, m0, n0, (w >> 1) * 64, (w & 1) * 64);
+}
+
+// 256x256x64 tile, 8 waves, LDS-DMA staging (gemm_core256.h).  Used when K % 64 == 0.
+template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmKArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = id / tiles;
+    id -= split * tiles;
+    const int mt = id / p.tiles_n, nt = id - mt * p.tiles_n;
+    const int m0 = mt * G256_BM, n0 = nt * G256_BN;
+    int kbeg = 0, kend = p.K;
+    if (p.k_splits > 1) {
+        const int ksteps = p.K / G256_BK;
+        const int per = (ksteps + p.k_splits - 1) / p.k_splits;
+        kbeg = split * per * G256_BK;
+        kend = min(p.K, (split + 1) * per * G256_BK);
+        if (kbeg >= kend) return;
+    }
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    g256_mainloop<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
+    const int w = threadIdx.x >> 6;
+    if (p.slab) {
+        GemmKArgs q = p;
+        q.C = p.slab + (long)split * p.M * p.N;
+        q.ldc = p.N;
+        q.bias = nullptr;
+        gemm_epilogue<UNIIR_EPI_F32, 8, 4>(q, acc, m0, n0, (w >> 2) * 128, (w & 3) * 64);
+        return;
+    }
+    gemm_epilogue_dispatch<8, 4>(p, acc, m0, n0, (w >> 2) * 128, (w & 3) * 64);
+}
+
+template <typename Elem>
+static int launch_gemm256(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
+    a.tiles_m = (a.M + G256_BM - 1) / G256_BM;
+    a.tiles_n = (a.N + G256_BN - 1) / G256_BN;
+    const int grid = a.tiles_m * a.tiles_n * a.k_splits;
+    dim3 g(grid), b(512);
+    const size_t sm = G256_LDS_BYTES;
+#define LAUNCH256(AT, BT)                                                                         \
+    do {                                                                                          \
+        static bool attr_set = false;                                                             \
+        if (!attr_set) {                                                                          \
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<Elem, AT, BT>,                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);       \
+            attr_set = true;                                                                      \
+        }                                                                                         \
+        hipLaunchKernelGGL((gemm256_kernel<Elem, AT, BT>), g, b, sm, st, a);                      \
+    } while (0)
+    if (!a_tmaj && !b_tmaj) LAUNCH256(false, false);
+    else if (!a_tmaj && b_tmaj) LAUNCH256(false, true);
+    else if (a_tmaj && !b_tmaj) LAUNCH256(true, false);
+    else LAUNCH256(true, true);
+#undef LAUNCH256
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+static bool use_256(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
+    static const char* force = getenv("UNIIR_GEMM_TILE");
+    if (force && force[0] == '1') return false;             // UNIIR_GEMM_TILE=128 forces the general kernel
+    if (a.K % G256_BK) return false;
+    if (a.M < 256 || a.N < 128) return false;               // small problems: the 128-tile kernel fills the chip better
+    if (a_tmaj && a.M < 8) return false;
+    if (b_tmaj && a.N < 8) return false;
+    return true;
 }
 
 template <typename Elem>
 static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t st) {
+    if (use_256(a, a_tmaj, b_tmaj)) return launch_gemm256<Elem>(a, a_tmaj, b_tmaj, st);
     const int grid = a.tiles_m * a.tiles_n * a.k_splits;
     dim3 g(grid), b(256);
     const size_t sm = GEMM_LDS_BYTES;
@@ -148,6 +237,19 @@ static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t s
 #undef LAUNCH
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
+}
+
+// C[m][n] (+)= sum_s slab[s][m][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, long mn, int N,
+                                                            float* __restrict__ C, long ldc) {
+    const long nv = mn >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        f32x4_t s = *reinterpret_cast<const f32x4_t*>(slab + 4 * i);
+        for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4_t*>(slab + (long)k * mn + 4 * i);
+        const long e = 4 * i, m = e / N, n = e - m * N;
+        f32x4_t* dst = reinterpret_cast<f32x4_t*>(C + m * ldc + n);
+        *dst = *dst + s;
+    }
 }
 
 extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
@@ -179,8 +281,32 @@ extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
     a.tiles_m = (d->M + GEMM_BM - 1) / GEMM_BM;
     a.tiles_n = (d->N + GEMM_BN - 1) / GEMM_BN;
     a.alpha = d->alpha;
+    a.slab = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == UNIIR_DT_BF16) return launch_gemm<ElemBF16>(a, d->a_tmaj, d->b_tmaj, st);
-    if (d->dtype == UNIIR_DT_F16) return launch_gemm<ElemF16>(a, d->a_tmaj, d->b_tmaj, st);
-    return UNIIR_EINVAL;
+    if (d->k_splits > 1) {
+        // never leave a split empty (an empty split would leave its slab unwritten)
+        const int bk = use_256(a, d->a_tmaj, d->b_tmaj) ? G256_BK : GEMM_BK;
+        const int ksteps = (d->K + bk - 1) / bk;
+        int splits = d->k_splits > ksteps ? ksteps : d->k_splits;
+        const int per = (ksteps + splits - 1) / splits;
+        splits = (ksteps + per - 1) / per;
+        a.k_splits = splits;
+        if (d->splitk_ws && !((uintptr_t)d->splitk_ws & 15) && (d->N % 4 == 0) &&
+            d->splitk_ws_bytes >= (int64_t)splits * d->M * d->N * 4)
+            a.slab = (float*)d->splitk_ws;
+    }
+    int rc;
+    if (d->dtype == UNIIR_DT_BF16) rc = launch_gemm<ElemBF16>(a, d->a_tmaj, d->b_tmaj, st);
+    else if (d->dtype == UNIIR_DT_F16) rc = launch_gemm<ElemF16>(a, d->a_tmaj, d->b_tmaj, st);
+    else return UNIIR_EINVAL;
+    if (rc) return rc;
+    if (a.slab) {
+        const long mn = (long)d->M * d->N;
+        long g = (mn / 4 + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, a.slab, a.k_splits, mn, d->N,
+                           (float*)d->C, (long)d->ldc);
+        HIP_LAUNCH_CHECK();
+    }
+    return UNIIR_OK;
 }

@@ -4,8 +4,9 @@
 #include "common.h"
 #include "../../include/uniir_hip.h"
 
-#define LN_MAXC 8  // float4 chunks per lane -> width <= 64*4*8 = 2048
+#define LN_MAXC 8  // float4 chunks per lane -> width <= 64*4*8 = 2048 (kernels are instantiated for NC = 2,3,4,8)
 
+template <int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long x_stride,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
@@ -17,10 +18,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float inv_w = 1.0f / (float)width;
     for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
         const float* xr = x + row * x_stride;
-        f32x4_t v[LN_MAXC];
+        f32x4_t v[NC];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 v[i] = *reinterpret_cast<const f32x4_t*>(xr + 4 * c);
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float mean = wave_sum(s) * inv_w;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 const f32x4_t d = v[i] - mean;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         }
         const float rstd = rsqrtf(wave_sum(q) * inv_w + eps);
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 const f32x4_t g = *reinterpret_cast<const f32x4_t*>(gamma + 4 * c);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy * gamma;  dgamma += dy*xhat; dbeta += dy
-template <bool DY_F32>
+template <int NC, bool DY_F32>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, long x_stride,
                                                      const float* __restrict__ gamma,
                                                      const void* __restrict__ dy_,
@@ -66,22 +67,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int rows, int width,
                                                      float eps) {
-    __shared__ float red[4][64 * 4 * LN_MAXC];  // per wave staging for the column reduction (8 KB/wave)
+    __shared__ float red[4][64 * 4 * NC];  // per wave staging for the column reduction
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nchunk = width >> 2;
     const float inv_w = 1.0f / (float)width;
-    f32x4_t ag[LN_MAXC], ab[LN_MAXC];
+    f32x4_t ag[NC], ab[NC];
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         ag[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         ab[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     for (long row = (long)blockIdx.x * 4 + w; row < rows; row += (long)gridDim.x * 4) {
         const float* xr = x + row * x_stride;
-        f32x4_t v[LN_MAXC], d[LN_MAXC];
+        f32x4_t v[NC], d[NC];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 v[i] = *reinterpret_cast<const f32x4_t*>(xr + 4 * c);
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         const float mean = wave_sum(s) * inv_w;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 v[i] = v[i] - mean;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         const float rstd = rsqrtf(wave_sum(q) * inv_w + eps);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 v[i] = v[i] * rstd;  // xhat
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         }
         const float c1 = wave_sum(s1) * inv_w, c2 = wave_sum(s2) * inv_w;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 f32x4_t o = (d[i] - c1 - v[i] * c2) * rstd;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     float* mine = &red[w][0];
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) *reinterpret_cast<f32x4_t*>(mine + 4 * c) = pass ? ab[i] : ag[i];
         }
@@ -159,14 +160,40 @@ static inline int ln_grid(int rows) {
     return g > 2048 ? 2048 : (g < 1 ? 1 : g);
 }
 
+template <int NC>
+static void launch_ln_fwd(const float* x, long x_stride, const float* gamma, const float* beta, unsigned short* yb,
+                          float* yf, int rows, int width, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(ln_fwd_kernel<NC>, dim3(ln_grid(rows)), dim3(256), 0, st, x, x_stride, gamma, beta, yb, yf, rows,
+                       width, eps);
+}
+template <int NC, bool F32>
+static void launch_ln_bwd(const float* x, long x_stride, const float* gamma, const void* dy, const float* dres,
+                          float* dx, long dx_stride, unsigned short* dxb, float* dgamma, float* dbeta, int rows,
+                          int width, float eps, hipStream_t st) {
+    int g = ln_grid(rows);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL((ln_bwd_kernel<NC, F32>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
+                       dx_stride, dxb, dgamma, dbeta, rows, width, eps);
+}
+static inline int ln_nc(int width) {
+    const int c = (width / 4 + 63) / 64;
+    return c <= 2 ? 2 : (c == 3 ? 3 : (c == 4 ? 4 : 8));
+}
+
 extern "C" int uniir_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta,
                                    void* y_bf16, float* y_f32, int32_t rows, int32_t width, float eps,
                                    void* stream) {
     if (!x || !gamma || !beta || (!y_bf16 && !y_f32) || rows < 0) return UNIIR_EINVAL;
     if (rows == 0) return UNIIR_OK;
     if (width % 4 || width > 64 * 4 * LN_MAXC || width <= 0 || x_stride % 4) return UNIIR_ESHAPE;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, (long)x_stride,
-                       gamma, beta, (unsigned short*)y_bf16, y_f32, rows, width, eps);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* yb = (unsigned short*)y_bf16;
+    switch (ln_nc(width)) {
+        case 2: launch_ln_fwd<2>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st); break;
+        case 3: launch_ln_fwd<3>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st); break;
+        case 4: launch_ln_fwd<4>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st); break;
+        default: launch_ln_fwd<8>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st); break;
+    }
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -178,16 +205,20 @@ extern "C" int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float
     if (!x || !gamma || !dy || !dx_f32 || !dgamma || !dbeta || rows < 0) return UNIIR_EINVAL;
     if (rows == 0) return UNIIR_OK;
     if (width % 4 || width > 64 * 4 * LN_MAXC || width <= 0 || x_stride % 4 || dx_stride % 4) return UNIIR_ESHAPE;
-    int g = ln_grid(rows);
-    if (g > 1024) g = 1024;
-    if (dy_is_f32)
-        hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (long)x_stride,
-                           gamma, dy, dres, dx_f32, (long)dx_stride, (unsigned short*)dx_bf16, dgamma, dbeta,
-                           rows, width, eps);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (long)x_stride,
-                           gamma, dy, dres, dx_f32, (long)dx_stride, (unsigned short*)dx_bf16, dgamma, dbeta,
-                           rows, width, eps);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* dxb = (unsigned short*)dx_bf16;
+#define LNB(NC)                                                                                                   \
+    do {                                                                                                          \
+        if (dy_is_f32) launch_ln_bwd<NC, true>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, rows, width, eps, st); \
+        else launch_ln_bwd<NC, false>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, rows, width, eps, st);          \
+    } while (0)
+    switch (ln_nc(width)) {
+        case 2: LNB(2); break;
+        case 3: LNB(3); break;
+        case 4: LNB(4); break;
+        default: LNB(8); break;
+    }
+#undef LNB
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }

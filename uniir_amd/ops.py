@@ -26,6 +26,18 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(device, nbytes):
+    """one reusable scratch buffer per device for the split-K slabs (stream-ordered reuse)"""
+    ws = _SPLITK_WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 128 << 20), device=device, dtype=torch.uint8)
+        _SPLITK_WS[device] = ws
+    return ws
+
+
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epilogue=EPI_BF16, bias=None,
          resid=None, aux=None, ldaux=0, C2=None, act=ACT_QUICKGELU, k_splits=1, alpha=1.0, dtype=DT_BF16):
     d = GemmDesc()
@@ -37,6 +49,9 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epi
     d.lda, d.ldb, d.ldc, d.ldaux = lda, ldb, ldc, ldaux
     d.a_tmaj, d.b_tmaj = int(a_tmaj), int(b_tmaj)
     d.epilogue, d.act, d.dtype, d.k_splits, d.alpha = epilogue, act, dtype, k_splits, alpha
+    if k_splits > 1:
+        ws = _splitk_workspace(A.device, 4 * k_splits * M * N)
+        d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
     if GEMM_TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -68,17 +83,30 @@ def linear_dgrad(dy, w, *, out=None, aux=None, act=ACT_QUICKGELU):
                 aux=aux, ldaux=K, act=act)
 
 
+N_CU = 256  # MI355X compute units; the 256x256 GEMM kernel runs one workgroup per CU
+
+
 def wgrad_splits(rows, tiles):
-    """split-K factor for dW: aim at >= 1024 workgroups, each with >= 8 K steps of 64."""
-    s = max(1, min((1024 + tiles - 1) // tiles, max(1, rows // 512)))
-    return s
+    """split-K factor for dW (256x256 output tiles): make tiles*splits land just under a multiple of the CU count
+    (no nearly-empty last round) while every split keeps >= 16 K steps of 64 rows."""
+    max_s = max(1, rows // (64 * 16))
+    best, best_eff = 1, 0.0
+    for s in range(1, min(max_s, 64) + 1):
+        blocks = tiles * s
+        rounds = -(-blocks // N_CU)
+        eff = blocks / (rounds * N_CU)
+        if blocks >= 0.9 * N_CU and eff >= 0.9:
+            return s            # smallest split count that fills the chip (least slab traffic)
+        if eff > best_eff + 1e-9:
+            best, best_eff = s, eff
+    return best
 
 
 def linear_wgrad(dy, x, dw):
     """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]."""
     M, N = dy.shape
     K = x.shape[1]
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
     return gemm(dy, x, dw, N, K, M, N, K, K, a_tmaj=True, b_tmaj=True, epilogue=EPI_ATOMIC_F32,
                 k_splits=wgrad_splits(M, tiles))
 
