@@ -1,0 +1,98 @@
+"""CPU tests of the host-side mirrors (ids, sampler, recall, string formatting, config loader, collator, config
+updater) against the golden values captured from the reference (tests/golden/g9_host.json) and hand-made cases."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "uniir_amd", "src")
+for p in (SRC, os.path.join(SRC, "common")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+G9 = json.load(open(os.path.join(ROOT, "tests", "golden", "g9_host.json")))
+
+
+def test_id_hashing_matches_reference():
+    from data.preprocessing.utils import hash_did, hash_qid, unhash_did, unhash_qid
+    for c in G9["hash"]:
+        assert hash_qid(c["qid"]) == c["hq"] and unhash_qid(c["hq"]) == c["uq"]
+        assert hash_did(c["qid"]) == c["hd"] and unhash_did(c["hd"]) == c["ud"]
+
+
+def test_contiguous_sampler_matches_reference_partitions():
+    from dist_utils import ContiguousDistributedSampler
+    from uniir_amd import comm
+    for c in G9["sampler"]:
+        n, W = c["n"], c["W"]
+        for r in range(W):
+            got = list(iter(ContiguousDistributedSampler(list(range(n)), num_replicas=W, rank=r)))
+            assert got == c["parts"][r], (n, W, r)
+            lo, hi = comm.contiguous_shard(n, W, r)
+            assert list(range(lo, hi)) == c["parts"][r]
+
+
+def test_recall_and_format_string_match_reference():
+    from data.preprocessing.utils import format_string
+    from mbeir_retriever import compute_recall_at_k
+    for c in G9["recall"]:
+        assert compute_recall_at_k(c["rel"], c["ret"], c["k"]) == c["v"]
+    for c in G9["format"]:
+        assert format_string(c["in"]) == c["out"]
+
+
+def test_task_tables():
+    from data.preprocessing.utils import MBEIR_TASK, get_mbeir_task_id, get_mbeir_task_name
+    assert get_mbeir_task_id("image,text", "image") == 7 and get_mbeir_task_name(3) == "image -> text"
+    assert sorted(MBEIR_TASK.values()) == list(range(9))
+
+
+def test_config_loader_interpolation(tmp_path):
+    from config import OmegaConf
+    p = tmp_path / "c.yaml"
+    p.write_text('experiment:\n  instruct_status: "Instruct"\n  exp_name: "InBatch"\n'
+                 '  path_suffix: "${model.short_name}/${experiment.instruct_status}/${experiment.exp_name}/"\n'
+                 'model:\n  short_name: "CLIP_SF"\n  size: "Large"\n  dup: ${model.size}\nseed: 2023\n'
+                 'data_config:\n  image_size: 224, 224\n  enable_query_instruct: True\n')
+    c = OmegaConf.load(str(p))
+    assert c.experiment.path_suffix == "CLIP_SF/Instruct/InBatch/" and c.model.dup == "Large" and c.seed == 2023
+    c.uniir_dir = "/x"
+    c.dist_config = {"gpu_id": 0}
+    assert c.dist_config.gpu_id == 0 and "uniir_dir" in OmegaConf.to_yaml(c)
+    from config_updater import update_mbeir_yaml_instruct_status
+    update_mbeir_yaml_instruct_status(str(p), False)
+    c2 = OmegaConf.load(str(p))
+    assert c2.experiment.instruct_status == "NoInstruct" and c2.data_config.enable_query_instruct is False
+    assert c2.experiment.path_suffix == "CLIP_SF/NoInstruct/InBatch/"
+
+
+def test_main_collator_batch_abi():
+    """flat interleaved order [query, pos_cand(, negs)] per instance, index_mapping, masks, black image / empty text
+    padding (mbeir_dataset.py:427-434,483-498 of the reference)."""
+    from data.mbeir_dataset import MBEIRCandidatePoolCollator, MBEIRMainCollator, Mode
+    tok = lambda txts: torch.tensor([[len(t)] + [0] * 76 for t in txts], dtype=torch.int32)
+    img = torch.ones(3, 8, 8)
+    batch = [
+        {"query": {"txt": "q0", "img": None}, "pos_cand": {"txt": "", "img": img},
+         "neg_cand_list": [{"txt": "n0", "img": None}, {"txt": "n1", "img": img}], "p_did": 77},
+        {"query": {"txt": "q1", "img": img}, "pos_cand": {"txt": "p1", "img": None},
+         "neg_cand_list": [{"txt": "n2", "img": None}, {"txt": "n3", "img": None}], "p_did": 78},
+    ]
+    out = MBEIRMainCollator(tok, (8, 8), mode=Mode.TRAIN)(batch)
+    assert out["index_mapping"] == {"query": [[0], [4]], "pos_cand": [[1], [5]], "neg_cand_list": [[2, 3], [6, 7]]}
+    assert out["txt_mask_batched"].tolist() == [1, 0, 1, 1, 1, 1, 1, 1]
+    assert out["image_mask_batched"].tolist() == [0, 1, 0, 1, 1, 0, 0, 0]
+    assert out["image_batched"].shape == (8, 3, 8, 8) and out["image_batched"][0].abs().sum() == 0
+    assert out["txt_batched"][1, 0] == 0 and out["p_did_list"].tolist() == [77, 78]
+    pool = MBEIRCandidatePoolCollator(tok, 8)([{"txt": "a", "img": None, "did": 5}, {"txt": "", "img": img, "did": 6}])
+    assert pool["did_list"] == [5, 6] and pool["txt_mask_batched"].tolist() == [1, 0]
+
+
+def test_wgrad_split_heuristic_fills_the_chip():
+    from uniir_amd.ops import wgrad_splits
+    for tiles in (12, 16, 48, 64):
+        s = wgrad_splits(263168, tiles)
+        assert 0.9 * 256 <= tiles * s <= 256, (tiles, s)

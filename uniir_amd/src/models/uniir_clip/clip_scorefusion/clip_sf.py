@@ -23,6 +23,10 @@ class CLIPScoreFusion(nn.Module):
             self.gather_embeddings = config.model.gather_embeddings
             self.in_batch_neg_num = config.data_config.in_batch_neg_num
 
+    def zero_grad(self, set_to_none=False):
+        """gradients live in the CLIP module's flat buffer: zero it (they are never detached to None)"""
+        self.clip_model.zero_grad()
+
     def get_img_preprocess_fn(self):
         return self.img_preprocess_fn
 

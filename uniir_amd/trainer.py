@@ -1,31 +1,97 @@
-"""Native train step for the CLIP_SF in-batch contrastive path on MI355X.
+"""Native optimizer + train step for the CLIP_SF in-batch contrastive path on MI355X.
 
-Mirrors UniIR src/models/uniir_clip/engine.py:19-50 (train_one_epoch inner loop: forward, loss /
-accumulation_steps, backward, optimizer step every accumulation_steps, scheduler.step) and
-clip_scorefusion/train.py:52-61,195-199,281-284 (AdamW lr 1e-5 betas (0.9,0.98) eps 1e-6, wd 0 for gains/biases and
-0.2 for the rest, CosineAnnealingLR(T_max, eta_min=0)).  Differences, all result-preserving:
+Mirrors UniIR src/models/uniir_clip/engine.py:19-50 (forward, loss / accumulation_steps, backward, optimizer step every
+accumulation_steps, scheduler.step) and clip_scorefusion/train.py:52-61,195-199,281-284 (AdamW lr 1e-5 betas
+(0.9,0.98) eps 1e-6, weight decay 0 for gains / biases / logit_scale and 0.2 for the rest,
+CosineAnnealingLR(T_max, eta_min=0)).  Differences, all result-preserving:
   * bf16 MFMA compute needs no GradScaler (the reference's fp16 autocast does);
-  * gradients live in one flat fp32 buffer: DDP's bucketed all-reduce(mean) becomes one RCCL all-reduce(sum) of
-    that buffer and a 1/world factor folded into the fused AdamW kernel;
+  * gradients live in one flat fp32 buffer: DDP's bucketed all-reduce(mean) becomes one RCCL all-reduce(sum) of that
+    buffer with the 1/world factor folded into the fused AdamW kernel;
   * AdamW is one fused kernel per weight-decay group and refreshes the bf16 weight shadow in the same pass.
 """
 import math
 
 import torch
-import torch.distributed as dist
 
-from . import ops
+from . import comm, ops
+
+
+class NativeAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics over the CLIP module's flat parameter buffer (two groups: [0, split) without weight
+    decay, [split, total) with).  It is a real torch Optimizer (param_groups / lr schedulers / state_dict work)."""
+
+    def __init__(self, clip_model, lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2, allreduce=True):
+        self.clip = clip_model
+        from .clip_model import _is_no_decay
+        named = list(clip_model.named_parameters())
+        nd = [p for n, p in named if _is_no_decay(n, p)]
+        d = [p for n, p in named if not _is_no_decay(n, p)]
+        super().__init__([{"params": nd, "weight_decay": 0.0}, {"params": d, "weight_decay": weight_decay}],
+                         dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.allreduce = allreduce
+        self.m = self.v = None
+        self.opt_step = 0
+
+    def _buffers(self):
+        fl = self.clip._ensure_flat()
+        if self.m is None or self.m.numel() != fl["total"] or self.m.device != fl["p32"].device:
+            m, v = torch.zeros_like(fl["p32"]), torch.zeros_like(fl["p32"])
+            if self.m is not None and self.m.numel() == fl["total"]:
+                m.copy_(self.m)
+                v.copy_(self.v)
+            self.m, self.v = m, v
+        return fl
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        fl = self._buffers()
+        world = comm.world() if self.allreduce else 1
+        if world > 1:
+            comm.allreduce_sum_(fl["g32"])         # one RCCL all-reduce; the mean is folded into grad_scale
+        self.opt_step += 1
+        split, total = fl["split"], fl["total"]
+        for (lo, hi), group in zip(((0, split), (split, total)), self.param_groups):
+            if hi > lo:
+                b1, b2 = group["betas"]
+                ops.call("uniir_adamw_step", fl["p32"][lo:hi], fl["g32"][lo:hi], self.m[lo:hi], self.v[lo:hi],
+                         fl["w16"][lo:hi], hi - lo, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                         self.opt_step, 1.0 / world)
+        self.clip._refresh_conv()
+
+    def zero_grad(self, set_to_none=False):
+        self.clip._ensure_flat()
+        self.clip.zero_grad()
+
+    def state_dict(self):
+        return {"opt_step": self.opt_step, "exp_avg": self.m, "exp_avg_sq": self.v,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.opt_step = sd["opt_step"]
+        self.m, self.v = sd["exp_avg"], sd["exp_avg_sq"]
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
 
 
 class CosineLR:
-    def __init__(self, base_lr, t_total):
-        self.base_lr, self.t_total, self.step_count = base_lr, max(1, t_total), 0
+    """closed form of torch CosineAnnealingLR(T_max=t_total, eta_min=0) driving NativeAdamW.param_groups"""
 
-    def lr(self):
-        return self.base_lr * (1 + math.cos(math.pi * self.step_count / self.t_total)) / 2
+    def __init__(self, optimizer, t_total):
+        self.opt, self.t_total, self.step_count = optimizer, max(1, t_total), 0
+        self.base = [g["lr"] for g in optimizer.param_groups]
 
     def step(self):
         self.step_count += 1
+        for g, b in zip(self.opt.param_groups, self.base):
+            g["lr"] = b * (1 + math.cos(math.pi * self.step_count / self.t_total)) / 2
+
+    def state_dict(self):
+        return {"step_count": self.step_count, "base": self.base, "t_total": self.t_total}
+
+    def load_state_dict(self, sd):
+        self.step_count, self.base, self.t_total = sd["step_count"], sd["base"], sd["t_total"]
+        self.step_count -= 1
+        self.step()
 
 
 class NativeTrainer:
@@ -33,49 +99,21 @@ class NativeTrainer:
                  accumulation_steps=1):
         self.model = model
         self.clip = model.clip_model
-        self.betas, self.eps, self.wd = betas, eps, weight_decay
-        self.sched = CosineLR(lr, t_total)
+        self.opt = NativeAdamW(self.clip, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.sched = CosineLR(self.opt, t_total)
         self.accum = accumulation_steps
         self.micro = 0
-        self.opt_step = 0
-        self.m = self.v = None
-
-    def _state(self):
-        fl = self.clip._ensure_flat()
-        if self.m is None or self.m.numel() != fl["total"] or self.m.device != fl["p32"].device:
-            self.m = torch.zeros_like(fl["p32"])
-            self.v = torch.zeros_like(fl["p32"])
-        return fl
-
-    def zero_grad(self):
-        self.clip._ensure_flat()
-        self.clip.zero_grad()
-
-    def optimizer_step(self):
-        fl = self._state()
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        if world > 1:
-            dist.all_reduce(fl["g32"], op=dist.ReduceOp.SUM)   # RCCL; mean is folded into grad_scale below
-        self.opt_step += 1
-        lr = self.sched.lr()
-        split, total = fl["split"], fl["total"]
-        gs = 1.0 / world
-        for lo, hi, wd in ((0, split, 0.0), (split, total, self.wd)):
-            if hi > lo:
-                ops.call("uniir_adamw_step", fl["p32"][lo:hi], fl["g32"][lo:hi], self.m[lo:hi], self.v[lo:hi],
-                         fl["w16"][lo:hi], hi - lo, lr, self.betas[0], self.betas[1], self.eps, wd, self.opt_step, gs)
-        self.clip._refresh_conv()
-        self.sched.step()
 
     def train_step(self, batch):
         """one micro-batch: returns the reference's outputs dict (loss un-scaled, as logged by engine.py:48)."""
         if self.micro == 0:
-            self.zero_grad()
+            self.opt.zero_grad()
         self.model.train()
         out = self.model(batch)
         (out["loss"] / self.accum).backward()
         self.micro += 1
         if self.micro == self.accum:
-            self.optimizer_step()
+            self.opt.step()
+            self.sched.step()
             self.micro = 0
         return out
