@@ -1,0 +1,82 @@
+"""world_size-2 gloo tests (CPU) of the N>1 exchange steps in uniir_amd/comm.py, the only collectives the path has:
+all-gather of p (rank-major) with its reduce-scatter backward, the target offsets, the flat-gradient mean, the
+top-k gather + merge inputs and the contiguous sharding.  The math between the collectives is the oracle's (the HIP
+kernels cannot run here); the expected values are the golden G2 vectors captured from the REFERENCE running under 2
+gloo ranks (tests/golden/g2_infonce_w2.npz)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+class _GatherFn(torch.autograd.Function):
+    """same comm calls as uniir_amd.losses.InBatchNCEFn (all_gather_rows fwd / reduce_scatter_rows bwd)"""
+
+    @staticmethod
+    def forward(ctx, p):
+        from uniir_amd import comm
+        ctx.b = p.shape[0]
+        return comm.all_gather_rows(p)
+
+    @staticmethod
+    def backward(ctx, d_all):
+        from uniir_amd import comm
+        return comm.reduce_scatter_rows(d_all.contiguous(), ctx.b)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import clip_oracle as O
+    from uniir_amd import comm
+    d = np.load(os.path.join(G, "g2_infonce_w2.npz"))
+    txt = torch.tensor(d[f"r{rank}_txt"], requires_grad=True)
+    img = torch.tensor(d[f"r{rank}_img"], requires_grad=True)
+    emb = img + txt
+    b = emb.shape[0] // 2
+    im = {"query": [[2 * i] for i in range(b)], "pos_cand": [[2 * i + 1] for i in range(b)]}
+    out = O.inbatch_contrastive_loss(emb, im, torch.tensor(float(np.exp(np.log(1 / 0.07)))), gather=_GatherFn.apply,
+                                     rank=comm.rank())
+    out["loss"].backward()
+    res = {"loss": out["loss"].item(), "acc": out["accuracy"].item(), "score": out["score"].detach().numpy(),
+           "dtxt": txt.grad.numpy(), "toff": comm.target_offset(b)}
+    # flat gradient mean (DDP semantics) through allreduce_sum_ + 1/world
+    flat = torch.full((5,), float(rank + 1))
+    comm.allreduce_sum_(flat)
+    res["flat"] = (flat / comm.world()).numpy()
+    # top-k gather
+    s, i = comm.gather_topk(torch.full((3, 2), float(rank)), torch.full((3, 2), rank, dtype=torch.int64))
+    res["gs"], res["gi"] = s.numpy(), i.numpy()
+    res["shard"] = comm.contiguous_shard(9)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_matches_reference_golden():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29533, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    d = np.load(os.path.join(G, "g2_infonce_w2.npz"))
+    for r in range(2):
+        assert abs(res[r]["loss"] - float(d[f"r{r}_loss"])) < 1e-5
+        assert res[r]["acc"] == float(d[f"r{r}_acc"])
+        assert np.abs(res[r]["score"] - d[f"r{r}_score"]).max() < 1e-4
+        assert np.abs(res[r]["dtxt"] - d[f"r{r}_dtxt"]).max() < 1e-5      # includes the reduce-scatter backward
+        assert res[r]["toff"] == r * 6
+        assert np.allclose(res[r]["flat"], 1.5)
+        assert res[r]["gs"].shape == (2, 3, 2) and res[r]["gi"][1, 0, 0] == 1
+    assert res[0]["shard"] == (0, 5) and res[1]["shard"] == (5, 9)

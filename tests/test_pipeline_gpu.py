@@ -1,0 +1,189 @@
+"""End-to-end drop-in check on a tiny synthetic M-BEIR tree (authored here, format per SURVEY.md section 5.6):
+train.py main() -> checkpoint -> mbeir_embedder main() -> create_index -> run_retrieval, all through the host mirrors
+under uniir_amd/src and the HIP path; retrieval output is compared with the C oracle on the saved embeddings."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "uniir_amd", "src")
+for p in (ROOT, SRC, os.path.join(SRC, "common")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _toy_tokenize(texts, context_length=77, truncate=True):
+    out = torch.zeros(len(texts), context_length, dtype=torch.int32)
+    for i, t in enumerate(texts):
+        ids = [510] + [1 + (sum(map(ord, w)) % 500) for w in t.split()][: context_length - 2] + [511]
+        out[i, : len(ids)] = torch.tensor(ids, dtype=torch.int32)
+    return out
+
+
+def _make_tree(root, n_cand=24, n_query=12):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    os.makedirs(os.path.join(root, "img"), exist_ok=True)
+    for sub in ("train", "val", "cand_pool", "instructions", "qrels/val"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    words = ["red", "blue", "dog", "cat", "tree", "car", "river", "house", "bird", "stone", "cloud", "road"]
+    cands = []
+    for i in range(n_cand):
+        rec = {"did": f"9:{i + 1}", "modality": "image,text" if i % 3 == 0 else ("image" if i % 3 == 1 else "text"),
+               "txt": None, "img_path": None}
+        if i % 3 != 1:
+            rec["txt"] = " ".join(rng.choice(words, 4))
+        if i % 3 != 2:
+            path = f"img/c{i}.png"
+            Image.fromarray(rng.integers(0, 255, (40, 52, 3), dtype=np.uint8)).save(os.path.join(root, path))
+            rec["img_path"] = path
+        cands.append(rec)
+    with open(os.path.join(root, "cand_pool", "mbeir_toy_cand_pool.jsonl"), "w") as f:
+        for c in cands:
+            f.write(json.dumps(c) + "\n")
+    qrels = []
+    for split in ("train", "val"):
+        with open(os.path.join(root, split, f"mbeir_toy_{split}.jsonl"), "w") as f:
+            for i in range(n_query):
+                pos = cands[(2 * i) % n_cand]
+                q = {"qid": f"9:{i + 1}", "query_txt": " ".join(rng.choice(words, 3)), "query_img_path": None,
+                     "query_modality": "text", "pos_cand_list": [pos["did"]], "neg_cand_list": []}
+                f.write(json.dumps(q) + "\n")
+                if split == "val":
+                    task = {"image": 0, "text": 1, "image,text": 2}[pos["modality"]]
+                    qrels.append(f"{q['qid']} 0 {pos['did']} 1 {task}")
+    with open(os.path.join(root, "qrels", "val", "mbeir_toy_val_qrels.txt"), "w") as f:
+        f.write("\n".join(qrels) + "\n")
+    with open(os.path.join(root, "instructions", "query_instructions.tsv"), "w") as f:
+        f.write("query_modality\tcand_modality\tdataset_name\tdataset_id\tprompt_1\tprompt_2\n")
+        for cm in ("image", "text", "image,text"):
+            f.write(f"text\t{cm}\tToy\t9\tfind a matching {cm.replace(',', ' and ')}\tretrieve the item\n")
+
+
+def _configs(tmp, uniir_dir):
+    common = f"""
+experiment: {{instruct_status: "Instruct", exp_name: "InBatch", description: "toy", path_suffix: "${{model.short_name}}/${{experiment.instruct_status}}/"}}
+model:
+  name: "CLIPScoreFusion"
+  short_name: "CLIP_SF"
+  size: "Tiny"
+  clip_vision_model_name: "tiny-test"
+  pretrained_clip_model_dir: "checkpoint/CLIP/"
+  gather_embeddings: True
+  ckpt_config: {{ckpt_dir: "checkpoint/toy/", resume_training: False, ckpt_name: "clip_sf_epoch_0.pth"}}
+seed: 2023
+dist_config: {{dist_url: "env://"}}
+"""
+    train = common + """
+logger_config: {logger_out_dir: "logger/toy", logger_out_file_name: "train.log"}
+data_config:
+  image_size: 64, 64
+  hard_neg_num: 0
+  in_batch_neg_num: 0
+  shuffle_cand: True
+  returns: null
+  enable_query_instruct: True
+  query_instruct_path: instructions/query_instructions.tsv
+  train_query_data_path: train/mbeir_toy_train.jsonl
+  train_cand_pool_path: cand_pool/mbeir_toy_cand_pool.jsonl
+  val_query_data_path: val/mbeir_toy_val.jsonl
+  val_cand_pool_path: cand_pool/mbeir_toy_cand_pool.jsonl
+dataloader_config: {num_workers: 0, train_batch_size: 4, valid_batch_size: 4}
+trainer_config: {gradient_accumulation_steps: 1, num_train_epochs: 1, learning_rate: 1e-4, warmup_steps: 0, eval_steps: 1, print_freq: 1}
+evaluator: {enable_eval: True, eval_freq: 1, print_freq: 1}
+"""
+    embed = common + """
+embed_config:
+  embed_dir_name: "embed"
+  use_fp16: True
+  val_datasets_config: {enable_embed: True, datasets_name: ["toy"], correspond_cand_pools_name: ["toy"]}
+  cand_pools_config: {enable_embed: True, embed_union_pool: False, cand_pools_name_to_embed: ["toy"]}
+dataloader_config: {num_workers: 0, batch_size: 5}
+data_config:
+  image_size: 64, 64
+  shuffle_cand: False
+  enable_query_instruct: True
+  train_dir_name: "train"
+  val_dir_name: "val"
+  test_dir_name: "test"
+  cand_pool_dir_name: "cand_pool"
+  query_instruct_path: instructions/query_instructions.tsv
+"""
+    index = common + """
+index_config:
+  faiss_config: {idx_type: Flat, dim: 64, metric: METRIC_INNER_PRODUCT}
+  embed_dir_name: "embed"
+  index_dir_name: "index"
+  cand_pools_config: {enable_idx: True, cand_pools_name_to_idx: ["toy"]}
+"""
+    retrieval = common + """
+retrieval_config:
+  embed_dir_name: "embed"
+  index_dir_name: "index"
+  results_dir_name: "retrieval_results"
+  qrel_dir_name: "qrels"
+  write_to_tsv: True
+  raw_retrieval: False
+  val_datasets_config:
+    enable_retrieve: True
+    datasets_name: ["toy"]
+    correspond_cand_pools_name: ["toy"]
+    correspond_qrels_name: ["toy"]
+    correspond_metrics_name: ["Recall@1, Recall@5, Recall@10"]
+"""
+    paths = {}
+    for name, txt in dict(train=train, embed=embed, index=index, retrieval=retrieval).items():
+        paths[name] = os.path.join(tmp, f"{name}.yaml")
+        with open(paths[name], "w") as f:
+            f.write(txt)
+    return paths
+
+
+def test_train_embed_index_retrieve_pipeline(tmp_path):
+    from oracle import c_oracle
+    from oracle import clip_oracle as O
+    from uniir_amd import clip_front, clip_model
+    from config import OmegaConf
+    clip_model.CLIP_CONFIGS["tiny-test"] = O.tiny_config()
+    clip_front.tokenize = _toy_tokenize
+    data_dir, uniir_dir = str(tmp_path / "mbeir"), str(tmp_path / "uniir")
+    _make_tree(data_dir)
+    cfgs = _configs(str(tmp_path), uniir_dir)
+
+    def load(name):
+        c = OmegaConf.load(cfgs[name])
+        c.uniir_dir, c.mbeir_data_dir = uniir_dir, data_dir
+        c.dist_config.gpu_id, c.dist_config.distributed_mode = 0, False
+        return c
+
+    from models.uniir_clip.clip_scorefusion import train as train_mod
+    train_mod.main(load("train"))
+    ckpt = os.path.join(uniir_dir, "checkpoint/toy/clip_sf_epoch_0.pth")
+    sd = torch.load(ckpt, map_location="cpu")
+    assert set(sd) >= {"model", "optimizer", "scheduler", "config", "epoch", "scaler"}
+    assert "clip_model.visual.transformer.resblocks.0.attn.in_proj_weight" in sd["model"]
+
+    import mbeir_embedder
+    import mbeir_retriever
+    mbeir_embedder.main(load("embed"))
+    base = os.path.join(uniir_dir, "embed", "CLIP_SF/Instruct")
+    cemb = np.load(os.path.join(base, "cand_pool", "mbeir_toy_cand_pool_embed.npy"))
+    cids = np.load(os.path.join(base, "cand_pool", "mbeir_toy_cand_pool_ids.npy"))
+    qemb = np.load(os.path.join(base, "val", "mbeir_toy_val_embed.npy"))
+    assert cemb.dtype == np.float16 and cemb.shape == (24, 64) and qemb.shape == (12, 64)
+    assert cids.tolist() == [9 * 10_000_000 + i + 1 for i in range(24)]
+    mbeir_retriever.create_index(load("index"))
+    results = mbeir_retriever.run_retrieval(load("retrieval"), None)
+    assert results and all(0.0 <= r["Recall@10"] <= 1.0 for r in results)
+    run = os.path.join(uniir_dir, "retrieval_results", "CLIP_SF/Instruct", "run_files", "mbeir_toy_single_pool_val_k10_run.txt")
+    lines = open(run).read().strip().split("\n")
+    assert len(lines) == 12 * 10 and lines[0].split()[1] == "Q0"
+    # retrieved ids == the C oracle's exact top-10 on the saved embeddings
+    want_s, want_i = c_oracle.topk(cemb, cids, qemb, 10)
+    got = np.array([[9 * 10_000_000 + int(l.split()[2].split(":")[1]) for l in lines[q * 10:(q + 1) * 10]] for q in range(12)])
+    assert np.array_equal(got, want_i)

@@ -59,11 +59,12 @@ def gather_topk(scores, ids):
     W = world()
     if W == 1:
         return scores.unsqueeze(0), ids.unsqueeze(0)
-    s = torch.empty((W,) + tuple(scores.shape), device=scores.device, dtype=scores.dtype)
-    i = torch.empty((W,) + tuple(ids.shape), device=ids.device, dtype=ids.dtype)
+    q, k = scores.shape
+    s = torch.empty(W * q, k, device=scores.device, dtype=scores.dtype)      # concatenation form (works on gloo too)
+    i = torch.empty(W * q, k, device=ids.device, dtype=ids.dtype)
     dist.all_gather_into_tensor(s, scores.contiguous())
     dist.all_gather_into_tensor(i, ids.contiguous())
-    return s, i
+    return s.view(W, q, k), i.view(W, q, k)
 
 
 def contiguous_shard(n, W=None, r=None):

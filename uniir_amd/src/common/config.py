@@ -6,6 +6,7 @@ import re
 import yaml
 
 _PAT = re.compile(r"\$\{([^}]+)\}")
+_SCI = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)[eE][+-]?\d+$")   # "1e-5": a float for OmegaConf, a string for YAML 1.1
 
 
 class Config(dict):
@@ -67,6 +68,8 @@ def _resolve(root, node, depth=0):
         if m:  # whole value is one reference: keep the referenced type
             return _resolve(root, _lookup(root, m.group(1)), depth + 1)
         return _resolve(root, _PAT.sub(lambda mm: str(_lookup(root, mm.group(1))), node), depth + 1)
+    if isinstance(node, str) and _SCI.match(node.strip()):
+        return float(node)
     return node
 
 
