@@ -116,14 +116,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const unsigned sh
         float m_run = -1e30f, l_run = 0.f;
         const int kmax = causal ? min(T, q0 + 16) : T;
         const int nkb = (kmax + 31) >> 5;
+        f32x4_t sn[2];   // S^T of the NEXT key block, computed one iteration ahead so its MFMAs overlap this softmax
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            sn[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) sn[kt] = mfma16(frag_rows(ldsK, kt * 16, s, lane), qf[s], sn[kt]);
+        }
         for (int kb = 0; kb < nkb; ++kb) {
-            f32x4_t st[2];
+            f32x4_t st[2] = {sn[0], sn[1]};
+            if (kb + 1 < nkb) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                st[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int kt = 0; kt < 2; ++kt) {
+                    sn[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    st[kt] = mfma16(frag_rows(ldsK, kb * 32 + kt * 16, s, lane), qf[s], st[kt]);
+                    for (int s = 0; s < 2; ++s)
+                        sn[kt] = mfma16(frag_rows(ldsK, (kb + 1) * 32 + kt * 16, s, lane), qf[s], sn[kt]);
+                }
             }
             float mx = -1e30f;
 #pragma unroll
@@ -138,13 +147,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const unsigned sh
                 }
             mx = group_max(mx);
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = (st[kt][r] <= -1e29f) ? 0.f : exp2f(st[kt][r] - m_new);
+                    const float p = (st[kt][r] <= -1e29f) ? 0.f : __builtin_amdgcn_exp2f(st[kt][r] - m_new);
                     st[kt][r] = p;
                     sum += p;
                 }
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const unsigned sh
 
 // Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
 // Phase 2 (per 16-query tile): dQ^T += K^T dS^T with S^T = K Q^T oriented [key][q].
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                        const unsigned short* __restrict__ out,
                                                        const unsigned short* __restrict__ dout,
                                                        const float* __restrict__ lse,
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const unsigned sh
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = qb * 32 + qt * 16 + 4 * g + r;
-                    float p = exp2f(sa[r] * SCALE_LOG2E - lse2[q]);
+                    float p = __builtin_amdgcn_exp2f(sa[r] * SCALE_LOG2E - lse2[q]);
                     if (causal && key > q) p = 0.f;
                     pt[qt][r] = p;
                     dst[qt][r] = p * (dp[r] - Dq[q]);
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const unsigned sh
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb * 32 + kt * 16 + 4 * g + r;
-                    float p = exp2f(sa[r] * SCALE_LOG2E - my_lse);
+                    float p = __builtin_amdgcn_exp2f(sa[r] * SCALE_LOG2E - my_lse);
                     if (key >= T || (causal && key > q)) p = 0.f;
                     dst[kt][r] = p * (dp[r] - my_D);
                 }

@@ -142,22 +142,115 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
     gemm_epilogue_dispatch<4, 4>(p, acc, m0, n0, (w >> 1) * 64, (w & 1) * 64);
 }
 
-// 256x256x64 tile, 8 waves, LDS-DMA staging (gemm_core256.h).  Used when K % 64 == 0.
-template <typename Elem, bool A_TMAJ, bool B_TMAJ>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmKArgs p) {
+// Epilogue of the 256x256 (8-wave) tile staged through LDS so that every global access is a full 16-B-per-lane,
+// row-contiguous transaction (the MFMA fragment layout alone gives 32-B pieces at a row stride).  The main loop's
+// 128 KiB of LDS are free at this point.
+//   bf16 outputs (EPI_BF16, EPI_BIAS_ACT): one pass, image [256][256] bf16, 16-B chunk index ^= (row & 7)
+//   fp32 math on the way out (EPI_RESID_F32, EPI_DACT, EPI_F32 / split-K slabs): two passes of 128 rows,
+//   image [128][256] f32, 16-B chunk index ^= (row & 7)
+DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int m0, int n0, int wm, int wn,
+                               char* lds, int epi) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int li = lane & 15, lg = lane >> 4;
+    if (epi == UNIIR_EPI_BF16 || epi == UNIIR_EPI_BIAS_ACT) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ml = wm + i * 16 + li;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nl = wn + j * 16 + 4 * lg;
+                f32x4_t v = acc[i][j] * p.alpha;
+                if (p.bias && n0 + nl < p.N) v += *reinterpret_cast<const f32x4_t*>(p.bias + n0 + nl);
+                const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2_t*>(lds + ml * 512 + ((((nl >> 3) ^ (ml & 7))) << 4) + ((nl & 7) << 1)) = o;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int c = it * 512 + tid;
+            const int row = c >> 5, ch = c & 31;
+            const int m = m0 + row, n = n0 + ch * 8;
+            if (m < p.M && n < p.N) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(lds + row * 512 + ((ch ^ (row & 7)) << 4));
+                const long off = (long)m * p.ldc + n;
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>((unsigned short*)p.C + off));
+                if (epi == UNIIR_EPI_BIAS_ACT) {
+                    u32x4_t g;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        g[e] = pack_bf16x2(act_fwd(__uint_as_float(v[e] << 16), p.act),
+                                           act_fwd(__uint_as_float(v[e] & 0xffff0000u), p.act));
+                    *reinterpret_cast<u32x4_t*>((unsigned short*)p.C2 + off) = g;
+                }
+            }
+        }
+        return;
+    }
+    // fp32 staging, two passes of 128 rows (the waves with wm == 128*h write in pass h)
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+        if (wm == 128 * h) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ml = i * 16 + li;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nl = wn + j * 16 + 4 * lg;
+                    f32x4_t v = acc[i][j] * p.alpha;
+                    if (p.bias && n0 + nl < p.N) v += *reinterpret_cast<const f32x4_t*>(p.bias + n0 + nl);
+                    *reinterpret_cast<f32x4_t*>(lds + ml * 1024 + ((((nl >> 2) ^ (ml & 7))) << 4)) = v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int c = it * 512 + tid;
+            const int row = c >> 6, ch = c & 63;
+            const int m = m0 + 128 * h + row, n = n0 + ch * 4;
+            if (m < p.M && n < p.N) {
+                f32x4_t v = *reinterpret_cast<const f32x4_t*>(lds + row * 1024 + ((ch ^ (row & 7)) << 4));
+                const long off = (long)m * p.ldc + n;
+                if (epi == UNIIR_EPI_RESID_F32) {
+                    if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
+                    *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
+                    if (p.C2) {
+                        const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o;
+                    }
+                } else if (epi == UNIIR_EPI_DACT) {
+                    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + (long)m * p.ldaux + n);
+                    const float f0 = __uint_as_float(a[0] << 16), f1 = __uint_as_float(a[0] & 0xffff0000u);
+                    const float f2 = __uint_as_float(a[1] << 16), f3 = __uint_as_float(a[1] & 0xffff0000u);
+                    const u32x2_t o = {pack_bf16x2(v[0] * act_bwd(f0, p.act), v[1] * act_bwd(f1, p.act)),
+                                       pack_bf16x2(v[2] * act_bwd(f2, p.act), v[3] * act_bwd(f3, p.act))};
+                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+                } else {  // UNIIR_EPI_F32 (also the split-K slabs)
+                    *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
+                }
+            }
+        }
+    }
+}
+
+// LDS-DMA GEMM (gemm_core256.h): block tile (128*WM) x (64*WN), K step BK.  Used when K % BK == 0.
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, int WM, int WN, int BK>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_glds_kernel(GemmKArgs p) {
+    using S = GldsShape<WM, WN, BK>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = p.tiles_m * p.tiles_n;
     const int split = id / tiles;
     id -= split * tiles;
     const int mt = id / p.tiles_n, nt = id - mt * p.tiles_n;
-    const int m0 = mt * G256_BM, n0 = nt * G256_BN;
+    const int m0 = mt * S::BM, n0 = nt * S::BN;
     int kbeg = 0, kend = p.K;
     if (p.k_splits > 1) {
-        const int ksteps = p.K / G256_BK;
+        const int ksteps = p.K / BK;
         const int per = (ksteps + p.k_splits - 1) / p.k_splits;
-        kbeg = split * per * G256_BK;
-        kend = min(p.K, (split + 1) * per * G256_BK);
+        kbeg = split * per * BK;
+        kend = min(p.K, (split + 1) * per * BK);
         if (kbeg >= kend) return;
     }
     f32x4_t acc[8][4];
@@ -165,58 +258,75 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmKArgs p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    g256_mainloop<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
+    glds_mainloop<Elem, A_TMAJ, B_TMAJ, WM, WN, BK>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
     const int w = threadIdx.x >> 6;
+    const int wm = (w / WN) * 128, wn = (w % WN) * 64;
+    if (WM * WN == 8) {   // 256x256 tile: LDS-staged, fully coalesced epilogue
+        if (p.slab) {
+            GemmKArgs q = p;
+            q.C = p.slab + (long)split * p.M * p.N;
+            q.ldc = p.N;
+            q.bias = nullptr;
+            epilogue256_staged(q, acc, m0, n0, wm, wn, lds, UNIIR_EPI_F32);
+        } else if (p.epilogue == UNIIR_EPI_ATOMIC_F32) {
+            gemm_epilogue<UNIIR_EPI_ATOMIC_F32, 8, 4>(p, acc, m0, n0, wm, wn);
+        } else {
+            epilogue256_staged(p, acc, m0, n0, wm, wn, lds, p.epilogue);
+        }
+        return;
+    }
     if (p.slab) {
         GemmKArgs q = p;
         q.C = p.slab + (long)split * p.M * p.N;
         q.ldc = p.N;
         q.bias = nullptr;
-        gemm_epilogue<UNIIR_EPI_F32, 8, 4>(q, acc, m0, n0, (w >> 2) * 128, (w & 3) * 64);
+        gemm_epilogue<UNIIR_EPI_F32, 8, 4>(q, acc, m0, n0, wm, wn);
         return;
     }
-    gemm_epilogue_dispatch<8, 4>(p, acc, m0, n0, (w >> 2) * 128, (w & 3) * 64);
+    gemm_epilogue_dispatch<8, 4>(p, acc, m0, n0, wm, wn);
 }
 
-template <typename Elem>
-static int launch_gemm256(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
-    a.tiles_m = (a.M + G256_BM - 1) / G256_BM;
-    a.tiles_n = (a.N + G256_BN - 1) / G256_BN;
+template <typename Elem, int WM, int WN, int BK>
+static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
+    using S = GldsShape<WM, WN, BK>;
+    a.tiles_m = (a.M + S::BM - 1) / S::BM;
+    a.tiles_n = (a.N + S::BN - 1) / S::BN;
     const int grid = a.tiles_m * a.tiles_n * a.k_splits;
-    dim3 g(grid), b(512);
-    const size_t sm = G256_LDS_BYTES;
-#define LAUNCH256(AT, BT)                                                                         \
+    dim3 g(grid), b(S::T);
+    const size_t sm = S::LDS_BYTES;
+#define LAUNCHG(AT, BT)                                                                           \
     do {                                                                                          \
         static bool attr_set = false;                                                             \
         if (!attr_set) {                                                                          \
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<Elem, AT, BT>,                  \
+            (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<Elem, AT, BT, WM, WN, BK>,    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);       \
             attr_set = true;                                                                      \
         }                                                                                         \
-        hipLaunchKernelGGL((gemm256_kernel<Elem, AT, BT>), g, b, sm, st, a);                      \
+        hipLaunchKernelGGL((gemm_glds_kernel<Elem, AT, BT, WM, WN, BK>), g, b, sm, st, a);        \
     } while (0)
-    if (!a_tmaj && !b_tmaj) LAUNCH256(false, false);
-    else if (!a_tmaj && b_tmaj) LAUNCH256(false, true);
-    else if (a_tmaj && !b_tmaj) LAUNCH256(true, false);
-    else LAUNCH256(true, true);
-#undef LAUNCH256
+    if (!a_tmaj && !b_tmaj) LAUNCHG(false, false);
+    else if (!a_tmaj && b_tmaj) LAUNCHG(false, true);
+    else if (a_tmaj && !b_tmaj) LAUNCHG(true, false);
+    else LAUNCHG(true, true);
+#undef LAUNCHG
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
 
-static bool use_256(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
-    static const char* force = getenv("UNIIR_GEMM_TILE");
-    if (force && force[0] == '1') return false;             // UNIIR_GEMM_TILE=128 forces the general kernel
-    if (a.K % G256_BK) return false;
-    if (a.M < 256 || a.N < 128) return false;               // small problems: the 128-tile kernel fills the chip better
-    if (a_tmaj && a.M < 8) return false;
-    if (b_tmaj && a.N < 8) return false;
-    return true;
+// shape choice: 0 = general 128x128 register-staged kernel, 1 = 256x256x64 (1 workgroup / CU), 2 = 256x128x32 (2-3 / CU)
+static int gemm_shape(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
+    static const char* force = getenv("UNIIR_GEMM_SHAPE");
+    if (a.K % 64) return 0;
+    if (a.M < 256 || a.N < 128) return 0;    // small problems: the 128-tile kernel fills the chip better
+    if (force && force[0] >= '0' && force[0] <= '2') return force[0] - '0';
+    return 1;
 }
 
 template <typename Elem>
 static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t st) {
-    if (use_256(a, a_tmaj, b_tmaj)) return launch_gemm256<Elem>(a, a_tmaj, b_tmaj, st);
+    const int shape = gemm_shape(a, a_tmaj, b_tmaj);
+    if (shape == 1) return launch_glds<Elem, 2, 4, 64>(a, a_tmaj, b_tmaj, st);
+    if (shape == 2) return launch_glds<Elem, 2, 2, 32>(a, a_tmaj, b_tmaj, st);
     const int grid = a.tiles_m * a.tiles_n * a.k_splits;
     dim3 g(grid), b(256);
     const size_t sm = GEMM_LDS_BYTES;
@@ -285,7 +395,7 @@ extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (d->k_splits > 1) {
         // never leave a split empty (an empty split would leave its slab unwritten)
-        const int bk = use_256(a, d->a_tmaj, d->b_tmaj) ? G256_BK : GEMM_BK;
+        const int bk = GEMM_BK;  // 64: every kernel shape splits K on multiples of 64
         const int ksteps = (d->K + bk - 1) / bk;
         int splits = d->k_splits > ksteps ? ksteps : d->k_splits;
         const int per = (ksteps + splits - 1) / splits;

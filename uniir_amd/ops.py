@@ -11,7 +11,9 @@ from ._lib import GemmDesc, check
 EPI_BF16, EPI_BIAS_ACT, EPI_RESID_F32, EPI_DACT, EPI_F32, EPI_ATOMIC_F32 = range(6)
 ACT_QUICKGELU, ACT_GELU_ERF, ACT_RELU = range(3)
 DT_BF16, DT_F16 = 0, 1
-GEMM_TIMING = None  # bench.py sets this to a list to collect (flops, start_event, end_event) per GEMM launch
+GEMM_TIMING = None  # bench.py sets this to a list to collect (flops, start_event, end_event) of sampled GEMM launches
+GEMM_TIMING_STRIDE = 17   # HIP events around every launch would stall the queue (~50 us each): sample 1 in 17
+_GEMM_COUNTER = [0]
 
 
 def _stream():
@@ -52,7 +54,8 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epi
     if k_splits > 1:
         ws = _splitk_workspace(A.device, 4 * k_splits * M * N)
         d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
-    if GEMM_TIMING is not None:
+    _GEMM_COUNTER[0] += 1
+    if GEMM_TIMING is not None and _GEMM_COUNTER[0] % GEMM_TIMING_STRIDE == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(_lib.load().uniir_gemm(C.byref(d), _stream()), "gemm")
