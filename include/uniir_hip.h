@@ -190,17 +190,19 @@ int uniir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
  * [TOPK] exact brute-force inner-product top-k over an fp16 pool (FAISS "IDMap,Flat" + normalize_L2).
  *   uniir_pool_inv_norms: inv[i] = 1/sqrt(sum_j x[i][j]^2) in the oracle's summation order
  *                         (sequential fp32, no fma), 0 for an all-zero row (FAISS leaves it untouched).
- *   uniir_topk_coarse:    MFMA fp16 scan, per query the best kc candidates of pool rows [row_begin,
- *                         row_begin+rows) by approximate score; kc >= k, kc <= 64.
+ *   uniir_topk_coarse:    MFMA fp16 scan; per query a shortlist of uniir_topk_ncand(nq, kc) pool rows that is
+ *                         guaranteed to contain the kc best by approximate score; kc >= k, kc <= 64.
  *   uniir_topk_rescore:   exact fp32 re-score of a shortlist in the oracle's summation order, sort by
  *                         (score desc, id asc), keep k.  exact_ws: nq*ncand floats of scratch.
  * Layouts: pool fp16 [n][dim] (dim % 64 == 0), queries fp16 [nq][dim] as stored by the embedder
- * (un-normalised), ids int64 [n].  Outputs: cand_idx int32 [nq][kc] pool-row indices (-1 = empty),
+ * (un-normalised), ids int64 [n].  Outputs: cand_idx int32 [nq][ncand] pool-row indices (-1 = empty),
  * out_scores f32 [nq][k] descending, out_ids int64 [nq][k] (-1 padded like FAISS).
  * workspace: uniir_topk_workspace_bytes(nq, kc) bytes.
  * ---------------------------------------------------------------------------------------------- */
 int uniir_pool_inv_norms(const void* x_f16, int64_t n, int32_t dim, float* inv_norm, void* stream);
 int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t rows);
+/* candidates per query that uniir_topk_coarse writes into cand_idx (group path: 2*kc groups of 16 rows) */
+int32_t uniir_topk_ncand(int32_t nq, int32_t kc);
 int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_norm, int64_t rows, int32_t dim,
                       const void* queries_f16, int32_t nq, int32_t kc, int32_t* cand_idx,
                       float* cand_score, void* workspace, int64_t workspace_bytes, void* stream);

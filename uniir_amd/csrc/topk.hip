@@ -8,10 +8,13 @@
 //   rescore: the shortlist is re-scored in fp32 in the oracle's exact summation order (sequential, no fma;
 //            oracle/topk_oracle.c) and sorted by (score desc, id asc) -> bit-exact distances, identical ids.
 #include "gemm_core.h"
+#include "gemm_core256.h"
 #include "../../include/uniir_hip.h"
+#include <stdlib.h>
 
-#define TK_QT 128        // queries per block tile (GEMM M)
-#define TK_CAP 256       // candidate buffer entries per (block, query)
+#define TK_QT 128        // queries per block tile (GEMM N)
+#define TK_CT 256        // candidates per MFMA tile (GEMM M): pool rows stream through the 256-row LDS-DMA operand
+#define TK_CAP 512       // candidate buffer entries per (block, query) (>= 2 * TK_CT)
 #define TK_MAXKC 64
 
 struct TkEntry { float score; int idx; };
@@ -92,6 +95,10 @@ DEVINL int wave_select(const TkEntry* buf, int cnt, int kc, int lane, float* tau
 }
 
 // grid = (nslices, nqtiles). Block scans pool rows [slice*rows_per_slice, ...) for queries [qt*128, +128).
+// MFMA tile = [256 candidates] x [128 queries] x dim via the LDS-DMA main loop <2,2,32> (48 KiB LDS, 4 waves, up to
+// three workgroups per CU so one workgroup's tile prologue / select epilogue hides under the others' streaming).
+using TkShape = GldsShape<2, 2, 32>;
+
 __global__ __launch_bounds__(256, 2) void topk_coarse_kernel(const unsigned short* __restrict__ pool,
                                                              const float* __restrict__ pinv, long rows, int dim,
                                                              const unsigned short* __restrict__ queries, int nq,
@@ -99,9 +106,9 @@ __global__ __launch_bounds__(256, 2) void topk_coarse_kernel(const unsigned shor
                                                              TkEntry* __restrict__ bufs,      // [blocks][128][CAP]
                                                              TkEntry* __restrict__ partial) { // [nslices][nq][kc]
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    float* tau = reinterpret_cast<float*>(lds + GEMM_LDS_BYTES);          // [128]
-    int* cnt = reinterpret_cast<int*>(lds + GEMM_LDS_BYTES + 512);        // [128]
-    int* flag = reinterpret_cast<int*>(lds + GEMM_LDS_BYTES + 1024);      // [1]
+    float* tau = reinterpret_cast<float*>(lds + TkShape::LDS_BYTES);          // [128]
+    int* cnt = reinterpret_cast<int*>(lds + TkShape::LDS_BYTES + 512);        // [128]
+    int* flag = reinterpret_cast<int*>(lds + TkShape::LDS_BYTES + 1024);      // [1]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int slice = blockIdx.x, qt = blockIdx.y;
     const int q0 = qt * TK_QT;
@@ -111,56 +118,55 @@ __global__ __launch_bounds__(256, 2) void topk_coarse_kernel(const unsigned shor
     if (tid < TK_QT) { tau[tid] = -INFINITY; cnt[tid] = 0; }
     if (tid == 0) flag[0] = 0;
     __syncthreads();
-    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
-    for (long n0 = r_begin; n0 < r_end; n0 += GEMM_BN) {
-        f32x4_t acc[4][4];
+    const int wm = (w >> 1) * 128, wn = (w & 1) * 64;
+    const int li = lane & 15, lg = lane >> 4;
+    for (long n0 = r_begin; n0 < r_end; n0 += TK_CT) {
+        f32x4_t acc[8][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        // B operand = pool rows [n0, n0+128) limited to r_end (rows beyond read as zero)
-        gemm_mainloop<ElemF16, false, false>(queries, dim, nq, pool + n0 * dim, dim, (int)min((long)GEMM_BN, r_end - n0),
-                                             q0, 0, 0, dim, lds, acc);
-        // threshold-select epilogue
+        // A operand = pool rows [n0, n0+256) (rows >= r_end are clamped duplicates, masked below); B = queries
+        glds_mainloop<ElemF16, false, false, 2, 2, 32>(pool, dim, (int)r_end, queries, dim, nq, (int)n0, q0, 0, dim, lds, acc);
+        // threshold-select epilogue: lane owns queries wn + j*16 + 4*lg + r of candidate row wm + i*16 + li
+        float t[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ml = wm + i * 16 + (lane & 15);
-            const float t = tau[ml];
-            const bool qok = (q0 + ml) < nq;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nl = wn + j * 16 + 4 * (lane >> 4);
-                const long n = n0 + nl;
-                f32x4_t iv = {0.f, 0.f, 0.f, 0.f};
-                if (n + 3 < r_end) iv = *reinterpret_cast<const f32x4_t*>(pinv + n);
-                else {
+            for (int r = 0; r < 4; ++r) {
+                const int ql = wn + j * 16 + 4 * lg + r;
+                t[j][r] = (q0 + ql < nq) ? tau[ql] : INFINITY;   // +inf: padded queries never append
+            }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) iv[r] = (n + r < r_end) ? pinv[n + r] : 0.f;
-                }
+        for (int i = 0; i < 8; ++i) {
+            const long n = n0 + wm + i * 16 + li;
+            const bool nok = n < r_end;
+            const float iv = nok ? pinv[n] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float sc = acc[i][j][r] * iv[r];
-                    if (qok && (n + r < r_end) && sc > t) {
-                        const int pos = atomicAdd(&cnt[ml], 1);
-                        if (pos < TK_CAP) { mybuf[ml * TK_CAP + pos].score = sc; mybuf[ml * TK_CAP + pos].idx = (int)(n + r); }
+                    const float sc = acc[i][j][r] * iv;
+                    if (nok && sc > t[j][r]) {
+                        const int ql = wn + j * 16 + 4 * lg + r;
+                        const int pos = atomicAdd(&cnt[ql], 1);
+                        if (pos < TK_CAP) { mybuf[ql * TK_CAP + pos].score = sc; mybuf[ql * TK_CAP + pos].idx = (int)n; }
                     }
                 }
-            }
         }
         __syncthreads();
-        if (tid < TK_QT && cnt[tid] >= TK_CAP - GEMM_BN) flag[0] = 1;
+        if (tid < TK_QT && cnt[tid] > TK_CAP - TK_CT) flag[0] = 1;
         __syncthreads();
         if (flag[0]) {
-            __threadfence_block();
             for (int ql = w; ql < TK_QT; ql += 4) {
                 int c = cnt[ql];
                 if (c > TK_CAP) c = TK_CAP;
                 if (c > kc) {
-                    float t, ms;
+                    float tt, ms;
                     int mi;
-                    const int keep = wave_select(mybuf + ql * TK_CAP, c, kc, lane, &t, &ms, &mi);
+                    const int keep = wave_select(mybuf + ql * TK_CAP, c, kc, lane, &tt, &ms, &mi);
                     if (lane < keep) { mybuf[ql * TK_CAP + lane].score = ms; mybuf[ql * TK_CAP + lane].idx = mi; }
-                    if (lane == 0) { cnt[ql] = keep; tau[ql] = t; }
+                    if (lane == 0) { cnt[ql] = keep; tau[ql] = tt; }
                 }
             }
             __syncthreads();
@@ -175,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void topk_coarse_kernel(const unsigned shor
         if (q >= nq) continue;
         int c = cnt[ql];
         if (c > TK_CAP) c = TK_CAP;
-        float t, ms;
+        float tt, ms;
         int mi;
-        const int keep = wave_select(mybuf + ql * TK_CAP, c, kc, lane, &t, &ms, &mi);
+        const int keep = wave_select(mybuf + ql * TK_CAP, c, kc, lane, &tt, &ms, &mi);
         TkEntry* dst = partial + ((long)slice * nq + q) * kc;
         if (lane < kc) {
             TkEntry e;
@@ -231,20 +237,202 @@ __global__ __launch_bounds__(256) void topk_merge_partial_kernel(const TkEntry* 
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Group-max path (nq <= TK_GPATH_MAXQ): the streaming kernel keeps NO per-query state.  Per 16-candidate group
+// (one MFMA row tile) and query it writes the group's best approximate score; a selection kernel then finds the
+// kc-th best group per query and hands every member of the qualifying groups to the exact re-score.  A true top-k
+// candidate always sits in a group whose maximum is at least its own score, so the result is exact (up to the same
+// near-tie margin kc - k as the buffered path).  No atomics, no compaction, no buffers in the HBM-bound sweep.
+#define TK_G 16
+#define TK_GMULT 2            // groups kept per query = TK_GMULT * kc
+#define TK_GPATH_MAXQ 1024
+
+template <int WM>   // WM = 1: 128-candidate tiles, 2 waves, 32 KiB LDS (many workgroups per CU); WM = 2: 256 / 4 / 48 KiB
+__global__ __launch_bounds__(128 * WM, 2) void topk_gmax_kernel(const unsigned short* __restrict__ pool,
+                                                                const float* __restrict__ pinv, long rows, int dim,
+                                                                const unsigned short* __restrict__ queries, int nq,
+                                                                long rows_per_slice, float* __restrict__ gmax,
+                                                                long ngroups) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int CT = 128 * WM;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int slice = blockIdx.x, q0 = blockIdx.y * TK_QT;
+    const long r_begin = (long)slice * rows_per_slice;
+    const long r_end = min(rows, r_begin + rows_per_slice);
+    const int wm = (w >> 1) * 128, wn = (w & 1) * 64;
+    const int li = lane & 15, lg = lane >> 4;
+    for (long n0 = r_begin; n0 < r_end; n0 += CT) {
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        glds_mainloop<ElemF16, false, false, WM, 2, 32>(pool, dim, (int)r_end, queries, dim, nq, (int)n0, q0, 0, dim, lds, acc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long n = n0 + wm + i * 16 + li;
+            const bool nok = n < r_end;
+            const float iv = nok ? pinv[n] : 0.f;
+            const long group = (n0 + wm + i * 16) >> 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4_t v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = nok ? acc[i][j][r] * iv : -INFINITY;
+                    x = fmaxf(x, __shfl_xor(x, 1, 64));     // max over the 16 candidate rows of the group (lanes li)
+                    x = fmaxf(x, __shfl_xor(x, 2, 64));
+                    x = fmaxf(x, __shfl_xor(x, 4, 64));
+                    x = fmaxf(x, __shfl_xor(x, 8, 64));
+                    v[r] = x;
+                }
+                if (li == 0 && group < ngroups) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = q0 + wn + j * 16 + 4 * lg + r;
+                        if (q < nq) gmax[(long)q * ngroups + group] = v[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// one block per query: the best groups by (group max desc, group index asc): the kc best plus ties of the kc-th
+// value (at most gcap groups); every member row of those groups becomes a re-score candidate.
+//   pass 1: per-thread maxima -> tau0 = kc-th largest of the 256 thread maxima (a valid lower bound of the kc-th
+//           largest group value: 256 distinct groups reach it)
+//   pass 2: groups >= tau0 are collected in LDS (a few dozen), ranked exactly, the best gcap kept.
+// If the collection overflows (massive exact ties) the kernel falls back to one-extraction-per-round selection.
+#define TK_SELCAP 1024
+__global__ __launch_bounds__(256) void topk_gsel_kernel(const float* __restrict__ gmax, long ngroups, long rows, int nq,
+                                                        int kc, int gcap, int* __restrict__ cand_idx) {
+    __shared__ float tmax[256];
+    __shared__ float bval[TK_SELCAP];
+    __shared__ int bgrp[TK_SELCAP];
+    __shared__ int bcnt;
+    __shared__ float tau0, tau;
+    __shared__ float ss[4];
+    __shared__ long long si[4];
+    __shared__ float wsel;
+    __shared__ long long isel;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* g = gmax + (long)q * ngroups;
+    int* out = cand_idx + (long)q * gcap * TK_G;
+    for (int e = tid; e < gcap * TK_G; e += 256) out[e] = -1;
+    float mx = -INFINITY;
+    for (long e = tid; e < ngroups; e += 256) mx = fmaxf(mx, g[e]);
+    tmax[tid] = mx;
+    if (tid == 0) { bcnt = 0; tau0 = -INFINITY; tau = -INFINITY; }
+    __syncthreads();
+    {
+        int rank = 0;
+        for (int t = 0; t < 256; ++t) {
+            const float o = tmax[t];
+            rank += (o > mx || (o == mx && t < tid)) ? 1 : 0;
+        }
+        if (rank == kc - 1) tau0 = mx;   // exactly one thread has this rank
+    }
+    __syncthreads();
+    const float t0 = tau0;
+    for (long e = tid; e < ngroups; e += 256) {
+        const float v = g[e];
+        if (v >= t0 && v > -INFINITY) {
+            const int pos = atomicAdd(&bcnt, 1);
+            if (pos < TK_SELCAP) { bval[pos] = v; bgrp[pos] = (int)e; }
+        }
+    }
+    __syncthreads();
+    const int n = bcnt;
+    if (n <= TK_SELCAP) {
+        // exact rank of every collected entry by (value desc, group asc)
+        for (int e = tid; e < n; e += 256) {
+            const float v = bval[e];
+            const int gi = bgrp[e];
+            int rank = 0;
+            for (int t = 0; t < n; ++t) {
+                const float o = bval[t];
+                const int og = bgrp[t];
+                rank += (o > v || (o == v && og < gi)) ? 1 : 0;
+            }
+            if (rank == min(kc, n) - 1) tau = v;
+        }
+        __syncthreads();
+        const float tt = tau;
+        for (int e = tid; e < n; e += 256) {
+            const float v = bval[e];
+            const int gi = bgrp[e];
+            int rank = 0;
+            for (int t = 0; t < n; ++t) {
+                const float o = bval[t];
+                const int og = bgrp[t];
+                rank += (o > v || (o == v && og < gi)) ? 1 : 0;
+            }
+            if (rank < gcap && v >= tt) {
+                for (int m = 0; m < TK_G; ++m) {
+                    const long row = (long)gi * TK_G + m;
+                    out[rank * TK_G + m] = row < rows ? (int)row : -1;
+                }
+            }
+        }
+        return;
+    }
+    // fallback: one extraction per round (value desc, group asc), stop after the kc-th value's ties or gcap groups
+    float last_s = INFINITY, tk = -INFINITY;
+    long long last_g = -1;
+    for (int j = 0; j < gcap; ++j) {
+        float bs = -INFINITY;
+        long long bg = 0x7fffffffffffffffLL;
+        for (long e = tid; e < ngroups; e += 256) {
+            const float v = g[e];
+            const bool after = (v < last_s) || (v == last_s && (long long)e > last_g);
+            if (after && (v > bs || (v == bs && (long long)e < bg))) { bs = v; bg = e; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const long long og = __shfl_xor(bg, o, 64);
+            if (os > bs || (os == bs && og < bg)) { bs = os; bg = og; }
+        }
+        if (lane == 0) { ss[w] = bs; si[w] = bg; }
+        __syncthreads();
+        if (tid == 0) {
+            float fs = ss[0]; long long fg = si[0];
+            for (int k = 1; k < 4; ++k) if (ss[k] > fs || (ss[k] == fs && si[k] < fg)) { fs = ss[k]; fg = si[k]; }
+            wsel = fs; isel = fg;
+        }
+        __syncthreads();
+        last_s = wsel; last_g = isel;
+        __syncthreads();
+        if (last_g == 0x7fffffffffffffffLL || last_s == -INFINITY) break;
+        if (j == kc - 1) tk = last_s;
+        if (j >= kc && last_s < tk) break;
+        if (tid < TK_G) {
+            const long row = last_g * TK_G + tid;
+            out[j * TK_G + tid] = row < rows ? (int)row : -1;
+        }
+    }
+}
+
 static void coarse_plan(int nq, long rows, int* nqt, int* nslices, long* rows_per_slice) {
     *nqt = (nq + TK_QT - 1) / TK_QT;
-    long tiles = (rows + GEMM_BN - 1) / GEMM_BN;
-    long want = (1024 + *nqt - 1) / *nqt;       // aim at ~1024 workgroups in flight
+    long tiles = (rows + TK_CT - 1) / TK_CT;
+    long want = (768 + *nqt - 1) / *nqt;        // aim at ~768 workgroups (3 per CU)
     if (want < 1) want = 1;
     if (want > tiles) want = tiles;
     long tps = (tiles + want - 1) / want;       // candidate tiles per slice
     if (tps < 1) tps = 1;
-    *rows_per_slice = tps * GEMM_BN;
+    *rows_per_slice = tps * TK_CT;
     *nslices = (int)((rows + *rows_per_slice - 1) / *rows_per_slice);
+}
+
+extern "C" int32_t uniir_topk_ncand(int32_t nq, int32_t kc) {
+    return nq <= TK_GPATH_MAXQ ? TK_GMULT * kc * TK_G : kc;
 }
 
 extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t rows) {
     if (nq <= 0 || kc <= 0 || rows <= 0) return 0;
+    if (nq <= TK_GPATH_MAXQ) return (int64_t)nq * ((rows + TK_G - 1) / TK_G) * 4 + 256;
     int nqt, nsl; long rps;
     coarse_plan(nq, rows, &nqt, &nsl, &rps);
     return (int64_t)nqt * nsl * TK_QT * TK_CAP * (int64_t)sizeof(TkEntry) + (int64_t)nsl * nq * kc * (int64_t)sizeof(TkEntry) + 256;
@@ -255,16 +443,48 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
                                  float* cand_score, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!pool_f16 || !pool_inv_norm || !queries_f16 || !cand_idx || !workspace) return UNIIR_EINVAL;
     if (rows <= 0 || nq <= 0 || kc <= 0) return UNIIR_EINVAL;
-    if (kc > TK_MAXKC || dim % 64 || dim <= 0 || rows > 0x7fffffffL) return UNIIR_ESHAPE;
+    if (kc > TK_MAXKC || dim % 32 || dim <= 0 || rows > 0x7fffffffL) return UNIIR_ESHAPE;
     if (((uintptr_t)pool_f16 & 15) || ((uintptr_t)queries_f16 & 15) || ((uintptr_t)pool_inv_norm & 15) ||
         ((uintptr_t)workspace & 15))
         return UNIIR_EALIGN;
     if (workspace_bytes < uniir_topk_workspace_bytes(nq, kc, rows)) return UNIIR_EINVAL;
     int nqt, nsl; long rps;
     coarse_plan(nq, rows, &nqt, &nsl, &rps);
+    hipStream_t st0 = (hipStream_t)stream;
+    if (nq <= TK_GPATH_MAXQ) {
+        const long ngroups = (rows + TK_G - 1) / TK_G;
+        float* gmax = (float*)workspace;
+        static const char* env_wm = getenv("UNIIR_TOPK_WM");
+        static const char* env_bl = getenv("UNIIR_TOPK_BLOCKS");
+        const int wmsel = (env_wm && env_wm[0] == '1') ? 1 : 2;
+        const long ct = 128 * wmsel;
+        const long want_blocks = env_bl ? atol(env_bl) : 768;
+        long tiles = (rows + ct - 1) / ct;
+        long want = (want_blocks + nqt - 1) / nqt;
+        if (want > tiles) want = tiles;
+        if (want < 1) want = 1;
+        const long tps = (tiles + want - 1) / want;
+        rps = tps * ct;
+        nsl = (int)((rows + rps - 1) / rps);
+        if (wmsel == 2) {
+            const size_t smg = GldsShape<2, 2, 32>::LDS_BYTES;
+            (void)hipFuncSetAttribute((const void*)topk_gmax_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg);
+            hipLaunchKernelGGL(topk_gmax_kernel<2>, dim3(nsl, nqt), dim3(256), smg, st0, (const unsigned short*)pool_f16,
+                               pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
+        } else {
+            const size_t smg = GldsShape<1, 2, 32>::LDS_BYTES;
+            (void)hipFuncSetAttribute((const void*)topk_gmax_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg);
+            hipLaunchKernelGGL(topk_gmax_kernel<1>, dim3(nsl, nqt), dim3(128), smg, st0, (const unsigned short*)pool_f16,
+                               pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
+        }
+        hipLaunchKernelGGL(topk_gsel_kernel, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
+                           TK_GMULT * kc, cand_idx);
+        HIP_LAUNCH_CHECK();
+        return UNIIR_OK;
+    }
     TkEntry* bufs = (TkEntry*)workspace;
     TkEntry* partial = bufs + (long)nqt * nsl * TK_QT * TK_CAP;
-    const size_t sm = GEMM_LDS_BYTES + 1024 + 64;
+    const size_t sm = TkShape::LDS_BYTES + 1024 + 64;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)topk_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -316,26 +536,46 @@ __global__ __launch_bounds__(256) void final_sort_kernel(const float* __restrict
                                                          const long long* __restrict__ ids, int nq, int ncand,
                                                          int k, float* __restrict__ out_s,
                                                          long long* __restrict__ out_i) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nq) return;
+    // one block per query: k rounds of "best entry strictly after the previous one" in (score desc, id asc) order
+    __shared__ float ss[4];
+    __shared__ long long si[4];
+    __shared__ float wsel;
+    __shared__ long long isel;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* es = exact + (long)q * ncand;
     const int* ci = cand_idx + (long)q * ncand;
     float last_s = INFINITY;
     long long last_id = -1;
     for (int j = 0; j < k; ++j) {
-        float bs = -INFINITY; long long bid = 0x7fffffffffffffffLL; bool found = false;
-        for (int c = 0; c < ncand; ++c) {
+        float bs = -INFINITY;
+        long long bid = 0x7fffffffffffffffLL;
+        for (int c = tid; c < ncand; c += 256) {
             if (ci[c] < 0) continue;
             const float s = es[c];
             const long long id = ids ? ids[ci[c]] : (long long)ci[c];
             const bool after = (s < last_s) || (s == last_s && id > last_id);
-            if (!after) continue;
-            if (!found || s > bs || (s == bs && id < bid)) { bs = s; bid = id; found = true; }
+            if (after && (s > bs || (s == bs && id < bid))) { bs = s; bid = id; }
         }
-        if (found) { out_s[(long)q * k + j] = bs; out_i[(long)q * k + j] = bid; last_s = bs; last_id = bid; }
-        else {  // FAISS pads missing results with -inf distance / id -1 for inner product
-            out_s[(long)q * k + j] = -INFINITY; out_i[(long)q * k + j] = -1; last_s = -INFINITY; last_id = 0x7fffffffffffffffLL;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const long long oi = __shfl_xor(bid, o, 64);
+            if (os > bs || (os == bs && oi < bid)) { bs = os; bid = oi; }
         }
+        if (lane == 0) { ss[w] = bs; si[w] = bid; }
+        __syncthreads();
+        if (tid == 0) {
+            float fs = ss[0]; long long fi = si[0];
+            for (int kk = 1; kk < 4; ++kk) if (ss[kk] > fs || (ss[kk] == fs && si[kk] < fi)) { fs = ss[kk]; fi = si[kk]; }
+            const bool found = fi != 0x7fffffffffffffffLL;
+            // FAISS pads missing results with -inf distance / id -1 for inner product
+            out_s[(long)q * k + j] = found ? fs : -INFINITY;
+            out_i[(long)q * k + j] = found ? fi : -1;
+            wsel = found ? fs : -INFINITY; isel = found ? fi : 0x7fffffffffffffffLL;
+        }
+        __syncthreads();
+        last_s = wsel; last_id = isel;
+        __syncthreads();
     }
 }
 
@@ -353,7 +593,7 @@ extern "C" int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_no
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
                        (const unsigned short*)pool_f16, pool_inv_norm, (const unsigned short*)queries_f16,
                        query_inv_norm, nq, dim, cand_idx, ncand, exact_ws);
-    hipLaunchKernelGGL(final_sort_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, exact_ws, cand_idx,
+    hipLaunchKernelGGL(final_sort_kernel, dim3(nq), dim3(256), 0, st, exact_ws, cand_idx,
                        (const long long*)pool_ids, nq, ncand, k, out_scores, (long long*)out_ids);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;

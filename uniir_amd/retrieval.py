@@ -51,13 +51,14 @@ def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None
     need = _lib.load().uniir_topk_workspace_bytes(nq, kc, shard.n)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, device=dev, dtype=torch.uint8)
-    cand = torch.empty(nq, kc, device=dev, dtype=torch.int32)
+    ncand = _lib.load().uniir_topk_ncand(nq, kc)
+    cand = torch.empty(nq, ncand, device=dev, dtype=torch.int32)
     cand_s = torch.empty(nq, kc, device=dev, dtype=torch.float32)
     ops.call("uniir_topk_coarse", shard.emb, shard.inv_norm, shard.n, shard.dim, queries_f16, nq, kc, cand, cand_s,
              workspace, workspace.numel())
-    exact = torch.empty(nq, kc, device=dev, dtype=torch.float32)
+    exact = torch.empty(nq, ncand, device=dev, dtype=torch.float32)
     ops.call("uniir_topk_rescore", shard.emb, shard.inv_norm, shard.ids, shard.n, shard.dim, queries_f16, q_inv, nq,
-             cand, kc, k, exact, out_s, out_i)
+             cand, ncand, k, exact, out_s, out_i)
     return out_s, out_i
 
 
