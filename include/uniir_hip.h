@@ -49,7 +49,7 @@ enum {
     UNIIR_EPI_BF16 = 0,          /* C(bf16) = v + bias?                                          */
     UNIIR_EPI_BIAS_ACT = 1,      /* f = bf16(v + bias) -> C ; act(f) -> C2 (both bf16)           */
     UNIIR_EPI_RESID_F32 = 2,     /* C(f32) = v + bias? + resid(f32, ldc) ; C2(bf16 copy) optional */
-    UNIIR_EPI_DACT = 3,          /* C(bf16) = v * act'(aux[m][n])   (aux bf16, ldaux)             */
+    UNIIR_EPI_DACT = 3,          /* C(bf16) = v * act'(aux[m][n]) (aux bf16, ldaux); C2(bf16, ldaux) = act(aux) opt. */
     UNIIR_EPI_F32 = 4,           /* C(f32) = v  (beta = 0)                                        */
     UNIIR_EPI_ATOMIC_F32 = 5     /* C(f32) += v via atomics; enables split-K (wgrad accumulate)  */
 };
@@ -72,6 +72,8 @@ typedef struct {
     float alpha;
     void* splitk_ws;          /* optional scratch for split-K: when it holds k_splits*M*N floats the splits write */
     int64_t splitk_ws_bytes;  /* plain fp32 slabs that one reduce kernel adds into C (no atomics)               */
+    float* colsum;            /* optional [N] fp32: += column sums of the result before rounding (bias gradient);
+                                 honoured by the 256x256 kernel with EPI_RESID_F32 / EPI_DACT / EPI_F32 only     */
 } uniir_gemm_desc;
 
 int uniir_gemm(const uniir_gemm_desc* d, void* stream);

@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
         ("a_tmaj", c_int), ("b_tmaj", c_int),
         ("epilogue", c_int), ("act", c_int), ("dtype", c_int),
         ("k_splits", c_int), ("alpha", c_float),
-        ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_i64),
+        ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_i64), ("colsum", c_void_p),
     ]
 
 

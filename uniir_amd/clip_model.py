@@ -247,19 +247,20 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal):
     dev = dx.device
     h = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
     g = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
+    df = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
     dh = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
     for i in reversed(range(layers)):
         b = _Blk(model, f"{prefix}.resblocks.{i}")
         x, qkv, ao, lse, x2, f = saved[i]
         saved[i] = None
-        ops.call("uniir_act_fwd", f, g, f.numel(), ops.ACT_QUICKGELU)
+        # d(mlp): df = (dx @ Wproj) * act'(f); the same epilogue re-materialises g = act(f) for dWproj and sums
+        # df's columns into the c_fc bias gradient
+        ops.linear_dgrad(dxb, b.w16("wproj"), out=df, aux=f, act_out=g, colsum=b.g("bfc"))
         ops.linear_wgrad(dxb, g, b.g("wproj"))
         ops.call("uniir_colsum_bf16", dxb, W, b.g("bproj"), R, W)
-        ops.linear_dgrad(dxb, b.w16("wproj"), out=g, aux=f)                      # g := df
         ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), out_bf16=h, rows=R, width=W)
-        ops.linear_wgrad(g, h, b.g("wfc"))
-        ops.call("uniir_colsum_bf16", g, 4 * W, b.g("bfc"), R, 4 * W)
-        ops.linear_dgrad(g, b.w16("wfc"), out=dh)                                # dh := d ln_2 out
+        ops.linear_wgrad(df, h, b.g("wfc"))
+        ops.linear_dgrad(df, b.w16("wfc"), out=dh)                               # dh := d ln_2 out
         dx2 = torch.empty(R, W, device=dev, dtype=torch.float32)
         ops.layernorm_bwd(x2, b.p32("ln2w"), dh, b.g("ln2w"), b.g("ln2b"), dres=dx, dx=dx2, dx_bf16=dxb,
                           rows=R, width=W)

@@ -19,6 +19,7 @@ struct GemmKArgs {
     int epilogue, act, k_splits, tiles_m, tiles_n;
     float alpha;
     float* slab;  // split-K slabs [k_splits][M][N] (plain stores) or nullptr (atomics)
+    float* colsum;  // optional [N]: += column sums of the fp32 result (bias gradient), 256-tile staged epilogue only
 };
 
 DEVINL float act_fwd(float x, int act) {
@@ -188,6 +189,7 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
         return;
     }
     // fp32 staging, two passes of 128 rows (the waves with wm == 128*h write in pass h)
+    f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < 2; ++h) {
         if (h) __syncthreads();
         if (wm == 128 * h) {
@@ -223,12 +225,38 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
                     const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + (long)m * p.ldaux + n);
                     const float f0 = __uint_as_float(a[0] << 16), f1 = __uint_as_float(a[0] & 0xffff0000u);
                     const float f2 = __uint_as_float(a[1] << 16), f3 = __uint_as_float(a[1] & 0xffff0000u);
-                    const u32x2_t o = {pack_bf16x2(v[0] * act_bwd(f0, p.act), v[1] * act_bwd(f1, p.act)),
-                                       pack_bf16x2(v[2] * act_bwd(f2, p.act), v[3] * act_bwd(f3, p.act))};
+                    v[0] *= act_bwd(f0, p.act); v[1] *= act_bwd(f1, p.act);
+                    v[2] *= act_bwd(f2, p.act); v[3] *= act_bwd(f3, p.act);
+                    const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                     *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+                    if (p.C2) {  // recomputed activation act(aux) for the wgrad of the next linear
+                        const u32x2_t g2 = {pack_bf16x2(act_fwd(f0, p.act), act_fwd(f1, p.act)),
+                                            pack_bf16x2(act_fwd(f2, p.act), act_fwd(f3, p.act))};
+                        *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + (long)m * p.ldaux + n) = g2;
+                    }
                 } else {  // UNIIR_EPI_F32 (also the split-K slabs)
                     *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
                 }
+                csum += v;
+            }
+        }
+    }
+    if (p.colsum) {
+        // this thread's 4 columns (ch = tid & 63) summed over its rows of both passes; 8 threads share a column group
+        __syncthreads();
+        f32x4_t* red = reinterpret_cast<f32x4_t*>(lds);
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 64) {
+            f32x4_t s = red[tid];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) s += red[tid + 64 * k];
+            const int n = n0 + tid * 4;
+            if (n < p.N) {
+                unsafeAtomicAdd(p.colsum + n + 0, s[0]);
+                unsafeAtomicAdd(p.colsum + n + 1, s[1]);
+                unsafeAtomicAdd(p.colsum + n + 2, s[2]);
+                unsafeAtomicAdd(p.colsum + n + 3, s[3]);
             }
         }
     }
@@ -392,6 +420,7 @@ extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
     a.tiles_n = (d->N + GEMM_BN - 1) / GEMM_BN;
     a.alpha = d->alpha;
     a.slab = nullptr;
+    a.colsum = d->colsum;
     hipStream_t st = (hipStream_t)stream;
     if (d->k_splits > 1) {
         // never leave a split empty (an empty split would leave its slab unwritten)

@@ -106,16 +106,27 @@ DEVINL void glds_mainloop(const unsigned short* __restrict__ A, long lda, int M,
             glds_stage<A_TMAJ, S::BM, BK, S::T>(A, lda, m0, M, k0, nxt, tid, w);
             glds_stage<B_TMAJ, S::BN, BK, S::T>(B, ldb, n0, N, k0, nxt + S::A_BYTES, tid, w);
         }
+        // B fragments of the whole K step up front, A fragments streamed one ahead of the MFMAs that use them:
+        // the LDS latency of fragment i+1 hides under the 4 MFMAs of fragment i (pinned with sched_group_barrier).
+        constexpr int NS = BK / 32;
+        u32x4_t bf[NS][4];
 #pragma unroll
-        for (int s = 0; s < BK / 32; ++s) {
-            u32x4_t bf[4];
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = glds_frag<B_TMAJ, S::BN, BK>(cur + S::A_BYTES, wn + j * 16, s, lane);
+            for (int j = 0; j < 4; ++j) bf[s][j] = glds_frag<B_TMAJ, S::BN, BK>(cur + S::A_BYTES, wn + j * 16, s, lane);
+        u32x4_t af = glds_frag<A_TMAJ, S::BM, BK>(cur, wm, 0, lane);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const u32x4_t af = glds_frag<A_TMAJ, S::BM, BK>(cur, wm + i * 16, s, lane);
+                u32x4_t an = af;
+                if (i + 1 < 8) an = glds_frag<A_TMAJ, S::BM, BK>(cur, wm + (i + 1) * 16, s, lane);
+                else if (s + 1 < NS) an = glds_frag<A_TMAJ, S::BM, BK>(cur, wm, s + 1, lane);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Elem::mfma(bf[j], af, acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = Elem::mfma(bf[s][j], af, acc[i][j]);
+                af = an;
+                if (i + 1 < 8 || s + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, A_TMAJ ? 2 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         }
         __syncthreads();

@@ -40,8 +40,15 @@ def _splitk_workspace(device, nbytes):
     return ws
 
 
+def uses_tile256(M, N, K):
+    """mirror of gemm_shape() in csrc/gemm.hip: the 256x256 LDS-DMA kernel (the only one with the fused column-sum
+    epilogue) runs when K % 64 == 0 and the problem is not tiny"""
+    return K % 64 == 0 and M >= 256 and N >= 128
+
+
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epilogue=EPI_BF16, bias=None,
-         resid=None, aux=None, ldaux=0, C2=None, act=ACT_QUICKGELU, k_splits=1, alpha=1.0, dtype=DT_BF16):
+         resid=None, aux=None, ldaux=0, C2=None, act=ACT_QUICKGELU, k_splits=1, alpha=1.0, dtype=DT_BF16,
+         colsum=None):
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = A.data_ptr(), B.data_ptr(), C_out.data_ptr(), (C2.data_ptr() if C2 is not None else None)
     d.bias = bias.data_ptr() if bias is not None else None
@@ -51,6 +58,7 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epi
     d.lda, d.ldb, d.ldc, d.ldaux = lda, ldb, ldc, ldaux
     d.a_tmaj, d.b_tmaj = int(a_tmaj), int(b_tmaj)
     d.epilogue, d.act, d.dtype, d.k_splits, d.alpha = epilogue, act, dtype, k_splits, alpha
+    d.colsum = colsum.data_ptr() if colsum is not None else None
     if k_splits > 1:
         ws = _splitk_workspace(A.device, 4 * k_splits * M * N)
         d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
@@ -76,14 +84,26 @@ def linear_fwd(x, w, bias=None, *, out=None, epilogue=EPI_BF16, resid=None, C2=N
     return gemm(x, w, out, M, N, K, K, K, N, epilogue=epilogue, bias=bias, resid=resid, C2=C2, act=act)
 
 
-def linear_dgrad(dy, w, *, out=None, aux=None, act=ACT_QUICKGELU):
-    """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * act'(aux))."""
+def linear_dgrad(dy, w, *, out=None, aux=None, act=ACT_QUICKGELU, act_out=None, colsum=None):
+    """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * act'(aux)).
+    act_out (bf16 [M,K]): also receives act(aux), the recomputed activation (needs aux).
+    colsum (fp32 [K]): += column sums of dx (the bias gradient of the layer that produced aux); fused into the GEMM
+    epilogue when the 256-tile kernel runs, otherwise done by the colsum kernel on the bf16 result."""
     M, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = torch.empty(M, K, device=dy.device, dtype=torch.bfloat16)
-    return gemm(dy, w, out, M, K, N, N, K, K, b_tmaj=True, epilogue=EPI_DACT if aux is not None else EPI_BF16,
-                aux=aux, ldaux=K, act=act)
+    fused = colsum is not None and aux is not None and uses_tile256(M, K, N)
+    if act_out is not None and not (aux is not None and uses_tile256(M, K, N)):
+        call("uniir_act_fwd", aux, act_out, aux.numel(), act)
+        act_out_arg = None
+    else:
+        act_out_arg = act_out
+    gemm(dy, w, out, M, K, N, N, K, K, b_tmaj=True, epilogue=EPI_DACT if aux is not None else EPI_BF16,
+         aux=aux, ldaux=K, act=act, C2=act_out_arg, colsum=colsum if fused else None)
+    if colsum is not None and not fused:
+        call("uniir_colsum_bf16", out, K, colsum, M, K)
+    return out
 
 
 N_CU = 256  # MI355X compute units; the 256x256 GEMM kernel runs one workgroup per CU
