@@ -19,6 +19,7 @@ struct GemmKArgs {
     int epilogue, act, k_splits, tiles_m, tiles_n;
     float alpha;
     float* slab;  // split-K slabs [k_splits][M][N] (plain stores) or nullptr (atomics)
+    int asm_loop;   // 1: hand-pipelined fragment reads (glds_mainloop_asm)
     float* colsum;  // optional [N]: += column sums of the fp32 result (bias gradient), 256-tile staged epilogue only
 };
 
@@ -263,8 +264,8 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
 }
 
 // LDS-DMA GEMM (gemm_core256.h): block tile (128*WM) x (64*WN), K step BK.  Used when K % BK == 0.
-template <typename Elem, bool A_TMAJ, bool B_TMAJ, int WM, int WN, int BK>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_glds_kernel(GemmKArgs p) {
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, int WM, int WN, int BK, bool ASM>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p) {
     using S = GldsShape<WM, WN, BK>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -286,7 +287,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_gld
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    glds_mainloop<Elem, A_TMAJ, B_TMAJ, WM, WN, BK>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
+    if (WM == 2 && WN == 4 && BK == 64 && ASM)
+        glds_mainloop_asm<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
+    else
+        glds_mainloop<Elem, A_TMAJ, B_TMAJ, WM, WN, BK>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
     const int w = threadIdx.x >> 6;
     const int wm = (w / WN) * 128, wn = (w % WN) * 64;
     if (WM * WN == 8) {   // 256x256 tile: LDS-staged, fully coalesced epilogue
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_gld
     gemm_epilogue_dispatch<8, 4>(p, acc, m0, n0, wm, wn);
 }
 
-template <typename Elem, int WM, int WN, int BK>
+template <typename Elem, int WM, int WN, int BK, bool ASM>
 static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
     using S = GldsShape<WM, WN, BK>;
     a.tiles_m = (a.M + S::BM - 1) / S::BM;
@@ -326,11 +330,11 @@ static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
     do {                                                                                          \
         static bool attr_set = false;                                                             \
         if (!attr_set) {                                                                          \
-            (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<Elem, AT, BT, WM, WN, BK>,    \
+            (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<Elem, AT, BT, WM, WN, BK, ASM>,    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);       \
             attr_set = true;                                                                      \
         }                                                                                         \
-        hipLaunchKernelGGL((gemm_glds_kernel<Elem, AT, BT, WM, WN, BK>), g, b, sm, st, a);        \
+        hipLaunchKernelGGL((gemm_glds_kernel<Elem, AT, BT, WM, WN, BK, ASM>), g, b, sm, st, a);        \
     } while (0)
     if (!a_tmaj && !b_tmaj) LAUNCHG(false, false);
     else if (!a_tmaj && b_tmaj) LAUNCHG(false, true);
@@ -353,8 +357,9 @@ static int gemm_shape(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
 template <typename Elem>
 static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t st) {
     const int shape = gemm_shape(a, a_tmaj, b_tmaj);
-    if (shape == 1) return launch_glds<Elem, 2, 4, 64>(a, a_tmaj, b_tmaj, st);
-    if (shape == 2) return launch_glds<Elem, 2, 2, 32>(a, a_tmaj, b_tmaj, st);
+    if (shape == 1 && a.asm_loop) return launch_glds<Elem, 2, 4, 64, true>(a, a_tmaj, b_tmaj, st);
+    if (shape == 1) return launch_glds<Elem, 2, 4, 64, false>(a, a_tmaj, b_tmaj, st);
+    if (shape == 2) return launch_glds<Elem, 2, 2, 32, false>(a, a_tmaj, b_tmaj, st);
     const int grid = a.tiles_m * a.tiles_n * a.k_splits;
     dim3 g(grid), b(256);
     const size_t sm = GEMM_LDS_BYTES;
@@ -421,6 +426,10 @@ extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
     a.alpha = d->alpha;
     a.slab = nullptr;
     a.colsum = d->colsum;
+    {
+        static const char* e = getenv("UNIIR_GEMM_ASM");
+        a.asm_loop = (e && e[0] == '0') ? 0 : 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d->k_splits > 1) {
         // never leave a split empty (an empty split would leave its slab unwritten)

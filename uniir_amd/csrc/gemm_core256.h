@@ -132,3 +132,122 @@ DEVINL void glds_mainloop(const unsigned short* __restrict__ A, long lda, int M,
         __syncthreads();
     }
 }
+
+// -------------------------------------------------------------------------------------------------------------------
+// Hand-pipelined variant of the K step for the 256x256x64 shape: the fragment reads are inline-asm ds_reads that the
+// compiler does not track, so they can be issued one fragment AHEAD of the MFMAs that consume them and retired with
+// COUNTED s_waitcnt lgkmcnt(N) (LDS returns in order) instead of the lgkmcnt(0) hipcc emits for builtin reads.
+// Only LDS-DMA (VMEM) and these asm reads touch LDS inside the loop, so no compiler-generated DS wait interferes.
+DEVINL unsigned lds_addr32(const char* p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF>
+DEVINL u32x4_t asm_ds_read_b128(unsigned addr) {
+    u32x4_t r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+    return r;
+}
+template <int OFF>
+DEVINL u32x2_t asm_ds_read_tr16(unsigned addr) {
+    u32x2_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+    return r;
+}
+template <int N>
+DEVINL void asm_wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// per-lane address state of one operand's fragments for the 256-extent, BK = 64 shape
+template <bool TMAJ>
+struct FragAddr {
+    unsigned a[TMAJ ? 8 : 2];   // KMAJ: one base per k-step s; TMAJ: one base per 16-wide tile (s, +4 rows are immediates)
+    DEVINL void init(int base16, int lane, int ntiles) {
+        if (!TMAJ) {
+            const int rl = base16 + (lane & 15);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) a[s] = rl * 128 + (((s * 4 + (lane >> 4)) ^ (rl & 7)) << 4);
+        } else {
+            const int t = lane & 15, g = lane >> 4;
+            const int krow = 8 * g + (t >> 2);
+            const int f = tmaj_f(krow);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int col = base16 + i * 16 + 4 * (t & 3);
+                a[i] = krow * 512 + (((col >> 4) ^ f) << 5) + (col & 15) * 2;
+            }
+        }
+    }
+    // fragment of tile I (16 rows/cols), k-step S, relative to stage base address `sb`
+    template <int I, int S>
+    DEVINL u32x4_t read(unsigned sb) const {
+        if (!TMAJ) {
+            return asm_ds_read_b128<I * 2048>(sb + a[S]);
+        } else {
+            const u32x2_t lo = asm_ds_read_tr16<S * 16384>(sb + a[I]);
+            const u32x2_t hi = asm_ds_read_tr16<S * 16384 + 2048>(sb + a[I]);
+            const u32x4_t r = {lo[0], lo[1], hi[0], hi[1]};
+            return r;
+        }
+    }
+};
+
+// fragment IDX (= S*8 + I) of the K step: issue fragment IDX + DIST, wait until fragment IDX has landed (counted:
+// the DIST younger fragments stay in flight), then the 4 MFMAs of fragment IDX.
+template <typename Elem, bool A_TMAJ, int IDX, int DIST>
+DEVINL void kstep_tile(const FragAddr<A_TMAJ>& fa, unsigned sa, const u32x4_t (&bf)[2][4], u32x4_t (&ring)[DIST + 1],
+                       f32x4_t (&acc)[8][4]) {
+    constexpr int NX = IDX + DIST;
+    if (NX < 16) ring[NX % (DIST + 1)] = fa.template read<(NX < 16 ? NX % 8 : 0), (NX < 16 ? NX / 8 : 0)>(sa);
+    constexpr int younger = (16 - 1 - IDX) < DIST ? (16 - 1 - IDX) : DIST;   // fragments issued after IDX
+    asm_wait_lgkm<younger * (A_TMAJ ? 2 : 1)>();
+    constexpr int I = IDX % 8, S = IDX / 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[I][j] = Elem::mfma(bf[S][j], ring[IDX % (DIST + 1)], acc[I][j]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+DEVINL void glds_mainloop_asm(const unsigned short* __restrict__ A, long lda, int M, const unsigned short* __restrict__ B,
+                              long ldb, int N, int m0, int n0, int kbeg, int kend, char* lds, f32x4_t (&acc)[8][4]) {
+    using S = GldsShape<2, 4, 64>;
+    constexpr int BK = 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (w / 4) * 128, wn = (w % 4) * 64;
+    const int nk = (kend - kbeg) / BK;
+    if (nk <= 0) return;
+    FragAddr<A_TMAJ> fa;
+    FragAddr<B_TMAJ> fb;
+    fa.init(wm, lane, 8);
+    fb.init(wn, lane, 4);
+    const unsigned lbase = lds_addr32(lds);
+    glds_stage<A_TMAJ, S::BM, BK, S::T>(A, lda, m0, M, kbeg, lds, tid, w);
+    glds_stage<B_TMAJ, S::BN, BK, S::T>(B, ldb, n0, N, kbeg, lds + S::A_BYTES, tid, w);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        char* nxt = lds + ((t + 1) & 1) * S::STAGE_BYTES;
+        if (t + 1 < nk) {
+            const int k0 = kbeg + (t + 1) * BK;
+            glds_stage<A_TMAJ, S::BM, BK, S::T>(A, lda, m0, M, k0, nxt, tid, w);
+            glds_stage<B_TMAJ, S::BN, BK, S::T>(B, ldb, n0, N, k0, nxt + S::A_BYTES, tid, w);
+        }
+        const unsigned sa = lbase + (t & 1) * S::STAGE_BYTES;
+        const unsigned sb = sa + S::A_BYTES;
+        u32x4_t bf[2][4];
+        bf[0][0] = fb.template read<0, 0>(sb); bf[0][1] = fb.template read<1, 0>(sb);
+        bf[0][2] = fb.template read<2, 0>(sb); bf[0][3] = fb.template read<3, 0>(sb);
+        bf[1][0] = fb.template read<0, 1>(sb); bf[1][1] = fb.template read<1, 1>(sb);
+        bf[1][2] = fb.template read<2, 1>(sb); bf[1][3] = fb.template read<3, 1>(sb);
+        constexpr int DIST = 1;
+        u32x4_t ring[DIST + 1];
+        ring[0] = fa.template read<0, 0>(sa);
+        if (DIST > 1) ring[1 % (DIST + 1)] = fa.template read<1, 0>(sa);
+#define KT(IDX) kstep_tile<Elem, A_TMAJ, IDX, DIST>(fa, sa, bf, ring, acc)
+        KT(0); KT(1); KT(2); KT(3); KT(4); KT(5); KT(6); KT(7);
+        KT(8); KT(9); KT(10); KT(11); KT(12); KT(13); KT(14); KT(15);
+#undef KT
+        __syncthreads();
+    }
+}
