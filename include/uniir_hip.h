@@ -103,6 +103,17 @@ int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32_t batch, i
 int uniir_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                         void* dqkv, int32_t batch, int32_t seq, int32_t heads, int32_t causal,
                         void* stream);
+/* General form: separate Q [batch*tq][q_ld] and K/V [batch*tk][kv_ld] tensors (head h at column h*64) for the BLIP
+ * MED cross-attention (uniir_blip/backbone/med.py:160-232 with encoder_hidden_states), and an optional per-item key
+ * length (keys >= key_len[m] masked: the BERT padding mask, med.py:687-688 "(1 - mask) * -10000").
+ * lse is [batch][heads][tq].  bwd writes dq [batch*tq][dq_ld], dk / dv [batch*tk][dkv_ld]. */
+int uniir_attention_fwd_ex(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld, void* out,
+                           int64_t out_ld, float* lse, const int32_t* key_len, int32_t batch, int32_t tq,
+                           int32_t tk, int32_t heads, int32_t causal, void* stream);
+int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld,
+                           const void* out, const void* dout, int64_t out_ld, const float* lse,
+                           const int32_t* key_len, void* dq, int64_t dq_ld, void* dk, void* dv, int64_t dkv_ld,
+                           int32_t batch, int32_t tq, int32_t tk, int32_t heads, int32_t causal, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] small fused pieces of the towers.
@@ -187,6 +198,21 @@ int uniir_sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_
 int uniir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                      void* param_bf16, int64_t count, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int32_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * [BLIP] extra pieces of the BLIP_FF path (src/models/uniir_blip): tanh pooler (backbone/med.py:499-511), momentum
+ * EMA p_m = m p_m + (1-m) p (blip_featurefusion/blip_ff.py:288-292) over a flat buffer (+ bf16 shadow), and the
+ * soft-target contrastive loss of blip_ff.py:219-231 on one similarity matrix sim [b][n] (n = b + queue):
+ *   target = alpha * softmax(sim_m) + (1-alpha) * pos / sum(pos), pos_j = (ids_all[j] == ids_row[i]);
+ *   row_loss[i] = -sum_j log_softmax(sim[i])_j target_j;  dsim = (softmax(sim) - target) * gscale (optional);
+ *   row_hit[i] = pos[argmax_j sim[i][j]]  (accuracy of blip_ff.py:250-252, first max).
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_tanh_fwd(const float* x, float* y, int64_t count, void* stream);
+int uniir_tanh_bwd(const float* y, const float* dy, float* dx, int64_t count, void* stream);
+int uniir_ema_update(float* param_m, const float* param, void* param_m_bf16, int64_t count, float momentum,
+                     void* stream);
+int uniir_softce(const float* sim, const float* sim_m, const int64_t* ids_row, const int64_t* ids_all, int32_t b,
+                 int32_t n, float alpha, float gscale, float* row_loss, float* row_hit, float* dsim, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [TOPK] exact brute-force inner-product top-k over an fp16 pool (FAISS "IDMap,Flat" + normalize_L2).

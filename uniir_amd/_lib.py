@@ -35,6 +35,9 @@ SIGNATURES = {
     "uniir_layernorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, c_int, c_int, c_float, S]),
     "uniir_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_attention_fwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, P, c_int, c_int, c_int, c_int, c_int, S]),
+    "uniir_attention_bwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, P, c_i64, P, P, P, c_i64, P, P, c_i64, c_int, c_int,
+                                       c_int, c_int, c_int, S]),
     "uniir_patchify": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_vit_assemble": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
     "uniir_vit_assemble_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
@@ -57,6 +60,10 @@ SIGNATURES = {
     "uniir_sgemm": (c_int, [P, c_i64, c_i64, P, c_i64, c_i64, P, c_i64, c_int, c_int, c_int, c_float, S]),
     "uniir_adamw_step": (c_int, [P, P, P, P, P, c_i64, c_float, c_float, c_float, c_float, c_float, c_int,
                                  c_float, S]),
+    "uniir_tanh_fwd": (c_int, [P, P, c_i64, S]),
+    "uniir_tanh_bwd": (c_int, [P, P, P, c_i64, S]),
+    "uniir_ema_update": (c_int, [P, P, P, c_i64, c_float, S]),
+    "uniir_softce": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, P, P, P, S]),
     "uniir_pool_inv_norms": (c_int, [P, c_i64, c_int, P, S]),
     "uniir_topk_workspace_bytes": (c_i64, [c_int, c_int, c_i64]),
     "uniir_topk_ncand": (c_int, [c_int, c_int]),

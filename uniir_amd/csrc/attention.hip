@@ -89,33 +89,53 @@ DEVINL float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
-__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const unsigned short* __restrict__ qkv,
-                                                       unsigned short* __restrict__ out,
-                                                       float* __restrict__ lse, int T, int H, int causal) {
+// Generalised argument block: self-attention on the packed in_proj layout (q|k|v per token, CLIP / BLIP ViT / BERT self)
+// and rectangular cross-attention (BLIP MED: Tq text tokens attending to Tk image tokens) share the kernels.
+struct AttnArgs {
+    const unsigned short* q;      // [batch][Tq] rows, row stride q_ld, head h at column h*64
+    const unsigned short* k;      // [batch][Tk] rows, row stride kv_ld
+    const unsigned short* v;
+    long q_ld, kv_ld;
+    unsigned short* out;          // [batch*Tq][out_ld]
+    long out_ld;
+    float* lse;                   // [batch][H][Tq]
+    const int* klen;              // optional [batch]: keys >= klen[m] are masked (BERT padding mask)
+    int Tq, Tk, H, causal;
+    const unsigned short* dout;   // backward only: [batch*Tq][out_ld]
+    unsigned short* dq;           // [batch][Tq] rows, stride dq_ld
+    unsigned short* dk;           // [batch][Tk] rows, stride dkv_ld
+    unsigned short* dv;
+    long dq_ld, dkv_ld;
+};
+
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int Tp = (T + 31) & ~31;
+    const int Tq = a.Tq, Tk = a.Tk, H = a.H, causal = a.causal;
+    const int Tkp = (Tk + 31) & ~31;
     char* ldsK = lds;
-    char* ldsV = lds + Tp * 128;
+    char* ldsV = lds + Tkp * 128;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = blockIdx.x / H, h = blockIdx.x % H;
-    const long W = (long)H * ATT_D, ld = 3 * W;
-    const unsigned short* qbase = qkv + (long)m * T * ld + h * ATT_D;
-    stage_head(ldsK, qbase + W, ld, T, Tp, tid);
-    stage_head(ldsV, qbase + 2 * W, ld, T, Tp, tid);
+    const unsigned short* qbase = a.q + (long)m * Tq * a.q_ld + h * ATT_D;
+    const unsigned short* kbase = a.k + (long)m * Tk * a.kv_ld + h * ATT_D;
+    const unsigned short* vbase = a.v + (long)m * Tk * a.kv_ld + h * ATT_D;
+    const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
+    stage_head(ldsK, kbase, a.kv_ld, Tk, Tkp, tid);
+    stage_head(ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
     __syncthreads();
-    const int nqt = (T + 15) >> 4;
+    const int nqt = (Tq + 15) >> 4;
     const int qi = lane & 15, g = lane >> 4;
     for (int qt = w; qt < nqt; qt += ATT_WAVES) {
         const int q0 = qt * 16, q = q0 + qi;
         bf16x8_t qf[2];
-        qf[0] = frag_rows_global(qbase, ld, q0, 0, lane, T);
-        qf[1] = frag_rows_global(qbase, ld, q0, 1, lane, T);
+        qf[0] = frag_rows_global(qbase, a.q_ld, q0, 0, lane, Tq);
+        qf[1] = frag_rows_global(qbase, a.q_ld, q0, 1, lane, Tq);
         f32x4_t o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         float m_run = -1e30f, l_run = 0.f;
-        const int kmax = causal ? min(T, q0 + 16) : T;
-        const int nkb = (kmax + 31) >> 5;
+        const int kmax = causal ? min(kvalid, q0 + 16) : kvalid;
+        const int nkb = max(1, (kmax + 31) >> 5);
         f32x4_t sn[2];   // S^T of the NEXT key block, computed one iteration ahead so its MFMAs overlap this softmax
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -141,7 +161,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const unsigned sh
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb * 32 + kt * 16 + 4 * g + r;
                     float v = st[kt][r] * SCALE_LOG2E;
-                    if (key >= T || (causal && key > q)) v = -1e30f;
+                    if (key >= kvalid || (causal && key > q)) v = -1e30f;
                     st[kt][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -167,75 +187,76 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const unsigned sh
                 o[dt] = mfma16(frag_cols_tr(ldsV, kb * 32, dt, lane), pf, o[dt]);
             }
         }
-        if (q < T) {
+        if (q < Tq) {
             const float inv = 1.0f / l_run;
-            unsigned short* orow = out + ((long)m * T + q) * W + h * ATT_D;
+            unsigned short* orow = a.out + ((long)m * Tq + q) * a.out_ld + h * ATT_D;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const f32x4_t v = o[dt] * inv;
                 u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *reinterpret_cast<u32x2_t*>(orow + 16 * dt + 4 * g) = pk;
             }
-            if (g == 0) lse[((long)m * H + h) * T + q] = m_run * LN2F + __logf(l_run);
+            if (g == 0) a.lse[((long)m * H + h) * Tq + q] = m_run * LN2F + __logf(l_run);
         }
     }
 }
 
 // Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
 // Phase 2 (per 16-query tile): dQ^T += K^T dS^T with S^T = K Q^T oriented [key][q].
-__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const unsigned short* __restrict__ qkv,
-                                                       const unsigned short* __restrict__ out,
-                                                       const unsigned short* __restrict__ dout,
-                                                       const float* __restrict__ lse,
-                                                       unsigned short* __restrict__ dqkv, int T, int H,
-                                                       int causal) {
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int Tp = (T + 31) & ~31;
-    char* bufA = lds;               // Q, later K
-    char* bufB = lds + Tp * 128;    // dO, later V
-    float* lse2 = reinterpret_cast<float*>(lds + 2 * Tp * 128);
-    float* Dq = lse2 + Tp;
+    const int Tq = a.Tq, Tk = a.Tk, H = a.H, causal = a.causal;
+    const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
+    const int Tmax = max(Tqp, Tkp);
+    char* bufA = lds;                 // Q, later K
+    char* bufB = lds + Tmax * 128;    // dO, later V
+    float* lse2 = reinterpret_cast<float*>(lds + 2 * Tmax * 128);
+    float* Dq = lse2 + Tqp;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = blockIdx.x / H, h = blockIdx.x % H;
-    const long W = (long)H * ATT_D, ld = 3 * W;
-    const unsigned short* qbase = qkv + (long)m * T * ld + h * ATT_D;
-    const unsigned short* obase = out + (long)m * T * W + h * ATT_D;
-    const unsigned short* dobase = dout + (long)m * T * W + h * ATT_D;
-    unsigned short* dqbase = dqkv + (long)m * T * ld + h * ATT_D;
+    const unsigned short* qbase = a.q + (long)m * Tq * a.q_ld + h * ATT_D;
+    const unsigned short* kbase = a.k + (long)m * Tk * a.kv_ld + h * ATT_D;
+    const unsigned short* vbase = a.v + (long)m * Tk * a.kv_ld + h * ATT_D;
+    const unsigned short* obase = a.out + (long)m * Tq * a.out_ld + h * ATT_D;
+    const unsigned short* dobase = a.dout + (long)m * Tq * a.out_ld + h * ATT_D;
+    unsigned short* dqbase = a.dq + (long)m * Tq * a.dq_ld + h * ATT_D;
+    unsigned short* dkbase = a.dk + (long)m * Tk * a.dkv_ld + h * ATT_D;
+    unsigned short* dvbase = a.dv + (long)m * Tk * a.dkv_ld + h * ATT_D;
+    const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
 
-    for (int r = tid; r < Tp; r += ATT_THREADS) {
+    for (int r = tid; r < Tqp; r += ATT_THREADS) {
         float d = 0.f, l = 0.f;
-        if (r < T) {
+        if (r < Tq) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const u32x4_t a = *reinterpret_cast<const u32x4_t*>(obase + (long)r * W + c * 8);
-                const u32x4_t b = *reinterpret_cast<const u32x4_t*>(dobase + (long)r * W + c * 8);
+                const u32x4_t x = *reinterpret_cast<const u32x4_t*>(obase + (long)r * a.out_ld + c * 8);
+                const u32x4_t y = *reinterpret_cast<const u32x4_t*>(dobase + (long)r * a.out_ld + c * 8);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    d += __uint_as_float(a[e] << 16) * __uint_as_float(b[e] << 16);
-                    d += __uint_as_float(a[e] & 0xffff0000u) * __uint_as_float(b[e] & 0xffff0000u);
+                    d += __uint_as_float(x[e] << 16) * __uint_as_float(y[e] << 16);
+                    d += __uint_as_float(x[e] & 0xffff0000u) * __uint_as_float(y[e] & 0xffff0000u);
                 }
             }
-            l = lse[((long)m * H + h) * T + r] * LOG2EF;
+            l = a.lse[((long)m * H + h) * Tq + r] * LOG2EF;
         }
         Dq[r] = d;
         lse2[r] = l;
     }
-    stage_head(bufA, qbase, ld, T, Tp, tid);
-    stage_head(bufB, dobase, W, T, Tp, tid);
+    stage_head(bufA, qbase, a.q_ld, Tq, Tqp, tid);
+    stage_head(bufB, dobase, a.out_ld, Tq, Tqp, tid);
     __syncthreads();
 
     const int li = lane & 15, g = lane >> 4;
-    const int ntile = (T + 15) >> 4;
-    const int nblk = Tp >> 5;
+    const int nktile = (Tk + 15) >> 4, nqtile = (Tq + 15) >> 4;
+    const int nqblk = Tqp >> 5;
     // ---------------- phase 1: dK, dV ----------------
-    for (int kt = w; kt < ntile; kt += ATT_WAVES) {
+    for (int kt = w; kt < nktile; kt += ATT_WAVES) {
         const int k0 = kt * 16, key = k0 + li;
         bf16x8_t kf[2], vf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            kf[s] = frag_rows_global(qbase + W, ld, k0, s, lane, T);
-            vf[s] = frag_rows_global(qbase + 2 * W, ld, k0, s, lane, T);
+            kf[s] = frag_rows_global(kbase, a.kv_ld, k0, s, lane, Tk);
+            vf[s] = frag_rows_global(vbase, a.kv_ld, k0, s, lane, Tk);
         }
         f32x4_t dv[4], dk[4];
 #pragma unroll
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const unsigned
             dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         const int qb0 = causal ? (k0 >> 5) : 0;
-        for (int qb = qb0; qb < nblk; ++qb) {
+        for (int qb = qb0; qb < nqblk; ++qb) {
             f32x4_t pt[2], dst[2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
@@ -254,12 +275,12 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const unsigned
                     sa = mfma16(frag_rows(bufA, qb * 32 + qt * 16, s, lane), kf[s], sa);
                     dp = mfma16(frag_rows(bufB, qb * 32 + qt * 16, s, lane), vf[s], dp);
                 }
-                // NOTE operand order: A rows = queries, B cols = keys -> acc[r] = S[q = 4g + r][key = li]
+                // A rows = queries, B cols = keys -> acc[r] = S[q = 4g + r][key = li]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = qb * 32 + qt * 16 + 4 * g + r;
                     float p = __builtin_amdgcn_exp2f(sa[r] * SCALE_LOG2E - lse2[q]);
-                    if (causal && key > q) p = 0.f;
+                    if (key >= kvalid || (causal && key > q)) p = 0.f;
                     pt[qt][r] = p;
                     dst[qt][r] = p * (dp[r] - Dq[q]);
                 }
@@ -271,13 +292,13 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const unsigned
                 dk[dt] = mfma16(frag_cols_tr(bufA, qb * 32, dt, lane), dsf, dk[dt]);
             }
         }
-        if (key < T) {
-            unsigned short* krow = dqbase + (long)key * ld + W;
-            unsigned short* vrow = dqbase + (long)key * ld + 2 * W;
+        if (key < Tk) {
+            unsigned short* krow = dkbase + (long)key * a.dkv_ld;
+            unsigned short* vrow = dvbase + (long)key * a.dkv_ld;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const f32x4_t a = dk[dt] * ATT_SCALE;
-                u32x2_t pk = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+                const f32x4_t x = dk[dt] * ATT_SCALE;
+                u32x2_t pk = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
                 *reinterpret_cast<u32x2_t*>(krow + 16 * dt + 4 * g) = pk;
                 u32x2_t pv = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
                 *reinterpret_cast<u32x2_t*>(vrow + 16 * dt + 4 * g) = pv;
@@ -285,23 +306,23 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const unsigned
         }
     }
     __syncthreads();
-    stage_head(bufA, qbase + W, ld, T, Tp, tid);
-    stage_head(bufB, qbase + 2 * W, ld, T, Tp, tid);
+    stage_head(bufA, kbase, a.kv_ld, Tk, Tkp, tid);
+    stage_head(bufB, vbase, a.kv_ld, Tk, Tkp, tid);
     __syncthreads();
     // ---------------- phase 2: dQ ----------------
-    for (int qt = w; qt < ntile; qt += ATT_WAVES) {
+    for (int qt = w; qt < nqtile; qt += ATT_WAVES) {
         const int q0 = qt * 16, q = q0 + li;
         bf16x8_t qf[2], dof[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            qf[s] = frag_rows_global(qbase, ld, q0, s, lane, T);
-            dof[s] = frag_rows_global(dobase, W, q0, s, lane, T);
+            qf[s] = frag_rows_global(qbase, a.q_ld, q0, s, lane, Tq);
+            dof[s] = frag_rows_global(dobase, a.out_ld, q0, s, lane, Tq);
         }
         const float my_lse = lse2[q0 + li], my_D = Dq[q0 + li];
         f32x4_t dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const int kmax = causal ? min(T, q0 + 16) : T;
+        const int kmax = causal ? min(kvalid, q0 + 16) : kvalid;
         const int nkb = (kmax + 31) >> 5;
         for (int kb = 0; kb < nkb; ++kb) {
             f32x4_t dst[2];
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const unsigned
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb * 32 + kt * 16 + 4 * g + r;
                     float p = __builtin_amdgcn_exp2f(sa[r] * SCALE_LOG2E - my_lse);
-                    if (key >= T || (causal && key > q)) p = 0.f;
+                    if (key >= kvalid || (causal && key > q)) p = 0.f;
                     dst[kt][r] = p * (dp[r] - my_D);
                 }
             }
@@ -325,16 +346,43 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const unsigned
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(frag_cols_tr(bufA, kb * 32, dt, lane), dsf, dq[dt]);
         }
-        if (q < T) {
-            unsigned short* qrow = dqbase + (long)q * ld;
+        if (q < Tq) {
+            unsigned short* qrow = dqbase + (long)q * a.dq_ld;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const f32x4_t a = dq[dt] * ATT_SCALE;
-                u32x2_t pk = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+                const f32x4_t x = dq[dt] * ATT_SCALE;
+                u32x2_t pk = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
                 *reinterpret_cast<u32x2_t*>(qrow + 16 * dt + 4 * g) = pk;
             }
         }
     }
+}
+
+static int launch_attn_fwd(const AttnArgs& a, int batch, hipStream_t st) {
+    const int Tkp = (a.Tk + 31) & ~31;
+    const int sm = 2 * Tkp * 128;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+static int launch_attn_bwd(const AttnArgs& a, int batch, hipStream_t st) {
+    const int Tqp = (a.Tq + 31) & ~31, Tkp = (a.Tk + 31) & ~31;
+    const int Tmax = Tqp > Tkp ? Tqp : Tkp;
+    const int sm = 2 * Tmax * 128 + 2 * Tqp * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * 512 * 128 + 2 * 512 * 4);
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
 }
 
 extern "C" int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32_t batch, int32_t seq,
@@ -343,17 +391,13 @@ extern "C" int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32
     if (batch == 0) return UNIIR_OK;
     if (seq < 1 || seq > 512) return UNIIR_ESHAPE;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return UNIIR_EALIGN;
-    const int Tp = (seq + 31) & ~31;
-    const int sm = 2 * Tp * 128;
-    static int attr = 0;
-    if (sm > attr) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
-        attr = 2 * 512 * 128;
-    }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(batch * heads), dim3(ATT_THREADS), sm, (hipStream_t)stream,
-                       (const unsigned short*)qkv, (unsigned short*)out, lse, seq, heads, causal);
-    HIP_LAUNCH_CHECK();
-    return UNIIR_OK;
+    const long W = (long)heads * ATT_D;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)qkv; a.k = a.q + W; a.v = a.q + 2 * W;
+    a.q_ld = a.kv_ld = 3 * W;
+    a.out = (unsigned short*)out; a.out_ld = W; a.lse = lse; a.klen = nullptr;
+    a.Tq = a.Tk = seq; a.H = heads; a.causal = causal;
+    return launch_attn_fwd(a, batch, (hipStream_t)stream);
 }
 
 extern "C" int uniir_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
@@ -364,17 +408,52 @@ extern "C" int uniir_attention_bwd(const void* qkv, const void* out, const void*
     if (seq < 1 || seq > 512) return UNIIR_ESHAPE;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15))
         return UNIIR_EALIGN;
-    const int Tp = (seq + 31) & ~31;
-    const int sm = 2 * Tp * 128 + 2 * Tp * 4;
-    static int attr = 0;
-    if (sm > attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * 512 * 128 + 2 * 512 * 4);
-        attr = 2 * 512 * 128 + 2 * 512 * 4;
-    }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * heads), dim3(ATT_THREADS), sm, (hipStream_t)stream,
-                       (const unsigned short*)qkv, (const unsigned short*)out, (const unsigned short*)dout, lse,
-                       (unsigned short*)dqkv, seq, heads, causal);
-    HIP_LAUNCH_CHECK();
-    return UNIIR_OK;
+    const long W = (long)heads * ATT_D;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)qkv; a.k = a.q + W; a.v = a.q + 2 * W;
+    a.q_ld = a.kv_ld = 3 * W;
+    a.out = (unsigned short*)out; a.out_ld = W; a.lse = const_cast<float*>(lse); a.klen = nullptr;
+    a.Tq = a.Tk = seq; a.H = heads; a.causal = causal;
+    a.dout = (const unsigned short*)dout;
+    a.dq = (unsigned short*)dqkv; a.dk = a.dq + W; a.dv = a.dq + 2 * W;
+    a.dq_ld = a.dkv_ld = 3 * W;
+    return launch_attn_bwd(a, batch, (hipStream_t)stream);
+}
+
+// general form: separate Q and K/V tensors (cross-attention), optional per-item key length (padding mask)
+extern "C" int uniir_attention_fwd_ex(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld,
+                                      void* out, int64_t out_ld, float* lse, const int32_t* key_len, int32_t batch,
+                                      int32_t tq, int32_t tk, int32_t heads, int32_t causal, void* stream) {
+    if (!q || !k || !v || !out || !lse || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (tq < 1 || tk < 1 || tq > 512 || tk > 512) return UNIIR_ESHAPE;
+    if (causal && tq != tk) return UNIIR_ESHAPE;
+    if ((q_ld % 8) || (kv_ld % 8) || (out_ld % 8)) return UNIIR_EALIGN;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15)) return UNIIR_EALIGN;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
+    a.q_ld = q_ld; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = out_ld; a.lse = lse; a.klen = key_len;
+    a.Tq = tq; a.Tk = tk; a.H = heads; a.causal = causal;
+    return launch_attn_fwd(a, batch, (hipStream_t)stream);
+}
+
+extern "C" int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld,
+                                      const void* out, const void* dout, int64_t out_ld, const float* lse,
+                                      const int32_t* key_len, void* dq, int64_t dq_ld, void* dk, void* dv,
+                                      int64_t dkv_ld, int32_t batch, int32_t tq, int32_t tk, int32_t heads,
+                                      int32_t causal, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (tq < 1 || tk < 1 || tq > 512 || tk > 512) return UNIIR_ESHAPE;
+    if (causal && tq != tk) return UNIIR_ESHAPE;
+    if ((q_ld % 8) || (kv_ld % 8) || (out_ld % 8) || (dq_ld % 4) || (dkv_ld % 4)) return UNIIR_EALIGN;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
+    a.q_ld = q_ld; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = out_ld;
+    a.lse = const_cast<float*>(lse); a.klen = key_len;
+    a.Tq = tq; a.Tk = tk; a.H = heads; a.causal = causal;
+    a.dout = (const unsigned short*)dout;
+    a.dq = (unsigned short*)dq; a.dk = (unsigned short*)dk; a.dv = (unsigned short*)dv;
+    a.dq_ld = dq_ld; a.dkv_ld = dkv_ld;
+    return launch_attn_bwd(a, batch, (hipStream_t)stream);
 }

@@ -556,3 +556,138 @@ extern "C" int uniir_adamw_step(float* param, const float* grad, float* exp_avg,
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// BLIP pieces (uniir_blip): tanh pooler (med.py:499-511), momentum EMA (blip_ff.py:288-292) and the soft-target
+// contrastive loss over [in-batch | queue] similarities (blip_ff.py:219-231).
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = tanhf(x[i]);
+}
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float t = y[i];
+        dx[i] = dy[i] * (1.0f - t * t);
+    }
+}
+extern "C" int uniir_tanh_fwd(const float* x, float* y, int64_t count, void* stream) {
+    if (!x || !y || count < 0) return UNIIR_EINVAL;
+    if (count == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid_for(count, 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)count);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+extern "C" int uniir_tanh_bwd(const float* y, const float* dy, float* dx, int64_t count, void* stream) {
+    if (!y || !dy || !dx || count < 0) return UNIIR_EINVAL;
+    if (count == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(count, 256)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, (long)count);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// p_m = m * p_m + (1 - m) * p over a flat buffer; refreshes the momentum model's bf16 shadow in the same pass
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pm, const float* __restrict__ p,
+                                                  unsigned short* __restrict__ pm16, long n, float m) {
+    const long nv = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        f32x4_t a = *reinterpret_cast<f32x4_t*>(pm + 4 * i);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p + 4 * i);
+        a = a * m + b * (1.0f - m);
+        *reinterpret_cast<f32x4_t*>(pm + 4 * i) = a;
+        if (pm16) {
+            u32x2_t o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+            *reinterpret_cast<u32x2_t*>(pm16 + 4 * i) = o;
+        }
+    }
+}
+extern "C" int uniir_ema_update(float* param_m, const float* param, void* param_m_bf16, int64_t count, float momentum,
+                                void* stream) {
+    if (!param_m || !param || count < 0) return UNIIR_EINVAL;
+    if (count == 0) return UNIIR_OK;
+    if (count % 4 || ((uintptr_t)param_m & 15) || ((uintptr_t)param & 15)) return UNIIR_EALIGN;
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(count / 4, 256, 16384)), dim3(256), 0, (hipStream_t)stream, param_m,
+                       param, (unsigned short*)param_m_bf16, (long)count, momentum);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// soft-target contrastive loss, one block per row i of sim [b][n]:
+//   pos_j = (ids_all[j] == ids_row[i]);  target = alpha * softmax(sim_m[i]) + (1 - alpha) * pos / sum(pos)
+//   loss_i = -sum_j log_softmax(sim[i])_j * target_j ;  dsim[i][j] = (softmax(sim[i])_j - target_j) * gscale
+// (sum_j target_j = 1).  hit_i = pos[argmax_j sim[i][j]] (first max), used for the accuracy of blip_ff.py:250-252.
+__global__ __launch_bounds__(256) void softce_kernel(const float* __restrict__ sim, const float* __restrict__ sim_m,
+                                                     const long long* __restrict__ ids_row,
+                                                     const long long* __restrict__ ids_all, int n, float alpha,
+                                                     float gscale, float* __restrict__ row_loss,
+                                                     float* __restrict__ row_hit, float* __restrict__ dsim) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* s = sim + (long)i * n;
+    const float* sm = sim_m + (long)i * n;
+    const long long my = ids_row[i];
+    auto block_max = [&](float v) {
+        v = wave_max(v);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        return r;
+    };
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        const float r = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+        return r;
+    };
+    float mx = -INFINITY, mxm = -INFINITY, npos = 0.f;
+    int am = 0x7fffffff;
+    for (int j = tid; j < n; j += 256) {
+        const float v = s[j];
+        if (v > mx) { mx = v; am = j; }
+        mxm = fmaxf(mxm, sm[j]);
+        npos += (ids_all[j] == my) ? 1.0f : 0.0f;
+    }
+    // first-index argmax over the block
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (ov > mx || (ov == mx && oa < am)) { mx = ov; am = oa; }
+    }
+    if (lane == 0) { red[w] = mx; redi[w] = am; }
+    __syncthreads();
+    mx = red[0]; am = redi[0];
+    for (int k = 1; k < 4; ++k) if (red[k] > mx || (red[k] == mx && redi[k] < am)) { mx = red[k]; am = redi[k]; }
+    __syncthreads();
+    mxm = block_max(mxm);
+    npos = block_sum(npos);
+    float se = 0.f, sem = 0.f;
+    for (int j = tid; j < n; j += 256) { se += expf(s[j] - mx); sem += expf(sm[j] - mxm); }
+    se = block_sum(se);
+    sem = block_sum(sem);
+    const float lse = mx + logf(se), inv_sem = 1.0f / sem, inv_pos = npos > 0.f ? 1.0f / npos : 0.f;
+    float loss = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const float lsm = s[j] - lse;
+        const float tgt = alpha * (expf(sm[j] - mxm) * inv_sem) + (1.0f - alpha) * ((ids_all[j] == my) ? inv_pos : 0.f);
+        loss -= lsm * tgt;
+        if (dsim) dsim[(long)i * n + j] = (expf(lsm) - tgt) * gscale;
+    }
+    loss = block_sum(loss);
+    if (tid == 0) {
+        row_loss[i] = loss;
+        row_hit[i] = (ids_all[am] == my) ? 1.0f : 0.0f;
+    }
+}
+extern "C" int uniir_softce(const float* sim, const float* sim_m, const int64_t* ids_row, const int64_t* ids_all,
+                            int32_t b, int32_t n, float alpha, float gscale, float* row_loss, float* row_hit,
+                            float* dsim, void* stream) {
+    if (!sim || !sim_m || !ids_row || !ids_all || !row_loss || !row_hit || b <= 0 || n <= 0) return UNIIR_EINVAL;
+    hipLaunchKernelGGL(softce_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, sim, sim_m, (const long long*)ids_row,
+                       (const long long*)ids_all, n, alpha, gscale, row_loss, row_hit, dsim);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
