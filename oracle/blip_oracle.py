@@ -1,0 +1,141 @@
+"""CPU ORACLE (test infrastructure, NOT the product path) -- plain PyTorch fp32 restatement of the BLIP_FF rows of the
+hot path (a17 encode_multimodal_input, a18 contrastive loss + momentum + queues, a19 MED BERT,
+a20 BLIP ViT).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
+
+Restated from (paths relative to the UniIR reference tree):
+  * src/models/uniir_blip/backbone/vit.py:24-268   VisionTransformer (pre-LN blocks, fused qkv Linear, erf GELU,
+    LayerNorm eps 1e-6, final norm, ALL tokens returned); PatchEmbed is timm's (Conv2d(3, D, 16, 16, bias=True) +
+    flatten(2).transpose(1, 2); third-party, restated from its published behaviour)
+  * src/models/uniir_blip/backbone/med.py:52-100 (embeddings), :101-232 (self / cross attention, additive
+    (1 - mask) * -10000 key mask :687-688), :235-247, :303-330 (post-LN residual sublayers), :499-511 (tanh pooler),
+    BertModel.forward in mode "multimodal" (:691-829)
+  * src/models/uniir_blip/blip_featurefusion/blip_ff.py:82-116 (encode), :118-257 (loss), :288-310 (momentum, queues)
+PARITY PINNING: tests/golden/g6_med.npz, g7_vit.npz, g8_blipff.npz were produced by importing those reference files
+here (tests/golden/make_golden_blip.py); tests/test_oracle_blip.py holds this restatement to them.
+Dropout / DropPath are not restated (the fixtures run with probability 0).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _ln(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+# ------------------------------------------------------------------------------------------------ BLIP ViT
+def vit_forward(sd, x, cfg, prefix=""):
+    """sd: state dict with timm-style keys under `prefix`; x [N,3,H,W] -> tokens [N, 1+g*g, D]"""
+    p = prefix
+    D, P, heads = cfg["embed_dim"], cfg["patch_size"], cfg["num_heads"]
+    t = F.conv2d(x, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=P)
+    t = t.flatten(2).transpose(1, 2)
+    t = torch.cat([sd[p + "cls_token"].expand(t.shape[0], -1, -1), t], dim=1)
+    t = t + sd[p + "pos_embed"][:, : t.shape[1], :]
+    hd = D // heads
+    for i in range(cfg["depth"]):
+        b = f"{p}blocks.{i}."
+        h = _ln(t, sd[b + "norm1.weight"], sd[b + "norm1.bias"], 1e-6)
+        N, L, _ = h.shape
+        qkv = (h @ sd[b + "attn.qkv.weight"].t() + sd[b + "attn.qkv.bias"]).reshape(N, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        a = torch.softmax((qkv[0] @ qkv[1].transpose(-2, -1)) * hd ** -0.5, dim=-1)
+        o = (a @ qkv[2]).transpose(1, 2).reshape(N, L, D)
+        t = t + (o @ sd[b + "attn.proj.weight"].t() + sd[b + "attn.proj.bias"])
+        h = _ln(t, sd[b + "norm2.weight"], sd[b + "norm2.bias"], 1e-6)
+        h = F.gelu(h @ sd[b + "mlp.fc1.weight"].t() + sd[b + "mlp.fc1.bias"])
+        t = t + (h @ sd[b + "mlp.fc2.weight"].t() + sd[b + "mlp.fc2.bias"])
+    return _ln(t, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ MED BERT
+def _attn(sd, pre, q_in, kv_in, heads, add_mask):
+    """BertSelfAttention: q from q_in, k/v from kv_in; additive mask [N,1,1,Lk] or None"""
+    N, Lq, W = q_in.shape
+    hd = W // heads
+    q = (q_in @ sd[pre + "query.weight"].t() + sd[pre + "query.bias"]).view(N, Lq, heads, hd).transpose(1, 2)
+    k = (kv_in @ sd[pre + "key.weight"].t() + sd[pre + "key.bias"]).view(N, -1, heads, hd).transpose(1, 2)
+    v = (kv_in @ sd[pre + "value.weight"].t() + sd[pre + "value.bias"]).view(N, -1, heads, hd).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if add_mask is not None:
+        s = s + add_mask
+    return (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(N, Lq, W)
+
+
+def bert_forward(sd, ids, mask, enc_hidden, cfg, prefix=""):
+    """BertModel(mode='multimodal'): -> (last_hidden_state [N,L,W], pooler_output [N,W])"""
+    p = prefix
+    eps, heads = cfg["layer_norm_eps"], cfg["num_attention_heads"]
+    L = ids.shape[1]
+    h = sd[p + "embeddings.word_embeddings.weight"][ids] + sd[p + "embeddings.position_embeddings.weight"][:L]
+    h = _ln(h, sd[p + "embeddings.LayerNorm.weight"], sd[p + "embeddings.LayerNorm.bias"], eps)
+    add_mask = (1.0 - mask[:, None, None, :].to(h.dtype)) * -10000.0
+    for i in range(cfg["num_hidden_layers"]):
+        b = f"{p}encoder.layer.{i}."
+        ctx = _attn(sd, b + "attention.self.", h, h, heads, add_mask)
+        h = _ln(ctx @ sd[b + "attention.output.dense.weight"].t() + sd[b + "attention.output.dense.bias"] + h,
+                sd[b + "attention.output.LayerNorm.weight"], sd[b + "attention.output.LayerNorm.bias"], eps)
+        ctx = _attn(sd, b + "crossattention.self.", h, enc_hidden, heads, None)   # image attention mask is all ones
+        h = _ln(ctx @ sd[b + "crossattention.output.dense.weight"].t() + sd[b + "crossattention.output.dense.bias"] + h,
+                sd[b + "crossattention.output.LayerNorm.weight"], sd[b + "crossattention.output.LayerNorm.bias"], eps)
+        f = F.gelu(h @ sd[b + "intermediate.dense.weight"].t() + sd[b + "intermediate.dense.bias"])
+        h = _ln(f @ sd[b + "output.dense.weight"].t() + sd[b + "output.dense.bias"] + h,
+                sd[b + "output.LayerNorm.weight"], sd[b + "output.LayerNorm.bias"], eps)
+    pooled = torch.tanh(h[:, 0] @ sd[p + "pooler.dense.weight"].t() + sd[p + "pooler.dense.bias"])
+    return h, pooled
+
+
+# ------------------------------------------------------------------------------------------------ BLIP_FF
+def encode_multimodal_input(sd, ids, mask, images, vit_cfg, med_cfg, momentum=False):
+    """blip_ff.py:82-116: pooler_output of BERT(text) cross-attending to ViT(image) tokens (masks unused there)"""
+    sfx = "_m" if momentum else ""
+    img = vit_forward(sd, images, vit_cfg, prefix=f"visual_encoder{sfx}.")
+    return bert_forward(sd, ids, mask, img, med_cfg, prefix=f"text_encoder{sfx}.")[1]
+
+
+def momentum_update(sd, m):
+    for k in list(sd.keys()):
+        for enc in ("visual_encoder", "text_encoder"):
+            if k.startswith(enc + "."):
+                km = enc + "_m." + k[len(enc) + 1:]
+                if km in sd and sd[km].dtype.is_floating_point:
+                    sd[km] = sd[km] * m + sd[k].detach() * (1.0 - m)
+
+
+def contrastive_loss(sd, state, batch, alpha, vit_cfg, med_cfg, momentum):
+    """blip_ff.py:118-257 (no hard negatives).  `sd`: parameters (online ones may require grad; momentum entries are
+    replaced in place), `state`: dict(query_queue [E,K], cand_queue [E,K], idx_queue [1,K] int64, ptr int)."""
+    with torch.no_grad():
+        sd["temp"].clamp_(0.001, 0.5)
+    temp = sd["temp"]
+    ids, mask, img = batch["ids"], batch["mask"], batch["img"]
+    emb = encode_multimodal_input(sd, ids, mask, img, vit_cfg, med_cfg)
+    qi = torch.tensor(batch["index_mapping"]["query"]).flatten()
+    pi = torch.tensor(batch["index_mapping"]["pos_cand"]).flatten()
+    q = F.normalize(emb[qi], dim=-1)
+    p = F.normalize(emb[pi], dim=-1)
+    pc_idx = batch["p_did_list"].view(-1, 1)
+    idx_all = torch.cat([pc_idx.t(), state["idx_queue"].clone()], dim=1)
+    pos = torch.eq(pc_idx, idx_all).float()
+    tgt = pos / pos.sum(1, keepdim=True)
+    with torch.no_grad():
+        momentum_update(sd, momentum)
+        emb_m = encode_multimodal_input(sd, ids, mask, img, vit_cfg, med_cfg, momentum=True)
+        q_m = F.normalize(emb_m[qi], dim=-1)
+        p_m = F.normalize(emb_m[pi], dim=-1)
+        q_m_all = torch.cat([q_m.t(), state["query_queue"].clone()], dim=1)
+        p_m_all = torch.cat([p_m.t(), state["cand_queue"].clone()], dim=1)
+        t_q2p = alpha * F.softmax(q_m @ p_m_all / temp, dim=1) + (1 - alpha) * tgt
+        t_p2q = alpha * F.softmax(p_m @ q_m_all / temp, dim=1) + (1 - alpha) * tgt
+    sim_q2p = q @ p_m_all / temp
+    sim_p2q = p @ q_m_all / temp
+    loss = (-(F.log_softmax(sim_q2p, dim=1) * t_q2p).sum(1).mean() - (F.log_softmax(sim_p2q, dim=1) * t_p2q).sum(1).mean()) / 2
+    with torch.no_grad():   # _dequeue_and_enqueue (world size 1)
+        b, K, ptr = q_m.shape[0], state["query_queue"].shape[1], state["ptr"]
+        assert K % b == 0
+        state["query_queue"][:, ptr:ptr + b] = q_m.t()
+        state["cand_queue"][:, ptr:ptr + b] = p_m.t()
+        state["idx_queue"][:, ptr:ptr + b] = pc_idx.t()
+        state["ptr"] = (ptr + b) % K
+    acc = pos.gather(1, sim_q2p.max(1)[1].unsqueeze(1)).squeeze().mean()
+    return {"loss": loss, "accuracy": acc, "sim_q2p": sim_q2p}
