@@ -202,17 +202,24 @@ int uniir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
 /* ------------------------------------------------------------------------------------------------
  * [BLIP] extra pieces of the BLIP_FF path (src/models/uniir_blip): tanh pooler (backbone/med.py:499-511), momentum
  * EMA p_m = m p_m + (1-m) p (blip_featurefusion/blip_ff.py:288-292) over a flat buffer (+ bf16 shadow), and the
- * soft-target contrastive loss of blip_ff.py:219-231 on one similarity matrix sim [b][n] (n = b + queue):
- *   target = alpha * softmax(sim_m) + (1-alpha) * pos / sum(pos), pos_j = (ids_all[j] == ids_row[i]);
- *   row_loss[i] = -sum_j log_softmax(sim[i])_j target_j;  dsim = (softmax(sim) - target) * gscale (optional);
+ * soft-target contrastive loss of blip_ff.py:219-231 on one matrix of dot products sim [b][n] (n = b + queue) with
+ * logits = sim / *temp (temp NULL -> 1):
+ *   target = alpha * softmax(sim_m / temp) + (1-alpha) * pos / sum(pos), pos_j = (ids_all[j] == ids_row[i]);
+ *   row_loss[i] = -sum_j log_softmax(logits[i])_j target_j;
+ *   with g = (softmax(logits) - target) * gscale * (dloss ? *dloss : 1):
+ *     dsim = g / temp (optional), row_dtemp[i] = -sum_j g_j logits_j / temp (optional);
  *   row_hit[i] = pos[argmax_j sim[i][j]]  (accuracy of blip_ff.py:250-252, first max).
  * ---------------------------------------------------------------------------------------------- */
 int uniir_tanh_fwd(const float* x, float* y, int64_t count, void* stream);
 int uniir_tanh_bwd(const float* y, const float* dy, float* dx, int64_t count, void* stream);
 int uniir_ema_update(float* param_m, const float* param, void* param_m_bf16, int64_t count, float momentum,
                      void* stream);
-int uniir_softce(const float* sim, const float* sim_m, const int64_t* ids_row, const int64_t* ids_all, int32_t b,
-                 int32_t n, float alpha, float gscale, float* row_loss, float* row_hit, float* dsim, void* stream);
+int uniir_softce(const float* sim, const float* sim_m, const float* temp, const int64_t* ids_row,
+                 const int64_t* ids_all, int32_t b, int32_t n, float alpha, float gscale, const float* dloss,
+                 float* row_loss, float* row_hit, float* dsim, float* row_dtemp, void* stream);
+/* uniir_sgemm with C += instead of C = (dq = dsim[:, :b] p_m + dsim[:, b:] queue^T without a concatenated copy) */
+int uniir_sgemm_acc(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                    float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [TOPK] exact brute-force inner-product top-k over an fp16 pool (FAISS "IDMap,Flat" + normalize_L2).

@@ -1,0 +1,157 @@
+"""BLIP_FF on the MI355X against the reference-generated goldens (G6 MED BERT, G7 BLIP ViT, G8 two BLIP_FF training
+steps) and the oracle.  The device path computes its GEMMs in bf16 (fp32 accumulate), so the comparisons are relative
+L2 errors: 2e-2 for forward tensors, 5e-2 for gradients (the reference's own fp16-autocast run is no closer to fp32);
+index / bookkeeping results (queue ids, pointer, accuracy) are exact."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu().flatten(), torch.as_tensor(b).double().cpu().flatten()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def tiny_model(med_cfg, vit_cfg, queue_size=16, momentum=0.9):
+    from uniir_amd.blip_model import BLIPFeatureFusion
+    return BLIPFeatureFusion(med_config=med_cfg, vit_config=vit_cfg, embed_dim=med_cfg["hidden_size"],
+                             queue_size=queue_size, momentum=momentum,
+                             config=types.SimpleNamespace(tokenizer_max_length=20))
+
+
+def load_sub(model, z, tag, prefix):
+    sd = {prefix + k[len(tag):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag)}
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    return sd
+
+
+def test_g7_vit_forward_backward():
+    from uniir_amd import blip_model as bm
+    z = np.load(os.path.join(G, "g7_vit.npz"))
+    vit_cfg = json.loads(str(z["cfg"]))
+    med_cfg = dict(hidden_size=128, intermediate_size=256, num_attention_heads=2, num_hidden_layers=1, vocab_size=64,
+                   max_position_embeddings=32)
+    model = tiny_model(med_cfg, vit_cfg).cuda()
+    load_sub(model, z, "sd::", "visual_encoder.")
+    model._sync()
+    model.zero_grad()
+    st = model._online
+    x = torch.from_numpy(z["x"]).cuda()
+    tok, T, stash = bm.vit_forward(st, model._conv16, "visual_encoder.", model.vit_cfg, model.image_size, x, True)
+    y = torch.from_numpy(z["y"])
+    assert rel(tok.float().view(y.shape), y) < 2e-2
+    w = torch.from_numpy(z["w"]).cuda().view(-1, y.shape[-1]).contiguous()
+    bm.vit_backward(st, model._dconv, "visual_encoder.", model.vit_cfg, w, stash)
+    for k in z.files:
+        if k.startswith("grad::"):
+            g = st.grad_view("visual_encoder." + k[6:])
+            assert rel(g, z[k]) < 5e-2, (k, rel(g, z[k]))
+
+
+def test_g6_med_bert_forward_backward():
+    from uniir_amd import blip_model as bm
+    z = np.load(os.path.join(G, "g6_med.npz"))
+    med_cfg = json.loads(str(z["cfg"]))
+    vit_cfg = dict(img_size=32, patch_size=16, embed_dim=med_cfg["encoder_width"], depth=1, num_heads=2)
+    model = tiny_model(med_cfg, vit_cfg).cuda()
+    load_sub(model, z, "sd::", "text_encoder.")
+    model._sync()
+    model.zero_grad()
+    st = model._online
+    ids = torch.from_numpy(z["ids"]).to(torch.int32).cuda()
+    key_len = torch.from_numpy(z["mask"]).sum(1).to(torch.int32).cuda()
+    img = torch.from_numpy(z["img"])
+    n, Ti, Ew = img.shape
+    img16 = img.cuda().to(torch.bfloat16).view(n * Ti, Ew).contiguous()
+    pooled, stash = bm.bert_forward(st, "text_encoder.", model.med_cfg, ids, key_len, img16, Ti, True)
+    assert rel(pooled, z["pooler_output"]) < 2e-2
+    dimg = bm.bert_backward(st, "text_encoder.", model.med_cfg, torch.from_numpy(z["w"]).cuda(), stash)
+    assert rel(dimg.view(n, Ti, Ew), z["dimg"]) < 5e-2
+    for k in z.files:
+        if k.startswith("grad::"):
+            g = st.grad_view("text_encoder." + k[6:])
+            assert rel(g, z[k]) < 5e-2, (k, rel(g, z[k]))
+
+
+def test_g8_blip_ff_two_training_steps():
+    z = np.load(os.path.join(G, "g8_blipff.npz"))
+    med_cfg, vit_cfg = json.loads(str(z["med_cfg"])), json.loads(str(z["vit_cfg"]))
+    model = tiny_model(med_cfg, vit_cfg, queue_size=int(z["queue_size"]), momentum=float(z["momentum"]))
+    load_sub(model, z, "sd0::", "")
+    model.copy_params()
+    model = model.cuda()
+    model.train()
+    for step in range(2):
+        b = len(z[f"s{step}_pdid"])
+        batch = {
+            "txt_batched": types.SimpleNamespace(input_ids=torch.from_numpy(z[f"s{step}_ids"]).cuda(),
+                                                 attention_mask=torch.from_numpy(z[f"s{step}_mask"]).cuda()),
+            "image_batched": torch.from_numpy(z[f"s{step}_img"]).cuda(),
+            "txt_mask_batched": torch.ones(2 * b, dtype=torch.long).cuda(),
+            "image_mask_batched": torch.ones(2 * b, dtype=torch.long).cuda(),
+            "p_did_list": torch.from_numpy(z[f"s{step}_pdid"]),
+            "index_mapping": {"query": [[2 * i] for i in range(b)], "pos_cand": [[2 * i + 1] for i in range(b)]},
+        }
+        model.zero_grad()
+        out = model(batch, alpha=float(z[f"s{step}_alpha"]))
+        out["loss"].backward()
+        assert abs(out["loss"].item() - float(z[f"s{step}_loss"])) < 2e-2, (out["loss"].item(), float(z[f"s{step}_loss"]))
+        assert out["accuracy"].item() == float(z[f"s{step}_acc"])
+        assert rel(model.query_queue, z[f"s{step}_query_queue"]) < 2e-2
+        assert rel(model.cand_queue, z[f"s{step}_cand_queue"]) < 2e-2
+        assert np.array_equal(model.idx_queue.cpu().numpy(), z[f"s{step}_idx_queue"])
+        assert int(model.new_ptr_queue.item()) == int(z[f"s{step}_ptr"].item())
+        assert rel(model.get_parameter("visual_encoder_m.blocks.0.attn.qkv.weight"), z[f"s{step}_m_vit_qkv0"]) < 1e-5
+        assert rel(model.temp.grad, z[f"s{step}_dtemp"]) < 8e-2
+        for name, key in (("visual_encoder.blocks.0.attn.qkv.weight", "g_vit_qkv0"),
+                          ("text_encoder.encoder.layer.0.attention.self.query.weight", "g_txt_q0"),
+                          ("text_encoder.pooler.dense.weight", "g_pool")):
+            r = rel(model.get_parameter(name).grad, z[f"s{step}_{key}"])
+            assert r < 8e-2, (step, name, r)
+        with torch.no_grad():   # the fixture's SGD nudge between its two steps
+            for n, p in model._online_params():
+                if n != "temp":
+                    p.add_(-0.05 * p.grad)
+
+
+def test_blip_ff_native_adamw_and_embedding_path():
+    """optimizer step through NativeAdamW (one weight-decay group), then the embedding extraction entry point"""
+    from uniir_amd.trainer import NativeAdamW
+    z = np.load(os.path.join(G, "g8_blipff.npz"))
+    med_cfg, vit_cfg = json.loads(str(z["med_cfg"])), json.loads(str(z["vit_cfg"]))
+    model = tiny_model(med_cfg, vit_cfg).cuda()
+    opt = NativeAdamW(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, allreduce=False)
+    b = 4
+    batch = {
+        "txt_batched": types.SimpleNamespace(input_ids=torch.from_numpy(z["s0_ids"]).cuda(),
+                                             attention_mask=torch.from_numpy(z["s0_mask"]).cuda()),
+        "image_batched": torch.from_numpy(z["s0_img"]).cuda(),
+        "p_did_list": torch.from_numpy(z["s0_pdid"]),
+        "index_mapping": {"query": [[2 * i] for i in range(b)], "pos_cand": [[2 * i + 1] for i in range(b)]},
+        "did_list": list(range(2 * b)),
+    }
+    w0 = model.get_parameter("text_encoder.pooler.dense.weight").detach().clone()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = model(batch, alpha=0.4)
+        out["loss"].backward()
+        g = model.get_parameter("text_encoder.pooler.dense.weight").grad.clone()
+        opt.step()
+        losses.append(out["loss"].item())
+    assert all(np.isfinite(losses))
+    w1 = model.get_parameter("text_encoder.pooler.dense.weight").detach()
+    assert (w1 - w0).abs().max().item() > 1e-4
+    assert g.abs().max().item() > 0
+    with torch.no_grad():
+        emb, ids = model(batch, encode_mbeir_batch=True)
+    assert emb.shape == (2 * b, med_cfg["hidden_size"]) and ids == list(range(2 * b))
+    assert torch.isfinite(emb).all() and emb.abs().max().item() <= 1.0

@@ -1,0 +1,638 @@
+"""MI355X-native BLIP feature-fusion model: BLIP ViT + MED BERT with cross-attention,
+momentum encoders, feature queues and the soft-target contrastive loss, behind the module surface of the reference's
+src/models/uniir_blip/blip_featurefusion/blip_ff.py:19-310 (same constructor arguments, attribute names, state-dict
+keys `visual_encoder.* / text_encoder.* / visual_encoder_m.* / text_encoder_m.* / temp / query_queue / cand_queue /
+idx_queue / new_ptr_queue`, forward(batch, alpha, encode_mbeir_batch)).
+
+All arithmetic is in libuniir_hip.so; this file is the launch sequence, the flat parameter stores and the activation
+stash.  Differences from the reference, stated once:
+  * bf16 MFMA GEMMs with fp32 accumulation / fp32 LayerNorm, softmax statistics, residual stream, loss (the reference
+    runs fp16 autocast); no GradScaler is needed;
+  * dropout (BERT 0.1) and DropPath (ViT-large 0.1) are not applied: the forward is the reference's expectation
+    (its eval-mode forward); see DESIGN.md "BLIP_FF";
+  * the BERT padding mask must be a prefix mask (tokenizer padding="max_length"), it travels as one key length per row;
+  * hard negatives (blip_ff.py:127-131,159-170) raise NotImplementedError.
+"""
+import json
+import math
+
+import torch
+from torch import nn
+
+from . import comm, ops
+from .clip_model import ALIGN, _Blk, _tower_bwd, _tower_fwd
+
+VIT_CONFIGS = {   # src/models/uniir_blip/backbone/blip.py:229-255 (create_vit)
+    "base": dict(patch_size=16, embed_dim=768, depth=12, num_heads=12),
+    "large": dict(patch_size=16, embed_dim=1024, depth=24, num_heads=16),
+}
+MED_DEFAULT = dict(hidden_size=768, intermediate_size=3072, layer_norm_eps=1e-12, max_position_embeddings=512,
+                   num_attention_heads=12, num_hidden_layers=12, vocab_size=30524)   # backbone/configs/med_config.json
+VIT_EPS = 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------------
+# names
+# ------------------------------------------------------------------------------------------------------------
+def vit_param_shapes(cfg, img_size):
+    D, P = cfg["embed_dim"], cfg["patch_size"]
+    T = (img_size // P) ** 2 + 1
+    out = [("cls_token", (1, 1, D)), ("pos_embed", (1, T, D)), ("patch_embed.proj.weight", (D, 3, P, P)),
+           ("patch_embed.proj.bias", (D,))]
+    for i in range(cfg["depth"]):
+        b = f"blocks.{i}."
+        out += [(b + "norm1.weight", (D,)), (b + "norm1.bias", (D,)), (b + "attn.qkv.weight", (3 * D, D)),
+                (b + "attn.qkv.bias", (3 * D,)), (b + "attn.proj.weight", (D, D)), (b + "attn.proj.bias", (D,)),
+                (b + "norm2.weight", (D,)), (b + "norm2.bias", (D,)), (b + "mlp.fc1.weight", (4 * D, D)),
+                (b + "mlp.fc1.bias", (4 * D,)), (b + "mlp.fc2.weight", (D, 4 * D)), (b + "mlp.fc2.bias", (D,))]
+    out += [("norm.weight", (D,)), ("norm.bias", (D,))]
+    return out
+
+
+def bert_param_shapes(cfg, enc_width):
+    """flat order: query/key/value weights (and biases) adjacent, so one [3W,W] (self) / [2W,enc] (cross) GEMM serves them"""
+    W, I = cfg["hidden_size"], cfg["intermediate_size"]
+    out = [("embeddings.word_embeddings.weight", (cfg["vocab_size"], W)),
+           ("embeddings.position_embeddings.weight", (cfg["max_position_embeddings"], W)),
+           ("embeddings.LayerNorm.weight", (W,)), ("embeddings.LayerNorm.bias", (W,))]
+    for i in range(cfg["num_hidden_layers"]):
+        b = f"encoder.layer.{i}."
+        s, c = b + "attention.self.", b + "crossattention.self."
+        out += [(s + "query.weight", (W, W)), (s + "key.weight", (W, W)), (s + "value.weight", (W, W)),
+                (s + "query.bias", (W,)), (s + "key.bias", (W,)), (s + "value.bias", (W,)),
+                (b + "attention.output.dense.weight", (W, W)), (b + "attention.output.dense.bias", (W,)),
+                (b + "attention.output.LayerNorm.weight", (W,)), (b + "attention.output.LayerNorm.bias", (W,)),
+                (c + "query.weight", (W, W)), (c + "query.bias", (W,)),
+                (c + "key.weight", (W, enc_width)), (c + "value.weight", (W, enc_width)),
+                (c + "key.bias", (W,)), (c + "value.bias", (W,)),
+                (b + "crossattention.output.dense.weight", (W, W)), (b + "crossattention.output.dense.bias", (W,)),
+                (b + "crossattention.output.LayerNorm.weight", (W,)), (b + "crossattention.output.LayerNorm.bias", (W,)),
+                (b + "intermediate.dense.weight", (I, W)), (b + "intermediate.dense.bias", (I,)),
+                (b + "output.dense.weight", (W, I)), (b + "output.dense.bias", (W,)),
+                (b + "output.LayerNorm.weight", (W,)), (b + "output.LayerNorm.bias", (W,))]
+    out += [("pooler.dense.weight", (W, W)), ("pooler.dense.bias", (W,))]
+    return out
+
+
+def _vit_blk_names(prefix, i):
+    b = f"{prefix}blocks.{i}."
+    return dict(wqkv=b + "attn.qkv.weight", bqkv=b + "attn.qkv.bias", wo=b + "attn.proj.weight", bo=b + "attn.proj.bias",
+                ln1w=b + "norm1.weight", ln1b=b + "norm1.bias", wfc=b + "mlp.fc1.weight", bfc=b + "mlp.fc1.bias",
+                wproj=b + "mlp.fc2.weight", bproj=b + "mlp.fc2.bias", ln2w=b + "norm2.weight", ln2b=b + "norm2.bias")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# flat stores
+# ------------------------------------------------------------------------------------------------------------
+class FlatStore:
+    """One flat fp32 buffer (+ optional flat gradient) + bf16 shadow for an ordered list of named tensors; every
+    tensor starts on a 256-B boundary.  Offers the small interface `_Blk` / the tower launch sequences use."""
+
+    def __init__(self, named_shapes, device, with_grad):
+        self.off, self.shapes, cur = {}, {}, 0
+        for n, shp in named_shapes:
+            self.off[n], self.shapes[n] = cur, tuple(shp)
+            cur += (math.prod(shp) + ALIGN - 1) // ALIGN * ALIGN
+        self.total = cur
+        self.p32 = torch.zeros(cur, device=device, dtype=torch.float32)
+        self.g32 = torch.zeros(cur, device=device, dtype=torch.float32) if with_grad else None
+        self.w16_buf = torch.empty(cur, device=device, dtype=torch.bfloat16)
+        self._flat = dict(off=self.off, shapes=self.shapes, p32=self.p32)
+
+    def _view(self, buf, name, shape=None, numel=None):
+        shape = shape or self.shapes[name]
+        o = self.off[name]
+        return buf[o:o + (numel or math.prod(shape))].view(shape)
+
+    def p(self, name, shape=None):
+        return self._view(self.p32, name, shape)
+
+    def w16(self, name, shape=None):
+        return self._view(self.w16_buf, name, shape)
+
+    def grad_view(self, name, shape=None):
+        return self._view(self.g32, name, shape)
+
+    def refresh_shadow(self):
+        ops.call("uniir_cast_f32_to_bf16", self.p32, self.w16_buf, self.total)
+
+
+def _attach(root, dotted, param):
+    mod = root
+    parts = dotted.split(".")
+    for part in parts[:-1]:
+        if part not in mod._modules:
+            mod.add_module(part, nn.Module())
+        mod = mod._modules[part]
+    mod.register_parameter(parts[-1], param)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# launch sequences
+# ------------------------------------------------------------------------------------------------------------
+def vit_forward(st, conv16, prefix, cfg, img_size, images, save):
+    """src/models/uniir_blip/backbone/vit.py:196-221 -> bf16 tokens [M*T, D] (after the final norm) + stash"""
+    D, P, depth = cfg["embed_dim"], cfg["patch_size"], cfg["depth"]
+    M, dev = images.shape[0], images.device
+    G = (img_size // P) ** 2
+    T = G + 1
+    heads = cfg["num_heads"]
+    kpad = conv16.shape[1]
+    patches = torch.empty(M * G, kpad, device=dev, dtype=torch.bfloat16)
+    ops.call("uniir_patchify", images.float().contiguous(), patches, M, img_size, P, kpad)
+    po = ops.linear_fwd(patches, conv16, st.p(prefix + "patch_embed.proj.bias"))
+    x0 = torch.empty(M * T, D, device=dev, dtype=torch.float32)
+    ops.call("uniir_vit_assemble", po, st.p(prefix + "cls_token"), st.p(prefix + "pos_embed"), x0, M, T, D)
+    del po
+    blk = lambda i: _Blk(st, None, _vit_blk_names(prefix, i))
+    x, saved = _tower_fwd(st, None, depth, x0, M, T, D, heads, False, save, eps=VIT_EPS, act=ops.ACT_GELU_ERF, blk=blk)
+    tok = ops.layernorm_fwd(x, st.p(prefix + "norm.weight"), st.p(prefix + "norm.bias"), VIT_EPS, rows=M * T, width=D)
+    stash = dict(patches=patches, x=x, saved=saved, M=M, T=T) if save else None
+    return tok, T, stash
+
+
+def vit_backward(st, dconv, prefix, cfg, dtok, stash):
+    """dtok fp32 [M*T, D]: gradient w.r.t. the normed tokens; parameter gradients accumulate into st.g32"""
+    D, P, depth, heads = cfg["embed_dim"], cfg["patch_size"], cfg["depth"], cfg["num_heads"]
+    M, T = stash["M"], stash["T"]
+    R, dev = M * T, dtok.device
+    dxb = torch.empty(R, D, device=dev, dtype=torch.bfloat16)
+    dx = ops.layernorm_bwd(stash["x"], st.p(prefix + "norm.weight"), dtok, st.grad_view(prefix + "norm.weight"),
+                           st.grad_view(prefix + "norm.bias"), VIT_EPS, dx_bf16=dxb, rows=R, width=D)
+    blk = lambda i: _Blk(st, None, _vit_blk_names(prefix, i))
+    dx = _tower_bwd(st, None, depth, dx, dxb, stash["saved"], M, T, D, heads, False, eps=VIT_EPS, act=ops.ACT_GELU_ERF,
+                    blk=blk)
+    G = T - 1
+    dpo = torch.empty(M * G, D, device=dev, dtype=torch.bfloat16)
+    ops.call("uniir_vit_assemble_bwd", dx, dpo, st.grad_view(prefix + "cls_token"), st.grad_view(prefix + "pos_embed"),
+             M, T, D)
+    ops.call("uniir_colsum_bf16", dpo, D, st.grad_view(prefix + "patch_embed.proj.bias"), M * G, D)
+    dconv.zero_()
+    ops.linear_wgrad(dpo, stash["patches"], dconv)
+    ops.call("uniir_unpad_add", dconv, st.grad_view(prefix + "patch_embed.proj.weight"), D, 3 * P * P, dconv.shape[1])
+
+
+def _ln2(st, x, wname, eps, R, W):
+    """post-LN sublayer output in both precisions: fp32 for the next residual, bf16 for the next GEMM"""
+    o32 = torch.empty(R, W, device=x.device, dtype=torch.float32)
+    o16 = torch.empty(R, W, device=x.device, dtype=torch.bfloat16)
+    ops.layernorm_fwd(x, st.p(wname + "weight"), st.p(wname + "bias"), eps, out_bf16=o16, out_f32=o32, rows=R, width=W)
+    return o32, o16
+
+
+def bert_forward(st, prefix, cfg, ids, key_len, img16, Ti, save):
+    """src/models/uniir_blip/backbone/med.py BertModel.forward(mode="multimodal") -> pooler_output fp32 [M,W] + stash.
+    ids int32 [M,L]; key_len int32 [M]; img16 bf16 [M*Ti, enc_width] (image attention mask all ones, blip_ff.py:98,108)"""
+    W, I, eps = cfg["hidden_size"], cfg["intermediate_size"], cfg["layer_norm_eps"]
+    heads, layers = cfg["num_attention_heads"], cfg["num_hidden_layers"]
+    M, L = ids.shape
+    R, dev = M * L, ids.device
+    e32 = torch.empty(R, W, device=dev, dtype=torch.float32)
+    scratch = torch.empty(M, device=dev, dtype=torch.int32)
+    ops.call("uniir_text_embed", ids, st.p(prefix + "embeddings.word_embeddings.weight"),
+             st.p(prefix + "embeddings.position_embeddings.weight"), e32, scratch, M, L, W, cfg["vocab_size"])
+    h32, h16 = _ln2(st, e32, prefix + "embeddings.LayerNorm.", eps, R, W)
+    stash = dict(ids=ids, e32=e32, layers=[], M=M, L=L, Ti=Ti, key_len=key_len, img16=img16) if save else None
+    g = torch.empty(R, I, device=dev, dtype=torch.bfloat16)
+    for i in range(layers):
+        b = f"{prefix}encoder.layer.{i}."
+        s, c = b + "attention.self.", b + "crossattention.self."
+        qkv = ops.linear_fwd(h16, st.w16(s + "query.weight", (3 * W, W)), st.p(s + "query.bias", (3 * W,)))
+        ao, lse1 = ops.attention_fwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, M, L, L, heads, key_len=key_len)
+        t1 = ops.linear_fwd(ao, st.w16(b + "attention.output.dense.weight"), st.p(b + "attention.output.dense.bias"),
+                            epilogue=ops.EPI_RESID_F32, resid=h32)
+        a32, a16 = _ln2(st, t1, b + "attention.output.LayerNorm.", eps, R, W)
+        cq = ops.linear_fwd(a16, st.w16(c + "query.weight"), st.p(c + "query.bias"))
+        ckv = ops.linear_fwd(img16, st.w16(c + "key.weight", (2 * W, img16.shape[1])), st.p(c + "key.bias", (2 * W,)))
+        co, lse2 = ops.attention_fwd_ex(cq, W, ckv, ckv[:, W:], 2 * W, M, L, Ti, heads)
+        t2 = ops.linear_fwd(co, st.w16(b + "crossattention.output.dense.weight"),
+                            st.p(b + "crossattention.output.dense.bias"), epilogue=ops.EPI_RESID_F32, resid=a32)
+        c32, c16 = _ln2(st, t2, b + "crossattention.output.LayerNorm.", eps, R, W)
+        f = torch.empty(R, I, device=dev, dtype=torch.bfloat16)
+        ops.linear_fwd(c16, st.w16(b + "intermediate.dense.weight"), st.p(b + "intermediate.dense.bias"), out=f,
+                       epilogue=ops.EPI_BIAS_ACT, C2=g, act=ops.ACT_GELU_ERF)
+        t3 = ops.linear_fwd(g, st.w16(b + "output.dense.weight"), st.p(b + "output.dense.bias"),
+                            epilogue=ops.EPI_RESID_F32, resid=c32)
+        if save:
+            stash["layers"].append(dict(h16=h16, qkv=qkv, ao=ao, lse1=lse1, t1=t1, a16=a16, cq=cq, ckv=ckv, co=co,
+                                        lse2=lse2, t2=t2, c16=c16, f=f, t3=t3))
+        h32, h16 = _ln2(st, t3, b + "output.LayerNorm.", eps, R, W)
+    rows = torch.empty(M, W, device=dev, dtype=torch.float32)
+    ops.call("uniir_gather_rows", h32, None, rows, M, L, W)
+    rows16 = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
+    ops.call("uniir_cast_f32_to_bf16", rows, rows16, rows.numel())
+    pre = ops.linear_fwd(rows16, st.w16(prefix + "pooler.dense.weight"), st.p(prefix + "pooler.dense.bias"),
+                         epilogue=ops.EPI_RESID_F32)
+    pooled = torch.empty_like(pre)
+    ops.call("uniir_tanh_fwd", pre, pooled, pre.numel())
+    if save:
+        stash.update(rows16=rows16, pooled=pooled)
+    return pooled, stash
+
+
+def bert_backward(st, prefix, cfg, dpooled, stash):
+    """returns d(img tokens) fp32 [M*Ti, enc_width]; parameter gradients accumulate into st.g32"""
+    W, I, eps = cfg["hidden_size"], cfg["intermediate_size"], cfg["layer_norm_eps"]
+    heads, layers = cfg["num_attention_heads"], cfg["num_hidden_layers"]
+    M, L, Ti, key_len, img16 = stash["M"], stash["L"], stash["Ti"], stash["key_len"], stash["img16"]
+    R, dev = M * L, dpooled.device
+    G = st.grad_view
+    f32 = dict(device=dev, dtype=torch.float32)
+    b16 = dict(device=dev, dtype=torch.bfloat16)
+
+    def colsum(x, cols, name, shape=None):
+        ops.call("uniir_colsum_bf16", x, cols, G(name, shape), x.shape[0], cols)
+
+    # pooler: pooled = tanh(rows @ Wp^T + bp)
+    dpre = torch.empty(M, W, **f32)
+    ops.call("uniir_tanh_bwd", stash["pooled"], dpooled.contiguous(), dpre, dpre.numel())
+    dpre16 = torch.empty(M, W, **b16)
+    ops.call("uniir_cast_f32_to_bf16", dpre, dpre16, dpre.numel())
+    ops.linear_wgrad(dpre16, stash["rows16"], G(prefix + "pooler.dense.weight"))
+    colsum(dpre16, W, prefix + "pooler.dense.bias")
+    drows = torch.empty(M, W, **f32)
+    ops.gemm(dpre16, st.w16(prefix + "pooler.dense.weight"), drows, M, W, W, W, W, W, b_tmaj=True, epilogue=ops.EPI_F32)
+    do = torch.zeros(R, W, **f32)
+    ops.call("uniir_scatter_rows", drows, None, do, M, L, W)
+    dimg = torch.zeros(M * Ti, img16.shape[1], **f32)
+    g = torch.empty(R, I, **b16)
+    for i in reversed(range(layers)):
+        b = f"{prefix}encoder.layer.{i}."
+        s, c = b + "attention.self.", b + "crossattention.self."
+        sv = stash["layers"][i]
+        stash["layers"][i] = None
+        # ---- feed-forward sublayer: o = LN(g @ Wout^T + bout + c32), g = gelu(c16 @ Wi^T + bi)
+        d16 = torch.empty(R, W, **b16)
+        dt3 = ops.layernorm_bwd(sv["t3"], st.p(b + "output.LayerNorm.weight"), do, G(b + "output.LayerNorm.weight"),
+                                G(b + "output.LayerNorm.bias"), eps, dx_bf16=d16, rows=R, width=W)
+        df = torch.empty(R, I, **b16)
+        ops.linear_dgrad(d16, st.w16(b + "output.dense.weight"), out=df, aux=sv["f"], act_out=g,
+                         colsum=G(b + "intermediate.dense.bias"), act=ops.ACT_GELU_ERF)
+        ops.linear_wgrad(d16, g, G(b + "output.dense.weight"))
+        colsum(d16, W, b + "output.dense.bias")
+        ops.linear_wgrad(df, sv["c16"], G(b + "intermediate.dense.weight"))
+        dc = torch.empty(R, W, **f32)       # d c32 = df @ Wi + dt3 (the residual branch)
+        ops.gemm(df, st.w16(b + "intermediate.dense.weight"), dc, R, W, I, I, W, W, b_tmaj=True,
+                 epilogue=ops.EPI_RESID_F32, resid=dt3)
+        # ---- cross-attention sublayer: c = LN(co @ Wco^T + bco + a32)
+        dt2 = ops.layernorm_bwd(sv["t2"], st.p(b + "crossattention.output.LayerNorm.weight"), dc,
+                                G(b + "crossattention.output.LayerNorm.weight"),
+                                G(b + "crossattention.output.LayerNorm.bias"), eps, dx_bf16=d16, rows=R, width=W)
+        ops.linear_wgrad(d16, sv["co"], G(b + "crossattention.output.dense.weight"))
+        colsum(d16, W, b + "crossattention.output.dense.bias")
+        dco = ops.linear_dgrad(d16, st.w16(b + "crossattention.output.dense.weight"))
+        dcq = torch.empty(R, W, **b16)
+        dckv = torch.empty(M * Ti, 2 * W, **b16)
+        ckv = sv["ckv"]
+        ops.attention_bwd_ex(sv["cq"], W, ckv, ckv[:, W:], 2 * W, sv["co"], dco, sv["lse2"], dcq, W, dckv, dckv[:, W:],
+                             2 * W, M, L, Ti, heads)
+        Ew = img16.shape[1]
+        ops.linear_wgrad(dckv, img16, G(c + "key.weight", (2 * W, Ew)))
+        colsum(dckv, 2 * W, c + "key.bias", (2 * W,))
+        ops.gemm(dckv, st.w16(c + "key.weight", (2 * W, Ew)), dimg, M * Ti, Ew, 2 * W, 2 * W, Ew, Ew, b_tmaj=True,
+                 epilogue=ops.EPI_RESID_F32, resid=dimg)          # dimg += dckv @ Wkv (in place: same element r/w)
+        ops.linear_wgrad(dcq, sv["a16"], G(c + "query.weight"))
+        colsum(dcq, W, c + "query.bias")
+        da = torch.empty(R, W, **f32)       # d a32 = dcq @ Wcq + dt2
+        ops.gemm(dcq, st.w16(c + "query.weight"), da, R, W, W, W, W, W, b_tmaj=True, epilogue=ops.EPI_RESID_F32,
+                 resid=dt2)
+        # ---- self-attention sublayer: a = LN(ao @ Wo^T + bo + h32)
+        dt1 = ops.layernorm_bwd(sv["t1"], st.p(b + "attention.output.LayerNorm.weight"), da,
+                                G(b + "attention.output.LayerNorm.weight"), G(b + "attention.output.LayerNorm.bias"),
+                                eps, dx_bf16=d16, rows=R, width=W)
+        ops.linear_wgrad(d16, sv["ao"], G(b + "attention.output.dense.weight"))
+        colsum(d16, W, b + "attention.output.dense.bias")
+        dao = ops.linear_dgrad(d16, st.w16(b + "attention.output.dense.weight"))
+        qkv = sv["qkv"]
+        dqkv = torch.empty(R, 3 * W, **b16)
+        ops.attention_bwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, sv["ao"], dao, sv["lse1"], dqkv, 3 * W,
+                             dqkv[:, W:], dqkv[:, 2 * W:], 3 * W, M, L, L, heads, key_len=key_len)
+        ops.linear_wgrad(dqkv, sv["h16"], G(s + "query.weight", (3 * W, W)))
+        colsum(dqkv, 3 * W, s + "query.bias", (3 * W,))
+        do = torch.empty(R, W, **f32)       # d h32 = dqkv @ Wqkv + dt1
+        ops.gemm(dqkv, st.w16(s + "query.weight", (3 * W, W)), do, R, W, 3 * W, 3 * W, W, W, b_tmaj=True,
+                 epilogue=ops.EPI_RESID_F32, resid=dt1)
+    de = ops.layernorm_bwd(stash["e32"], st.p(prefix + "embeddings.LayerNorm.weight"), do,
+                           G(prefix + "embeddings.LayerNorm.weight"), G(prefix + "embeddings.LayerNorm.bias"), eps,
+                           rows=R, width=W)
+    ops.call("uniir_text_embed_bwd", stash["ids"], de, G(prefix + "embeddings.word_embeddings.weight"),
+             G(prefix + "embeddings.position_embeddings.weight"), M, L, W, cfg["vocab_size"])
+    return dimg
+
+
+# ------------------------------------------------------------------------------------------------------------
+# module
+# ------------------------------------------------------------------------------------------------------------
+class _EncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, ids, key_len, images, anchor):
+        save = bool(ctx.needs_input_grad[4])
+        st = model._online
+        tok, Ti, vst = vit_forward(st, model._conv16, "visual_encoder.", model.vit_cfg, model.image_size, images, save)
+        pooled, bst = bert_forward(st, "text_encoder.", model.med_cfg, ids, key_len, tok, Ti, save)
+        ctx.model, ctx.vst, ctx.bst = model, vst, bst
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        model, st = ctx.model, ctx.model._online
+        bst, vst = ctx.bst, ctx.vst
+        ctx.bst = ctx.vst = None
+        dimg = bert_backward(st, "text_encoder.", model.med_cfg, dpooled, bst)
+        vit_backward(st, model._dconv, "visual_encoder.", model.vit_cfg, dimg, vst)
+        return None, None, None, None, None
+
+
+class _SoftTargetLossFn(torch.autograd.Function):
+    """blip_ff.py:155-231,250-252 for the no-hard-negative case.  Everything that reads the queues runs in forward
+    (the queues are overwritten before backward): the unit gradients are kept and scaled by d(loss) in backward."""
+
+    @staticmethod
+    def forward(ctx, emb, temp, model, emb_m, qi, pi, ids_row, alpha):
+        b, E, dev = qi.numel(), emb.shape[1], emb.device
+        K = model.queue_size
+        n = b + K
+        f32 = dict(device=dev, dtype=torch.float32)
+
+        def sel(src, idx):
+            out, inv = torch.empty(b, E, **f32), torch.empty(b, **f32)
+            ops.call("uniir_select_normalize", src, idx, out, inv, b, E)
+            return out, inv
+
+        q, invq = sel(emb, qi)
+        p, invp = sel(emb, pi)
+        q_m, _ = sel(emb_m, qi)
+        p_m, _ = sel(emb_m, pi)
+        ids_all = torch.cat([ids_row, model.idx_queue[0]])
+
+        def sims(a, feats_m, queue):
+            """[a @ feats_m^T | a @ queue] without materialising the concatenation (queue is [E,K] like the reference)"""
+            out = torch.empty(b, n, **f32)
+            ops.call("uniir_sgemm", a, E, 1, feats_m, 1, E, out, n, b, b, E, 1.0)
+            ops.call("uniir_sgemm", a, E, 1, queue, K, 1, out[:, b:], n, b, K, E, 1.0)
+            return out
+
+        need = ctx.needs_input_grad[0]
+        rl, hit, rdt, dfeat = [], None, [], []
+        for a, a_m, feats_m, queue in ((q, q_m, p_m, model.cand_queue), (p, p_m, q_m, model.query_queue)):
+            s, s_m = sims(a, feats_m, queue), sims(a_m, feats_m, queue)
+            row_loss, row_hit = torch.empty(b, **f32), torch.empty(b, **f32)
+            dsim = torch.empty(b, n, **f32) if need else None
+            row_dt = torch.empty(b, **f32) if need else None
+            ops.call("uniir_softce", s, s_m, temp, ids_row, ids_all, b, n, float(alpha), 1.0 / (2 * b), None, row_loss,
+                     row_hit, dsim, row_dt)
+            rl.append(row_loss)
+            hit = row_hit if hit is None else hit
+            if need:
+                da = torch.empty(b, E, **f32)
+                ops.call("uniir_sgemm", dsim, n, 1, feats_m, E, 1, da, E, b, E, b, 1.0)
+                ops.call("uniir_sgemm_acc", dsim[:, b:], n, 1, queue, 1, K, da, E, b, E, K, 1.0)
+                dfeat.append(da)
+                rdt.append(row_dt)
+        loss = (rl[0].sum() + rl[1].sum()) / (2 * b)
+        acc = hit.mean()
+        if need:
+            demb = torch.zeros_like(emb)
+            ops.call("uniir_select_normalize_bwd", q, invq, dfeat[0], qi, demb, b, E)
+            ops.call("uniir_select_normalize_bwd", p, invp, dfeat[1], pi, demb, b, E)
+            ctx.save_for_backward(demb, rdt[0].sum() + rdt[1].sum())
+        ctx.mark_non_differentiable(acc, q_m, p_m)
+        return loss, acc, q_m, p_m
+
+    @staticmethod
+    def backward(ctx, dloss, _dacc, _dq, _dp):
+        demb, dtemp = ctx.saved_tensors
+        return demb * dloss, dtemp * dloss, None, None, None, None, None, None
+
+
+class BLIPFeatureFusion(nn.Module):
+    def __init__(self, med_config="backbone/configs/med_config.json", image_size=224, vit="base", vit_grad_ckpt=False,
+                 vit_ckpt_layer=0, embed_dim=768, queue_size=57600, momentum=0.995, config=None, seed=0,
+                 vit_config=None):
+        super().__init__()
+        if isinstance(med_config, str):
+            med_config = json.load(open(med_config))
+        self.med_cfg = dict(MED_DEFAULT)
+        self.med_cfg.update({k: v for k, v in dict(med_config).items() if k in MED_DEFAULT})
+        self.vit_cfg = dict(vit_config or VIT_CONFIGS[vit])
+        self.image_size = self.vit_cfg.get("img_size", image_size)
+        W, D = self.med_cfg["hidden_size"], self.vit_cfg["embed_dim"]
+        if W // self.med_cfg["num_attention_heads"] != 64 or D // self.vit_cfg["num_heads"] != 64 or W % 64 or D % 64:
+            raise ValueError("the attention kernels are built for head_dim 64 (BLIP base / large both are)")
+        if embed_dim != W:
+            raise ValueError("BLIP_FF returns the BERT pooler output: embed_dim must equal the hidden size")
+        self.med_cfg["encoder_width"] = D
+        self.queue_size, self.momentum, self.embed_dim, self.config = queue_size, momentum, embed_dim, config
+        self._shapes = ([("visual_encoder." + n, s) for n, s in vit_param_shapes(self.vit_cfg, self.image_size)]
+                        + [("text_encoder." + n, s) for n, s in bert_param_shapes(self.med_cfg, D)])
+        g = torch.Generator().manual_seed(seed)
+        for n, shp in self._shapes:
+            leaf = n.rsplit(".", 1)[-1]
+            if "norm" in n.lower() and leaf == "weight":
+                v = torch.ones(shp)
+            elif leaf == "bias":
+                v = torch.zeros(shp)
+            else:
+                v = torch.randn(shp, generator=g) * 0.02
+            _attach(self, n, nn.Parameter(v))
+        for n, shp in self._shapes:      # momentum encoders start as copies (blip_ff.py:280-285 copy_params)
+            enc, rest = n.split(".", 1)
+            _attach(self, f"{enc}_m.{rest}", nn.Parameter(self.get_parameter(n).detach().clone(), requires_grad=False))
+        self.text_encoder.embeddings.register_buffer(
+            "position_ids", torch.arange(self.med_cfg["max_position_embeddings"]).expand((1, -1)))
+        self.text_encoder_m.embeddings.register_buffer(
+            "position_ids", torch.arange(self.med_cfg["max_position_embeddings"]).expand((1, -1)))
+        self.register_buffer("query_queue", nn.functional.normalize(torch.randn(embed_dim, queue_size, generator=g), dim=0))
+        self.register_buffer("cand_queue", nn.functional.normalize(torch.randn(embed_dim, queue_size, generator=g), dim=0))
+        self.register_buffer("idx_queue", torch.full((1, queue_size), -100))
+        self.register_buffer("new_ptr_queue", torch.zeros(1, dtype=torch.long))
+        self.temp = nn.Parameter(0.07 * torch.ones([]))
+        self._online = self._mom = None
+        self._ptr_host = None
+        self.check_masks = True
+
+    # ---- reference surface ---------------------------------------------------------------------------------
+    def get_img_preprocess_fn(self):
+        from .blip_front import get_blip_transform
+        return get_blip_transform(self.image_size, min_scale=0.5, is_train=self.training)
+
+    def get_tokenizer(self):
+        from .blip_front import init_tokenizer
+        tok = init_tokenizer()
+        max_len = self.config.tokenizer_max_length
+
+        def tokenizer_wrapper(txt):
+            return tok(txt, padding="max_length", truncation=True, max_length=max_len, return_tensors="pt")
+
+        return tokenizer_wrapper
+
+    @torch.no_grad()
+    def copy_params(self):
+        for n, _ in self._shapes:
+            enc, rest = n.split(".", 1)
+            self.get_parameter(f"{enc}_m.{rest}").data.copy_(self.get_parameter(n).data)
+
+    # ---- flat storage --------------------------------------------------------------------------------------
+    def _online_params(self):
+        return [(n, self.get_parameter(n)) for n, _ in self._shapes] + [("temp", self.temp)]
+
+    def _ensure_flat(self):
+        dev = self.temp.device
+        if dev.type != "cuda":
+            raise RuntimeError("uniir_amd BLIPFeatureFusion runs on an MI355X only (no CPU path); move the model to cuda")
+        st = self._online
+        if st is not None and st.p32.device == dev and all(
+                p.data_ptr() == st.p32.data_ptr() + 4 * st.off[n] for n, p in self._online_params()):
+            return self._flat_dict()
+        online = FlatStore(self._shapes + [("temp", ())], dev, True)
+        mom = FlatStore(self._shapes, dev, False)
+        for n, p in self._online_params():
+            online.p(n).copy_(p.data.float())
+            p.data = online.p(n)
+            p.grad = online.grad_view(n)
+        for n, _ in self._shapes:
+            enc, rest = n.split(".", 1)
+            pm = self.get_parameter(f"{enc}_m.{rest}")
+            mom.p(n).copy_(pm.data.float())
+            pm.data = mom.p(n)
+        self._online, self._mom = online, mom
+        D, P = self.vit_cfg["embed_dim"], self.vit_cfg["patch_size"]
+        kpad = (3 * P * P + 63) // 64 * 64
+        self._conv16 = torch.zeros(D, kpad, device=dev, dtype=torch.bfloat16)
+        self._conv16_m = torch.zeros(D, kpad, device=dev, dtype=torch.bfloat16)
+        self._dconv = torch.zeros(D, kpad, device=dev, dtype=torch.float32)
+        self._version = -1
+        self.refresh_shadow()
+        return self._flat_dict()
+
+    def _flat_dict(self):
+        """what NativeAdamW reads: one weight-decay group over everything (uniir_blip/train.py:193-197)"""
+        st = self._online
+        return dict(p32=st.p32, g32=st.g32, w16=st.w16_buf, total=st.total, split=0)
+
+    def optimizer_groups(self):
+        """(no-decay params, decay params) for NativeAdamW: the reference applies weight decay to every parameter"""
+        return [], [p for _, p in self._online_params()]
+
+    def _refresh_conv(self, momentum_too=True):
+        D, P = self.vit_cfg["embed_dim"], self.vit_cfg["patch_size"]
+        pairs = [(self._online, self._conv16)] + ([(self._mom, self._conv16_m)] if momentum_too else [])
+        for st, dst in pairs:
+            ops.call("uniir_cast_pad_rows", st.p("visual_encoder.patch_embed.proj.weight"), dst, D, 3 * P * P, dst.shape[1])
+
+    def refresh_shadow(self):
+        self._online.refresh_shadow()
+        self._mom.refresh_shadow()
+        self._refresh_conv()
+        self._version = self._param_version()
+
+    def _param_version(self):
+        # torch-side writes (load_state_dict, manual edits) bump these; the kernels' own updates (AdamW, EMA) refresh
+        # the bf16 shadows themselves.  temp has no shadow, and is clamp_()ed every step: left out.
+        return sum(p._version for n, p in self.named_parameters() if n != "temp")
+
+    def _sync(self):
+        self._ensure_flat()
+        if self._version != self._param_version():
+            self.refresh_shadow()
+
+    def zero_grad(self, set_to_none=False):
+        if self._online is not None:
+            self._online.g32.zero_()
+            for n, p in self._online_params():
+                if p.grad is None or p.grad.data_ptr() != self._online.grad_view(n).data_ptr():
+                    p.grad = self._online.grad_view(n)
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._ptr_host = None
+        return out
+
+    # ---- encoders ------------------------------------------------------------------------------------------
+    def _text_inputs(self, txt):
+        ids = txt["input_ids"] if isinstance(txt, dict) else txt.input_ids
+        mask = txt["attention_mask"] if isinstance(txt, dict) else txt.attention_mask
+        if self.check_masks and not bool((mask[:, :-1] >= mask[:, 1:]).all()):
+            raise ValueError("attention_mask must be a prefix mask (ones, then padding): tokenizer padding='max_length'")
+        return ids.to(torch.int32).contiguous(), mask.sum(1).to(torch.int32).contiguous()
+
+    def encode_multimodal_input(self, txt_dict_batched, image_batched, txt_mask=None, img_mask=None, use_momentum=False):
+        """blip_ff.py:82-116: BERT(text) cross-attending to ViT(image) tokens -> pooler_output [n, embed_dim]"""
+        self._sync()
+        ids, key_len = self._text_inputs(txt_dict_batched)
+        if use_momentum:
+            with torch.no_grad():
+                tok, Ti, _ = vit_forward(self._mom, self._conv16_m, "visual_encoder.", self.vit_cfg, self.image_size,
+                                         image_batched, False)
+                return bert_forward(self._mom, "text_encoder.", self.med_cfg, ids, key_len, tok, Ti, False)[0]
+        anchor = torch.zeros(1, device=ids.device, requires_grad=torch.is_grad_enabled())
+        return _EncodeFn.apply(self, ids, key_len, image_batched, anchor)
+
+    @torch.no_grad()
+    def _momentum_update(self):
+        """blip_ff.py:287-292 as one fused pass over the flat encoder region (temp sits after it)"""
+        self._sync()
+        ops.call("uniir_ema_update", self._mom.p32, self._online.p32, self._mom.w16_buf, self._mom.total,
+                 float(self.momentum))
+        self._refresh_conv()
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, query_feats, cand_feats, idxs):
+        """blip_ff.py:294-310"""
+        idxs = comm.all_gather_rows(idxs.view(-1, 1))
+        query_feats = comm.all_gather_rows(query_feats)
+        cand_feats = comm.all_gather_rows(cand_feats)
+        bsz = query_feats.shape[0]
+        if self._ptr_host is None:
+            self._ptr_host = int(self.new_ptr_queue)
+        ptr = self._ptr_host
+        assert self.queue_size % bsz == 0  # same requirement as the reference
+        self.query_queue[:, ptr:ptr + bsz] = query_feats.T
+        self.cand_queue[:, ptr:ptr + bsz] = cand_feats.T
+        self.idx_queue[:, ptr:ptr + bsz] = idxs.T
+        self._ptr_host = (ptr + bsz) % self.queue_size
+        self.new_ptr_queue.fill_(self._ptr_host)
+
+    def compute_contrastive_loss(self, batch, alpha):
+        index_mapping = batch["index_mapping"]
+        if "neg_cand_list" in index_mapping:
+            raise NotImplementedError("hard negatives are not on the MI355X BLIP_FF path yet")
+        dev = self.temp.device
+        txt, img = batch["txt_batched"], batch["image_batched"]
+        ids_row = torch.as_tensor(batch["p_did_list"], device=dev).to(torch.int64).flatten()
+        qi = torch.tensor(index_mapping["query"], dtype=torch.int32).flatten().to(dev)
+        pi = torch.tensor(index_mapping["pos_cand"], dtype=torch.int32).flatten().to(dev)
+        with torch.no_grad():
+            self.temp.clamp_(0.001, 0.5)
+        emb = self.encode_multimodal_input(txt, img, batch.get("txt_mask_batched"), batch.get("image_mask_batched"))
+        self._momentum_update()
+        emb_m = self.encode_multimodal_input(txt, img, use_momentum=True)
+        loss, acc, q_m, p_m = _SoftTargetLossFn.apply(emb, self.temp, self, emb_m, qi, pi, ids_row, alpha)
+        self._dequeue_and_enqueue(q_m.detach(), p_m.detach(), ids_row)
+        return {"loss": loss, "accuracy": acc}
+
+    def encode_mbeir_batch(self, batch):
+        id_list = batch.get("did_list") or batch.get("qid_list")
+        if id_list is None:
+            raise ValueError("id_list not found in batch.")
+        emb = self.encode_multimodal_input(batch["txt_batched"], batch["image_batched"], batch.get("txt_mask_batched"),
+                                           batch.get("image_mask_batched"))
+        assert emb.size(0) == len(id_list), "embeddings and id_batched must have the same batch size."
+        return emb, id_list
+
+    def forward(self, batch, alpha=None, encode_mbeir_batch=False):
+        if encode_mbeir_batch:
+            return self.encode_mbeir_batch(batch)
+        return self.compute_contrastive_loss(batch, alpha)
+
+
+def blip_ff(pretrained="", **kwargs):
+    model = BLIPFeatureFusion(**kwargs)
+    if pretrained:
+        sd = torch.load(pretrained, map_location="cpu")
+        msg = model.load_state_dict(sd.get("model", sd), strict=False)
+        print("missing keys:")
+        print(msg.missing_keys)
+    return model

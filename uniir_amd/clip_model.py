@@ -198,9 +198,9 @@ class CLIP(nn.Module):
 class _Blk:
     """names of one residual block's tensors inside the flat buffers"""
 
-    def __init__(self, model, prefix):
+    def __init__(self, model, prefix, names=None):
         p = prefix
-        self.names = dict(wqkv=f"{p}.attn.in_proj_weight", bqkv=f"{p}.attn.in_proj_bias", wo=f"{p}.attn.out_proj.weight",
+        self.names = names or dict(wqkv=f"{p}.attn.in_proj_weight", bqkv=f"{p}.attn.in_proj_bias", wo=f"{p}.attn.out_proj.weight",
                           bo=f"{p}.attn.out_proj.bias", ln1w=f"{p}.ln_1.weight", ln1b=f"{p}.ln_1.bias",
                           wfc=f"{p}.mlp.c_fc.weight", bfc=f"{p}.mlp.c_fc.bias", wproj=f"{p}.mlp.c_proj.weight",
                           bproj=f"{p}.mlp.c_proj.bias", ln2w=f"{p}.ln_2.weight", ln2b=f"{p}.ln_2.bias")
@@ -219,21 +219,23 @@ class _Blk:
         return self.m.grad_view(self.names[k])
 
 
-def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save):
+def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5, act=ops.ACT_QUICKGELU, blk=None):
+    """pre-LN residual blocks (CLIP resblocks; with eps / act / blk(i) overridden also the BLIP ViT blocks)"""
+    blk = blk or (lambda i: _Blk(model, f"{prefix}.resblocks.{i}"))
     R = M * T
     dev = x.device
     h = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
     g = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
     saved = []
     for i in range(layers):
-        b = _Blk(model, f"{prefix}.resblocks.{i}")
-        ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), out_bf16=h, rows=R, width=W)
+        b = blk(i)
+        ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), eps, out_bf16=h, rows=R, width=W)
         qkv = ops.linear_fwd(h, b.w16("wqkv"), b.p32("bqkv"))
         ao, lse = ops.attention_fwd(qkv, M, T, heads, causal)
         x2 = ops.linear_fwd(ao, b.w16("wo"), b.p32("bo"), epilogue=ops.EPI_RESID_F32, resid=x)
-        ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), out_bf16=h, rows=R, width=W)
+        ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), eps, out_bf16=h, rows=R, width=W)
         f = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
-        ops.linear_fwd(h, b.w16("wfc"), b.p32("bfc"), out=f, epilogue=ops.EPI_BIAS_ACT, C2=g)
+        ops.linear_fwd(h, b.w16("wfc"), b.p32("bfc"), out=f, epilogue=ops.EPI_BIAS_ACT, C2=g, act=act)
         xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32, resid=x2)
         if save:
             saved.append((x, qkv, ao, lse, x2, f))
@@ -241,8 +243,10 @@ def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save):
     return x, saved
 
 
-def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal):
+def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, eps=1e-5, act=ops.ACT_QUICKGELU,
+               blk=None):
     """dx fp32 [R,W] and its bf16 copy dxb: gradient w.r.t. the tower output.  Returns d(tower input) (fp32)."""
+    blk = blk or (lambda i: _Blk(model, f"{prefix}.resblocks.{i}"))
     R = M * T
     dev = dx.device
     h = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
@@ -250,19 +254,19 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal):
     df = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
     dh = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
     for i in reversed(range(layers)):
-        b = _Blk(model, f"{prefix}.resblocks.{i}")
+        b = blk(i)
         x, qkv, ao, lse, x2, f = saved[i]
         saved[i] = None
         # d(mlp): df = (dx @ Wproj) * act'(f); the same epilogue re-materialises g = act(f) for dWproj and sums
         # df's columns into the c_fc bias gradient
-        ops.linear_dgrad(dxb, b.w16("wproj"), out=df, aux=f, act_out=g, colsum=b.g("bfc"))
+        ops.linear_dgrad(dxb, b.w16("wproj"), out=df, aux=f, act_out=g, colsum=b.g("bfc"), act=act)
         ops.linear_wgrad(dxb, g, b.g("wproj"))
         ops.call("uniir_colsum_bf16", dxb, W, b.g("bproj"), R, W)
-        ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), out_bf16=h, rows=R, width=W)
+        ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), eps, out_bf16=h, rows=R, width=W)
         ops.linear_wgrad(df, h, b.g("wfc"))
         ops.linear_dgrad(df, b.w16("wfc"), out=dh)                               # dh := d ln_2 out
         dx2 = torch.empty(R, W, device=dev, dtype=torch.float32)
-        ops.layernorm_bwd(x2, b.p32("ln2w"), dh, b.g("ln2w"), b.g("ln2b"), dres=dx, dx=dx2, dx_bf16=dxb,
+        ops.layernorm_bwd(x2, b.p32("ln2w"), dh, b.g("ln2w"), b.g("ln2b"), eps, dres=dx, dx=dx2, dx_bf16=dxb,
                           rows=R, width=W)
         del x2, f
         ops.linear_wgrad(dxb, ao, b.g("wo"))
@@ -270,12 +274,12 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal):
         ops.linear_dgrad(dxb, b.w16("wo"), out=dh)                               # dh := d attn out
         dqkv = ops.attention_bwd(qkv, ao, dh, lse, M, T, heads, causal)
         del qkv, ao, lse
-        ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), out_bf16=h, rows=R, width=W)
+        ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), eps, out_bf16=h, rows=R, width=W)
         ops.linear_wgrad(dqkv, h, b.g("wqkv"))
         ops.call("uniir_colsum_bf16", dqkv, 3 * W, b.g("bqkv"), R, 3 * W)
         ops.linear_dgrad(dqkv, b.w16("wqkv"), out=dh)                            # dh := d ln_1 out
         del dqkv
-        ops.layernorm_bwd(x, b.p32("ln1w"), dh, b.g("ln1w"), b.g("ln1b"), dres=dx2, dx=dx, dx_bf16=dxb,
+        ops.layernorm_bwd(x, b.p32("ln1w"), dh, b.g("ln1w"), b.g("ln1b"), eps, dres=dx2, dx=dx, dx_bf16=dxb,
                           rows=R, width=W)
         del x, dx2
     return dx

@@ -616,15 +616,18 @@ extern "C" int uniir_ema_update(float* param_m, const float* param, void* param_
 //   loss_i = -sum_j log_softmax(sim[i])_j * target_j ;  dsim[i][j] = (softmax(sim[i])_j - target_j) * gscale
 // (sum_j target_j = 1).  hit_i = pos[argmax_j sim[i][j]] (first max), used for the accuracy of blip_ff.py:250-252.
 __global__ __launch_bounds__(256) void softce_kernel(const float* __restrict__ sim, const float* __restrict__ sim_m,
+                                                     const float* __restrict__ temp,
                                                      const long long* __restrict__ ids_row,
                                                      const long long* __restrict__ ids_all, int n, float alpha,
-                                                     float gscale, float* __restrict__ row_loss,
-                                                     float* __restrict__ row_hit, float* __restrict__ dsim) {
+                                                     float gscale, const float* __restrict__ dloss,
+                                                     float* __restrict__ row_loss, float* __restrict__ row_hit,
+                                                     float* __restrict__ dsim, float* __restrict__ row_dtemp) {
     __shared__ float red[4];
     __shared__ int redi[4];
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* s = sim + (long)i * n;
     const float* sm = sim_m + (long)i * n;
+    const float T = temp ? *temp : 1.0f;   // logits are dot / temp (a division, like blip_ff.py:219-223)
     const long long my = ids_row[i];
     auto block_max = [&](float v) {
         v = wave_max(v);
@@ -645,9 +648,9 @@ __global__ __launch_bounds__(256) void softce_kernel(const float* __restrict__ s
     float mx = -INFINITY, mxm = -INFINITY, npos = 0.f;
     int am = 0x7fffffff;
     for (int j = tid; j < n; j += 256) {
-        const float v = s[j];
+        const float v = s[j] / T;
         if (v > mx) { mx = v; am = j; }
-        mxm = fmaxf(mxm, sm[j]);
+        mxm = fmaxf(mxm, sm[j] / T);
         npos += (ids_all[j] == my) ? 1.0f : 0.0f;
     }
     // first-index argmax over the block
@@ -665,29 +668,37 @@ __global__ __launch_bounds__(256) void softce_kernel(const float* __restrict__ s
     mxm = block_max(mxm);
     npos = block_sum(npos);
     float se = 0.f, sem = 0.f;
-    for (int j = tid; j < n; j += 256) { se += expf(s[j] - mx); sem += expf(sm[j] - mxm); }
+    for (int j = tid; j < n; j += 256) { se += expf(s[j] / T - mx); sem += expf(sm[j] / T - mxm); }
     se = block_sum(se);
     sem = block_sum(sem);
     const float lse = mx + logf(se), inv_sem = 1.0f / sem, inv_pos = npos > 0.f ? 1.0f / npos : 0.f;
-    float loss = 0.f;
+    const float gs = gscale * (dloss ? *dloss : 1.0f);
+    float loss = 0.f, dT = 0.f;
     for (int j = tid; j < n; j += 256) {
-        const float lsm = s[j] - lse;
-        const float tgt = alpha * (expf(sm[j] - mxm) * inv_sem) + (1.0f - alpha) * ((ids_all[j] == my) ? inv_pos : 0.f);
+        const float sj = s[j] / T;
+        const float lsm = sj - lse;
+        const float tgt = alpha * (expf(sm[j] / T - mxm) * inv_sem) + (1.0f - alpha) * ((ids_all[j] == my) ? inv_pos : 0.f);
         loss -= lsm * tgt;
-        if (dsim) dsim[(long)i * n + j] = (expf(lsm) - tgt) * gscale;
+        const float g = (expf(lsm) - tgt) * gs;        // d loss / d logit_j
+        if (dsim) dsim[(long)i * n + j] = g / T;       // d loss / d dot_j
+        dT -= g * sj;                                  // d logit_j / d temp = -logit_j / temp
     }
     loss = block_sum(loss);
+    dT = block_sum(dT);
     if (tid == 0) {
         row_loss[i] = loss;
         row_hit[i] = (ids_all[am] == my) ? 1.0f : 0.0f;
+        if (row_dtemp) row_dtemp[i] = dT / T;
     }
 }
-extern "C" int uniir_softce(const float* sim, const float* sim_m, const int64_t* ids_row, const int64_t* ids_all,
-                            int32_t b, int32_t n, float alpha, float gscale, float* row_loss, float* row_hit,
-                            float* dsim, void* stream) {
+extern "C" int uniir_softce(const float* sim, const float* sim_m, const float* temp, const int64_t* ids_row,
+                            const int64_t* ids_all, int32_t b, int32_t n, float alpha, float gscale,
+                            const float* dloss, float* row_loss, float* row_hit, float* dsim, float* row_dtemp,
+                            void* stream) {
     if (!sim || !sim_m || !ids_row || !ids_all || !row_loss || !row_hit || b <= 0 || n <= 0) return UNIIR_EINVAL;
-    hipLaunchKernelGGL(softce_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, sim, sim_m, (const long long*)ids_row,
-                       (const long long*)ids_all, n, alpha, gscale, row_loss, row_hit, dsim);
+    hipLaunchKernelGGL(softce_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, sim, sim_m, temp,
+                       (const long long*)ids_row, (const long long*)ids_all, n, alpha, gscale, dloss, row_loss, row_hit,
+                       dsim, row_dtemp);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }

@@ -15,7 +15,8 @@
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, long sam, long sak,
                                                     const float* __restrict__ B, long sbk, long sbn,
                                                     float* __restrict__ C, long ldc, int M, int N, int K,
-                                                    float alpha_host, const float* __restrict__ alpha_dev) {
+                                                    float alpha_host, const float* __restrict__ alpha_dev,
+                                                    int accumulate) {
     __shared__ float As[SG_BK * SG_PITCH];
     __shared__ float Bs[SG_BK * SG_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -66,15 +67,19 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm + i * 16 + 4 * (lane >> 4) + r;
                 const int n = n0 + wn + j * 16 + (lane & 15);
-                if (m < M && n < N) C[(long)m * ldc + n] = acc[i][j][r] * alpha;
+                if (m < M && n < N) {
+                    float* c = C + (long)m * ldc + n;
+                    *c = accumulate ? *c + acc[i][j][r] * alpha : acc[i][j][r] * alpha;
+                }
             }
 }
 
 static int launch_sgemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
-                        long ldc, int M, int N, int K, float alpha, const float* alpha_dev, hipStream_t st) {
+                        long ldc, int M, int N, int K, float alpha, const float* alpha_dev, hipStream_t st,
+                        int accumulate = 0) {
     dim3 grid((N + SG_BN - 1) / SG_BN, (M + SG_BM - 1) / SG_BM);
     hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha,
-                       alpha_dev);
+                       alpha_dev, accumulate);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -83,6 +88,11 @@ extern "C" int uniir_sgemm(const float* A, int64_t sam, int64_t sak, const float
                            float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return UNIIR_EINVAL;
     return launch_sgemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, nullptr, (hipStream_t)stream);
+}
+extern "C" int uniir_sgemm_acc(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                               float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return UNIIR_EINVAL;
+    return launch_sgemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, nullptr, (hipStream_t)stream, 1);
 }
 
 // one block per row: lse, first-argmax, per-row loss and hit.  stats = [lse(b) | loss_i(b) | hit_i(b)]

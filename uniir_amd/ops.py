@@ -177,6 +177,22 @@ def attention_bwd(qkv, out, dout, lse, batch, seq, heads, causal, *, dqkv=None):
     return dqkv
 
 
+def attention_fwd_ex(q, q_ld, k, v, kv_ld, batch, tq, tk, heads, *, key_len=None, causal=False):
+    """separate Q / K / V views (head h at column h*64 of rows with the given leading dimension); out [batch*tq, heads*64]"""
+    out = torch.empty(batch * tq, heads * 64, device=q.device, dtype=torch.bfloat16)
+    lse = torch.empty(batch, heads, tq, device=q.device, dtype=torch.float32)
+    check(_lib.load().uniir_attention_fwd_ex(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), heads * 64, _p(lse), _p(key_len),
+                                             batch, tq, tk, heads, int(causal), _stream()), "attention_fwd_ex")
+    return out, lse
+
+
+def attention_bwd_ex(q, q_ld, k, v, kv_ld, out, dout, lse, dq, dq_ld, dk, dv, dkv_ld, batch, tq, tk, heads, *,
+                     key_len=None, causal=False):
+    check(_lib.load().uniir_attention_bwd_ex(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), _p(dout), heads * 64, _p(lse),
+                                             _p(key_len), _p(dq), dq_ld, _p(dk), _p(dv), dkv_ld, batch, tq, tk, heads,
+                                             int(causal), _stream()), "attention_bwd_ex")
+
+
 def call(name, *args):
     """Generic checked call: tensors are converted to device pointers, the stream is appended."""
     conv = [(_p(a) if isinstance(a, torch.Tensor) else a) for a in args]

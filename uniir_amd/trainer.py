@@ -22,10 +22,13 @@ class NativeAdamW(torch.optim.Optimizer):
 
     def __init__(self, clip_model, lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2, allreduce=True):
         self.clip = clip_model
-        from .clip_model import _is_no_decay
-        named = list(clip_model.named_parameters())
-        nd = [p for n, p in named if _is_no_decay(n, p)]
-        d = [p for n, p in named if not _is_no_decay(n, p)]
+        if hasattr(clip_model, "optimizer_groups"):      # e.g. BLIPFeatureFusion: one group, uniform weight decay
+            nd, d = clip_model.optimizer_groups()
+        else:
+            from .clip_model import _is_no_decay
+            named = list(clip_model.named_parameters())
+            nd = [p for n, p in named if _is_no_decay(n, p)]
+            d = [p for n, p in named if not _is_no_decay(n, p)]
         super().__init__([{"params": nd, "weight_decay": 0.0}, {"params": d, "weight_decay": weight_decay}],
                          dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.allreduce = allreduce
