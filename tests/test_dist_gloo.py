@@ -80,3 +80,39 @@ def test_two_rank_exchange_matches_reference_golden():
         assert np.allclose(res[r]["flat"], 1.5)
         assert res[r]["gs"].shape == (2, 3, 2) and res[r]["gi"][1, 0, 0] == 1
     assert res[0]["shard"] == (0, 5) and res[1]["shard"] == (5, 9)
+
+
+def _blip_queue_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uniir_amd.blip_model import BLIPFeatureFusion
+    med = dict(hidden_size=128, intermediate_size=256, num_attention_heads=2, num_hidden_layers=1, vocab_size=64,
+               max_position_embeddings=32)
+    vit = dict(img_size=32, patch_size=16, embed_dim=128, depth=1, num_heads=2)
+    m = BLIPFeatureFusion(med_config=med, vit_config=vit, embed_dim=128, queue_size=8, momentum=0.9)
+    for step in range(3):          # 3 x (2 ranks x 2 rows) = 12 rows through a queue of 8: wraps once
+        qf = torch.full((2, 128), float(10 * step + rank))
+        cf = -qf
+        m._dequeue_and_enqueue(qf, cf, torch.tensor([100 * step + 2 * rank, 100 * step + 2 * rank + 1]))
+    q.put((rank, {"qq": m.query_queue[0].numpy().copy(), "cq": m.cand_queue[0].numpy().copy(),
+                  "idx": m.idx_queue[0].numpy().copy(), "ptr": int(m.new_ptr_queue)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_blip_queue_update_is_rank_major_and_identical_on_every_rank():
+    """blip_ff.py:294-310 under 2 ranks: all-gathered (idx, q_m, c_m) are written rank-major at the pointer"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_blip_queue_worker, args=(r, 2, 29534, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    want_q = np.array([20, 20, 21, 21, 10, 10, 11, 11], dtype=np.float32)     # step 2 wrapped over step 0
+    want_idx = np.array([200, 201, 202, 203, 100, 101, 102, 103])
+    for r in range(2):
+        assert np.array_equal(res[r]["qq"], want_q) and np.array_equal(res[r]["cq"], -want_q)
+        assert np.array_equal(res[r]["idx"], want_idx) and res[r]["ptr"] == 4

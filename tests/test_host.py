@@ -96,3 +96,44 @@ def test_wgrad_split_heuristic_fills_the_chip():
     for tiles in (12, 16, 48, 64):
         s = wgrad_splits(263168, tiles)
         assert 0.9 * 256 <= tiles * s <= 256, (tiles, s)
+
+
+def test_blip_ff_state_dict_keys_match_reference_checkpoint_layout():
+    """the golden G8 holds the reference module's own state-dict keys; ours must be a superset with equal shapes"""
+    import json as _json
+    import numpy as np
+    from models.uniir_blip.blip_featurefusion.blip_ff import BLIPFeatureFusion
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g8_blipff.npz"))
+    med_cfg, vit_cfg = _json.loads(str(z["med_cfg"])), _json.loads(str(z["vit_cfg"]))
+    m = BLIPFeatureFusion(med_config=med_cfg, vit_config=vit_cfg, embed_dim=med_cfg["hidden_size"],
+                          queue_size=int(z["queue_size"]), momentum=float(z["momentum"]))
+    own = m.state_dict()
+    ref = {k[5:]: z[k].shape for k in z.files if k.startswith("sd0::")}
+    for k, shp in ref.items():
+        assert k in own and tuple(own[k].shape) == tuple(shp), k
+        if k.startswith(("visual_encoder.", "text_encoder.")):
+            km = k.replace("_encoder.", "_encoder_m.", 1)
+            assert km in own and not m.get_parameter(km).requires_grad
+    assert own["idx_queue"].dtype == torch.int64 and int(own["idx_queue"][0, 0]) == -100
+    # full-size geometry from the reference's relative med_config path: BERT-base + ViT-B/16 parameter count
+    full = BLIPFeatureFusion(med_config="../models/uniir_blip/backbone/configs/med_config.json", vit="base", queue_size=8)
+    n_online = sum(p.numel() for n, p in full.named_parameters() if p.requires_grad)
+    assert n_online == 85_798_656 + 137_849_088 + 1        # ViT-B/16 @224 + MED BERT-base with cross-attention + temp
+    with pytest.raises(RuntimeError):                       # no CPU product path
+        full._ensure_flat()
+
+
+def test_blip_front_pos_embed_and_transforms():
+    from PIL import Image
+    from uniir_amd import blip_front
+    pe = torch.arange(1 * 5 * 4, dtype=torch.float32).view(1, 5, 4)            # 2x2 grid + cls
+    out = blip_front.interpolate_pos_embed(pe, 16)
+    assert out.shape == (1, 17, 4) and torch.equal(out[:, 0], pe[:, 0])
+    ref = torch.nn.functional.interpolate(pe[:, 1:].reshape(1, 2, 2, 4).permute(0, 3, 1, 2), size=(4, 4), mode="bicubic",
+                                          align_corners=False).permute(0, 2, 3, 1).flatten(1, 2)
+    assert torch.equal(out[:, 1:], ref)
+    assert blip_front.interpolate_pos_embed(pe, 4) is pe
+    img = Image.new("RGB", (40, 30), (255, 0, 0))
+    for train in (False, True):
+        t = blip_front.get_blip_transform(32, is_train=train)(img)
+        assert t.shape == (3, 32, 32) and abs(t[0].mean().item() - (1 - 0.48145466) / 0.26862954) < 1e-4

@@ -39,6 +39,9 @@ def generate_embeds_and_ids_for_dataset_with_gather(model, data_loader, device, 
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 batch[k] = v.to(device, non_blocking=True)
+            elif hasattr(v, "input_ids") and hasattr(v, "items"):     # BLIP: transformers BatchEncoding
+                for kk, vv in v.items():
+                    v[kk] = vv.to(device)
         emb, ids = model(batch, encode_mbeir_batch=True)
         chunks.append(emb.half())          # fp16 on disk, like the reference
         id_list.extend(ids)

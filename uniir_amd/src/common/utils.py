@@ -1,5 +1,5 @@
 """Model factory and file helpers (drop-in for UniIR src/common/utils.py: load_qrel :16-31, load_runfile :35-65,
-build_model_from_config :64-153, set_seed).  Only CLIPScoreFusion is built on the MI355X path in this round."""
+build_model_from_config :64-153, set_seed).  CLIPScoreFusion and BLIPFeatureFusion are built on the MI355X path."""
 import os
 import random
 
@@ -45,9 +45,22 @@ def load_runfile(filename, load_task_id=False):
 
 def build_model_from_config(config):
     name = config.model.name
+    if name == "BLIPFeatureFusion":
+        from models.uniir_blip.blip_featurefusion.blip_ff import BLIPFeatureFusion
+        mc = config.model
+        model = BLIPFeatureFusion(med_config=os.path.join("../models/uniir_blip", "backbone/configs/med_config.json"),
+                                  image_size=mc.image_size, vit=mc.vit, vit_grad_ckpt=mc.vit_grad_ckpt,
+                                  vit_ckpt_layer=mc.vit_ckpt_layer, embed_dim=mc.embed_dim, queue_size=mc.queue_size,
+                                  config=mc)
+        ckpt = mc.ckpt_config
+        path = os.path.join(config.uniir_dir, ckpt.ckpt_dir, ckpt.ckpt_name)
+        assert os.path.exists(path), f"Checkpoint file {path} does not exist."
+        print(f"loading BLIPFeatureFusion checkpoint from {path}")
+        model.load_state_dict(torch.load(path, map_location="cpu")["model"])
+        return model
     if name != "CLIPScoreFusion":
-        raise NotImplementedError(f"{name}: only CLIPScoreFusion is on the MI355X hot path in this round "
-                                  "(CLIP_FF / BLIP_FF / BLIP_SF are listed as next in DESIGN.md)")
+        raise NotImplementedError(f"{name}: CLIPScoreFusion and BLIPFeatureFusion are on the MI355X hot path "
+                                  "(CLIP_FF / BLIP_SF are listed as next in DESIGN.md)")
     from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
     mc = config.model
     download_root = os.path.join(config.uniir_dir, mc.pretrained_clip_model_dir)
