@@ -248,3 +248,35 @@ def test_elementwise_misc():
         ops.call("uniir_adamw_step", pp, g, m, v, pb, 1003, 1e-3, 0.9, 0.98, 1e-6, 0.2, step, 1.0)
     assert (pp - pt.detach()).abs().max() < 1e-6
     assert torch.equal(pb.float(), bf(pp).float())
+
+
+@pytest.mark.parametrize("a_t,b_t", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 192), (512, 384, 256), (777, 520, 320), (2048, 1024, 1024), (1000, 264, 4096)])
+def test_gemm_pingpong_all_layouts(a_t, b_t, M, N, K):
+    """256x256x64 ping-pong loop (gemm_core_pp.h): every operand layout, 3..64 K steps, ragged M / N edges; each case
+    runs 3 times (race screen: the loop's LDS-DMA ordering is by counted vmcnt + barriers only) and must be bitwise
+    repeatable and equal to the compiler-scheduled loop's result (same MFMA order per output element)."""
+    ops = _ops()
+    torch.manual_seed(7)
+    Mp = (M + 7) // 8 * 8 if a_t else M
+    A = bf(torch.randn((K, Mp) if a_t else (Mp, K), device=DEV))
+    B = bf(torch.randn((K, N) if b_t else (N, K), device=DEV))
+    Af = (A.float().t() if a_t else A.float())[:Mp]
+    Bf = B.float() if b_t else B.float().t()
+    ref = Af @ Bf
+    outs = []
+    for _ in range(3):
+        C = torch.empty(Mp, N, device=DEV, dtype=torch.float32)
+        ops.gemm(A, B, C, Mp, N, K, Mp if a_t else K, N if b_t else K, N, a_tmaj=bool(a_t), b_tmaj=bool(b_t),
+                 epilogue=ops.EPI_F32)
+        outs.append(C)
+    assert rel_err(outs[0], ref) < 2e-3, rel_err(outs[0], ref)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    Cb = torch.empty(Mp, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(A, B, Cb, Mp, N, K, Mp if a_t else K, N if b_t else K, N, a_tmaj=bool(a_t), b_tmaj=bool(b_t))
+    assert rel_err(Cb, ref) < 4e-3
+    # split-K accumulate through the atomic epilogue and through the slab workspace
+    Cacc = torch.ones(Mp, N, device=DEV, dtype=torch.float32)
+    ops.gemm(A, B, Cacc, Mp, N, K, Mp if a_t else K, N if b_t else K, N, a_tmaj=bool(a_t), b_tmaj=bool(b_t),
+             epilogue=ops.EPI_ATOMIC_F32, k_splits=max(1, K // 192))
+    assert rel_err(Cacc, ref + 1.0) < 2e-3

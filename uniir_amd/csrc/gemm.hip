@@ -3,6 +3,7 @@
 // CLIP towers (openai/CLIP model.py as called from clip_sf.py:43-47) and their autograd backward.
 #include "gemm_core.h"
 #include "gemm_core256.h"
+#include "gemm_core_pp.h"
 #include "../../include/uniir_hip.h"
 #include <stdlib.h>
 
@@ -150,17 +151,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
 //   bf16 outputs (EPI_BF16, EPI_BIAS_ACT): one pass, image [256][256] bf16, 16-B chunk index ^= (row & 7)
 //   fp32 math on the way out (EPI_RESID_F32, EPI_DACT, EPI_F32 / split-K slabs): two passes of 128 rows,
 //   image [128][256] f32, 16-B chunk index ^= (row & 7)
+// PP = accumulator map of gemm_core_pp.h (acc[4h+i][2h'+j] at rows 128h + 64wr + 16i, cols 128h' + 32wc + 16j) instead
+// of the contiguous 128x64 wave tile at (wm, wn).
+template <bool PP, int H>
+DEVINL void epi_stage_f32_pass(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int n0, int wm, int wn, char* lds) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    if (!PP && wm != 128 * H) return;
+#pragma unroll
+    for (int ii = 0; ii < (PP ? 4 : 8); ++ii) {
+        const int i = PP ? 4 * H + ii : ii;
+        const int ml = PP ? (w >> 2) * 64 + ii * 16 + li : ii * 16 + li;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = PP ? (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 + 4 * lg : wn + j * 16 + 4 * lg;
+            f32x4_t v = acc[i][j] * p.alpha;
+            if (p.bias && n0 + nl < p.N) v += *reinterpret_cast<const f32x4_t*>(p.bias + n0 + nl);
+            *reinterpret_cast<f32x4_t*>(lds + ml * 1024 + ((((nl >> 2) ^ (ml & 7))) << 4)) = v;
+        }
+    }
+}
+
+template <bool PP>
 DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int m0, int n0, int wm, int wn,
                                char* lds, int epi) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
+    const int w = tid >> 6;
     if (epi == UNIIR_EPI_BF16 || epi == UNIIR_EPI_BIAS_ACT) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int ml = wm + i * 16 + li;
+            const int ml = PP ? (i >> 2) * 128 + (w >> 2) * 64 + (i & 3) * 16 + li : wm + i * 16 + li;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int nl = wn + j * 16 + 4 * lg;
+                const int nl = PP ? (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 + 4 * lg : wn + j * 16 + 4 * lg;
                 f32x4_t v = acc[i][j] * p.alpha;
                 if (p.bias && n0 + nl < p.N) v += *reinterpret_cast<const f32x4_t*>(p.bias + n0 + nl);
                 const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -193,19 +217,8 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
     f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < 2; ++h) {
         if (h) __syncthreads();
-        if (wm == 128 * h) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int ml = i * 16 + li;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int nl = wn + j * 16 + 4 * lg;
-                    f32x4_t v = acc[i][j] * p.alpha;
-                    if (p.bias && n0 + nl < p.N) v += *reinterpret_cast<const f32x4_t*>(p.bias + n0 + nl);
-                    *reinterpret_cast<f32x4_t*>(lds + ml * 1024 + ((((nl >> 2) ^ (ml & 7))) << 4)) = v;
-                }
-            }
-        }
+        if (h == 0) epi_stage_f32_pass<PP, 0>(p, acc, n0, wm, wn, lds);
+        else epi_stage_f32_pass<PP, 1>(p, acc, n0, wm, wn, lds);
         __syncthreads();
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
@@ -264,7 +277,30 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
 }
 
 // LDS-DMA GEMM (gemm_core256.h): block tile (128*WM) x (64*WN), K step BK.  Used when K % BK == 0.
-template <typename Elem, bool A_TMAJ, bool B_TMAJ, int WM, int WN, int BK, bool ASM>
+// split-K / wgrad accumulate epilogue for the ping-pong accumulator map
+DEVINL void epilogue_atomic_pp(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int m0, int n0) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + (i >> 2) * 128 + (w >> 2) * 64 + (i & 3) * 16 + li;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 + 4 * lg;
+            if (m < p.M && n < p.N) {
+                float* c = (float*)p.C + (long)m * p.ldc + n;
+                const f32x4_t v = acc[i][j] * p.alpha;
+                unsafeAtomicAdd(c + 0, v[0]);
+                unsafeAtomicAdd(c + 1, v[1]);
+                unsafeAtomicAdd(c + 2, v[2]);
+                unsafeAtomicAdd(c + 3, v[3]);
+            }
+        }
+    }
+}
+
+// LOOP: 0 = compiler-scheduled loop, 1 = counted-lgkmcnt asm loop, 2 = ping-pong 8-phase loop (gemm_core_pp.h)
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, int WM, int WN, int BK, int LOOP>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p) {
     using S = GldsShape<WM, WN, BK>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -287,7 +323,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (WM == 2 && WN == 4 && BK == 64 && ASM)
+    constexpr bool PP = (WM == 2 && WN == 4 && BK == 64 && LOOP == 2);
+    if (PP)
+        glds_mainloop_pp<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
+    else if (WM == 2 && WN == 4 && BK == 64 && LOOP == 1)
         glds_mainloop_asm<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
     else
         glds_mainloop<Elem, A_TMAJ, B_TMAJ, WM, WN, BK>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
@@ -299,11 +338,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
             q.C = p.slab + (long)split * p.M * p.N;
             q.ldc = p.N;
             q.bias = nullptr;
-            epilogue256_staged(q, acc, m0, n0, wm, wn, lds, UNIIR_EPI_F32);
+            epilogue256_staged<PP>(q, acc, m0, n0, wm, wn, lds, UNIIR_EPI_F32);
         } else if (p.epilogue == UNIIR_EPI_ATOMIC_F32) {
-            gemm_epilogue<UNIIR_EPI_ATOMIC_F32, 8, 4>(p, acc, m0, n0, wm, wn);
+            if (PP) epilogue_atomic_pp(p, acc, m0, n0);
+            else gemm_epilogue<UNIIR_EPI_ATOMIC_F32, 8, 4>(p, acc, m0, n0, wm, wn);
         } else {
-            epilogue256_staged(p, acc, m0, n0, wm, wn, lds, p.epilogue);
+            epilogue256_staged<PP>(p, acc, m0, n0, wm, wn, lds, p.epilogue);
         }
         return;
     }
@@ -318,7 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
     gemm_epilogue_dispatch<8, 4>(p, acc, m0, n0, wm, wn);
 }
 
-template <typename Elem, int WM, int WN, int BK, bool ASM>
+template <typename Elem, int WM, int WN, int BK, int ASM>
 static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
     using S = GldsShape<WM, WN, BK>;
     a.tiles_m = (a.M + S::BM - 1) / S::BM;
@@ -357,9 +397,15 @@ static int gemm_shape(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
 template <typename Elem>
 static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t st) {
     const int shape = gemm_shape(a, a_tmaj, b_tmaj);
-    if (shape == 1 && a.asm_loop) return launch_glds<Elem, 2, 4, 64, true>(a, a_tmaj, b_tmaj, st);
-    if (shape == 1) return launch_glds<Elem, 2, 4, 64, false>(a, a_tmaj, b_tmaj, st);
-    if (shape == 2) return launch_glds<Elem, 2, 2, 32, false>(a, a_tmaj, b_tmaj, st);
+    if (shape == 1) {
+        // the ping-pong loop needs >= 3 K steps in every split
+        const int ksteps = a.K / 64, per = (ksteps + a.k_splits - 1) / a.k_splits;
+        const int last = ksteps - per * (a.k_splits - 1);
+        if (a.asm_loop == 2 && last >= 3) return launch_glds<Elem, 2, 4, 64, 2>(a, a_tmaj, b_tmaj, st);
+        if (a.asm_loop >= 1) return launch_glds<Elem, 2, 4, 64, 1>(a, a_tmaj, b_tmaj, st);
+        return launch_glds<Elem, 2, 4, 64, 0>(a, a_tmaj, b_tmaj, st);
+    }
+    if (shape == 2) return launch_glds<Elem, 2, 2, 32, 0>(a, a_tmaj, b_tmaj, st);
     const int grid = a.tiles_m * a.tiles_n * a.k_splits;
     dim3 g(grid), b(256);
     const size_t sm = GEMM_LDS_BYTES;
@@ -427,8 +473,8 @@ extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
     a.slab = nullptr;
     a.colsum = d->colsum;
     {
-        static const char* e = getenv("UNIIR_GEMM_ASM");
-        a.asm_loop = (e && e[0] == '0') ? 0 : 1;
+        static const char* e = getenv("UNIIR_GEMM_LOOP");   // 0 compiler loop, 1 counted-lgkmcnt asm loop, 2 ping-pong
+        a.asm_loop = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
     }
     hipStream_t st = (hipStream_t)stream;
     if (d->k_splits > 1) {

@@ -1,0 +1,223 @@
+// Ping-pong ("8-phase") main loop of the 256x256x64 LDS-DMA GEMM for gfx950.
+//
+// 8 waves = two groups of four (group g = waves 4g..4g+3, one wave per SIMD each).  Group 1 runs ONE s_barrier behind
+// group 0, and every phase is  [LDS fragment reads + one half-tile of LDS-DMA prefetch] s_barrier [16 MFMAs] s_barrier,
+// so in every barrier interval one group feeds the four matrix pipes while the other group issues its LDS / DMA
+// traffic: the matrix pipe of a SIMD always has exactly one wave in its MFMA segment.
+//
+// Tile decomposition.  The 256x64 A image of a K step is staged as two half-tiles A0 = rows [0,128), A1 = rows
+// [128,256) (B alike along N), each 16 KiB, in the SAME swizzled layouts as gemm_core256.h with extent 128.  A wave
+// (wr = w >> 2 in 0..1, wc = w & 3) owns rows {128 h + 64 wr + [0,64)} x cols {128 h' + 32 wc + [0,32)}, h, h' in {0,1}:
+// four 64x32 quadrants (h,h'), each 4x2 MFMA tiles x 2 k-substeps = 16 MFMAs = one phase.  Quadrant order per K step
+// (A0,B0) (A0,B1) (A1,B1) (A1,B0): 12 / 4 / 8 / 0 fragment reads; every half-tile is read in exactly one phase
+// (q = 0,0,1,2 for A0,B0,B1,A1).
+//
+// LDS ring: 2 K steps x 4 half-tiles x 16 KiB = 128 KiB, slot(t, j) = ((t & 1) * 4 + j), j = 0:A0 1:B0 2:B1 3:A1.
+// Staging runs D = 6 half-tiles ahead in the order A0,B0,B1,A1: phase (t,q) stages half-tile 4t+q+6, i.e.
+//   q=0 -> (t+1,B1)   q=1 -> (t+1,A1)   q=2 -> (t+2,A0)   q=3 -> (t+2,B0).
+// Hazards (MI355X guide: LDS-DMA is ordered for a ds_read only by the issuing waves' counted vmcnt followed by a
+// barrier the reader has passed, one barrier more for the staggered group; a slot may be re-staged >= 2 phases after
+// its last ds_read):
+//   RAW: every load segment ends with s_waitcnt vmcnt(8) = "all but the 4 youngest half-tiles have landed" BEFORE the
+//        phase's first barrier; phase P reads half-tiles <= 4t+{1,2,3} which is <= (P-1)+6-4: retired one phase earlier.
+//   WAR: the slot staged in phase (t,q) was last read in phase (t-1,1) / (t-1,2) / (t,0) / (t,0): >= 2 phases before.
+// The last two K steps stage nothing / less and use exact smaller counts (MODE 1, 2).  Needs nk >= 3 K steps.
+#pragma once
+#include "gemm_core256.h"
+
+template <int N>
+DEVINL void asm_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+DEVINL void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// per-lane LDS byte offsets of the fragment reads inside one 128-extent half-tile image
+template <bool TMAJ>
+struct HalfFrag {
+    unsigned a[TMAJ ? 4 : 2];
+    DEVINL void init(int base16, int lane) {
+        if (!TMAJ) {
+            const int rl = base16 + (lane & 15);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) a[s] = rl * 128 + (((s * 4 + (lane >> 4)) ^ (rl & 7)) << 4);
+        } else {
+            const int t = lane & 15, g = lane >> 4;
+            const int krow = 8 * g + (t >> 2);
+            const int f = tmaj_f(krow);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = base16 + i * 16 + 4 * (t & 3);
+                a[i] = krow * 256 + (((col >> 4) ^ f) << 5) + (col & 15) * 2;
+            }
+        }
+    }
+    template <int I, int S>
+    DEVINL u32x4_t read(unsigned sb) const {
+        if (!TMAJ) {
+            return asm_ds_read_b128<I * 2048>(sb + a[S]);
+        } else {
+            const u32x2_t lo = asm_ds_read_tr16<S * 8192>(sb + a[I]);
+            const u32x2_t hi = asm_ds_read_tr16<S * 8192 + 1024>(sb + a[I]);
+            const u32x4_t r = {lo[0], lo[1], hi[0], hi[1]};
+            return r;
+        }
+    }
+};
+
+// this thread's two global source pointers (at k = kbeg) of one half-tile; same source-side swizzles as glds_stage
+template <bool TMAJ>
+DEVINL void pp_src(const unsigned short* __restrict__ base, long ld, int mn0, int mn_total, int kbeg, int tid,
+                   const unsigned short* (&gp)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = i * 512 + tid;
+        long off;
+        if (!TMAJ) {
+            const int row = c >> 3, slot = c & 7;
+            const int src = slot ^ (row & 7);
+            const int gm = min(mn0 + row, mn_total - 1);
+            off = (long)gm * ld + kbeg + src * 8;
+        } else {
+            const int krow = c >> 4, slot = c & 15;
+            const int src = (((slot >> 1) ^ tmaj_f(krow)) << 1) | (slot & 1);
+            const int gm = min(mn0 + src * 8, mn_total - 8);
+            off = (long)(kbeg + krow) * ld + gm;
+        }
+        gp[i] = base + off;
+    }
+}
+
+DEVINL void pp_stage(const unsigned short* const (&gp)[2], long koff, char* slot, int w) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        char* dst = slot + (i * 512 + w * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gp[i] + koff),
+                                         (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+}
+
+template <typename Elem, int H, int HP>
+DEVINL void pp_mfma16(const u32x4_t (&af)[4][2], const u32x4_t (&bf)[2][2], f32x4_t (&acc)[8][4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[H * 4 + i][HP * 2 + j] = Elem::mfma(bf[j][s], af[i][s], acc[H * 4 + i][HP * 2 + j]);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+struct PPState {
+    HalfFrag<A_TMAJ> fa;
+    HalfFrag<B_TMAJ> fb;
+    const unsigned short* gA[2][2];   // [half][load]
+    const unsigned short* gB[2][2];
+    long kstepA, kstepB;              // element offset of one K step
+    unsigned lbase;
+    char* lds;
+    int w;
+};
+
+// one K step (4 phases).  MODE 0: steady state; 1: second to last K step (stages q=0,1 only); 2: last (stages nothing)
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, int MODE>
+DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&acc)[8][4]) {
+    const unsigned sb = st.lbase + (t & 1) * 65536;            // this K step's four slots
+    char* const cur = st.lds + (t & 1) * 65536;
+    char* const oth = st.lds + ((t + 1) & 1) * 65536;
+    const long kA1 = (long)(t + 1) * st.kstepA, kB1 = (long)(t + 1) * st.kstepB;
+    const long kA2 = (long)(t + 2) * st.kstepA, kB2 = (long)(t + 2) * st.kstepB;
+    u32x4_t af[4][2], b0[2][2], b1[2][2];
+    // ---- phase 0: quadrant (A0,B0); reads B0 then A0; stages (t+1, B1)
+    b0[0][0] = st.fb.template read<0, 0>(sb + 16384); b0[1][0] = st.fb.template read<1, 0>(sb + 16384);
+    b0[0][1] = st.fb.template read<0, 1>(sb + 16384); b0[1][1] = st.fb.template read<1, 1>(sb + 16384);
+    __builtin_amdgcn_sched_barrier(0);
+    af[0][0] = st.fa.template read<0, 0>(sb); af[1][0] = st.fa.template read<1, 0>(sb);
+    af[2][0] = st.fa.template read<2, 0>(sb); af[3][0] = st.fa.template read<3, 0>(sb);
+    af[0][1] = st.fa.template read<0, 1>(sb); af[1][1] = st.fa.template read<1, 1>(sb);
+    af[2][1] = st.fa.template read<2, 1>(sb); af[3][1] = st.fa.template read<3, 1>(sb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE <= 1) pp_stage(st.gB[1], kB1, oth + 2 * 16384, st.w);
+    __builtin_amdgcn_sched_barrier(0);
+    asm_wait_vm<MODE <= 1 ? 8 : 2>();
+    pp_barrier();
+    asm_wait_lgkm<0>();
+    pp_mfma16<Elem, 0, 0>(af, b0, acc);
+    pp_barrier();
+    // ---- phase 1: quadrant (A0,B1); reads B1; stages (t+1, A1)
+    b1[0][0] = st.fb.template read<0, 0>(sb + 2 * 16384); b1[1][0] = st.fb.template read<1, 0>(sb + 2 * 16384);
+    b1[0][1] = st.fb.template read<0, 1>(sb + 2 * 16384); b1[1][1] = st.fb.template read<1, 1>(sb + 2 * 16384);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE <= 1) pp_stage(st.gA[1], kA1, oth + 3 * 16384, st.w);
+    __builtin_amdgcn_sched_barrier(0);
+    asm_wait_vm<MODE <= 1 ? 8 : 0>();
+    pp_barrier();
+    asm_wait_lgkm<0>();
+    pp_mfma16<Elem, 0, 1>(af, b1, acc);
+    pp_barrier();
+    // ---- phase 2: quadrant (A1,B1); reads A1; stages (t+2, A0)
+    af[0][0] = st.fa.template read<0, 0>(sb + 3 * 16384); af[1][0] = st.fa.template read<1, 0>(sb + 3 * 16384);
+    af[2][0] = st.fa.template read<2, 0>(sb + 3 * 16384); af[3][0] = st.fa.template read<3, 0>(sb + 3 * 16384);
+    af[0][1] = st.fa.template read<0, 1>(sb + 3 * 16384); af[1][1] = st.fa.template read<1, 1>(sb + 3 * 16384);
+    af[2][1] = st.fa.template read<2, 1>(sb + 3 * 16384); af[3][1] = st.fa.template read<3, 1>(sb + 3 * 16384);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 0) pp_stage(st.gA[0], kA2, cur + 0 * 16384, st.w);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 0) asm_wait_vm<8>();
+    pp_barrier();
+    asm_wait_lgkm<0>();
+    pp_mfma16<Elem, 1, 1>(af, b1, acc);
+    pp_barrier();
+    // ---- phase 3: quadrant (A1,B0), B0 still in registers; stages (t+2, B0)
+    if (MODE == 0) pp_stage(st.gB[0], kB2, cur + 1 * 16384, st.w);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 0) asm_wait_vm<8>();
+    if (MODE == 1) asm_wait_vm<4>();
+    pp_barrier();
+    pp_mfma16<Elem, 1, 0>(af, b0, acc);
+    pp_barrier();
+}
+
+// accumulators: acc[4h + i][2h' + j] = MFMA tile at rows 128h + 64wr + 16i, cols 128h' + 32wc + 16j (swapped operands:
+// a lane owns 4 consecutive N, like gemm_core256.h)
+template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int M, const unsigned short* __restrict__ B,
+                             long ldb, int N, int m0, int n0, int kbeg, int kend, char* lds, f32x4_t (&acc)[8][4]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int nk = (kend - kbeg) / 64;
+    PPState<Elem, A_TMAJ, B_TMAJ> st;
+    st.fa.init(wr * 64, lane);
+    st.fb.init(wc * 32, lane);
+    pp_src<A_TMAJ>(A, lda, m0, M, kbeg, tid, st.gA[0]);
+    pp_src<A_TMAJ>(A, lda, m0 + 128, M, kbeg, tid, st.gA[1]);
+    pp_src<B_TMAJ>(B, ldb, n0, N, kbeg, tid, st.gB[0]);
+    pp_src<B_TMAJ>(B, ldb, n0 + 128, N, kbeg, tid, st.gB[1]);
+    st.kstepA = A_TMAJ ? 64 * lda : 64;
+    st.kstepB = B_TMAJ ? 64 * ldb : 64;
+    st.lbase = lds_addr32(lds);
+    st.lds = lds;
+    st.w = w;
+    // prologue: half-tiles 0..5 = (0,A0) (0,B0) (0,B1) (0,A1) (1,A0) (1,B0)
+    pp_stage(st.gA[0], 0, lds + 0 * 16384, w);
+    pp_stage(st.gB[0], 0, lds + 1 * 16384, w);
+    pp_stage(st.gB[1], 0, lds + 2 * 16384, w);
+    pp_stage(st.gA[1], 0, lds + 3 * 16384, w);
+    pp_stage(st.gA[0], st.kstepA, lds + 65536 + 0 * 16384, w);
+    pp_stage(st.gB[0], st.kstepB, lds + 65536 + 1 * 16384, w);
+    __builtin_amdgcn_sched_barrier(0);
+    asm_wait_vm<8>();
+    pp_barrier();
+    if (wr == 1) pp_barrier();          // group 1 runs one barrier behind from here on
+    for (int t = 0; t < nk - 2; ++t) pp_kstep<Elem, A_TMAJ, B_TMAJ, 0>(st, t, acc);
+    pp_kstep<Elem, A_TMAJ, B_TMAJ, 1>(st, nk - 2, acc);
+    pp_kstep<Elem, A_TMAJ, B_TMAJ, 2>(st, nk - 1, acc);
+    if (wr == 0) pp_barrier();          // re-align the groups
+}
