@@ -4,8 +4,8 @@ import torch
 from uniir_amd import ops
 from tools.microbench import timeit
 dev = "cuda"
-M, N = 65536, 1024
-for K in (64, 128, 256, 512, 1024, 2048, 4096, 8192):
+M, N = int(os.environ.get("M", 65536)), int(os.environ.get("N", 1024))
+for K in [int(k) for k in os.environ.get("KS", "64,128,256,512,1024,2048,4096,8192").split(",")]:
     x = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16()
     y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     t = timeit(lambda: ops.linear_fwd(x, w, out=y), iters=20)

@@ -23,15 +23,13 @@ typedef unsigned short f16_t;    // raw fp16 bits (only moved around / fed to MF
 #define DEVINL __device__ __forceinline__
 
 DEVINL float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-// round-to-nearest-even, NaN kept quiet
-DEVINL bf16_t f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even in hardware (gfx950 v_cvt_pk_bf16_f32: one instruction per pair)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 hwbf16x2_t;
+DEVINL bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 DEVINL unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hwbf16x2_t));
 }
 DEVINL float f16_to_f32(f16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 DEVINL f16_t f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }

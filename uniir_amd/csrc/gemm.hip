@@ -20,18 +20,19 @@ struct GemmKArgs {
     int epilogue, act, k_splits, tiles_m, tiles_n;
     float alpha;
     float* slab;  // split-K slabs [k_splits][M][N] (plain stores) or nullptr (atomics)
-    int asm_loop;   // 1: hand-pipelined fragment reads (glds_mainloop_asm)
+    int asm_loop;   // 0 compiler loop, 1 counted-lgkmcnt asm loop, 2 ping-pong loop
     float* colsum;  // optional [N]: += column sums of the fp32 result (bias gradient), 256-tile staged epilogue only
 };
 
 DEVINL float act_fwd(float x, int act) {
-    if (act == UNIIR_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+    // __builtin_amdgcn_rcpf: 1 ulp, one instruction (an IEEE division is ~10); the results are rounded to bf16
+    if (act == UNIIR_ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     if (act == UNIIR_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
     return fmaxf(x, 0.0f);
 }
 DEVINL float act_bwd(float x, int act) {
     if (act == UNIIR_ACT_QUICKGELU) {
-        const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
         return s * (1.0f + 1.702f * x * (1.0f - s));
     }
     if (act == UNIIR_ACT_GELU_ERF) {
@@ -153,23 +154,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
 //   image [128][256] f32, 16-B chunk index ^= (row & 7)
 // PP = accumulator map of gemm_core_pp.h (acc[4h+i][2h'+j] at rows 128h + 64wr + 16i, cols 128h' + 32wc + 16j) instead
 // of the contiguous 128x64 wave tile at (wm, wn).
-template <bool PP, int H>
-DEVINL void epi_stage_f32_pass(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int n0, int wm, int wn, char* lds) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-    if (!PP && wm != 128 * H) return;
-#pragma unroll
-    for (int ii = 0; ii < (PP ? 4 : 8); ++ii) {
-        const int i = PP ? 4 * H + ii : ii;
-        const int ml = PP ? (w >> 2) * 64 + ii * 16 + li : ii * 16 + li;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nl = PP ? (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 + 4 * lg : wn + j * 16 + 4 * lg;
-            f32x4_t v = acc[i][j] * p.alpha;
-            if (p.bias && n0 + nl < p.N) v += *reinterpret_cast<const f32x4_t*>(p.bias + n0 + nl);
-            *reinterpret_cast<f32x4_t*>(lds + ml * 1024 + ((((nl >> 2) ^ (ml & 7))) << 4)) = v;
-        }
-    }
+// The epilogue is VALU-issue bound (2 waves per SIMD, ~4 clk per instruction), so it is written for instruction count:
+// hardware bf16 packing, LDS / global addresses as one per-thread base plus compile-time immediates, bounds checks
+// hoisted to one wave-uniform "full tile" test, alpha skipped when it is 1.
+template <bool PP>
+DEVINL int epi_row(int i, int w, int wm) {   // first row of accumulator tile i inside the 256-row block tile
+    return PP ? (i >> 2) * 128 + (w >> 2) * 64 + (i & 3) * 16 : wm + i * 16;
+}
+template <bool PP>
+DEVINL int epi_col(int j, int w, int wn) {
+    return PP ? (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 : wn + j * 16;
 }
 
 template <bool PP>
@@ -177,57 +171,103 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
                                char* lds, int epi) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
-    const int w = tid >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool full = (m0 + 256 <= p.M) && (n0 + 256 <= p.N);
+    const bool scale = p.alpha != 1.0f;
+    f32x4_t bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + epi_col<PP>(j, w, wn) + 4 * lg;
+        bv[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     if (epi == UNIIR_EPI_BF16 || epi == UNIIR_EPI_BIAS_ACT) {
+        // image [256][256] bf16, 512 B per row, 16-B chunk index ^= (row & 7); row & 7 == li & 7 for every tile
+        char* sj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = epi_col<PP>(j, w, wn) + 4 * lg;
+            sj[j] = lds + li * 512 + (((nl >> 3) ^ (li & 7)) << 4) + ((nl & 7) << 1);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int ml = PP ? (i >> 2) * 128 + (w >> 2) * 64 + (i & 3) * 16 + li : wm + i * 16 + li;
+            const int rb = epi_row<PP>(i, w, wm) * 512;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int nl = PP ? (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 + 4 * lg : wn + j * 16 + 4 * lg;
-                f32x4_t v = acc[i][j] * p.alpha;
-                if (p.bias && n0 + nl < p.N) v += *reinterpret_cast<const f32x4_t*>(p.bias + n0 + nl);
+                f32x4_t v = acc[i][j];
+                if (scale) v *= p.alpha;
+                v += bv[j];
                 const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *reinterpret_cast<u32x2_t*>(lds + ml * 512 + ((((nl >> 3) ^ (ml & 7))) << 4) + ((nl & 7) << 1)) = o;
+                *reinterpret_cast<u32x2_t*>(sj[j] + rb) = o;
             }
         }
         __syncthreads();
-#pragma unroll 4
+        // thread -> (row r0 + 16 it, 16-B chunk ch): LDS address and global offset advance by constants
+        const int r0 = tid >> 5, ch = tid & 31;
+        const char* src = lds + r0 * 512 + ((ch ^ (r0 & 7)) << 4);
+        const long off0 = (long)(m0 + r0) * p.ldc + n0 + ch * 8;
+        unsigned short* c1 = (unsigned short*)p.C + off0;
+        unsigned short* c2 = (unsigned short*)p.C2 + off0;
+        const long rstep = 16L * p.ldc;
+        const bool colok = n0 + ch * 8 < p.N;
+        const int rows_left = p.M - m0 - r0;
+        const bool act = epi == UNIIR_EPI_BIAS_ACT;
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const int c = it * 512 + tid;
-            const int row = c >> 5, ch = c & 31;
-            const int m = m0 + row, n = n0 + ch * 8;
-            if (m < p.M && n < p.N) {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(lds + row * 512 + ((ch ^ (row & 7)) << 4));
-                const long off = (long)m * p.ldc + n;
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>((unsigned short*)p.C + off));
-                if (epi == UNIIR_EPI_BIAS_ACT) {
+            if (full || (colok && 16 * it < rows_left)) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + it * 8192);
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1 + it * rstep));
+                if (act) {
                     u32x4_t g;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         g[e] = pack_bf16x2(act_fwd(__uint_as_float(v[e] << 16), p.act),
                                            act_fwd(__uint_as_float(v[e] & 0xffff0000u), p.act));
-                    *reinterpret_cast<u32x4_t*>((unsigned short*)p.C2 + off) = g;
+                    *reinterpret_cast<u32x4_t*>(c2 + it * rstep) = g;
                 }
             }
         }
         return;
     }
-    // fp32 staging, two passes of 128 rows (the waves with wm == 128*h write in pass h)
+    // fp32 math on the way out: two passes of 128 rows, image [128][256] f32 (1 KiB per row), 16-B chunk ^= (row & 7).
+    // !PP: the waves with wm == 128 h stage all their 8 tiles in pass h; PP: every wave stages tiles 4h..4h+3.
+    char* sj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nl = epi_col<PP>(j, w, wn) + 4 * lg;
+        sj[j] = lds + li * 1024 + (((nl >> 2) ^ (li & 7)) << 4);
+    }
+    const int r0 = tid >> 6, ch = tid & 63;   // copy-out: row r0 + 8 it of the pass, 16-B chunk ch (4 floats)
+    const char* src = lds + r0 * 1024 + ((ch ^ (r0 & 7)) << 4);
+    const bool colok = n0 + ch * 4 < p.N;
+    const long rstep = 8L * p.ldc, rstep_aux = 8L * p.ldaux;
     f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h) __syncthreads();
-        if (h == 0) epi_stage_f32_pass<PP, 0>(p, acc, n0, wm, wn, lds);
-        else epi_stage_f32_pass<PP, 1>(p, acc, n0, wm, wn, lds);
+        if (PP || wm == 128 * h) {
+#pragma unroll
+            for (int ii = 0; ii < (PP ? 4 : 8); ++ii) {
+                const int i = PP ? 4 * h + ii : ii;
+                const int rb = (PP ? (w >> 2) * 64 + ii * 16 : ii * 16) * 1024;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4_t v = acc[i][j];
+                    if (scale) v *= p.alpha;
+                    v += bv[j];
+                    *reinterpret_cast<f32x4_t*>(sj[j] + rb) = v;
+                }
+            }
+        }
         __syncthreads();
+        const int mrow = m0 + 128 * h + r0;
+        const long off0 = (long)mrow * p.ldc + n0 + ch * 4;
+        const long offa = (long)mrow * p.ldaux + n0 + ch * 4;
+        const int rows_left = p.M - mrow;
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
-            const int c = it * 512 + tid;
-            const int row = c >> 6, ch = c & 63;
-            const int m = m0 + 128 * h + row, n = n0 + ch * 4;
-            if (m < p.M && n < p.N) {
-                f32x4_t v = *reinterpret_cast<const f32x4_t*>(lds + row * 1024 + ((ch ^ (row & 7)) << 4));
-                const long off = (long)m * p.ldc + n;
+            if (full || (colok && 8 * it < rows_left)) {
+                f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + it * 8192);
+                const long off = off0 + it * rstep;
                 if (epi == UNIIR_EPI_RESID_F32) {
                     if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
                     *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
@@ -236,7 +276,8 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
                         *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o;
                     }
                 } else if (epi == UNIIR_EPI_DACT) {
-                    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + (long)m * p.ldaux + n);
+                    const long oa = offa + it * rstep_aux;
+                    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + oa);
                     const float f0 = __uint_as_float(a[0] << 16), f1 = __uint_as_float(a[0] & 0xffff0000u);
                     const float f2 = __uint_as_float(a[1] << 16), f3 = __uint_as_float(a[1] & 0xffff0000u);
                     v[0] *= act_bwd(f0, p.act); v[1] *= act_bwd(f1, p.act);
@@ -246,7 +287,7 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
                     if (p.C2) {  // recomputed activation act(aux) for the wgrad of the next linear
                         const u32x2_t g2 = {pack_bf16x2(act_fwd(f0, p.act), act_fwd(f1, p.act)),
                                             pack_bf16x2(act_fwd(f2, p.act), act_fwd(f3, p.act))};
-                        *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + (long)m * p.ldaux + n) = g2;
+                        *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + oa) = g2;
                     }
                 } else {  // UNIIR_EPI_F32 (also the split-K slabs)
                     *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
