@@ -7,6 +7,7 @@ dev = "cuda"
 M, N = int(os.environ.get("M", 65536)), int(os.environ.get("N", 1024))
 for K in [int(k) for k in os.environ.get("KS", "64,128,256,512,1024,2048,4096,8192").split(",")]:
     x = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16()
+    if os.environ.get('ZERO'): x.zero_(); w.zero_()
     y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     t = timeit(lambda: ops.linear_fwd(x, w, out=y), iters=20)
     tiles = (M // 256) * (N // 256)

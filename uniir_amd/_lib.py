@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuniir_hip.so")
+LIB_PATH = os.environ.get("UNIIR_HIP_LIB") or os.path.join(_HERE, "libuniir_hip.so")   # env: kernel experiments only
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

@@ -417,10 +417,15 @@ static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
         }                                                                                         \
         hipLaunchKernelGGL((gemm_glds_kernel<Elem, AT, BT, WM, WN, BK, ASM>), g, b, sm, st, a);        \
     } while (0)
+#ifdef UNIIR_EXP_BUILD   // fast experimental build (tools/build_exp.sh): NT ping-pong kernel only
+    if (!a_tmaj && !b_tmaj && ASM == 2) LAUNCHG(false, false);
+    else return UNIIR_EUNSUPPORTED;
+#else
     if (!a_tmaj && !b_tmaj) LAUNCHG(false, false);
     else if (!a_tmaj && b_tmaj) LAUNCHG(false, true);
     else if (a_tmaj && !b_tmaj) LAUNCHG(true, false);
     else LAUNCHG(true, true);
+#endif
 #undef LAUNCHG
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
@@ -442,7 +447,10 @@ static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t s
         // the ping-pong loop needs >= 3 K steps in every split
         const int ksteps = a.K / 64, per = (ksteps + a.k_splits - 1) / a.k_splits;
         const int last = ksteps - per * (a.k_splits - 1);
-        if (a.asm_loop == 2 && last >= 3) return launch_glds<Elem, 2, 4, 64, 2>(a, a_tmaj, b_tmaj, st);
+        // ... and addresses the K advance of a T-major operand as a 32-bit byte offset
+        const bool k32 = (!a_tmaj || (uint64_t)a.K * a.lda * 2 < (1ull << 32)) &&
+                         (!b_tmaj || (uint64_t)a.K * a.ldb * 2 < (1ull << 32));
+        if (a.asm_loop == 2 && last >= 3 && k32) return launch_glds<Elem, 2, 4, 64, 2>(a, a_tmaj, b_tmaj, st);
         if (a.asm_loop >= 1) return launch_glds<Elem, 2, 4, 64, 1>(a, a_tmaj, b_tmaj, st);
         return launch_glds<Elem, 2, 4, 64, 0>(a, a_tmaj, b_tmaj, st);
     }
@@ -460,10 +468,14 @@ static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t s
         }                                                                                         \
         hipLaunchKernelGGL((gemm_kernel<Elem, AT, BT>), g, b, sm, st, a);                         \
     } while (0)
+#ifdef UNIIR_EXP_BUILD
+    return UNIIR_EUNSUPPORTED;
+#else
     if (!a_tmaj && !b_tmaj) LAUNCH(false, false);
     else if (!a_tmaj && b_tmaj) LAUNCH(false, true);
     else if (a_tmaj && !b_tmaj) LAUNCH(true, false);
     else LAUNCH(true, true);
+#endif
 #undef LAUNCH
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
@@ -532,7 +544,9 @@ extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
     }
     int rc;
     if (d->dtype == UNIIR_DT_BF16) rc = launch_gemm<ElemBF16>(a, d->a_tmaj, d->b_tmaj, st);
+#ifndef UNIIR_EXP_BUILD
     else if (d->dtype == UNIIR_DT_F16) rc = launch_gemm<ElemF16>(a, d->a_tmaj, d->b_tmaj, st);
+#endif
     else return UNIIR_EINVAL;
     if (rc) return rc;
     if (a.slab) {

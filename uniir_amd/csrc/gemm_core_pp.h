@@ -25,8 +25,13 @@
 #pragma once
 #include "gemm_core256.h"
 
+#ifndef PP_EXP
+#define PP_EXP 0   // timing experiments only (tools/build_exp.sh): 1 no staging, 2 no fragment reads, 4 no MFMA, 8 no vmcnt
+#endif
+
 template <int N>
 DEVINL void asm_wait_vm() {
+    if (PP_EXP & 9) return;
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N));
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -58,6 +63,7 @@ struct HalfFrag {
     }
     template <int I, int S>
     DEVINL u32x4_t read(unsigned sb) const {
+        if (PP_EXP & 2) return u32x4_t{sb, a[0], sb, a[1]};
         if (!TMAJ) {
             return asm_ds_read_b128<I * 2048>(sb + a[S]);
         } else {
@@ -69,10 +75,12 @@ struct HalfFrag {
     }
 };
 
-// this thread's two global source pointers (at k = kbeg) of one half-tile; same source-side swizzles as glds_stage
+// this thread's two source byte offsets of one half-tile, relative to the block's operand base (row / column mn_base
+// of the block tile, K offset kbeg); same source-side swizzles as glds_stage.  The loads are MUBUF LDS-DMA
+// (buffer_load_dwordx4 ... offen lds): one SGPR descriptor per operand, a 32-bit per-lane offset, and the K advance as
+// the scalar soffset -- no 64-bit per-lane address arithmetic in the loop and half the address traffic of global_load.
 template <bool TMAJ>
-DEVINL void pp_src(const unsigned short* __restrict__ base, long ld, int mn0, int mn_total, int kbeg, int tid,
-                   const unsigned short* (&gp)[2]) {
+DEVINL void pp_src(long ld, int mn_base, int mn0, int mn_total, int tid, unsigned (&vo)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int c = i * 512 + tid;
@@ -80,29 +88,30 @@ DEVINL void pp_src(const unsigned short* __restrict__ base, long ld, int mn0, in
         if (!TMAJ) {
             const int row = c >> 3, slot = c & 7;
             const int src = slot ^ (row & 7);
-            const int gm = min(mn0 + row, mn_total - 1);
-            off = (long)gm * ld + kbeg + src * 8;
+            const int gm = min(mn0 + row, mn_total - 1) - mn_base;
+            off = (long)gm * ld + src * 8;
         } else {
             const int krow = c >> 4, slot = c & 15;
             const int src = (((slot >> 1) ^ tmaj_f(krow)) << 1) | (slot & 1);
-            const int gm = min(mn0 + src * 8, mn_total - 8);
-            off = (long)(kbeg + krow) * ld + gm;
+            const int gm = min(mn0 + src * 8, mn_total - 8) - mn_base;
+            off = (long)krow * ld + gm;
         }
-        gp[i] = base + off;
+        vo[i] = (unsigned)(off * 2);
     }
 }
 
-DEVINL void pp_stage(const unsigned short* const (&gp)[2], long koff, char* slot, int w) {
+DEVINL void pp_stage(__amdgpu_buffer_rsrc_t rs, const unsigned (&vo)[2], unsigned koff_bytes, char* slot, int w) {
+    if (PP_EXP & 1) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         char* dst = slot + (i * 512 + w * 64) * 16;
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gp[i] + koff),
-                                         (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)dst, 16, vo[i], koff_bytes, 0, 0);
     }
 }
 
 template <typename Elem, int H, int HP>
 DEVINL void pp_mfma16(const u32x4_t (&af)[4][2], const u32x4_t (&bf)[2][2], f32x4_t (&acc)[8][4]) {
+    if (PP_EXP & 4) return;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -117,9 +126,9 @@ template <typename Elem, bool A_TMAJ, bool B_TMAJ>
 struct PPState {
     HalfFrag<A_TMAJ> fa;
     HalfFrag<B_TMAJ> fb;
-    const unsigned short* gA[2][2];   // [half][load]
-    const unsigned short* gB[2][2];
-    long kstepA, kstepB;              // element offset of one K step
+    __amdgpu_buffer_rsrc_t rA, rB;    // operand bases of this block tile (at k = kbeg)
+    unsigned gA[2][2], gB[2][2];      // [half][load] per-lane byte offsets
+    unsigned kstepA, kstepB;          // byte offset of one K step
     unsigned lbase;
     char* lds;
     int w;
@@ -131,8 +140,8 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     const unsigned sb = st.lbase + (t & 1) * 65536;            // this K step's four slots
     char* const cur = st.lds + (t & 1) * 65536;
     char* const oth = st.lds + ((t + 1) & 1) * 65536;
-    const long kA1 = (long)(t + 1) * st.kstepA, kB1 = (long)(t + 1) * st.kstepB;
-    const long kA2 = (long)(t + 2) * st.kstepA, kB2 = (long)(t + 2) * st.kstepB;
+    const unsigned kA1 = (unsigned)(t + 1) * st.kstepA, kB1 = (unsigned)(t + 1) * st.kstepB;
+    const unsigned kA2 = (unsigned)(t + 2) * st.kstepA, kB2 = (unsigned)(t + 2) * st.kstepB;
     u32x4_t af[4][2], b0[2][2], b1[2][2];
     // ---- phase 0: quadrant (A0,B0); reads B0 then A0; stages (t+1, B1)
     b0[0][0] = st.fb.template read<0, 0>(sb + 16384); b0[1][0] = st.fb.template read<1, 0>(sb + 16384);
@@ -143,7 +152,7 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     af[0][1] = st.fa.template read<0, 1>(sb); af[1][1] = st.fa.template read<1, 1>(sb);
     af[2][1] = st.fa.template read<2, 1>(sb); af[3][1] = st.fa.template read<3, 1>(sb);
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE <= 1) pp_stage(st.gB[1], kB1, oth + 2 * 16384, st.w);
+    if (MODE <= 1) pp_stage(st.rB, st.gB[1], kB1, oth + 2 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
     asm_wait_vm<MODE <= 1 ? 8 : 2>();
     pp_barrier();
@@ -154,7 +163,7 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     b1[0][0] = st.fb.template read<0, 0>(sb + 2 * 16384); b1[1][0] = st.fb.template read<1, 0>(sb + 2 * 16384);
     b1[0][1] = st.fb.template read<0, 1>(sb + 2 * 16384); b1[1][1] = st.fb.template read<1, 1>(sb + 2 * 16384);
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE <= 1) pp_stage(st.gA[1], kA1, oth + 3 * 16384, st.w);
+    if (MODE <= 1) pp_stage(st.rA, st.gA[1], kA1, oth + 3 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
     asm_wait_vm<MODE <= 1 ? 8 : 0>();
     pp_barrier();
@@ -167,7 +176,7 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     af[0][1] = st.fa.template read<0, 1>(sb + 3 * 16384); af[1][1] = st.fa.template read<1, 1>(sb + 3 * 16384);
     af[2][1] = st.fa.template read<2, 1>(sb + 3 * 16384); af[3][1] = st.fa.template read<3, 1>(sb + 3 * 16384);
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE == 0) pp_stage(st.gA[0], kA2, cur + 0 * 16384, st.w);
+    if (MODE == 0) pp_stage(st.rA, st.gA[0], kA2, cur + 0 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
     if (MODE == 0) asm_wait_vm<8>();
     pp_barrier();
@@ -175,7 +184,7 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     pp_mfma16<Elem, 1, 1>(af, b1, acc);
     pp_barrier();
     // ---- phase 3: quadrant (A1,B0), B0 still in registers; stages (t+2, B0)
-    if (MODE == 0) pp_stage(st.gB[0], kB2, cur + 1 * 16384, st.w);
+    if (MODE == 0) pp_stage(st.rB, st.gB[0], kB2, cur + 1 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
     if (MODE == 0) asm_wait_vm<8>();
     if (MODE == 1) asm_wait_vm<4>();
@@ -196,22 +205,26 @@ DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int
     PPState<Elem, A_TMAJ, B_TMAJ> st;
     st.fa.init(wr * 64, lane);
     st.fb.init(wc * 32, lane);
-    pp_src<A_TMAJ>(A, lda, m0, M, kbeg, tid, st.gA[0]);
-    pp_src<A_TMAJ>(A, lda, m0 + 128, M, kbeg, tid, st.gA[1]);
-    pp_src<B_TMAJ>(B, ldb, n0, N, kbeg, tid, st.gB[0]);
-    pp_src<B_TMAJ>(B, ldb, n0 + 128, N, kbeg, tid, st.gB[1]);
-    st.kstepA = A_TMAJ ? 64 * lda : 64;
-    st.kstepB = B_TMAJ ? 64 * ldb : 64;
+    pp_src<A_TMAJ>(lda, m0, m0, M, tid, st.gA[0]);
+    pp_src<A_TMAJ>(lda, m0, m0 + 128, M, tid, st.gA[1]);
+    pp_src<B_TMAJ>(ldb, n0, n0, N, tid, st.gB[0]);
+    pp_src<B_TMAJ>(ldb, n0, n0 + 128, N, tid, st.gB[1]);
+    const unsigned short* baseA = A + (A_TMAJ ? (long)kbeg * lda + m0 : (long)m0 * lda + kbeg);
+    const unsigned short* baseB = B + (B_TMAJ ? (long)kbeg * ldb + n0 : (long)n0 * ldb + kbeg);
+    st.rA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, -1, 0x00020000);
+    st.rB = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, -1, 0x00020000);
+    st.kstepA = (unsigned)(A_TMAJ ? 128 * lda : 128);
+    st.kstepB = (unsigned)(B_TMAJ ? 128 * ldb : 128);
     st.lbase = lds_addr32(lds);
     st.lds = lds;
     st.w = w;
     // prologue: half-tiles 0..5 = (0,A0) (0,B0) (0,B1) (0,A1) (1,A0) (1,B0)
-    pp_stage(st.gA[0], 0, lds + 0 * 16384, w);
-    pp_stage(st.gB[0], 0, lds + 1 * 16384, w);
-    pp_stage(st.gB[1], 0, lds + 2 * 16384, w);
-    pp_stage(st.gA[1], 0, lds + 3 * 16384, w);
-    pp_stage(st.gA[0], st.kstepA, lds + 65536 + 0 * 16384, w);
-    pp_stage(st.gB[0], st.kstepB, lds + 65536 + 1 * 16384, w);
+    pp_stage(st.rA, st.gA[0], 0, lds + 0 * 16384, w);
+    pp_stage(st.rB, st.gB[0], 0, lds + 1 * 16384, w);
+    pp_stage(st.rB, st.gB[1], 0, lds + 2 * 16384, w);
+    pp_stage(st.rA, st.gA[1], 0, lds + 3 * 16384, w);
+    pp_stage(st.rA, st.gA[0], st.kstepA, lds + 65536 + 0 * 16384, w);
+    pp_stage(st.rB, st.gB[0], st.kstepB, lds + 65536 + 1 * 16384, w);
     __builtin_amdgcn_sched_barrier(0);
     asm_wait_vm<8>();
     pp_barrier();
