@@ -82,15 +82,16 @@ int uniir_gemm(const uniir_gemm_desc* d, void* stream);
  * [ENC] building block 2: LayerNorm over the last dim (fp32 statistics, CLIP eps 1e-5).
  * x is the fp32 residual stream [rows][x_stride]; y is bf16 [rows][width] (GEMM operand) and/or f32.
  * bwd: dx_f32 = (dres ? dres : 0) + LN'(dy); also writes a bf16 copy when dx_bf16 != NULL;
- * dgamma/dbeta are ACCUMULATED (+=) in fp32 (zero them once per optimizer step).
+ * dgamma/dbeta are ACCUMULATED (+=) in fp32 (zero them once per optimizer step); dx_colsum (optional, [width]) +=
+ * the column sums of dx_f32 as written (the bias gradient of the linear layer that produced x).
  * dy may be bf16 (dy_is_f32 = 0) or fp32.
  * ---------------------------------------------------------------------------------------------- */
 int uniir_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta,
                         void* y_bf16, float* y_f32, int32_t rows, int32_t width, float eps, void* stream);
 int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float* gamma, const void* dy,
                         int32_t dy_is_f32, const float* dres, float* dx_f32, int64_t dx_stride,
-                        void* dx_bf16, float* dgamma, float* dbeta, int32_t rows, int32_t width,
-                        float eps, void* stream);
+                        void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int32_t rows,
+                        int32_t width, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] building block 3: fused multi-head attention, head_dim 64, seq <= 512.

@@ -32,7 +32,7 @@ SIGNATURES = {
     "uniir_abi_version": (c_int, []),
     "uniir_gemm": (c_int, [C.POINTER(GemmDesc), S]),
     "uniir_layernorm_fwd": (c_int, [P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
-    "uniir_layernorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, c_int, c_int, c_float, S]),
+    "uniir_layernorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
     "uniir_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_attention_fwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, P, c_int, c_int, c_int, c_int, c_int, S]),

@@ -229,16 +229,20 @@ def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5,
     saved = []
     for i in range(layers):
         b = blk(i)
-        ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), eps, out_bf16=h, rows=R, width=W)
-        qkv = ops.linear_fwd(h, b.w16("wqkv"), b.p32("bqkv"))
+        # with save, the two LayerNorm outputs are kept for the weight gradients (26 GB at ViT-L/14 x 1024 items:
+        # cheaper than re-reading the fp32 stream to recompute them in backward)
+        h1 = torch.empty(R, W, device=dev, dtype=torch.bfloat16) if save else h
+        ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), eps, out_bf16=h1, rows=R, width=W)
+        qkv = ops.linear_fwd(h1, b.w16("wqkv"), b.p32("bqkv"))
         ao, lse = ops.attention_fwd(qkv, M, T, heads, causal)
         x2 = ops.linear_fwd(ao, b.w16("wo"), b.p32("bo"), epilogue=ops.EPI_RESID_F32, resid=x)
-        ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), eps, out_bf16=h, rows=R, width=W)
+        h2 = torch.empty(R, W, device=dev, dtype=torch.bfloat16) if save else h
+        ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), eps, out_bf16=h2, rows=R, width=W)
         f = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
-        ops.linear_fwd(h, b.w16("wfc"), b.p32("bfc"), out=f, epilogue=ops.EPI_BIAS_ACT, C2=g, act=act)
+        ops.linear_fwd(h2, b.w16("wfc"), b.p32("bfc"), out=f, epilogue=ops.EPI_BIAS_ACT, C2=g, act=act)
         xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32, resid=x2)
         if save:
-            saved.append((x, qkv, ao, lse, x2, f))
+            saved.append((x, qkv, ao, lse, x2, f, h1, h2))
         x = xn
     return x, saved
 
@@ -249,38 +253,36 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
     blk = blk or (lambda i: _Blk(model, f"{prefix}.resblocks.{i}"))
     R = M * T
     dev = dx.device
-    h = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
     g = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
     df = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
     dh = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
+    # bias gradient of the last block's c_proj: column sums of the incoming gradient (the other blocks get theirs from
+    # the LayerNorm backward that produces their incoming gradient)
+    ops.call("uniir_colsum_bf16", dxb, W, blk(layers - 1).g("bproj"), R, W)
     for i in reversed(range(layers)):
         b = blk(i)
-        x, qkv, ao, lse, x2, f = saved[i]
+        x, qkv, ao, lse, x2, f, h1, h2 = saved[i]
         saved[i] = None
         # d(mlp): df = (dx @ Wproj) * act'(f); the same epilogue re-materialises g = act(f) for dWproj and sums
         # df's columns into the c_fc bias gradient
         ops.linear_dgrad(dxb, b.w16("wproj"), out=df, aux=f, act_out=g, colsum=b.g("bfc"), act=act)
         ops.linear_wgrad(dxb, g, b.g("wproj"))
-        ops.call("uniir_colsum_bf16", dxb, W, b.g("bproj"), R, W)
-        ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), eps, out_bf16=h, rows=R, width=W)
-        ops.linear_wgrad(df, h, b.g("wfc"))
+        ops.linear_wgrad(df, h2, b.g("wfc"))
         ops.linear_dgrad(df, b.w16("wfc"), out=dh)                               # dh := d ln_2 out
         dx2 = torch.empty(R, W, device=dev, dtype=torch.float32)
         ops.layernorm_bwd(x2, b.p32("ln2w"), dh, b.g("ln2w"), b.g("ln2b"), eps, dres=dx, dx=dx2, dx_bf16=dxb,
-                          rows=R, width=W)
-        del x2, f
+                          rows=R, width=W, dx_colsum=b.g("bo"))                  # d x2 also is d(out_proj out): its bias grad
+        del x2, f, h2
         ops.linear_wgrad(dxb, ao, b.g("wo"))
-        ops.call("uniir_colsum_bf16", dxb, W, b.g("bo"), R, W)
         ops.linear_dgrad(dxb, b.w16("wo"), out=dh)                               # dh := d attn out
         dqkv = ops.attention_bwd(qkv, ao, dh, lse, M, T, heads, causal)
         del qkv, ao, lse
-        ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), eps, out_bf16=h, rows=R, width=W)
-        ops.linear_wgrad(dqkv, h, b.g("wqkv"))
+        ops.linear_wgrad(dqkv, h1, b.g("wqkv"))
         ops.call("uniir_colsum_bf16", dqkv, 3 * W, b.g("bqkv"), R, 3 * W)
         ops.linear_dgrad(dqkv, b.w16("wqkv"), out=dh)                            # dh := d ln_1 out
-        del dqkv
+        del dqkv, h1
         ops.layernorm_bwd(x, b.p32("ln1w"), dh, b.g("ln1w"), b.g("ln1b"), eps, dres=dx2, dx=dx, dx_bf16=dxb,
-                          rows=R, width=W)
+                          rows=R, width=W, dx_colsum=(blk(i - 1).g("bproj") if i > 0 else None))
         del x, dx2
     return dx
 

@@ -65,17 +65,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ dx, long dx_stride,
                                                      unsigned short* __restrict__ dx_bf16,
                                                      float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int width,
+                                                     float* __restrict__ dbeta,
+                                                     float* __restrict__ dx_colsum, int rows, int width,
                                                      float eps) {
     __shared__ float red[4][64 * 4 * NC];  // per wave staging for the column reduction
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nchunk = width >> 2;
     const float inv_w = 1.0f / (float)width;
-    f32x4_t ag[NC], ab[NC];
+    f32x4_t ag[NC], ab[NC], ac[NC];   // column partials of dgamma, dbeta and (optional) of dx itself
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         ag[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         ab[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        ac[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     for (long row = (long)blockIdx.x * 4 + w; row < rows; row += (long)gridDim.x * 4) {
         const float* xr = x + row * x_stride;
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                 f32x4_t o = (d[i] - c1 - v[i] * c2) * rstd;
                 if (dres) o += *reinterpret_cast<const f32x4_t*>(dres + row * dx_stride + 4 * c);
                 *reinterpret_cast<f32x4_t*>(dx + row * dx_stride + 4 * c) = o;
+                if (dx_colsum) ac[i] += o;
                 if (dx_bf16) {
                     u32x2_t pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                     *reinterpret_cast<u32x2_t*>(dx_bf16 + row * width + 4 * c) = pk;
@@ -139,14 +142,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
     // block reduction of the per-wave column partials, then one atomic per column per block
     float* mine = &red[w][0];
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (dx_colsum ? 3 : 2); ++pass) {
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) *reinterpret_cast<f32x4_t*>(mine + 4 * c) = pass ? ab[i] : ag[i];
+            if (c < nchunk) *reinterpret_cast<f32x4_t*>(mine + 4 * c) = pass == 0 ? ag[i] : (pass == 1 ? ab[i] : ac[i]);
         }
         __syncthreads();
-        float* dst = pass ? dbeta : dgamma;
+        float* dst = pass == 0 ? dgamma : (pass == 1 ? dbeta : dx_colsum);
         for (int col = threadIdx.x; col < width; col += 256) {
             const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
             unsafeAtomicAdd(dst + col, t);
@@ -168,12 +171,12 @@ static void launch_ln_fwd(const float* x, long x_stride, const float* gamma, con
 }
 template <int NC, bool F32>
 static void launch_ln_bwd(const float* x, long x_stride, const float* gamma, const void* dy, const float* dres,
-                          float* dx, long dx_stride, unsigned short* dxb, float* dgamma, float* dbeta, int rows,
-                          int width, float eps, hipStream_t st) {
+                          float* dx, long dx_stride, unsigned short* dxb, float* dgamma, float* dbeta, float* dxsum,
+                          int rows, int width, float eps, hipStream_t st) {
     int g = ln_grid(rows);
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL((ln_bwd_kernel<NC, F32>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
-                       dx_stride, dxb, dgamma, dbeta, rows, width, eps);
+                       dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps);
 }
 static inline int ln_nc(int width) {
     const int c = (width / 4 + 63) / 64;
@@ -200,8 +203,8 @@ extern "C" int uniir_layernorm_fwd(const float* x, int64_t x_stride, const float
 
 extern "C" int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float* gamma, const void* dy,
                                    int32_t dy_is_f32, const float* dres, float* dx_f32, int64_t dx_stride,
-                                   void* dx_bf16, float* dgamma, float* dbeta, int32_t rows, int32_t width,
-                                   float eps, void* stream) {
+                                   void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int32_t rows,
+                                   int32_t width, float eps, void* stream) {
     if (!x || !gamma || !dy || !dx_f32 || !dgamma || !dbeta || rows < 0) return UNIIR_EINVAL;
     if (rows == 0) return UNIIR_OK;
     if (width % 4 || width > 64 * 4 * LN_MAXC || width <= 0 || x_stride % 4 || dx_stride % 4) return UNIIR_ESHAPE;
@@ -209,8 +212,8 @@ extern "C" int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float
     unsigned short* dxb = (unsigned short*)dx_bf16;
 #define LNB(NC)                                                                                                   \
     do {                                                                                                          \
-        if (dy_is_f32) launch_ln_bwd<NC, true>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, rows, width, eps, st); \
-        else launch_ln_bwd<NC, false>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, rows, width, eps, st);          \
+        if (dy_is_f32) launch_ln_bwd<NC, true>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, dx_colsum, rows, width, eps, st); \
+        else launch_ln_bwd<NC, false>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, dx_colsum, rows, width, eps, st);          \
     } while (0)
     switch (ln_nc(width)) {
         case 2: LNB(2); break;

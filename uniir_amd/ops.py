@@ -146,7 +146,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, *, out_bf16=None, out_f32=None, rows
 
 
 def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5, *, dres=None, dx=None, dx_bf16=None, rows=None,
-                  width=None, x_stride=None, dx_stride=None):
+                  width=None, x_stride=None, dx_stride=None, dx_colsum=None):
+    """dx_colsum (fp32 [width]): += column sums of dx (bias gradient of the linear layer that produced x)"""
     width = width or x.shape[-1]
     rows = rows if rows is not None else x.numel() // width
     x_stride = x_stride or width
@@ -154,8 +155,8 @@ def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5, *, dres=None, dx=None, 
     if dx is None:
         dx = torch.empty(rows, width, device=x.device, dtype=torch.float32)
     check(_lib.load().uniir_layernorm_bwd(_p(x), x_stride, _p(gamma), _p(dy), int(dy.dtype == torch.float32),
-                                          _p(dres), _p(dx), dx_stride, _p(dx_bf16), _p(dgamma), _p(dbeta), rows,
-                                          width, eps, _stream()), "layernorm_bwd")
+                                          _p(dres), _p(dx), dx_stride, _p(dx_bf16), _p(dgamma), _p(dbeta),
+                                          _p(dx_colsum), rows, width, eps, _stream()), "layernorm_bwd")
     return dx
 
 
