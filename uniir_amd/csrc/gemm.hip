@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
 // Epilogue of the 256x256 (8-wave) tile staged through LDS so that every global access is a full 16-B-per-lane,
 // row-contiguous transaction (the MFMA fragment layout alone gives 32-B pieces at a row stride).  The main loop's
 // 128 KiB of LDS are free at this point.
-//   bf16 outputs (EPI_BF16, EPI_BIAS_ACT): one pass, image [256][256] bf16, 16-B chunk index ^= (row & 7)
+//   bf16 outputs (EPI_BF16, EPI_BIAS_ACT): one pass, image [256][256] bf16, 16-B chunk index ^= (row & 15)
 //   fp32 math on the way out (EPI_RESID_F32, EPI_DACT, EPI_F32 / split-K slabs): two passes of 128 rows,
 //   image [128][256] f32, 16-B chunk index ^= (row & 7)
 // PP = accumulator map of gemm_core_pp.h (acc[4h+i][2h'+j] at rows 128h + 64wr + 16i, cols 128h' + 32wc + 16j) instead
@@ -166,6 +166,65 @@ DEVINL int epi_col(int j, int w, int wn) {
     return PP ? (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 : wn + j * 16;
 }
 
+// copy-out of one 128-row fp32 pass: thread -> rows r0 + 8 it, one 16-B chunk; EPI / ACT are compile-time so that the
+// loop body carries no per-element branching
+template <int EPI, int ACT>
+DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long offa, long rstep, long rstep_aux, bool full,
+                         bool colok, int rows_left, f32x4_t& csum) {
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        if (full || (colok && 8 * it < rows_left)) {
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + it * 8192);
+            const long off = off0 + it * rstep;
+            if (EPI == UNIIR_EPI_RESID_F32) {
+                if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
+                *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
+                if (p.C2) {
+                    const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o;
+                }
+            } else if (EPI == UNIIR_EPI_DACT) {
+                const long oa = offa + it * rstep_aux;
+                const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + oa);
+                const float f0 = __uint_as_float(a[0] << 16), f1 = __uint_as_float(a[0] & 0xffff0000u);
+                const float f2 = __uint_as_float(a[1] << 16), f3 = __uint_as_float(a[1] & 0xffff0000u);
+                v[0] *= act_bwd(f0, ACT); v[1] *= act_bwd(f1, ACT);
+                v[2] *= act_bwd(f2, ACT); v[3] *= act_bwd(f3, ACT);
+                const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+                if (p.C2) {  // recomputed activation act(aux) for the wgrad of the next linear
+                    const u32x2_t g2 = {pack_bf16x2(act_fwd(f0, ACT), act_fwd(f1, ACT)),
+                                        pack_bf16x2(act_fwd(f2, ACT), act_fwd(f3, ACT))};
+                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + oa) = g2;
+                }
+            } else {  // UNIIR_EPI_F32 (also the split-K slabs)
+                *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
+            }
+            csum += v;
+        }
+    }
+}
+
+// bf16 copy-out with the activation copy (EPI_BIAS_ACT): C <- f, C2 <- act(f)
+template <int ACT>
+DEVINL void epi_bf16_copy_act(const char* src, unsigned short* c1, unsigned short* c2, long rstep, bool full, bool colok,
+                              int rows_left) {
+#pragma unroll 2
+    for (int it = 0; it < 16; ++it) {
+        if (full || (colok && 16 * it < rows_left)) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + it * 8192);
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1));
+            u32x4_t g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                g[e] = pack_bf16x2(act_fwd(__uint_as_float(v[e] << 16), ACT), act_fwd(__uint_as_float(v[e] & 0xffff0000u), ACT));
+            *reinterpret_cast<u32x4_t*>(c2) = g;
+        }
+        c1 += rstep;
+        c2 += rstep;
+    }
+}
+
 template <bool PP>
 DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int m0, int n0, int wm, int wn,
                                char* lds, int epi) {
@@ -173,7 +232,7 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
     const int li = lane & 15, lg = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool full = (m0 + 256 <= p.M) && (n0 + 256 <= p.N);
-    const bool scale = p.alpha != 1.0f;
+    const f32x4_t alpha4 = {p.alpha, p.alpha, p.alpha, p.alpha};
     f32x4_t bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -181,21 +240,19 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
         bv[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     if (epi == UNIIR_EPI_BF16 || epi == UNIIR_EPI_BIAS_ACT) {
-        // image [256][256] bf16, 512 B per row, 16-B chunk index ^= (row & 7); row & 7 == li & 7 for every tile
+        // image [256][256] bf16, 512 B per row, 16-B chunk index ^= (row & 15) (== li): rows r and r+8 of a ds_write_b64 lane group land on different banks
         char* sj[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nl = epi_col<PP>(j, w, wn) + 4 * lg;
-            sj[j] = lds + li * 512 + (((nl >> 3) ^ (li & 7)) << 4) + ((nl & 7) << 1);
+            sj[j] = lds + li * 512 + (((nl >> 3) ^ li) << 4) + ((nl & 7) << 1);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int rb = epi_row<PP>(i, w, wm) * 512;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4_t v = acc[i][j];
-                if (scale) v *= p.alpha;
-                v += bv[j];
+                const f32x4_t v = acc[i][j] * alpha4 + bv[j];     // two v_pk_fma_f32 (alpha == 1 is exact)
                 const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *reinterpret_cast<u32x2_t*>(sj[j] + rb) = o;
             }
@@ -203,7 +260,7 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
         __syncthreads();
         // thread -> (row r0 + 16 it, 16-B chunk ch): LDS address and global offset advance by constants
         const int r0 = tid >> 5, ch = tid & 31;
-        const char* src = lds + r0 * 512 + ((ch ^ (r0 & 7)) << 4);
+        const char* src = lds + r0 * 512 + ((ch ^ r0) << 4);
         const long off0 = (long)(m0 + r0) * p.ldc + n0 + ch * 8;
         unsigned short* c1 = (unsigned short*)p.C + off0;
         unsigned short* c2 = (unsigned short*)p.C2 + off0;
@@ -211,20 +268,30 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
         const bool colok = n0 + ch * 8 < p.N;
         const int rows_left = p.M - m0 - r0;
         const bool act = epi == UNIIR_EPI_BIAS_ACT;
+        if (full && !act) {          // the common case: straight copy, one pointer bump per row group
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            if (full || (colok && 16 * it < rows_left)) {
+            for (int it = 0; it < 16; ++it) {
                 const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + it * 8192);
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1 + it * rstep));
-                if (act) {
-                    u32x4_t g;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        g[e] = pack_bf16x2(act_fwd(__uint_as_float(v[e] << 16), p.act),
-                                           act_fwd(__uint_as_float(v[e] & 0xffff0000u), p.act));
-                    *reinterpret_cast<u32x4_t*>(c2 + it * rstep) = g;
-                }
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1));
+                c1 += rstep;
             }
+            return;
+        }
+        if (!act) {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                if (colok && 16 * it < rows_left) {
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + it * 8192);
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1));
+                }
+                c1 += rstep;
+            }
+        } else if (p.act == UNIIR_ACT_QUICKGELU) {
+            epi_bf16_copy_act<UNIIR_ACT_QUICKGELU>(src, c1, c2, rstep, full, colok, rows_left);
+        } else if (p.act == UNIIR_ACT_GELU_ERF) {
+            epi_bf16_copy_act<UNIIR_ACT_GELU_ERF>(src, c1, c2, rstep, full, colok, rows_left);
+        } else {
+            epi_bf16_copy_act<UNIIR_ACT_RELU>(src, c1, c2, rstep, full, colok, rows_left);
         }
         return;
     }
@@ -250,12 +317,8 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
                 const int i = PP ? 4 * h + ii : ii;
                 const int rb = (PP ? (w >> 2) * 64 + ii * 16 : ii * 16) * 1024;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4_t v = acc[i][j];
-                    if (scale) v *= p.alpha;
-                    v += bv[j];
-                    *reinterpret_cast<f32x4_t*>(sj[j] + rb) = v;
-                }
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4_t*>(sj[j] + rb) = acc[i][j] * alpha4 + bv[j];
             }
         }
         __syncthreads();
@@ -263,38 +326,16 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
         const long off0 = (long)mrow * p.ldc + n0 + ch * 4;
         const long offa = (long)mrow * p.ldaux + n0 + ch * 4;
         const int rows_left = p.M - mrow;
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            if (full || (colok && 8 * it < rows_left)) {
-                f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + it * 8192);
-                const long off = off0 + it * rstep;
-                if (epi == UNIIR_EPI_RESID_F32) {
-                    if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
-                    *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
-                    if (p.C2) {
-                        const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o;
-                    }
-                } else if (epi == UNIIR_EPI_DACT) {
-                    const long oa = offa + it * rstep_aux;
-                    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + oa);
-                    const float f0 = __uint_as_float(a[0] << 16), f1 = __uint_as_float(a[0] & 0xffff0000u);
-                    const float f2 = __uint_as_float(a[1] << 16), f3 = __uint_as_float(a[1] & 0xffff0000u);
-                    v[0] *= act_bwd(f0, p.act); v[1] *= act_bwd(f1, p.act);
-                    v[2] *= act_bwd(f2, p.act); v[3] *= act_bwd(f3, p.act);
-                    const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
-                    if (p.C2) {  // recomputed activation act(aux) for the wgrad of the next linear
-                        const u32x2_t g2 = {pack_bf16x2(act_fwd(f0, p.act), act_fwd(f1, p.act)),
-                                            pack_bf16x2(act_fwd(f2, p.act), act_fwd(f3, p.act))};
-                        *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + oa) = g2;
-                    }
-                } else {  // UNIIR_EPI_F32 (also the split-K slabs)
-                    *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
-                }
-                csum += v;
-            }
-        }
+        if (epi == UNIIR_EPI_RESID_F32)
+            epi_f32_copy<UNIIR_EPI_RESID_F32, 0>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
+        else if (epi == UNIIR_EPI_F32)
+            epi_f32_copy<UNIIR_EPI_F32, 0>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
+        else if (p.act == UNIIR_ACT_QUICKGELU)
+            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_QUICKGELU>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
+        else if (p.act == UNIIR_ACT_GELU_ERF)
+            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_GELU_ERF>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
+        else
+            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_RELU>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
     }
     if (p.colsum) {
         // this thread's 4 columns (ch = tid & 63) summed over its rows of both passes; 8 threads share a column group

@@ -195,16 +195,16 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
 
 // accumulators: acc[4h + i][2h' + j] = MFMA tile at rows 128h + 64wr + 16i, cols 128h' + 32wc + 16j (swapped operands:
 // a lane owns 4 consecutive N, like gemm_core256.h)
+//
+// pp_setup: per-tile state (source offsets + descriptors); pp_prologue: stage half-tiles 0..5 (the ring must not be
+// read any more: call after pp_main's final barrier); pp_main: everything from the first wait to the re-aligning barrier.
 template <typename Elem, bool A_TMAJ, bool B_TMAJ>
-DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int M, const unsigned short* __restrict__ B,
-                             long ldb, int N, int m0, int n0, int kbeg, int kend, char* lds, f32x4_t (&acc)[8][4]) {
+DEVINL void pp_setup(PPState<Elem, A_TMAJ, B_TMAJ>& st, const unsigned short* __restrict__ A, long lda, int M,
+                     const unsigned short* __restrict__ B, long ldb, int N, int m0, int n0, int kbeg, char* lds) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 2, wc = w & 3;
-    const int nk = (kend - kbeg) / 64;
-    PPState<Elem, A_TMAJ, B_TMAJ> st;
-    st.fa.init(wr * 64, lane);
-    st.fb.init(wc * 32, lane);
+    st.fa.init((w >> 2) * 64, lane);
+    st.fb.init((w & 3) * 32, lane);
     pp_src<A_TMAJ>(lda, m0, m0, M, tid, st.gA[0]);
     pp_src<A_TMAJ>(lda, m0, m0 + 128, M, tid, st.gA[1]);
     pp_src<B_TMAJ>(ldb, n0, n0, N, tid, st.gB[0]);
@@ -218,14 +218,24 @@ DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int
     st.lbase = lds_addr32(lds);
     st.lds = lds;
     st.w = w;
-    // prologue: half-tiles 0..5 = (0,A0) (0,B0) (0,B1) (0,A1) (1,A0) (1,B0)
-    pp_stage(st.rA, st.gA[0], 0, lds + 0 * 16384, w);
-    pp_stage(st.rB, st.gB[0], 0, lds + 1 * 16384, w);
-    pp_stage(st.rB, st.gB[1], 0, lds + 2 * 16384, w);
-    pp_stage(st.rA, st.gA[1], 0, lds + 3 * 16384, w);
-    pp_stage(st.rA, st.gA[0], st.kstepA, lds + 65536 + 0 * 16384, w);
-    pp_stage(st.rB, st.gB[0], st.kstepB, lds + 65536 + 1 * 16384, w);
+}
+
+template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+DEVINL void pp_prologue(const PPState<Elem, A_TMAJ, B_TMAJ>& st) {
+    // half-tiles 0..5 = (0,A0) (0,B0) (0,B1) (0,A1) (1,A0) (1,B0)
+    char* lds = st.lds;
+    pp_stage(st.rA, st.gA[0], 0, lds + 0 * 16384, st.w);
+    pp_stage(st.rB, st.gB[0], 0, lds + 1 * 16384, st.w);
+    pp_stage(st.rB, st.gB[1], 0, lds + 2 * 16384, st.w);
+    pp_stage(st.rA, st.gA[1], 0, lds + 3 * 16384, st.w);
+    pp_stage(st.rA, st.gA[0], st.kstepA, lds + 65536 + 0 * 16384, st.w);
+    pp_stage(st.rB, st.gB[0], st.kstepB, lds + 65536 + 1 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+DEVINL void pp_main(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int nk, f32x4_t (&acc)[8][4]) {
+    const int wr = st.w >> 2;
     asm_wait_vm<8>();
     pp_barrier();
     if (wr == 1) pp_barrier();          // group 1 runs one barrier behind from here on
@@ -233,4 +243,13 @@ DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int
     pp_kstep<Elem, A_TMAJ, B_TMAJ, 1>(st, nk - 2, acc);
     pp_kstep<Elem, A_TMAJ, B_TMAJ, 2>(st, nk - 1, acc);
     if (wr == 0) pp_barrier();          // re-align the groups
+}
+
+template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int M, const unsigned short* __restrict__ B,
+                             long ldb, int N, int m0, int n0, int kbeg, int kend, char* lds, f32x4_t (&acc)[8][4]) {
+    PPState<Elem, A_TMAJ, B_TMAJ> st;
+    pp_setup(st, A, lda, M, B, ldb, N, m0, n0, kbeg, lds);
+    pp_prologue(st);
+    pp_main(st, (kend - kbeg) / 64, acc);
 }
