@@ -301,33 +301,34 @@ __global__ __launch_bounds__(128 * WM, 2) void topk_gmax_kernel(const unsigned s
 // one block per query: the best groups by (group max desc, group index asc): the kc best plus ties of the kc-th
 // value (at most gcap groups); every member row of those groups becomes a re-score candidate.
 //   pass 1: per-thread maxima -> tau0 = kc-th largest of the 256 thread maxima (a valid lower bound of the kc-th
-//           largest group value: 256 distinct groups reach it)
+//           largest group value: that many distinct groups reach it)
 //   pass 2: groups >= tau0 are collected in LDS (a few dozen), ranked exactly, the best gcap kept.
 // If the collection overflows (massive exact ties) the kernel falls back to one-extraction-per-round selection.
 #define TK_SELCAP 1024
-__global__ __launch_bounds__(256) void topk_gsel_kernel(const float* __restrict__ gmax, long ngroups, long rows, int nq,
+template <int BS>   // threads per query (256: many queries; 1024: <= 64 queries, where one block per query leaves CUs idle)
+__global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__ gmax, long ngroups, long rows, int nq,
                                                         int kc, int gcap, int* __restrict__ cand_idx) {
-    __shared__ float tmax[256];
+    __shared__ float tmax[BS];
     __shared__ float bval[TK_SELCAP];
     __shared__ int bgrp[TK_SELCAP];
     __shared__ int bcnt;
     __shared__ float tau0, tau;
-    __shared__ float ss[4];
-    __shared__ long long si[4];
+    __shared__ float ss[BS / 64];
+    __shared__ long long si[BS / 64];
     __shared__ float wsel;
     __shared__ long long isel;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* g = gmax + (long)q * ngroups;
     int* out = cand_idx + (long)q * gcap * TK_G;
-    for (int e = tid; e < gcap * TK_G; e += 256) out[e] = -1;
+    for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
     float mx = -INFINITY;
-    for (long e = tid; e < ngroups; e += 256) mx = fmaxf(mx, g[e]);
+    for (long e = tid; e < ngroups; e += BS) mx = fmaxf(mx, g[e]);
     tmax[tid] = mx;
     if (tid == 0) { bcnt = 0; tau0 = -INFINITY; tau = -INFINITY; }
     __syncthreads();
     {
         int rank = 0;
-        for (int t = 0; t < 256; ++t) {
+        for (int t = 0; t < BS; ++t) {
             const float o = tmax[t];
             rank += (o > mx || (o == mx && t < tid)) ? 1 : 0;
         }
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void topk_gsel_kernel(const float* __restrict_
     }
     __syncthreads();
     const float t0 = tau0;
-    for (long e = tid; e < ngroups; e += 256) {
+    for (long e = tid; e < ngroups; e += BS) {
         const float v = g[e];
         if (v >= t0 && v > -INFINITY) {
             const int pos = atomicAdd(&bcnt, 1);
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void topk_gsel_kernel(const float* __restrict_
     const int n = bcnt;
     if (n <= TK_SELCAP) {
         // exact rank of every collected entry by (value desc, group asc)
-        for (int e = tid; e < n; e += 256) {
+        for (int e = tid; e < n; e += BS) {
             const float v = bval[e];
             const int gi = bgrp[e];
             int rank = 0;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) void topk_gsel_kernel(const float* __restrict_
         }
         __syncthreads();
         const float tt = tau;
-        for (int e = tid; e < n; e += 256) {
+        for (int e = tid; e < n; e += BS) {
             const float v = bval[e];
             const int gi = bgrp[e];
             int rank = 0;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256) void topk_gsel_kernel(const float* __restrict_
     for (int j = 0; j < gcap; ++j) {
         float bs = -INFINITY;
         long long bg = 0x7fffffffffffffffLL;
-        for (long e = tid; e < ngroups; e += 256) {
+        for (long e = tid; e < ngroups; e += BS) {
             const float v = g[e];
             const bool after = (v < last_s) || (v == last_s && (long long)e > last_g);
             if (after && (v > bs || (v == bs && (long long)e < bg))) { bs = v; bg = e; }
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void topk_gsel_kernel(const float* __restrict_
         __syncthreads();
         if (tid == 0) {
             float fs = ss[0]; long long fg = si[0];
-            for (int k = 1; k < 4; ++k) if (ss[k] > fs || (ss[k] == fs && si[k] < fg)) { fs = ss[k]; fg = si[k]; }
+            for (int k = 1; k < BS / 64; ++k) if (ss[k] > fs || (ss[k] == fs && si[k] < fg)) { fs = ss[k]; fg = si[k]; }
             wsel = fs; isel = fg;
         }
         __syncthreads();
@@ -430,6 +431,95 @@ extern "C" int32_t uniir_topk_ncand(int32_t nq, int32_t kc) {
     return nq <= TK_GPATH_MAXQ ? TK_GMULT * kc * TK_G : kc;
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Streaming group-max scan for nq <= 64 (the interactive regime: HBM-bound).  The queries
+// (<= 64 x dim fp16, <= 96 KiB) live in LDS for the whole kernel; every wave streams its own 16-candidate tiles
+// straight from HBM into registers in the MFMA A-fragment layout (lane -> row lane & 15, 16 B at k = 32 s + 8 (lane >> 4))
+// -- no LDS staging of the pool, no barrier in the loop, two tiles of loads (2 x dim/32 x 1 KiB per wave) in flight
+// while the previous tile's MFMAs run: 8 waves x ~36 KiB keep ~290 KiB per CU in flight, enough for the HBM
+// latency-bandwidth product.  Output: the same gmax[q][group] matrix as topk_gmax_kernel (group = 16 candidates).
+#define TKS_CH 8     // tiles (groups) per work item: one 32-B run of gmax per query
+#ifndef TKS_LOAD
+#define TKS_LOAD(p) (*(p))   // plain loads measured 8 % faster than nontemporal here
+#endif
+template <int NK>    // dim = 32 * NK
+__global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* __restrict__ pool,
+                                                          const float* __restrict__ pinv, long rows,
+                                                          const unsigned short* __restrict__ queries, int nq,
+                                                          float* __restrict__ gmax, long ngroups, long nchunks) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int DIM = 32 * NK, QS = DIM * 2 + 16;    // padded query row: 16 rows of a B fragment hit 16 different bank slots
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    char* qs = lds;
+    float* stage = reinterpret_cast<float*>(lds + 64 * QS) + w * (64 * TKS_CH);
+    for (int c = tid; c < 64 * (DIM / 8); c += 512) {
+        const int q = c / (DIM / 8), kc = c - q * (DIM / 8);
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (q < nq) v = *reinterpret_cast<const u32x4_t*>(queries + (long)q * DIM + kc * 8);
+        *reinterpret_cast<u32x4_t*>(qs + q * QS + kc * 16) = v;
+    }
+    __syncthreads();
+    const char* qb = qs + li * QS + lg * 16;     // + j * 16 * QS + s * 64
+    const long gw = (long)blockIdx.x * 8 + w, nw = (long)gridDim.x * 8;
+    for (long chunk = gw; chunk < nchunks; chunk += nw) {
+        const long tile0 = chunk * TKS_CH;
+        u32x4_t a[2][NK];
+        auto load_tile = [&](long tile, u32x4_t (&dst)[NK]) {
+            long row = tile * 16 + li;
+            if (row > rows - 1) row = rows - 1;
+            const u32x4_t* src = reinterpret_cast<const u32x4_t*>(pool + row * DIM) + lg;
+#pragma unroll
+            for (int s = 0; s < NK; ++s) dst[s] = TKS_LOAD(src + 4 * s);
+        };
+        auto do_tile = [&](long tile, int t, const u32x4_t (&af)[NK]) {
+            f32x4_t acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NK; ++s) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(qb + j * 16 * QS + s * 64);
+                    acc[j] = ElemF16::mfma(af[s], b, acc[j]);
+                }
+            }
+            // D: lane -> query j*16 + li, candidates 4 lg + r of the tile
+            const long r0 = tile * 16 + 4 * lg;
+            f32x4_t iv = {0.f, 0.f, 0.f, 0.f};
+            if (r0 + 3 < rows) iv = *reinterpret_cast<const f32x4_t*>(pinv + r0);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r0 + r < rows) iv[r] = pinv[r0 + r];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                if (lg == 0) stage[(j * 16 + li) * TKS_CH + t] = m;
+            }
+        };
+        load_tile(tile0, a[0]);
+#pragma unroll
+        for (int t = 0; t < TKS_CH; t += 2) {
+            load_tile(tile0 + t + 1, a[1]);
+            do_tile(tile0 + t, t, a[0]);
+            if (t + 2 < TKS_CH) load_tile(tile0 + t + 2, a[0]);
+            do_tile(tile0 + t + 1, t + 1, a[1]);
+        }
+        // lane q writes its TKS_CH consecutive groups (wave-private staging: program order suffices)
+        if (lane < nq) {
+            float* dst = gmax + (long)lane * ngroups + tile0;
+#pragma unroll
+            for (int g = 0; g < TKS_CH; ++g)
+                if (tile0 + g < ngroups) dst[g] = stage[lane * TKS_CH + g];
+        }
+    }
+}
+
 extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t rows) {
     if (nq <= 0 || kc <= 0 || rows <= 0) return 0;
     if (nq <= TK_GPATH_MAXQ) return (int64_t)nq * ((rows + TK_G - 1) / TK_G) * 4 + 256;
@@ -454,6 +544,26 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
     if (nq <= TK_GPATH_MAXQ) {
         const long ngroups = (rows + TK_G - 1) / TK_G;
         float* gmax = (float*)workspace;
+        static const char* env_st = getenv("UNIIR_TOPK_STREAM");     // "0" disables the streaming scan (experiments)
+        if (nq <= 64 && (dim == 768 || dim == 512) && !(env_st && env_st[0] == '0')) {
+            const long nchunks = (ngroups + TKS_CH - 1) / TKS_CH;
+            const size_t sms = 64 * (dim * 2 + 16) + 8 * 64 * TKS_CH * 4;
+            int grid = 256;
+            if (nchunks < (long)grid * 8) grid = (int)((nchunks + 7) / 8);
+            if (dim == 768) {
+                (void)hipFuncSetAttribute((const void*)topk_stream_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sms);
+                hipLaunchKernelGGL(topk_stream_kernel<24>, dim3(grid), dim3(512), sms, st0, (const unsigned short*)pool_f16,
+                                   pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, nchunks);
+            } else {
+                (void)hipFuncSetAttribute((const void*)topk_stream_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sms);
+                hipLaunchKernelGGL(topk_stream_kernel<16>, dim3(grid), dim3(512), sms, st0, (const unsigned short*)pool_f16,
+                                   pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, nchunks);
+            }
+            hipLaunchKernelGGL(topk_gsel_kernel<1024>, dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq, kc,
+                               TK_GMULT * kc, cand_idx);
+            HIP_LAUNCH_CHECK();
+            return UNIIR_OK;
+        }
         static const char* env_wm = getenv("UNIIR_TOPK_WM");
         static const char* env_bl = getenv("UNIIR_TOPK_BLOCKS");
         const int wmsel = (env_wm && env_wm[0] == '1') ? 1 : 2;
@@ -477,7 +587,7 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
             hipLaunchKernelGGL(topk_gmax_kernel<1>, dim3(nsl, nqt), dim3(128), smg, st0, (const unsigned short*)pool_f16,
                                pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
         }
-        hipLaunchKernelGGL(topk_gsel_kernel, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
+        hipLaunchKernelGGL(topk_gsel_kernel<256>, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
                            TK_GMULT * kc, cand_idx);
         HIP_LAUNCH_CHECK();
         return UNIIR_OK;
