@@ -185,6 +185,18 @@ int uniir_infonce_bwd(const float* q, const float* all_p, const float* scale, co
                       const float* row_lse, const float* dloss, int32_t b, int32_t B, int32_t dim,
                       int32_t target_offset, float* gbuf, float* dq, float* d_all_p, float* dscale,
                       void* stream);
+/* Hard-negative branch of the same loss (clip_sf.py:105-131).  q, p [b][dim], n [b][N][dim] are L2-normalised fp32 rows;
+ * the logit row of query i is [<q_i,p_i>, <q_i,n_i,0..N-1>, I more copies of <q_i,p_i>] * scale, I = min(b - 1,
+ * in_batch_neg_num): the reference's expand/mask expression for the "in-batch negatives" yields the query's own
+ * positive I times, which is reproduced as is (golden G3).  fwd: logits [b][1+N+I], row_lse, row_loss (= -log_softmax(row)[0]) and
+ * row_hit (first arg-max == 0) per query; loss = mean(row_loss), accuracy = mean(row_hit).
+ * bwd (dloss: device scalar): dq, dn written; dp and dscale ACCUMULATED (zero them first). */
+int uniir_hardneg_fwd(const float* q, const float* p, const float* n, const float* scale, int32_t b, int32_t N,
+                      int32_t I, int32_t dim, float* logits, float* row_lse, float* row_loss, float* row_hit,
+                      void* stream);
+int uniir_hardneg_bwd(const float* q, const float* p, const float* n, const float* scale, const float* logits,
+                      const float* row_lse, const float* dloss, int32_t b, int32_t N, int32_t I, int32_t dim,
+                      float* dq, float* dp, float* dn, float* dscale, void* stream);
 /* generic strided fp32 MFMA GEMM used by the two above (exported for tests):
  * C[m][n] (ldc) = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]  */
 int uniir_sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,

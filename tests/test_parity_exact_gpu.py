@@ -89,3 +89,52 @@ def test_topk_bit_exact_vs_c_oracle(n, nq, d, k):
     s, i = retrieval.search_shard(shard, torch.tensor(qs, device=DEV), k)
     assert np.array_equal(i.cpu().numpy(), want_i)
     assert np.array_equal(s.cpu().numpy(), want_s)            # bit-exact distances
+
+
+@pytest.mark.parametrize("tag,ibn", [("n0", 0), ("n2", 2)])
+def test_hard_negative_branch_matches_reference_golden(tag, ibn):
+    """G3 was produced by the reference's own compute_inbatch_contrastive_loss (hard-negative branch) on CPU"""
+    from uniir_amd.losses import HardNegNCEFn
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g3_hardneg.npz"))
+    emb = torch.tensor(d[f"{tag}_txt"] + d[f"{tag}_img"], device="cuda", requires_grad=True)
+    b, nneg = 4, 2
+    iq, ip, ineg, c = [], [], [], 0
+    for i in range(b):
+        iq.append(c); c += 1
+        ip.append(c); c += 1
+        ineg += list(range(c, c + nneg)); c += nneg
+    t = lambda x: torch.tensor(x, dtype=torch.int32, device="cuda")
+    scale = torch.tensor(1 / 0.07, device="cuda", requires_grad=True)
+    loss, acc = HardNegNCEFn.apply(emb, t(iq), t(ip), t(ineg), scale, ibn)
+    loss.backward()
+    assert abs(loss.item() - float(d[f"{tag}_loss"])) < 1e-5
+    assert acc.item() == float(d[f"{tag}_acc"])
+    assert np.abs(emb.grad.cpu().numpy() - d[f"{tag}_dtxt"]).max() < 1e-5
+    # the golden holds d loss / d logit_scale (the log-domain parameter): d/d exp(.) times exp(.)
+    want = float(d[f"{tag}_dscale"])
+    assert abs(scale.grad.item() / 0.07 - want) < 1e-4 * max(1.0, abs(want))
+
+
+def test_hard_negative_branch_random_vs_oracle():
+    from oracle import clip_oracle as O
+    from uniir_amd.losses import HardNegNCEFn
+    torch.manual_seed(5)
+    b, nneg, E, ibn = 24, 3, 512, 7
+    M = b * (2 + nneg)
+    emb_c = torch.randn(M, E, requires_grad=True)
+    im = {"query": [], "pos_cand": [], "neg_cand_list": []}
+    c = 0
+    for i in range(b):
+        im["query"].append([c]); c += 1
+        im["pos_cand"].append([c]); c += 1
+        im["neg_cand_list"].append(list(range(c, c + nneg))); c += nneg
+    ref = O.inbatch_contrastive_loss(emb_c, im, torch.tensor(14.0), in_batch_neg_num=ibn)
+    ref["loss"].backward()
+    emb = emb_c.detach().cuda().requires_grad_(True)
+    t = lambda x: torch.tensor(x, dtype=torch.int32, device="cuda").flatten()
+    loss, acc = HardNegNCEFn.apply(emb, t(im["query"]), t(im["pos_cand"]), t(im["neg_cand_list"]),
+                                   torch.tensor(14.0, device="cuda"), ibn)
+    (2.0 * loss).backward()      # upstream gradient other than 1
+    assert abs(loss.item() - ref["loss"].item()) < 2e-5
+    assert acc.item() == ref["accuracy"].item()
+    assert (emb.grad.cpu() - 2.0 * emb_c.grad).abs().max().item() < 2e-5

@@ -57,6 +57,8 @@ SIGNATURES = {
     "uniir_fuse_embeddings_bwd": (c_int, [P, P, P, P, P, c_int, c_int, S]),
     "uniir_infonce_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, S]),
     "uniir_infonce_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, S]),
+    "uniir_hardneg_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, S]),
+    "uniir_hardneg_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, S]),
     "uniir_sgemm": (c_int, [P, c_i64, c_i64, P, c_i64, c_i64, P, c_i64, c_int, c_int, c_int, c_float, S]),
     "uniir_adamw_step": (c_int, [P, P, P, P, P, c_i64, c_float, c_float, c_float, c_float, c_float, c_int,
                                  c_float, S]),

@@ -223,3 +223,123 @@ extern "C" int uniir_infonce_bwd(const float* q, const float* all_p, const float
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
+
+// -------------------------------------------------------------------------------------------------------------------
+// Hard-negative branch of the CLIP_SF loss (clip_sf.py:105-131): for query i the logit row is
+//   [ <q_i,p_i>, <q_i,n_{i,0}> .. <q_i,n_{i,N-1}>, then I "in-batch negatives" ] * scale,  I = min(b-1, in_batch_neg_num).
+// The reference builds the in-batch negatives as p.unsqueeze(1).expand(-1, bs, -1)[eye == 0].reshape(bs, bs-1, -1)[:, :I]:
+// element [i, j] of the expanded tensor is p_i (the expansion runs along dim 1), so every one of the I entries of row i
+// is the query's OWN positive p_i.  That is reproduced as is (parity with the reference, golden G3 case n2);
+// loss = mean_i -log_softmax(row_i)[0]; accuracy = mean_i [first arg-max of row_i == 0].  All fp32, one block per query.
+// -------------------------------------------------------------------------------------------------------------------
+DEVINL const float* hn_vec(const float* p, const float* n, int i, int c, int N, int dim) {
+    if (c == 0) return p + (long)i * dim;
+    if (c <= N) return n + ((long)i * N + (c - 1)) * dim;
+    return p + (long)i * dim;      // see the note above: the reference's in-batch entries are p_i itself
+}
+
+__global__ __launch_bounds__(256) void hardneg_fwd_kernel(const float* __restrict__ q, const float* __restrict__ p,
+                                                          const float* __restrict__ n, const float* __restrict__ scale,
+                                                          int N, int I, int dim, float* __restrict__ logits,
+                                                          float* __restrict__ row_lse, float* __restrict__ row_loss,
+                                                          float* __restrict__ row_hit) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int C = 1 + N + I;
+    const float s = *scale;
+    const float* qi = q + (long)i * dim;
+    float* lrow = logits + (long)i * C;
+    for (int c = w; c < C; c += 4) {               // one wave per logit
+        const float* v = hn_vec(p, n, i, c, N, dim);
+        float a = 0.f;
+        for (int e = lane; e < dim; e += 64) a = fmaf(qi[e], v[e], a);
+        a = wave_sum(a);
+        if (lane == 0) lrow[c] = a * s;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int c = tid; c < C; c += 256) {
+        const float v = lrow[c];
+        if (v > mx) { mx = v; am = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (ov > mx || (ov == mx && oa < am)) { mx = ov; am = oa; }
+    }
+    if (lane == 0) { red[w] = mx; redi[w] = am; }
+    __syncthreads();
+    mx = red[0]; am = redi[0];
+    for (int k = 1; k < 4; ++k) if (red[k] > mx || (red[k] == mx && redi[k] < am)) { mx = red[k]; am = redi[k]; }
+    __syncthreads();
+    float se = 0.f;
+    for (int c = tid; c < C; c += 256) se += expf(lrow[c] - mx);
+    se = wave_sum(se);
+    if (lane == 0) red[w] = se;
+    __syncthreads();
+    if (tid == 0) {
+        const float lse = mx + logf((red[0] + red[1]) + (red[2] + red[3]));
+        row_lse[i] = lse;
+        row_loss[i] = lse - lrow[0];
+        row_hit[i] = am == 0 ? 1.0f : 0.0f;
+    }
+}
+
+// dq [b][dim] (written), dn [b*N][dim] (written), dp [b][dim] and dscale (ACCUMULATED with atomics: zero them first)
+__global__ __launch_bounds__(256) void hardneg_bwd_kernel(const float* __restrict__ q, const float* __restrict__ p,
+                                                          const float* __restrict__ n, const float* __restrict__ scale,
+                                                          const float* __restrict__ logits, const float* __restrict__ row_lse,
+                                                          const float* __restrict__ dloss, int b, int N, int I, int dim,
+                                                          float* __restrict__ dq, float* __restrict__ dp,
+                                                          float* __restrict__ dn, float* __restrict__ dscale) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int C = 1 + N + I;
+    const float s = *scale, g = *dloss / (float)b, lse = row_lse[i];
+    const float* qi = q + (long)i * dim;
+    const float* lrow = logits + (long)i * C;
+    float ds = 0.f;
+    for (int c = tid; c < C; c += 256) ds += (expf(lrow[c] - lse) - (c == 0 ? 1.f : 0.f)) * g * lrow[c];
+    ds = wave_sum(ds);
+    if (lane == 0) red[w] = ds;
+    __syncthreads();
+    if (tid == 0) atomicAdd(dscale, ((red[0] + red[1]) + (red[2] + red[3])) / s);
+    for (int e = tid; e < dim; e += 256) {
+        const float qe = qi[e];
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float dl = (expf(lrow[c] - lse) - (c == 0 ? 1.f : 0.f)) * g * s;   // d loss / d <q, v_c>
+            const float* v = hn_vec(p, n, i, c, N, dim);
+            acc = fmaf(dl, v[e], acc);
+            if (c >= 1 && c <= N) dn[((long)i * N + (c - 1)) * dim + e] = dl * qe;
+            else atomicAdd(dp + (v - p) + e, dl * qe);
+        }
+        dq[(long)i * dim + e] = acc;
+    }
+}
+
+extern "C" int uniir_hardneg_fwd(const float* q, const float* p, const float* n, const float* scale, int32_t b, int32_t N,
+                                 int32_t I, int32_t dim, float* logits, float* row_lse, float* row_loss, float* row_hit,
+                                 void* stream) {
+    if (!q || !p || (N > 0 && !n) || !scale || !logits || !row_lse || !row_loss || !row_hit) return UNIIR_EINVAL;
+    if (b <= 0 || N < 0 || I < 0 || I > b - 1 || dim <= 0) return UNIIR_EINVAL;
+    hipLaunchKernelGGL(hardneg_fwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, q, p, n, scale, N, I, dim, logits,
+                       row_lse, row_loss, row_hit);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+extern "C" int uniir_hardneg_bwd(const float* q, const float* p, const float* n, const float* scale, const float* logits,
+                                 const float* row_lse, const float* dloss, int32_t b, int32_t N, int32_t I, int32_t dim,
+                                 float* dq, float* dp, float* dn, float* dscale, void* stream) {
+    if (!q || !p || (N > 0 && (!n || !dn)) || !scale || !logits || !row_lse || !dloss || !dq || !dp || !dscale)
+        return UNIIR_EINVAL;
+    if (b <= 0 || N < 0 || I < 0 || I > b - 1 || dim <= 0) return UNIIR_EINVAL;
+    hipLaunchKernelGGL(hardneg_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, q, p, n, scale, logits, row_lse, dloss,
+                       b, N, I, dim, dq, dp, dn, dscale);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}

@@ -70,3 +70,50 @@ class InBatchNCEFn(torch.autograd.Function):
         ops.call("uniir_select_normalize_bwd", q, qinv, dq, idx_q, demb, b, E)
         ops.call("uniir_select_normalize_bwd", p, pinv, dp, idx_p, demb, b, E)
         return demb, None, None, dscale.reshape(()), None
+
+
+class HardNegNCEFn(torch.autograd.Function):
+    """Hard-negative branch (clip_sf.py:105-131): (emb [M,E], idx_q [b], idx_p [b], idx_n [b*N], scale 0-dim,
+    in_batch_neg_num) -> (loss, accuracy).  No collective: the reference's loss uses local embeddings only here."""
+
+    @staticmethod
+    def forward(ctx, emb, idx_q, idx_p, idx_n, scale, in_batch_neg_num):
+        dev = emb.device
+        b, E = idx_q.numel(), emb.shape[1]
+        N = idx_n.numel() // b
+        inb = min(b - 1, int(in_batch_neg_num))
+        emb = emb.contiguous()
+
+        def sel(idx, rows):
+            out, inv = torch.empty(rows, E, device=dev), torch.empty(rows, device=dev)
+            ops.call("uniir_select_normalize", emb, idx, out, inv, rows, E)
+            return out, inv
+
+        q, qinv = sel(idx_q, b)
+        p, pinv = sel(idx_p, b)
+        n, ninv = sel(idx_n, b * N)
+        sc = scale.detach().reshape(1).float().contiguous()
+        C = 1 + N + inb
+        logits = torch.empty(b, C, device=dev)
+        lse, rl, hit = torch.empty(b, device=dev), torch.empty(b, device=dev), torch.empty(b, device=dev)
+        ops.call("uniir_hardneg_fwd", q, p, n, sc, b, N, inb, E, logits, lse, rl, hit)
+        ctx.save_for_backward(q, p, n, qinv, pinv, ninv, idx_q, idx_p, idx_n, sc, logits, lse)
+        ctx.meta = (b, N, inb, E, emb.shape[0])
+        acc = hit.mean()
+        ctx.mark_non_differentiable(acc)
+        return rl.mean(), acc
+
+    @staticmethod
+    def backward(ctx, dloss, _dacc):
+        q, p, n, qinv, pinv, ninv, idx_q, idx_p, idx_n, sc, logits, lse = ctx.saved_tensors
+        b, N, inb, E, M = ctx.meta
+        dev = q.device
+        dq, dn = torch.empty(b, E, device=dev), torch.empty(b * N, E, device=dev)
+        dp, dscale = torch.zeros(b, E, device=dev), torch.zeros(1, device=dev)
+        dl = dloss.reshape(1).float().contiguous()
+        ops.call("uniir_hardneg_bwd", q, p, n, sc, logits, lse, dl, b, N, inb, E, dq, dp, dn, dscale)
+        demb = torch.zeros(M, E, device=dev)
+        ops.call("uniir_select_normalize_bwd", q, qinv, dq, idx_q, demb, b, E)
+        ops.call("uniir_select_normalize_bwd", p, pinv, dp, idx_p, demb, b, E)
+        ops.call("uniir_select_normalize_bwd", n, ninv, dn, idx_n, demb, b * N, E)
+        return demb, None, None, None, dscale.reshape(()), None

@@ -3,14 +3,13 @@ methods, batch dictionary and output dictionary; the towers and the loss run on 
 
 Reference lines mirrored: __init__ :14-30, get_tokenizer :35-41, encode_multimodal_input :53-63,
 get_logit_scale :65-66, compute_inbatch_contrastive_loss :68-147, forward :149-152, encode_mbeir_batch :154-168.
-Not built as a kernel: the hard-negative branch (:105-131) -- every shipped config has hard_neg_num 0
-(marked OUT); requesting it raises.
+The hard-negative branch (:105-131) runs on `uniir_hardneg_{fwd,bwd}` (one workgroup per query, fp32).
 """
 import torch
 from torch import nn
 
 from uniir_amd import clip_front
-from uniir_amd.losses import FuseFn, InBatchNCEFn
+from uniir_amd.losses import FuseFn, HardNegNCEFn, InBatchNCEFn
 
 
 class CLIPScoreFusion(nn.Module):
@@ -55,15 +54,16 @@ class CLIPScoreFusion(nn.Module):
 
     def compute_inbatch_contrastive_loss(self, batch):
         index_mapping = batch["index_mapping"]
-        if "neg_cand_list" in index_mapping:
-            raise NotImplementedError(
-                "hard-negative branch (clip_sf.py:105-131) is outside the MI355X hot path: all shipped configs "
-                "train with hard_neg_num 0; see DESIGN.md 'out of scope'")
         embeddings = self.encode_multimodal_input(batch["txt_batched"], batch["image_batched"],
                                                   batch["txt_mask_batched"], batch["image_mask_batched"])
         dev = embeddings.device
         idx_q = torch.tensor(index_mapping["query"], dtype=torch.int32).flatten().to(dev, non_blocking=True)
         idx_p = torch.tensor(index_mapping["pos_cand"], dtype=torch.int32).flatten().to(dev, non_blocking=True)
+        if "neg_cand_list" in index_mapping:       # hard negatives: [bs, neg_num] rows of the flat batch
+            idx_n = torch.tensor(index_mapping["neg_cand_list"], dtype=torch.int32).flatten().to(dev, non_blocking=True)
+            loss, accuracy = HardNegNCEFn.apply(embeddings, idx_q, idx_p, idx_n, self.get_logit_scale(),
+                                                int(getattr(self, "in_batch_neg_num", 0)))
+            return {"loss": loss, "accuracy": accuracy}
         gather = bool(getattr(self, "gather_embeddings", False))
         loss, accuracy, _score = InBatchNCEFn.apply(embeddings, idx_q, idx_p, self.get_logit_scale(), gather)
         return {"loss": loss, "accuracy": accuracy}
