@@ -127,3 +127,36 @@ def test_no_grad_embedding_path():
                                       batch["txt_mask_batched"], batch["image_mask_batched"])
     assert ids == dbatch["did_list"]
     assert rel(emb, emb_o) < 2e-2
+
+
+def test_hard_negative_batch_through_the_model():
+    """a batch whose index_mapping carries neg_cand_list ([query, pos, neg, neg] per instance) takes the hard-negative
+    branch (clip_sf.py:105-131) end to end: towers + uniir_hardneg_{fwd,bwd}; compared with the oracle"""
+    from oracle import clip_oracle as O
+    cfg = O.tiny_config()
+    model, oracle, O = _build(cfg, seed=3)
+    model.in_batch_neg_num = 2
+    b, nneg = 4, 2
+    M = b * (2 + nneg)
+    flat = O.synthetic_batch(cfg, M // 2, seed=19)       # M items; only the mapping differs from the in-batch case
+    im = {"query": [], "pos_cand": [], "neg_cand_list": []}
+    c = 0
+    for _ in range(b):
+        im["query"].append([c]); c += 1
+        im["pos_cand"].append([c]); c += 1
+        im["neg_cand_list"].append(list(range(c, c + nneg))); c += nneg
+    flat["index_mapping"] = im
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in flat.items()}
+    emb_o = O.encode_multimodal_input(oracle.sd(), cfg, flat["txt_batched"], flat["image_batched"],
+                                      flat["txt_mask_batched"], flat["image_mask_batched"])
+    out_o = O.inbatch_contrastive_loss(emb_o, im, oracle.logit_scale.exp(), in_batch_neg_num=2)
+    out_o["loss"].backward()
+    model.train()
+    model.clip_model._ensure_flat()
+    model.clip_model.zero_grad()
+    out_d = model(dbatch)
+    out_d["loss"].backward()
+    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 3e-2 * max(1.0, abs(out_o["loss"].item()))
+    g_d = model.clip_model.visual.proj.grad
+    g_o = oracle.visual__proj.grad
+    assert rel(g_d, g_o) < 8e-2, rel(g_d, g_o)
