@@ -103,19 +103,29 @@ def momentum_update(sd, m):
 
 
 def contrastive_loss(sd, state, batch, alpha, vit_cfg, med_cfg, momentum):
-    """blip_ff.py:118-257 (no hard negatives).  `sd`: parameters (online ones may require grad; momentum entries are
-    replaced in place), `state`: dict(query_queue [E,K], cand_queue [E,K], idx_queue [1,K] int64, ptr int)."""
+    """blip_ff.py:118-257.  `sd`: parameters (online ones may require grad; momentum entries are replaced in place),
+    `state`: dict(query_queue [E,K], cand_queue [E,K], idx_queue [1,K] int64, ptr int).  With
+    index_mapping["neg_cand_list"] ([b,N]) and batch["nc_dids_list"] the hard-negative variant (:127-131,159-170,
+    196-205,233-246) runs; its enqueue choice draws torch.rand(1) from the global CPU generator like the reference."""
     with torch.no_grad():
         sd["temp"].clamp_(0.001, 0.5)
     temp = sd["temp"]
     ids, mask, img = batch["ids"], batch["mask"], batch["img"]
+    im = batch["index_mapping"]
+    hard = "neg_cand_list" in im
     emb = encode_multimodal_input(sd, ids, mask, img, vit_cfg, med_cfg)
-    qi = torch.tensor(batch["index_mapping"]["query"]).flatten()
-    pi = torch.tensor(batch["index_mapping"]["pos_cand"]).flatten()
+    qi = torch.tensor(im["query"]).flatten()
+    pi = torch.tensor(im["pos_cand"]).flatten()
     q = F.normalize(emb[qi], dim=-1)
     p = F.normalize(emb[pi], dim=-1)
+    bs, E = q.shape
     pc_idx = batch["p_did_list"].view(-1, 1)
-    idx_all = torch.cat([pc_idx.t(), state["idx_queue"].clone()], dim=1)
+    if hard:
+        nc_idx = torch.as_tensor(batch["nc_dids_list"]).view(-1, 1)
+        hn = nc_idx.size(0)
+        idx_all = torch.cat([pc_idx.t(), nc_idx.t(), state["idx_queue"].clone()[:, hn:]], dim=1)
+    else:
+        idx_all = torch.cat([pc_idx.t(), state["idx_queue"].clone()], dim=1)
     pos = torch.eq(pc_idx, idx_all).float()
     tgt = pos / pos.sum(1, keepdim=True)
     with torch.no_grad():
@@ -124,18 +134,32 @@ def contrastive_loss(sd, state, batch, alpha, vit_cfg, med_cfg, momentum):
         q_m = F.normalize(emb_m[qi], dim=-1)
         p_m = F.normalize(emb_m[pi], dim=-1)
         q_m_all = torch.cat([q_m.t(), state["query_queue"].clone()], dim=1)
-        p_m_all = torch.cat([p_m.t(), state["cand_queue"].clone()], dim=1)
+        if hard:
+            nc_m = emb_m[torch.tensor(im["neg_cand_list"])]              # [b, N, E], NOT normalised (blip_ff.py:187-190)
+            p_m_all = torch.cat([p_m.t(), nc_m.view(hn, E).t(), state["cand_queue"].clone()[:, hn:]], dim=1)
+        else:
+            p_m_all = torch.cat([p_m.t(), state["cand_queue"].clone()], dim=1)
         t_q2p = alpha * F.softmax(q_m @ p_m_all / temp, dim=1) + (1 - alpha) * tgt
         t_p2q = alpha * F.softmax(p_m @ q_m_all / temp, dim=1) + (1 - alpha) * tgt
     sim_q2p = q @ p_m_all / temp
     sim_p2q = p @ q_m_all / temp
     loss = (-(F.log_softmax(sim_q2p, dim=1) * t_q2p).sum(1).mean() - (F.log_softmax(sim_p2q, dim=1) * t_p2q).sum(1).mean()) / 2
-    with torch.no_grad():   # _dequeue_and_enqueue (world size 1)
-        b, K, ptr = q_m.shape[0], state["query_queue"].shape[1], state["ptr"]
-        assert K % b == 0
-        state["query_queue"][:, ptr:ptr + b] = q_m.t()
-        state["cand_queue"][:, ptr:ptr + b] = p_m.t()
-        state["idx_queue"][:, ptr:ptr + b] = pc_idx.t()
-        state["ptr"] = (ptr + b) % K
+
+    def enqueue(qf, cf, idxs):   # _dequeue_and_enqueue (world size 1)
+        with torch.no_grad():
+            b, K, ptr = qf.shape[0], state["query_queue"].shape[1], state["ptr"]
+            assert K % b == 0
+            state["query_queue"][:, ptr:ptr + b] = qf.t()
+            state["cand_queue"][:, ptr:ptr + b] = cf.t()
+            state["idx_queue"][:, ptr:ptr + b] = idxs.view(1, -1)
+            state["ptr"] = (ptr + b) % K
+
+    if hard:
+        if torch.rand(1) < 0.5:
+            enqueue(q_m, p_m, pc_idx)
+        else:
+            enqueue(q_m, nc_m[:, 0, :].contiguous(), nc_idx.view(bs, -1)[:, 0].contiguous())
+    else:
+        enqueue(q_m, p_m, pc_idx)
     acc = pos.gather(1, sim_q2p.max(1)[1].unsqueeze(1)).squeeze().mean()
     return {"loss": loss, "accuracy": acc, "sim_q2p": sim_q2p}

@@ -223,6 +223,73 @@ def g8():
     print("g8 ok", steps)
 
 
+def g8h():
+    """BLIP_FF with hard negatives (blip_ff.py:127-131,159-170,196-205,233-246): two steps, N = 1 negative per query;
+    torch.manual_seed before each step pins the reference's `torch.rand(1) < 0.5` enqueue choice"""
+    import torch.distributed as dist
+    from models.uniir_blip.backbone import med
+    from models.uniir_blip.backbone.vit import VisionTransformer
+    from models.uniir_blip.blip_featurefusion import blip_ff
+    med.BertPreTrainedModel.init_weights = lambda s: s.apply(s._init_weights)
+    med.BertPreTrainedModel.get_head_mask = lambda s, h, n, *a, **k: [None] * n
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29548")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    blip_ff.create_vit = lambda vit, image_size, *a, **k: (VisionTransformer(**TINY_VIT), TINY_VIT["embed_dim"])
+    blip_ff.init_tokenizer = lambda: None
+    cfg_path = os.path.join("/tmp", "tiny_med_config.json")
+    json.dump(TINY_MED, open(cfg_path, "w"))
+    torch.manual_seed(181)
+    E, K, b, N = TINY_MED["hidden_size"], 16, 4, 1
+    model = blip_ff.BLIPFeatureFusion(med_config=cfg_path, image_size=32, vit="base", embed_dim=E, queue_size=K,
+                                      momentum=0.9, config=types.SimpleNamespace(tokenizer_max_length=20))
+    perturb(model.visual_encoder, 182)
+    perturb(model.text_encoder, 183)
+    model.copy_params()
+    model.train()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    M = b * (2 + N)
+    out = {}
+    steps = []
+    for step, alpha in enumerate([0.4, 0.4]):
+        ids, mask, _ = med_inputs(190 + step, n=M, L=20)
+        img = torch.randn(M, 3, 32, 32, generator=torch.Generator().manual_seed(195 + step))
+        batch = {
+            "txt_batched": types.SimpleNamespace(input_ids=ids, attention_mask=mask),
+            "image_batched": img,
+            "txt_mask_batched": torch.ones(M, dtype=torch.long), "image_mask_batched": torch.ones(M, dtype=torch.long),
+            "p_did_list": torch.tensor([7, 8, 7, 9]) + 10 * step,
+            "nc_dids_list": (torch.tensor([[31], [32], [8], [33]]) + 10 * step),     # one negative equals another row's positive id
+            "index_mapping": {"query": [[3 * i] for i in range(b)], "pos_cand": [[3 * i + 1] for i in range(b)],
+                              "neg_cand_list": [[3 * i + 2] for i in range(b)]},
+        }
+        model.zero_grad()
+        torch.manual_seed(1000 + step)
+        res = model(batch, alpha=alpha)
+        res["loss"].backward()
+        steps.append((res["loss"].item(), res["accuracy"].item()))
+        out.update({f"s{step}_ids": ids.numpy(), f"s{step}_mask": mask.numpy(), f"s{step}_img": img.numpy(),
+                    f"s{step}_pdid": batch["p_did_list"].numpy(), f"s{step}_ncdid": batch["nc_dids_list"].numpy(),
+                    f"s{step}_alpha": alpha, f"s{step}_loss": res["loss"].item(), f"s{step}_acc": res["accuracy"].item(),
+                    f"s{step}_dtemp": model.temp.grad.numpy(),
+                    f"s{step}_g_pool": model.text_encoder.pooler.dense.weight.grad.numpy(),
+                    f"s{step}_query_queue": model.query_queue.numpy().copy(), f"s{step}_cand_queue": model.cand_queue.numpy().copy(),
+                    f"s{step}_idx_queue": model.idx_queue.numpy().copy(), f"s{step}_ptr": model.new_ptr_queue.numpy().copy()})
+        with torch.no_grad():
+            for p in list(model.visual_encoder.parameters()) + list(model.text_encoder.parameters()):
+                if p.grad is not None:
+                    p.add_(-0.05 * p.grad)
+    for k, v in sd0.items():
+        if "encoder_m." in k:
+            continue
+        if v.dtype.is_floating_point or k.endswith("idx_queue") or k.endswith("new_ptr_queue"):
+            out[f"sd0::{k}"] = v.numpy()
+    out.update(med_cfg=json.dumps(TINY_MED), vit_cfg=json.dumps(TINY_VIT), queue_size=K, momentum=0.9)
+    np.savez_compressed(os.path.join(HERE, "g8h_blipff_hardneg.npz"), **out)
+    print("g8h ok", steps)
+
+
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)

@@ -155,3 +155,46 @@ def test_blip_ff_native_adamw_and_embedding_path():
         emb, ids = model(batch, encode_mbeir_batch=True)
     assert emb.shape == (2 * b, med_cfg["hidden_size"]) and ids == list(range(2 * b))
     assert torch.isfinite(emb).all() and emb.abs().max().item() <= 1.0
+
+
+def test_g8h_blip_ff_hard_negatives():
+    """two training steps with one hard negative per query against the reference golden (G8h): loss, accuracy, the
+    [p | negatives | queue] id row, the coin-flip enqueue (same host generator seed as the fixture)"""
+    z = np.load(os.path.join(G, "g8h_blipff_hardneg.npz"))
+    med_cfg, vit_cfg = json.loads(str(z["med_cfg"])), json.loads(str(z["vit_cfg"]))
+    model = tiny_model(med_cfg, vit_cfg, queue_size=int(z["queue_size"]), momentum=float(z["momentum"]))
+    load_sub(model, z, "sd0::", "")
+    model.copy_params()
+    model = model.cuda()
+    model.train()
+    for step in range(2):
+        b = len(z[f"s{step}_pdid"])
+        M = 3 * b
+        batch = {
+            "txt_batched": types.SimpleNamespace(input_ids=torch.from_numpy(z[f"s{step}_ids"]).cuda(),
+                                                 attention_mask=torch.from_numpy(z[f"s{step}_mask"]).cuda()),
+            "image_batched": torch.from_numpy(z[f"s{step}_img"]).cuda(),
+            "txt_mask_batched": torch.ones(M, dtype=torch.long).cuda(),
+            "image_mask_batched": torch.ones(M, dtype=torch.long).cuda(),
+            "p_did_list": torch.from_numpy(z[f"s{step}_pdid"]),
+            "nc_dids_list": torch.from_numpy(z[f"s{step}_ncdid"]),
+            "index_mapping": {"query": [[3 * i] for i in range(b)], "pos_cand": [[3 * i + 1] for i in range(b)],
+                              "neg_cand_list": [[3 * i + 2] for i in range(b)]},
+        }
+        model.zero_grad()
+        torch.manual_seed(1000 + step)
+        out = model(batch, alpha=float(z[f"s{step}_alpha"]))
+        out["loss"].backward()
+        want = float(z[f"s{step}_loss"])
+        assert abs(out["loss"].item() - want) < 2e-2 * max(1.0, abs(want)), (out["loss"].item(), want)
+        assert out["accuracy"].item() == float(z[f"s{step}_acc"])
+        assert rel(model.query_queue, z[f"s{step}_query_queue"]) < 2e-2
+        assert rel(model.cand_queue, z[f"s{step}_cand_queue"]) < 2e-2
+        assert np.array_equal(model.idx_queue.cpu().numpy(), z[f"s{step}_idx_queue"])
+        assert int(model.new_ptr_queue.item()) == int(z[f"s{step}_ptr"].item())
+        r = rel(model.get_parameter("text_encoder.pooler.dense.weight").grad, z[f"s{step}_g_pool"])
+        assert r < 8e-2, (step, r)
+        with torch.no_grad():
+            for n, p in model._online_params():
+                if n != "temp":
+                    p.add_(-0.05 * p.grad)

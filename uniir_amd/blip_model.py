@@ -11,7 +11,8 @@ stash.  Differences from the reference, stated once:
   * dropout (BERT 0.1) and DropPath (ViT-large 0.1) are not applied: the forward is the reference's expectation
     (its eval-mode forward); see DESIGN.md "BLIP_FF";
   * the BERT padding mask must be a prefix mask (tokenizer padding="max_length"), it travels as one key length per row;
-  * hard negatives (blip_ff.py:127-131,159-170) raise NotImplementedError.
+  * hard negatives (blip_ff.py:127-131,159-170,233-246) are supported; like the reference their momentum features are
+    used un-normalised and a host coin flip decides what is enqueued.
 """
 import json
 import math
@@ -344,38 +345,72 @@ class _EncodeFn(torch.autograd.Function):
 
 
 class _SoftTargetLossFn(torch.autograd.Function):
-    """blip_ff.py:155-231,250-252 for the no-hard-negative case.  Everything that reads the queues runs in forward
-    (the queues are overwritten before backward): the unit gradients are kept and scaled by d(loss) in backward."""
+    """blip_ff.py:155-231,250-252.  Everything that reads the queues runs in forward (the queues are overwritten before
+    backward): the unit gradients are kept and scaled by d(loss) in backward.  With hard negatives (`ni` [b*N] rows of
+    the flat batch, `ids_neg` their candidate ids) the candidate side is [p_m | nc_m (un-normalised, like the
+    reference) | cand_queue[:, b*N:]] and the id row [p ids | negative ids | idx_queue[b*N:]] (:159-170,196-205)."""
 
     @staticmethod
-    def forward(ctx, emb, temp, model, emb_m, qi, pi, ids_row, alpha):
+    def forward(ctx, emb, temp, model, emb_m, qi, pi, ids_row, alpha, ni, ids_neg):
         b, E, dev = qi.numel(), emb.shape[1], emb.device
         K = model.queue_size
         n = b + K
         f32 = dict(device=dev, dtype=torch.float32)
 
         def sel(src, idx):
-            out, inv = torch.empty(b, E, **f32), torch.empty(b, **f32)
-            ops.call("uniir_select_normalize", src, idx, out, inv, b, E)
+            rows = idx.numel()
+            out, inv = torch.empty(rows, E, **f32), torch.empty(rows, **f32)
+            ops.call("uniir_select_normalize", src, idx, out, inv, rows, E)
             return out, inv
 
         q, invq = sel(emb, qi)
         p, invp = sel(emb, pi)
         q_m, _ = sel(emb_m, qi)
         p_m, _ = sel(emb_m, pi)
-        ids_all = torch.cat([ids_row, model.idx_queue[0]])
+        hn = 0
+        nc_m = None
+        if ni is not None:
+            hn = ni.numel()
+            nc_m = emb_m.index_select(0, ni.long()).contiguous()      # rows emb_m[ni], not normalised (a copy, no arithmetic)
+            ids_all = torch.cat([ids_row, ids_neg, model.idx_queue[0, hn:]])
+        else:
+            ids_all = torch.cat([ids_row, model.idx_queue[0]])
+        # column blocks of the two logit matrices: (row-major features [r,E]) or (queue [E,K], first column used)
+        cand_blocks = [("rows", p_m, b)] + ([("rows", nc_m, hn)] if hn else []) + [("queue", model.cand_queue, hn)]
+        query_blocks = [("rows", q_m, b), ("queue", model.query_queue, 0)]
 
-        def sims(a, feats_m, queue):
-            """[a @ feats_m^T | a @ queue] without materialising the concatenation (queue is [E,K] like the reference)"""
+        def sims(a, blocks):
+            """[a @ block_0^T | a @ block_1^T | ...] without materialising the concatenation"""
             out = torch.empty(b, n, **f32)
-            ops.call("uniir_sgemm", a, E, 1, feats_m, 1, E, out, n, b, b, E, 1.0)
-            ops.call("uniir_sgemm", a, E, 1, queue, K, 1, out[:, b:], n, b, K, E, 1.0)
+            col = 0
+            for kind, t, arg in blocks:
+                if kind == "rows":
+                    ops.call("uniir_sgemm", a, E, 1, t, 1, E, out[:, col:], n, b, arg, E, 1.0)
+                    col += arg
+                else:
+                    ops.call("uniir_sgemm", a, E, 1, t[:, arg:], K, 1, out[:, col:], n, b, K - arg, E, 1.0)
+                    col += K - arg
             return out
 
+        def dfeat(dsim, blocks):
+            """d a = sum over blocks of dsim[:, cols] @ block (the momentum / queue features carry no gradient)"""
+            da = torch.empty(b, E, **f32)
+            col, first = 0, True
+            for kind, t, arg in blocks:
+                fn = "uniir_sgemm" if first else "uniir_sgemm_acc"
+                if kind == "rows":
+                    ops.call(fn, dsim[:, col:], n, 1, t, E, 1, da, E, b, E, arg, 1.0)
+                    col += arg
+                else:
+                    ops.call(fn, dsim[:, col:], n, 1, t[:, arg:], 1, K, da, E, b, E, K - arg, 1.0)
+                    col += K - arg
+                first = False
+            return da
+
         need = ctx.needs_input_grad[0]
-        rl, hit, rdt, dfeat = [], None, [], []
-        for a, a_m, feats_m, queue in ((q, q_m, p_m, model.cand_queue), (p, p_m, q_m, model.query_queue)):
-            s, s_m = sims(a, feats_m, queue), sims(a_m, feats_m, queue)
+        rl, hit, rdt, dfe = [], None, [], []
+        for a, a_m, blocks in ((q, q_m, cand_blocks), (p, p_m, query_blocks)):
+            s, s_m = sims(a, blocks), sims(a_m, blocks)
             row_loss, row_hit = torch.empty(b, **f32), torch.empty(b, **f32)
             dsim = torch.empty(b, n, **f32) if need else None
             row_dt = torch.empty(b, **f32) if need else None
@@ -384,25 +419,24 @@ class _SoftTargetLossFn(torch.autograd.Function):
             rl.append(row_loss)
             hit = row_hit if hit is None else hit
             if need:
-                da = torch.empty(b, E, **f32)
-                ops.call("uniir_sgemm", dsim, n, 1, feats_m, E, 1, da, E, b, E, b, 1.0)
-                ops.call("uniir_sgemm_acc", dsim[:, b:], n, 1, queue, 1, K, da, E, b, E, K, 1.0)
-                dfeat.append(da)
+                dfe.append(dfeat(dsim, blocks))
                 rdt.append(row_dt)
         loss = (rl[0].sum() + rl[1].sum()) / (2 * b)
         acc = hit.mean()
         if need:
             demb = torch.zeros_like(emb)
-            ops.call("uniir_select_normalize_bwd", q, invq, dfeat[0], qi, demb, b, E)
-            ops.call("uniir_select_normalize_bwd", p, invp, dfeat[1], pi, demb, b, E)
+            ops.call("uniir_select_normalize_bwd", q, invq, dfe[0], qi, demb, b, E)
+            ops.call("uniir_select_normalize_bwd", p, invp, dfe[1], pi, demb, b, E)
             ctx.save_for_backward(demb, rdt[0].sum() + rdt[1].sum())
-        ctx.mark_non_differentiable(acc, q_m, p_m)
-        return loss, acc, q_m, p_m
+        if nc_m is None:
+            nc_m = q_m.new_zeros(0, E)
+        ctx.mark_non_differentiable(acc, q_m, p_m, nc_m)
+        return loss, acc, q_m, p_m, nc_m
 
     @staticmethod
-    def backward(ctx, dloss, _dacc, _dq, _dp):
+    def backward(ctx, dloss, _dacc, _dq, _dp, _dn):
         demb, dtemp = ctx.saved_tensors
-        return demb * dloss, dtemp * dloss, None, None, None, None, None, None
+        return demb * dloss, dtemp * dloss, None, None, None, None, None, None, None, None
 
 
 class BLIPFeatureFusion(nn.Module):
@@ -597,20 +631,30 @@ class BLIPFeatureFusion(nn.Module):
 
     def compute_contrastive_loss(self, batch, alpha):
         index_mapping = batch["index_mapping"]
-        if "neg_cand_list" in index_mapping:
-            raise NotImplementedError("hard negatives are not on the MI355X BLIP_FF path yet")
+        hard = "neg_cand_list" in index_mapping
         dev = self.temp.device
         txt, img = batch["txt_batched"], batch["image_batched"]
         ids_row = torch.as_tensor(batch["p_did_list"], device=dev).to(torch.int64).flatten()
         qi = torch.tensor(index_mapping["query"], dtype=torch.int32).flatten().to(dev)
         pi = torch.tensor(index_mapping["pos_cand"], dtype=torch.int32).flatten().to(dev)
+        ni = ids_neg = None
+        if hard:     # blip_ff.py:127-131: [bs, neg_num] rows of the flat batch and their candidate ids
+            ni = torch.tensor(index_mapping["neg_cand_list"], dtype=torch.int32).flatten().to(dev)
+            ids_neg = torch.as_tensor(batch["nc_dids_list"], device=dev).to(torch.int64).flatten()
         with torch.no_grad():
             self.temp.clamp_(0.001, 0.5)
         emb = self.encode_multimodal_input(txt, img, batch.get("txt_mask_batched"), batch.get("image_mask_batched"))
         self._momentum_update()
         emb_m = self.encode_multimodal_input(txt, img, use_momentum=True)
-        loss, acc, q_m, p_m = _SoftTargetLossFn.apply(emb, self.temp, self, emb_m, qi, pi, ids_row, alpha)
-        self._dequeue_and_enqueue(q_m.detach(), p_m.detach(), ids_row)
+        loss, acc, q_m, p_m, nc_m = _SoftTargetLossFn.apply(emb, self.temp, self, emb_m, qi, pi, ids_row, alpha, ni, ids_neg)
+        if hard and not bool(torch.rand(1) < 0.5):
+            # blip_ff.py:233-246: a coin flip (same host generator as the reference) enqueues each query's FIRST negative
+            bs = qi.numel()
+            nneg = ni.numel() // bs
+            self._dequeue_and_enqueue(q_m.detach(), nc_m.detach().view(bs, nneg, -1)[:, 0, :].contiguous(),
+                                      ids_neg.view(bs, nneg)[:, 0].contiguous())
+        else:
+            self._dequeue_and_enqueue(q_m.detach(), p_m.detach(), ids_row)
         return {"loss": loss, "accuracy": acc}
 
     def encode_mbeir_batch(self, batch):
