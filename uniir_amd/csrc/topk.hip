@@ -9,8 +9,10 @@
 //            oracle/topk_oracle.c) and sorted by (score desc, id asc) -> bit-exact distances, identical ids.
 #include "gemm_core.h"
 #include "gemm_core256.h"
+#include "gemm_core_pp.h"
 #include "../../include/uniir_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define TK_QT 128        // queries per block tile (GEMM N)
 #define TK_CT 256        // candidates per MFMA tile (GEMM M): pool rows stream through the 256-row LDS-DMA operand
@@ -431,6 +433,73 @@ extern "C" int32_t uniir_topk_ncand(int32_t nq, int32_t kc) {
     return nq <= TK_GPATH_MAXQ ? TK_GMULT * kc * TK_G : kc;
 }
 
+// max over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane: four DPP steps, no LDS crossbar
+DEVINL float row16_max(float x) {
+    auto step = [](float v, auto ctrl) {
+        const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true);
+        return fmaxf(v, __builtin_bit_cast(float, o));
+    };
+    x = step(x, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    x = step(x, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    x = step(x, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    x = step(x, std::integral_constant<int, 0x140>{});   // row_mirror
+    return x;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Group-max scan for many queries (129 .. 1024 per call: the MFMA-bound regime): one 256-candidate x 256-query tile per
+// workgroup on the ping-pong LDS-DMA loop of the training GEMMs (gemm_core_pp.h, fp16 operands, K = dim), group maxima
+// straight from the accumulators.  Accumulator map: acc[4h+i][2h'+j][r] = candidate 128h + 64wr + 16i + (lane & 15),
+// query 128h' + 32wc + 16j + 4 (lane >> 4) + r.
+__global__ __launch_bounds__(512, 2) void topk_gmax_pp_kernel(const unsigned short* __restrict__ pool,
+                                                              const float* __restrict__ pinv, long rows, int dim,
+                                                              const unsigned short* __restrict__ queries, int nq,
+                                                              float* __restrict__ gmax, long ngroups, int tiles_q) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = id / tiles_q, qt = id - ct * tiles_q;       // consecutive workgroups share the candidate tile
+    const int m0 = ct * 256, q0 = qt * 256;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    glds_mainloop_pp<ElemF16, false, false>(pool, dim, (int)rows, queries, dim, nq, m0, q0, 0, dim, lds, acc);
+    // group maxima -> LDS image [256 queries][16 groups] (the ring is idle now), then 32-B runs per query to gmax
+    float* stage = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rl = (i >> 2) * 128 + (w >> 2) * 64 + (i & 3) * 16;     // first candidate row of this accumulator tile
+        const long n = (long)m0 + rl + li;
+        const bool nok = n < rows;
+        const float iv = nok ? pinv[n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ql = (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 + 4 * lg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = row16_max(nok ? acc[i][j][r] * iv : -INFINITY);
+                if (li == r) stage[(ql + r) * 16 + (rl >> 4)] = x;          // lane r of the row stores query ql + r
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int ql = threadIdx.x >> 1, half = threadIdx.x & 1;
+        const int q = q0 + ql;
+        const long g0 = ((long)m0 >> 4) + half * 8;
+        if (q < nq) {
+            float* dst = gmax + (long)q * ngroups + g0;
+            const float* src = stage + ql * 16 + half * 8;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (g0 + g < ngroups) dst[g] = src[g];
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------------------
 // Streaming group-max scan for nq <= 64 (the interactive regime: HBM-bound).  The queries
 // (<= 64 x dim fp16, <= 96 KiB) live in LDS for the whole kernel; every wave streams its own 16-candidate tiles
@@ -560,6 +629,23 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
                                    pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, nchunks);
             }
             hipLaunchKernelGGL(topk_gsel_kernel<1024>, dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq, kc,
+                               TK_GMULT * kc, cand_idx);
+            HIP_LAUNCH_CHECK();
+            return UNIIR_OK;
+        }
+        static const char* env_pp = getenv("UNIIR_TOPK_PP");         // "0" disables the ping-pong scan (experiments)
+        if (nq > 128 && dim % 64 == 0 && dim >= 192 && !(env_pp && env_pp[0] == '0')) {
+            const int tiles_q = (nq + 255) / 256;
+            const long tiles_c = (rows + 255) / 256;
+            static bool attr_pp = false;
+            if (!attr_pp) {
+                (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                attr_pp = true;
+            }
+            hipLaunchKernelGGL(topk_gmax_pp_kernel, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
+                               (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
+                               (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
+            hipLaunchKernelGGL(topk_gsel_kernel<256>, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
                                TK_GMULT * kc, cand_idx);
             HIP_LAUNCH_CHECK();
             return UNIIR_OK;
