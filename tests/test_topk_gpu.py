@@ -16,7 +16,7 @@ def _ref(pool, ids, queries, k):
     return v, ids[i]
 
 
-@pytest.mark.parametrize("n,nq,d,k", [(1000, 7, 64, 10), (5000, 130, 512, 10), (70000, 33, 768, 10), (20000, 300, 768, 50), (5, 3, 64, 10)])
+@pytest.mark.parametrize("n,nq,d,k", [(1000, 7, 64, 10), (5000, 130, 512, 10), (70000, 33, 768, 10), (20000, 300, 768, 50), (5, 3, 64, 10), (3000, 2300, 256, 10)])
 def test_topk_matches_reference(n, nq, d, k):
     from uniir_amd import retrieval
     torch.manual_seed(0)

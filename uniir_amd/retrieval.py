@@ -33,6 +33,9 @@ def query_inv_norms(queries_f16: torch.Tensor) -> torch.Tensor:
     return inv
 
 
+QUERY_CHUNK = 1024   # queries per sweep of the shard (uniir_topk_coarse's group-max path takes <= 1024)
+
+
 def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None, workspace=None):
     """Exact top-k of `queries` against one shard -> (scores f32 [q,k] desc, ids int64 [q,k], -1 padded)."""
     from . import _lib
@@ -42,6 +45,16 @@ def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None
     out_s = torch.full((nq, k), float("-inf"), device=dev, dtype=torch.float32)
     out_i = torch.full((nq, k), -1, device=dev, dtype=torch.int64)
     if nq == 0 or shard.n == 0:
+        return out_s, out_i
+    if nq > QUERY_CHUNK:      # many queries (the reference hands over all of them at once): sweep the shard per 1024-query
+        ws = workspace        # chunk on the MFMA group-max path, reusing one workspace
+        for lo in range(0, nq, QUERY_CHUNK):
+            hi = min(nq, lo + QUERY_CHUNK)
+            if ws is None:
+                need = _lib.load().uniir_topk_workspace_bytes(QUERY_CHUNK, min(64, k + COARSE_MARGIN), shard.n)
+                ws = torch.empty(need, device=dev, dtype=torch.uint8)
+            s_, i_ = search_shard(shard, queries_f16[lo:hi], k, None if q_inv is None else q_inv[lo:hi], ws)
+            out_s[lo:hi], out_i[lo:hi] = s_, i_
         return out_s, out_i
     if q_inv is None:
         q_inv = query_inv_norms(queries_f16)
