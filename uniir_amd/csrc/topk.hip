@@ -433,6 +433,12 @@ extern "C" int32_t uniir_topk_ncand(int32_t nq, int32_t kc) {
     return nq <= TK_GPATH_MAXQ ? TK_GMULT * kc * TK_G : kc;
 }
 
+struct ElemF16Direct {   // operands in the order the main loop hands them over (B fragment, A fragment) -> mfma(A, B)
+    static DEVINL f32x4_t mfma(u32x4_t b, u32x4_t a, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
 // max over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane: four DPP steps, no LDS crossbar
 DEVINL float row16_max(float x) {
     auto step = [](float v, auto ctrl) {
@@ -466,23 +472,36 @@ __global__ __launch_bounds__(512, 2) void topk_gmax_pp_kernel(const unsigned sho
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    glds_mainloop_pp<ElemF16, false, false>(pool, dim, (int)rows, queries, dim, nq, m0, q0, 0, dim, lds, acc);
+    // un-swapped MFMA operands here: D[row = 4 (lane >> 4) + r -> candidate][col = lane & 15 -> query], so the maximum over
+    // the 16 candidates of a group is 3 in-lane max + 2 cross-row exchanges per 16x16 tile (instead of 16 DPP steps)
+    glds_mainloop_pp<ElemF16Direct, false, false>(pool, dim, (int)rows, queries, dim, nq, m0, q0, 0, dim, lds, acc);
     // group maxima -> LDS image [256 queries][16 groups] (the ring is idle now), then 32-B runs per query to gmax
     float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int rl = (i >> 2) * 128 + (w >> 2) * 64 + (i & 3) * 16;     // first candidate row of this accumulator tile
-        const long n = (long)m0 + rl + li;
-        const bool nok = n < rows;
-        const float iv = nok ? pinv[n] : 0.f;
+        const long n0r = (long)m0 + rl + 4 * lg;                          // this lane's 4 candidates
+        f32x4_t iv = {0.f, 0.f, 0.f, 0.f};
+        if (n0r + 3 < rows) iv = *reinterpret_cast<const f32x4_t*>(pinv + n0r);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n0r + r < rows) iv[r] = pinv[n0r + r];
+        }
+        const bool full = n0r + 3 < rows;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ql = (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 + 4 * lg;
+            const int ql = (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 + li;
+            const f32x4_t v = acc[i][j] * iv;
+            float x;
+            if (full) x = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            else {
+                x = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x = row16_max(nok ? acc[i][j][r] * iv : -INFINITY);
-                if (li == r) stage[(ql + r) * 16 + (rl >> 4)] = x;          // lane r of the row stores query ql + r
+                for (int r = 0; r < 4; ++r) if (n0r + r < rows) x = fmaxf(x, v[r]);
             }
+            x = fmaxf(x, __shfl_xor(x, 16, 64));
+            x = fmaxf(x, __shfl_xor(x, 32, 64));
+            if (lg == 0) stage[ql * 16 + (rl >> 4)] = x;
         }
     }
     __syncthreads();
