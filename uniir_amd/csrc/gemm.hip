@@ -20,7 +20,7 @@ struct GemmKArgs {
     int epilogue, act, k_splits, tiles_m, tiles_n;
     float alpha;
     float* slab;  // split-K slabs [k_splits][M][N] (plain stores) or nullptr (atomics)
-    int asm_loop;   // 0 compiler loop, 1 counted-lgkmcnt asm loop, 2 ping-pong loop
+    int asm_loop;   // 1 counted-lgkmcnt double-buffer loop, 2 ping-pong loop
     float* colsum;  // optional [N]: += column sums of the fp32 result (bias gradient), 256-tile staged epilogue only
 };
 
@@ -472,12 +472,12 @@ static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
     return UNIIR_OK;
 }
 
-// shape choice: 0 = general 128x128 register-staged kernel, 1 = 256x256x64 (1 workgroup / CU), 2 = 256x128x32 (2-3 / CU)
+// shape choice: 0 = general 128x128 register-staged kernel, 1 = 256x256x64 LDS-DMA kernel (1 workgroup / CU)
 static int gemm_shape(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
-    static const char* force = getenv("UNIIR_GEMM_SHAPE");
+    static const char* force = getenv("UNIIR_GEMM_SHAPE");      // "0": force the general kernel (tests / experiments)
     if (a.K % 64) return 0;
     if (a.M < 256 || a.N < 128) return 0;    // small problems: the 128-tile kernel fills the chip better
-    if (force && force[0] >= '0' && force[0] <= '2') return force[0] - '0';
+    if (force && force[0] == '0') return 0;
     return 1;
 }
 
@@ -492,10 +492,8 @@ static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t s
         const bool k32 = (!a_tmaj || (uint64_t)a.K * a.lda * 2 < (1ull << 32)) &&
                          (!b_tmaj || (uint64_t)a.K * a.ldb * 2 < (1ull << 32));
         if (a.asm_loop == 2 && last >= 3 && k32) return launch_glds<Elem, 2, 4, 64, 2>(a, a_tmaj, b_tmaj, st);
-        if (a.asm_loop >= 1) return launch_glds<Elem, 2, 4, 64, 1>(a, a_tmaj, b_tmaj, st);
-        return launch_glds<Elem, 2, 4, 64, 0>(a, a_tmaj, b_tmaj, st);
+        return launch_glds<Elem, 2, 4, 64, 1>(a, a_tmaj, b_tmaj, st);
     }
-    if (shape == 2) return launch_glds<Elem, 2, 2, 32, 0>(a, a_tmaj, b_tmaj, st);
     const int grid = a.tiles_m * a.tiles_n * a.k_splits;
     dim3 g(grid), b(256);
     const size_t sm = GEMM_LDS_BYTES;
@@ -567,8 +565,8 @@ extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
     a.slab = nullptr;
     a.colsum = d->colsum;
     {
-        static const char* e = getenv("UNIIR_GEMM_LOOP");   // 0 compiler loop, 1 counted-lgkmcnt asm loop, 2 ping-pong
-        a.asm_loop = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+        static const char* e = getenv("UNIIR_GEMM_LOOP");   // "1": counted-lgkmcnt double-buffer loop instead of ping-pong
+        a.asm_loop = (e && e[0] == '1') ? 1 : 2;
     }
     hipStream_t st = (hipStream_t)stream;
     if (d->k_splits > 1) {

@@ -2,9 +2,9 @@
 //
 // Every wave owns a 128x64 sub-tile (8x4 MFMA 16x16x32 tiles = 128 accumulator registers); a workgroup is
 // WAVES_M x WAVES_N waves, i.e. a (128*WAVES_M) x (64*WAVES_N) block tile, K step BK (32 or 64).
-//   <2,4,64>: 256x256x64, 8 waves, 128 KiB LDS, 1 workgroup / CU   (long-K GEMMs: wgrad)
-//   <2,2,32>: 256x128x32, 4 waves,  48 KiB LDS, 2-3 workgroups / CU (short-K GEMMs: one workgroup's prologue /
-//             epilogue / barrier bubbles are covered by the other's MFMAs)
+//   <2,4,64>: 256x256x64, 8 waves, 128 KiB LDS, 1 workgroup / CU: the GEMM fallback loop (glds_mainloop_asm) when a K
+//             split has fewer than 3 steps; the production loop of this shape is the ping-pong one in gemm_core_pp.h
+//   <2,2,32>: 256x128x32, 4 waves,  48 KiB LDS, 2-3 workgroups / CU: the top-k scan for 65..128 queries (topk.hip)
 // Operands go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass), double
 // buffered, one barrier per K step.  global_load_lds writes LDS lane-linearly (wave-uniform base + lane*16 B), so
 // the bank-conflict swizzles are applied to the per-lane SOURCE address and undone on the fragment reads (the same
