@@ -235,6 +235,27 @@ int uniir_sgemm_acc(const float* A, int64_t sam, int64_t sak, const float* B, in
                     float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * [CLIP_FF] pieces of the feature-fusion stack of src/models/uniir_clip/clip_featurefusion/clip_ff.py:80-96,161-192
+ * (transformers T5Stack, encoder mode): RMS norm (T5LayerNorm: y = gamma * x * rsqrt(mean(x^2) + eps), no bias; same
+ * argument meaning as uniir_layernorm_*), self-attention with logits = scale * q.k + rel_emb[rel_bucket[key - query +
+ * seq - 1]][head] on packed qkv (T5Attention: scale 1, bucketed relative position bias; rel_bucket is the host-computed
+ * bucket of every offset, [2 seq - 1] int32; bwd ACCUMULATES d rel_emb into drel [buckets][heads]), and the mean over the
+ * tokens of an item.
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_rmsnorm_fwd(const float* x, int64_t x_stride, const float* gamma, void* y_bf16, float* y_f32, int32_t rows,
+                      int32_t width, float eps, void* stream);
+int uniir_rmsnorm_bwd(const float* x, int64_t x_stride, const float* gamma, const void* dy, int32_t dy_is_f32,
+                      const float* dres, float* dx_f32, int64_t dx_stride, void* dx_bf16, float* dgamma, int32_t rows,
+                      int32_t width, float eps, void* stream);
+int uniir_attention_rel_fwd(const void* qkv, void* out, float* lse, const float* rel_emb, const int32_t* rel_bucket,
+                            int32_t nbuckets, float scale, int32_t batch, int32_t seq, int32_t heads, void* stream);
+int uniir_attention_rel_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                            const float* rel_emb, const int32_t* rel_bucket, int32_t nbuckets, float scale, float* drel,
+                            int32_t batch, int32_t seq, int32_t heads, void* stream);
+int uniir_meanpool_fwd(const float* x, float* out, int32_t n, int32_t tokens, int32_t width, void* stream);
+int uniir_meanpool_bwd(const float* dout, float* dx, int32_t n, int32_t tokens, int32_t width, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * [TOPK] exact brute-force inner-product top-k over an fp16 pool (FAISS "IDMap,Flat" + normalize_L2).
  *   uniir_pool_inv_norms: inv[i] = 1/sqrt(sum_j x[i][j]^2) in the oracle's summation order
  *                         (sequential fp32, no fma), 0 for an all-zero row (FAISS leaves it untouched).

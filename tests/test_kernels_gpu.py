@@ -280,3 +280,65 @@ def test_gemm_pingpong_all_layouts(a_t, b_t, M, N, K):
     ops.gemm(A, B, Cacc, Mp, N, K, Mp if a_t else K, N if b_t else K, N, a_tmaj=bool(a_t), b_tmaj=bool(b_t),
              epilogue=ops.EPI_ATOMIC_F32, k_splits=max(1, K // 192))
     assert rel_err(Cacc, ref + 1.0) < 2e-3
+
+
+@pytest.mark.parametrize("rows,width", [(9, 512), (700, 768)])
+def test_rmsnorm_fwd_bwd(rows, width):
+    """T5LayerNorm (no mean subtraction, no bias) through the LayerNorm kernels' rms mode"""
+    ops = _ops()
+    torch.manual_seed(11)
+    x = torch.randn(rows, width, device=DEV) * 1.7 + 0.3
+    gamma = torch.randn(width, device=DEV) * 0.2 + 1.0
+    xr, gr = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True)
+    ref = gr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    y32 = torch.empty(rows, width, device=DEV)
+    y16 = torch.empty(rows, width, device=DEV, dtype=torch.bfloat16)
+    ops.call("uniir_rmsnorm_fwd", x, width, gamma, y16, y32, rows, width, 1e-6)
+    assert rel_err(y32, ref) < 1e-5 and rel_err(y16, ref) < 4e-3
+    dy = torch.randn(rows, width, device=DEV)
+    dres = torch.randn(rows, width, device=DEV)
+    ref.backward(dy)
+    dx, dg = torch.empty(rows, width, device=DEV), torch.zeros(width, device=DEV)
+    ops.call("uniir_rmsnorm_bwd", x, width, gamma, dy, 1, dres, dx, width, None, dg, rows, width, 1e-6)
+    assert rel_err(dx, xr.grad + dres) < 1e-5
+    assert rel_err(dg, gr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("batch,seq,heads", [(3, 334, 2), (2, 50, 3), (1, 16, 1)])
+def test_attention_relative_bias_fwd_bwd(batch, seq, heads):
+    """T5-style attention: no 1/sqrt(d) scaling, bucketed relative position bias, gradient of the bias table"""
+    import math
+    ops = _ops()
+    torch.manual_seed(13)
+    W = heads * 64
+    qkv = bf(torch.randn(batch * seq, 3 * W, device=DEV) * 0.35)
+    nb = 32
+    emb = torch.randn(nb, heads, device=DEV)
+    pos = torch.arange(seq)
+    rel = pos[None, :] - pos[:, None]                                     # key - query
+    half = nb // 2
+    n = rel.abs()
+    large = 8 + (torch.log(n.float().clamp_min(1) / 8) / math.log(128 / 8) * (half - 8)).long()
+    bucket2d = (rel > 0).long() * half + torch.where(n < 8, n, torch.min(large, torch.full_like(large, half - 1)))
+    offs = torch.arange(-(seq - 1), seq)                                  # table indexed by key - query + seq - 1
+    on = offs.abs()
+    olarge = 8 + (torch.log(on.float().clamp_min(1) / 8) / math.log(128 / 8) * (half - 8)).long()
+    table = ((offs > 0).long() * half + torch.where(on < 8, on, torch.min(olarge, torch.full_like(olarge, half - 1)))).to(torch.int32).to(DEV)
+    out = torch.empty(batch * seq, W, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(batch, heads, seq, device=DEV)
+    ops.call("uniir_attention_rel_fwd", qkv, out, lse, emb, table, nb, 1.0, batch, seq, heads)
+    # reference
+    embr = emb.clone().requires_grad_(True)
+    x = qkv.float().view(batch, seq, 3, heads, 64).requires_grad_(True)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    bias = embr[bucket2d.to(DEV)].permute(2, 0, 1)
+    p = torch.softmax(q @ k.transpose(-1, -2) + bias[None], dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(batch * seq, W)
+    assert rel_err(out, ref) < 8e-3, rel_err(out, ref)
+    dout = bf(torch.randn(batch * seq, W, device=DEV))
+    ref.backward(dout.float())
+    dqkv = torch.empty_like(qkv)
+    drel = torch.zeros(nb, heads, device=DEV)
+    ops.call("uniir_attention_rel_bwd", qkv, out, dout, lse, dqkv, emb, table, nb, 1.0, drel, batch, seq, heads)
+    assert rel_err(dqkv, x.grad.reshape(batch * seq, 3 * W)) < 2e-2, rel_err(dqkv, x.grad.reshape(batch * seq, 3 * W))
+    assert rel_err(drel, embr.grad) < 2e-2, rel_err(drel, embr.grad)

@@ -62,6 +62,12 @@ SIGNATURES = {
     "uniir_sgemm": (c_int, [P, c_i64, c_i64, P, c_i64, c_i64, P, c_i64, c_int, c_int, c_int, c_float, S]),
     "uniir_adamw_step": (c_int, [P, P, P, P, P, c_i64, c_float, c_float, c_float, c_float, c_float, c_int,
                                  c_float, S]),
+    "uniir_rmsnorm_fwd": (c_int, [P, c_i64, P, P, P, c_int, c_int, c_float, S]),
+    "uniir_rmsnorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, c_int, c_int, c_float, S]),
+    "uniir_attention_rel_fwd": (c_int, [P, P, P, P, P, c_int, c_float, c_int, c_int, c_int, S]),
+    "uniir_attention_rel_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_float, P, c_int, c_int, c_int, S]),
+    "uniir_meanpool_fwd": (c_int, [P, P, c_int, c_int, c_int, S]),
+    "uniir_meanpool_bwd": (c_int, [P, P, c_int, c_int, c_int, S]),
     "uniir_tanh_fwd": (c_int, [P, P, c_i64, S]),
     "uniir_tanh_bwd": (c_int, [P, P, P, c_i64, S]),
     "uniir_ema_update": (c_int, [P, P, P, c_i64, c_float, S]),

@@ -106,8 +106,15 @@ struct AttnArgs {
     unsigned short* dk;           // [batch][Tk] rows, stride dkv_ld
     unsigned short* dv;
     long dq_ld, dkv_ld;
+    // T5-style attention (CLIP_FF fusion stack): logits = scale * q.k + rel_emb[rel_bucket[key - query + Tq - 1]][h]
+    float scale;                  // 1/8 for CLIP / BLIP, 1 for T5
+    const float* rel_emb;         // optional [buckets][H] fp32
+    const int* rel_bucket;        // [Tq + Tk - 1] bucket of every key - query offset
+    float* drel;                  // backward, optional: [buckets][H] += d loss / d rel_emb
+    int nbuckets;
 };
 
+template <bool REL>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tq = a.Tq, Tk = a.Tk, H = a.H, causal = a.causal;
@@ -120,6 +127,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     const unsigned short* kbase = a.k + (long)m * Tk * a.kv_ld + h * ATT_D;
     const unsigned short* vbase = a.v + (long)m * Tk * a.kv_ld + h * ATT_D;
     const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
+    const float sl2 = REL ? a.scale * LOG2EF : SCALE_LOG2E;
+    float* dbias = reinterpret_cast<float*>(lds + 2 * Tkp * 128);    // bias of every diagonal key - query (x log2 e)
+    if (REL)
+        for (int d = tid; d < Tq + Tk - 1; d += ATT_THREADS) dbias[d] = a.rel_emb[a.rel_bucket[d] * H + h] * LOG2EF;
     stage_head(ldsK, kbase, a.kv_ld, Tk, Tkp, tid);
     stage_head(ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
     __syncthreads();
@@ -160,7 +171,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb * 32 + kt * 16 + 4 * g + r;
-                    float v = st[kt][r] * SCALE_LOG2E;
+                    float v = st[kt][r] * sl2;
+                    if (REL) v += dbias[min(max(key - q + Tq - 1, 0), Tq + Tk - 2)];
                     if (key >= kvalid || (causal && key > q)) v = -1e30f;
                     st[kt][r] = v;
                     mx = fmaxf(mx, v);
@@ -203,7 +215,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 
 // Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
 // Phase 2 (per 16-query tile): dQ^T += K^T dS^T with S^T = K Q^T oriented [key][q].
-__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
+template <bool REL>
+__global__ __launch_bounds__(ATT_THREADS, REL ? 2 : 4) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tq = a.Tq, Tk = a.Tk, H = a.H, causal = a.causal;
     const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
@@ -212,6 +225,10 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     char* bufB = lds + Tmax * 128;    // dO, later V
     float* lse2 = reinterpret_cast<float*>(lds + 2 * Tmax * 128);
     float* Dq = lse2 + Tqp;
+    float* dbias = Dq + Tqp;               // [Tq + Tk - 1] bias per diagonal (x log2 e), only with rel_emb
+    float* ddiag = dbias + (Tq + Tk);      // [Tq + Tk - 1] gradient per diagonal
+    const float sl2 = REL ? a.scale * LOG2EF : SCALE_LOG2E;
+    const float oscale = REL ? a.scale : ATT_SCALE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = blockIdx.x / H, h = blockIdx.x % H;
     const unsigned short* qbase = a.q + (long)m * Tq * a.q_ld + h * ATT_D;
@@ -242,6 +259,11 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
         Dq[r] = d;
         lse2[r] = l;
     }
+    if (REL)
+        for (int d = tid; d < Tq + Tk - 1; d += ATT_THREADS) {
+            dbias[d] = a.rel_emb[a.rel_bucket[d] * H + h] * LOG2EF;
+            ddiag[d] = 0.f;
+        }
     stage_head(bufA, qbase, a.q_ld, Tq, Tqp, tid);
     stage_head(bufB, dobase, a.out_ld, Tq, Tqp, tid);
     __syncthreads();
@@ -279,10 +301,13 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = qb * 32 + qt * 16 + 4 * g + r;
-                    float p = __builtin_amdgcn_exp2f(sa[r] * SCALE_LOG2E - lse2[q]);
-                    if (key >= kvalid || (causal && key > q)) p = 0.f;
+                    const int dg = min(max(key - q + Tq - 1, 0), Tq + Tk - 2);
+                    float p = __builtin_amdgcn_exp2f(sa[r] * sl2 + (REL ? dbias[dg] : 0.f) - lse2[q]);
+                    if (key >= kvalid || (causal && key > q) || q >= Tq) p = 0.f;
                     pt[qt][r] = p;
                     dst[qt][r] = p * (dp[r] - Dq[q]);
+                    // d bias = d logits; a wave-instruction touches ~28 distinct diagonals: cheap LDS atomics
+                    if (REL && a.drel && key < Tk && q < Tq) atomicAdd(&ddiag[dg], dst[qt][r]);
                 }
             }
             const bf16x8_t pf = pack8(pt[0], pt[1]), dsf = pack8(dst[0], dst[1]);
@@ -297,7 +322,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
             unsigned short* vrow = dvbase + (long)key * a.dkv_ld;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const f32x4_t x = dk[dt] * ATT_SCALE;
+                const f32x4_t x = dk[dt] * oscale;
                 u32x2_t pk = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
                 *reinterpret_cast<u32x2_t*>(krow + 16 * dt + 4 * g) = pk;
                 u32x2_t pv = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
@@ -337,7 +362,8 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb * 32 + kt * 16 + 4 * g + r;
-                    float p = __builtin_amdgcn_exp2f(sa[r] * SCALE_LOG2E - my_lse);
+                    float p = __builtin_amdgcn_exp2f(
+                        sa[r] * sl2 + (REL ? dbias[min(max(key - q + Tq - 1, 0), Tq + Tk - 2)] : 0.f) - my_lse);
                     if (key >= kvalid || (causal && key > q)) p = 0.f;
                     dst[kt][r] = p * (dp[r] - my_D);
                 }
@@ -350,37 +376,53 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
             unsigned short* qrow = dqbase + (long)q * a.dq_ld;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const f32x4_t x = dq[dt] * ATT_SCALE;
+                const f32x4_t x = dq[dt] * oscale;
                 u32x2_t pk = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
                 *reinterpret_cast<u32x2_t*>(qrow + 16 * dt + 4 * g) = pk;
             }
         }
     }
+    if (REL && a.drel) {      // diagonals -> buckets -> global (one atomic per touched bucket and workgroup)
+        __syncthreads();
+        float* bsum = lse2;     // phase 2 is over: reuse
+        for (int b = tid; b < a.nbuckets; b += ATT_THREADS) bsum[b] = 0.f;
+        __syncthreads();
+        for (int d = tid; d < Tq + Tk - 1; d += ATT_THREADS) atomicAdd(&bsum[a.rel_bucket[d]], ddiag[d]);
+        __syncthreads();
+        for (int b = tid; b < a.nbuckets; b += ATT_THREADS)
+            if (bsum[b] != 0.f) atomicAdd(a.drel + b * H + h, bsum[b]);
+    }
 }
 
 static int launch_attn_fwd(const AttnArgs& a, int batch, hipStream_t st) {
     const int Tkp = (a.Tk + 31) & ~31;
-    const int sm = 2 * Tkp * 128;
+    const int sm = 2 * Tkp * 128 + (a.rel_emb ? (a.Tq + a.Tk) * 4 : 0);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * 512 * 128 + 1024 * 4);
         attr = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
+    if (a.rel_emb) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
 static int launch_attn_bwd(const AttnArgs& a, int batch, hipStream_t st) {
     const int Tqp = (a.Tq + 31) & ~31, Tkp = (a.Tk + 31) & ~31;
     const int Tmax = Tqp > Tkp ? Tqp : Tkp;
-    const int sm = 2 * Tmax * 128 + 2 * Tqp * 4;
+    const int sm = 2 * Tmax * 128 + 2 * Tqp * 4 + (a.rel_emb ? 2 * (a.Tq + a.Tk) * 4 : 0);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * 512 * 128 + 2 * 512 * 4);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * 512 * 128 + 2 * 512 * 4 + 2 * 1024 * 4);
         attr = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
+    if (a.rel_emb) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
+    else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -396,7 +438,7 @@ extern "C" int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32
     a.q = (const unsigned short*)qkv; a.k = a.q + W; a.v = a.q + 2 * W;
     a.q_ld = a.kv_ld = 3 * W;
     a.out = (unsigned short*)out; a.out_ld = W; a.lse = lse; a.klen = nullptr;
-    a.Tq = a.Tk = seq; a.H = heads; a.causal = causal;
+    a.Tq = a.Tk = seq; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
     return launch_attn_fwd(a, batch, (hipStream_t)stream);
 }
 
@@ -413,7 +455,7 @@ extern "C" int uniir_attention_bwd(const void* qkv, const void* out, const void*
     a.q = (const unsigned short*)qkv; a.k = a.q + W; a.v = a.q + 2 * W;
     a.q_ld = a.kv_ld = 3 * W;
     a.out = (unsigned short*)out; a.out_ld = W; a.lse = const_cast<float*>(lse); a.klen = nullptr;
-    a.Tq = a.Tk = seq; a.H = heads; a.causal = causal;
+    a.Tq = a.Tk = seq; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
     a.dout = (const unsigned short*)dout;
     a.dq = (unsigned short*)dqkv; a.dk = a.dq + W; a.dv = a.dq + 2 * W;
     a.dq_ld = a.dkv_ld = 3 * W;
@@ -433,7 +475,7 @@ extern "C" int uniir_attention_fwd_ex(const void* q, int64_t q_ld, const void* k
     AttnArgs a = {};
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
     a.q_ld = q_ld; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = out_ld; a.lse = lse; a.klen = key_len;
-    a.Tq = tq; a.Tk = tk; a.H = heads; a.causal = causal;
+    a.Tq = tq; a.Tk = tk; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
     return launch_attn_fwd(a, batch, (hipStream_t)stream);
 }
 
@@ -451,9 +493,47 @@ extern "C" int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
     a.q_ld = q_ld; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = out_ld;
     a.lse = const_cast<float*>(lse); a.klen = key_len;
-    a.Tq = tq; a.Tk = tk; a.H = heads; a.causal = causal;
+    a.Tq = tq; a.Tk = tk; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
     a.dout = (const unsigned short*)dout;
     a.dq = (unsigned short*)dq; a.dk = (unsigned short*)dk; a.dv = (unsigned short*)dv;
     a.dq_ld = dq_ld; a.dkv_ld = dkv_ld;
+    return launch_attn_bwd(a, batch, (hipStream_t)stream);
+}
+
+// T5-style self-attention for the CLIP_FF fusion stack: logits = scale * q.k + rel_emb[rel_bucket[key - query + seq - 1]][head]
+// (transformers T5Attention: scale 1, bucketed relative position bias shared by all layers), packed qkv like
+// uniir_attention_fwd.  bwd adds d loss / d rel_emb into drel (fp32 [buckets][heads], zero it once per step).
+extern "C" int uniir_attention_rel_fwd(const void* qkv, void* out, float* lse, const float* rel_emb,
+                                       const int32_t* rel_bucket, int32_t nbuckets, float scale, int32_t batch,
+                                       int32_t seq, int32_t heads, void* stream) {
+    if (!qkv || !out || !lse || !rel_emb || !rel_bucket || batch < 0 || heads <= 0 || nbuckets <= 0 || nbuckets > 64)
+        return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (seq < 1 || seq > 512) return UNIIR_ESHAPE;
+    const long W = (long)heads * ATT_D;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)qkv; a.k = a.q + W; a.v = a.q + 2 * W;
+    a.q_ld = a.kv_ld = 3 * W; a.out = (unsigned short*)out; a.out_ld = W; a.lse = lse;
+    a.Tq = a.Tk = seq; a.H = heads; a.causal = 0; a.scale = scale;
+    a.rel_emb = rel_emb; a.rel_bucket = rel_bucket; a.nbuckets = nbuckets;
+    return launch_attn_fwd(a, batch, (hipStream_t)stream);
+}
+
+extern "C" int uniir_attention_rel_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                       const float* rel_emb, const int32_t* rel_bucket, int32_t nbuckets, float scale,
+                                       float* drel, int32_t batch, int32_t seq, int32_t heads, void* stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || !rel_emb || !rel_bucket || batch < 0 || heads <= 0 || nbuckets <= 0 ||
+        nbuckets > 64)
+        return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (seq < 1 || seq > 512) return UNIIR_ESHAPE;
+    const long W = (long)heads * ATT_D;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)qkv; a.k = a.q + W; a.v = a.q + 2 * W;
+    a.q_ld = a.kv_ld = 3 * W; a.out = (unsigned short*)const_cast<void*>(out); a.out_ld = W;
+    a.lse = const_cast<float*>(lse); a.dout = (const unsigned short*)dout;
+    a.dq = (unsigned short*)dqkv; a.dk = a.dq + W; a.dv = a.dq + 2 * W; a.dq_ld = a.dkv_ld = 3 * W;
+    a.Tq = a.Tk = seq; a.H = heads; a.causal = 0; a.scale = scale;
+    a.rel_emb = rel_emb; a.rel_bucket = rel_bucket; a.nbuckets = nbuckets; a.drel = drel;
     return launch_attn_bwd(a, batch, (hipStream_t)stream);
 }

@@ -702,3 +702,41 @@ extern "C" int uniir_softce(const float* sim, const float* sim_m, const float* t
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// [CLIP_FF] mean over the tokens of each item (clip_ff.py:186-191) and its backward.
+//   fwd: out[n][w] = (1/T) sum_t x[n][t][w];  bwd: dx[n][t][w] = dout[n][w] / T (fp32)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void meanpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int W) {
+    const int n = blockIdx.x;
+    const float inv = 1.0f / (float)T;
+    for (int c = threadIdx.x; c < W / 4; c += 256) {
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+        const float* base = x + (long)n * T * W + 4 * c;
+        for (int t = 0; t < T; ++t) s += *reinterpret_cast<const f32x4_t*>(base + (long)t * W);
+        *reinterpret_cast<f32x4_t*>(out + (long)n * W + 4 * c) = s * inv;
+    }
+}
+__global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int T, int W) {
+    const int n = blockIdx.x;
+    const float inv = 1.0f / (float)T;
+    for (int c = threadIdx.x; c < W / 4; c += 256) {
+        const f32x4_t g = *reinterpret_cast<const f32x4_t*>(dout + (long)n * W + 4 * c) * inv;
+        float* base = dx + (long)n * T * W + 4 * c;
+        for (int t = blockIdx.y; t < T; t += gridDim.y) *reinterpret_cast<f32x4_t*>(base + (long)t * W) = g;
+    }
+}
+extern "C" int uniir_meanpool_fwd(const float* x, float* out, int32_t n, int32_t tokens, int32_t width, void* stream) {
+    if (!x || !out || n < 0 || tokens <= 0 || width <= 0 || width % 4) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, out, tokens, width);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+extern "C" int uniir_meanpool_bwd(const float* dout, float* dx, int32_t n, int32_t tokens, int32_t width, void* stream) {
+    if (!dout || !dx || n < 0 || tokens <= 0 || width <= 0 || width % 4) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(n, 8), dim3(256), 0, (hipStream_t)stream, dout, dx, tokens, width);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}

@@ -12,7 +12,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta,
                                                      unsigned short* __restrict__ y_bf16,
                                                      float* __restrict__ y_f32, int rows, int width,
-                                                     float eps) {
+                                                     float eps, int rms) {
+    // rms != 0: T5 / RMS norm (y = gamma * x * rsqrt(mean(x^2) + eps)): no mean subtraction, no beta
     const int lane = threadIdx.x & 63;
     const int nchunk = width >> 2;
     const float inv_w = 1.0f / (float)width;
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
         }
-        const float mean = wave_sum(s) * inv_w;
+        const float mean = rms ? 0.f : wave_sum(s) * inv_w;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 const f32x4_t g = *reinterpret_cast<const f32x4_t*>(gamma + 4 * c);
-                const f32x4_t b = *reinterpret_cast<const f32x4_t*>(beta + 4 * c);
+                const f32x4_t b = rms ? f32x4_t{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4_t*>(beta + 4 * c);
                 const f32x4_t o = (v[i] - mean) * rstd * g + b;
                 if (y_bf16) {
                     u32x2_t pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta,
                                                      float* __restrict__ dx_colsum, int rows, int width,
-                                                     float eps) {
+                                                     float eps, int rms) {
     __shared__ float red[4][64 * 4 * NC];  // per wave staging for the column reduction
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nchunk = width >> 2;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                 }
             }
         }
-        const float mean = wave_sum(s) * inv_w;
+        const float mean = rms ? 0.f : wave_sum(s) * inv_w;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                 s2 += (g[0] * v[i][0] + g[1] * v[i][1]) + (g[2] * v[i][2] + g[3] * v[i][3]);
             }
         }
-        const float c1 = wave_sum(s1) * inv_w, c2 = wave_sum(s2) * inv_w;
+        const float c1 = rms ? 0.f : wave_sum(s1) * inv_w, c2 = wave_sum(s2) * inv_w;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     // block reduction of the per-wave column partials, then one atomic per column per block
     float* mine = &red[w][0];
     for (int pass = 0; pass < (dx_colsum ? 3 : 2); ++pass) {
+        if (pass == 1 && rms) continue;      // no beta
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
@@ -165,18 +167,18 @@ static inline int ln_grid(int rows) {
 
 template <int NC>
 static void launch_ln_fwd(const float* x, long x_stride, const float* gamma, const float* beta, unsigned short* yb,
-                          float* yf, int rows, int width, float eps, hipStream_t st) {
+                          float* yf, int rows, int width, float eps, hipStream_t st, int rms = 0) {
     hipLaunchKernelGGL(ln_fwd_kernel<NC>, dim3(ln_grid(rows)), dim3(256), 0, st, x, x_stride, gamma, beta, yb, yf, rows,
-                       width, eps);
+                       width, eps, rms);
 }
 template <int NC, bool F32>
 static void launch_ln_bwd(const float* x, long x_stride, const float* gamma, const void* dy, const float* dres,
                           float* dx, long dx_stride, unsigned short* dxb, float* dgamma, float* dbeta, float* dxsum,
-                          int rows, int width, float eps, hipStream_t st) {
+                          int rows, int width, float eps, hipStream_t st, int rms = 0) {
     int g = ln_grid(rows);
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL((ln_bwd_kernel<NC, F32>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
-                       dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps);
+                       dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms);
 }
 static inline int ln_nc(int width) {
     const int c = (width / 4 + 63) / 64;
@@ -222,6 +224,48 @@ extern "C" int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float
         default: LNB(8); break;
     }
 #undef LNB
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// RMS norm (transformers T5LayerNorm, used by the CLIP_FF fusion stack): same kernels, rms = 1
+extern "C" int uniir_rmsnorm_fwd(const float* x, int64_t x_stride, const float* gamma, void* y_bf16, float* y_f32,
+                                 int32_t rows, int32_t width, float eps, void* stream) {
+    if (!x || !gamma || (!y_bf16 && !y_f32) || rows < 0) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    if (width % 4 || width > 64 * 4 * LN_MAXC || width <= 0 || x_stride % 4) return UNIIR_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* yb = (unsigned short*)y_bf16;
+    switch (ln_nc(width)) {
+        case 2: launch_ln_fwd<2>(x, x_stride, gamma, nullptr, yb, y_f32, rows, width, eps, st, 1); break;
+        case 3: launch_ln_fwd<3>(x, x_stride, gamma, nullptr, yb, y_f32, rows, width, eps, st, 1); break;
+        case 4: launch_ln_fwd<4>(x, x_stride, gamma, nullptr, yb, y_f32, rows, width, eps, st, 1); break;
+        default: launch_ln_fwd<8>(x, x_stride, gamma, nullptr, yb, y_f32, rows, width, eps, st, 1); break;
+    }
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+extern "C" int uniir_rmsnorm_bwd(const float* x, int64_t x_stride, const float* gamma, const void* dy, int32_t dy_is_f32,
+                                 const float* dres, float* dx_f32, int64_t dx_stride, void* dx_bf16, float* dgamma,
+                                 int32_t rows, int32_t width, float eps, void* stream) {
+    if (!x || !gamma || !dy || !dx_f32 || !dgamma || rows < 0) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    if (width % 4 || width > 64 * 4 * LN_MAXC || width <= 0 || x_stride % 4 || dx_stride % 4) return UNIIR_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* dxb = (unsigned short*)dx_bf16;
+#define RMSB(NC)                                                                                                       \
+    do {                                                                                                               \
+        if (dy_is_f32) launch_ln_bwd<NC, true>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, nullptr, nullptr, rows, width, eps, st, 1); \
+        else launch_ln_bwd<NC, false>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, nullptr, nullptr, rows, width, eps, st, 1);          \
+    } while (0)
+    switch (ln_nc(width)) {
+        case 2: RMSB(2); break;
+        case 3: RMSB(3); break;
+        case 4: RMSB(4); break;
+        default: RMSB(8); break;
+    }
+#undef RMSB
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
