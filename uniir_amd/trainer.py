@@ -20,8 +20,13 @@ class NativeAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics over the CLIP module's flat parameter buffer (two groups: [0, split) without weight
     decay, [split, total) with).  It is a real torch Optimizer (param_groups / lr schedulers / state_dict work)."""
 
-    def __init__(self, clip_model, lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2, allreduce=True):
+    def __init__(self, clip_model, lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2, allreduce=True, extra=None):
+        """extra: further flat parameter stores, each one param group of its own -- objects with .params (list of
+        nn.Parameter), .store() (-> FlatStore with p32 / g32 / w16_buf / total), .weight_decay and .lr (CLIP_FF's T5
+        stack: clip_featurefusion/train.py:52-61 gives it weight decay 0.2 on everything and its own learning rate)"""
         self.clip = clip_model
+        self.extra = list(extra or [])
+        self.extra_mv = [None] * len(self.extra)
         if hasattr(clip_model, "optimizer_groups"):      # e.g. BLIPFeatureFusion: one group, uniform weight decay
             nd, d = clip_model.optimizer_groups()
         else:
@@ -29,8 +34,9 @@ class NativeAdamW(torch.optim.Optimizer):
             named = list(clip_model.named_parameters())
             nd = [p for n, p in named if _is_no_decay(n, p)]
             d = [p for n, p in named if not _is_no_decay(n, p)]
-        super().__init__([{"params": nd, "weight_decay": 0.0}, {"params": d, "weight_decay": weight_decay}],
-                         dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        groups = [{"params": nd, "weight_decay": 0.0}, {"params": d, "weight_decay": weight_decay}]
+        groups += [{"params": e.params, "weight_decay": e.weight_decay, "lr": e.lr} for e in self.extra]
+        super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.allreduce = allreduce
         self.m = self.v = None
         self.opt_step = 0
@@ -60,18 +66,31 @@ class NativeAdamW(torch.optim.Optimizer):
                          fl["w16"][lo:hi], hi - lo, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                          self.opt_step, 1.0 / world)
         self.clip._refresh_conv()
+        for i, (e, group) in enumerate(zip(self.extra, self.param_groups[2:])):
+            st = e.store()
+            if self.extra_mv[i] is None or self.extra_mv[i][0].numel() != st.total:
+                self.extra_mv[i] = (torch.zeros_like(st.p32), torch.zeros_like(st.p32))
+            if world > 1:
+                comm.allreduce_sum_(st.g32)
+            b1, b2 = group["betas"]
+            m, v = self.extra_mv[i]
+            ops.call("uniir_adamw_step", st.p32, st.g32, m, v, st.w16_buf, st.total, float(group["lr"]), b1, b2,
+                     group["eps"], group["weight_decay"], self.opt_step, 1.0 / world)
 
     def zero_grad(self, set_to_none=False):
         self.clip._ensure_flat()
         self.clip.zero_grad()
+        for e in self.extra:
+            e.store().g32.zero_()
 
     def state_dict(self):
-        return {"opt_step": self.opt_step, "exp_avg": self.m, "exp_avg_sq": self.v,
+        return {"opt_step": self.opt_step, "exp_avg": self.m, "exp_avg_sq": self.v, "extra": self.extra_mv,
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         self.opt_step = sd["opt_step"]
         self.m, self.v = sd["exp_avg"], sd["exp_avg_sq"]
+        self.extra_mv = list(sd.get("extra", self.extra_mv))
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
 
