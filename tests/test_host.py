@@ -137,3 +137,25 @@ def test_blip_front_pos_embed_and_transforms():
     for train in (False, True):
         t = blip_front.get_blip_transform(32, is_train=train)(img)
         assert t.shape == (3, 32, 32) and abs(t[0].mean().item() - (1 - 0.48145466) / 0.26862954) < 1e-4
+
+
+def test_clip_ff_state_dict_layout_and_t5_group():
+    """checkpoint layout of the reference's CLIPFeatureFusion: clip_model.* without text_projection, t5_layers.block...;
+    every T5 parameter forms the third optimizer group"""
+    from models.uniir_clip.clip_featurefusion.clip_ff import CLIPFeatureFusion
+    m = CLIPFeatureFusion("ViT-B/32", device="cpu")
+    keys = set(m.state_dict().keys())
+    assert "clip_model.text_projection" not in keys and "clip_model.visual.proj" in keys
+    for k in ("t5_layers.block.0.layer.0.SelfAttention.q.weight", "t5_layers.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
+              "t5_layers.block.1.layer.1.DenseReluDense.wo.weight", "t5_layers.final_layer_norm.weight"):
+        assert k in keys, k
+    assert "t5_layers.block.1.layer.0.SelfAttention.relative_attention_bias.weight" not in keys
+    assert m.state_dict()["t5_layers.block.0.layer.0.SelfAttention.q.weight"].shape == (768, 512)     # 12 heads x 64, d_model 512
+    assert m.state_dict()["t5_layers.block.0.layer.1.DenseReluDense.wi.weight"].shape == (2048, 512)
+    grp = m.t5_optimizer_group(lr=1e-4)
+    assert len(grp.params) == 18 and sum(p.numel() for p in grp.params) == sum(v.numel() for k, v in m.state_dict().items() if k.startswith("t5_layers."))
+    with pytest.raises(RuntimeError):
+        grp.store()            # no CPU product path
+    from uniir_amd.clipff_model import rel_bucket_table
+    t = rel_bucket_table(334)
+    assert t.shape == (667,) and int(t[333]) == 0 and int(t[334]) == 17 and int(t[332]) == 1 and int(t.max()) == 31 and int(t[0]) == 15

@@ -1,5 +1,5 @@
 """Model factory and file helpers (drop-in for UniIR src/common/utils.py: load_qrel :16-31, load_runfile :35-65,
-build_model_from_config :64-153, set_seed).  CLIPScoreFusion and BLIPFeatureFusion are built on the MI355X path."""
+build_model_from_config :64-153, set_seed).  CLIPScoreFusion, CLIPFeatureFusion and BLIPFeatureFusion are built on the MI355X path."""
 import os
 import random
 
@@ -58,10 +58,13 @@ def build_model_from_config(config):
         print(f"loading BLIPFeatureFusion checkpoint from {path}")
         model.load_state_dict(torch.load(path, map_location="cpu")["model"])
         return model
-    if name != "CLIPScoreFusion":
-        raise NotImplementedError(f"{name}: CLIPScoreFusion and BLIPFeatureFusion are on the MI355X hot path "
-                                  "(CLIP_FF / BLIP_SF are listed as next in DESIGN.md)")
-    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    if name not in ("CLIPScoreFusion", "CLIPFeatureFusion"):
+        raise NotImplementedError(f"{name}: CLIPScoreFusion, CLIPFeatureFusion and BLIPFeatureFusion are on the MI355X "
+                                  "hot path (BLIP_SF is listed as next in DESIGN.md)")
+    if name == "CLIPFeatureFusion":
+        from models.uniir_clip.clip_featurefusion.clip_ff import CLIPFeatureFusion as CLIPScoreFusion
+    else:
+        from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
     mc = config.model
     download_root = os.path.join(config.uniir_dir, mc.pretrained_clip_model_dir)
     model = CLIPScoreFusion(model_name=mc.clip_vision_model_name, download_root=download_root)
@@ -69,6 +72,6 @@ def build_model_from_config(config):
     ckpt = mc.ckpt_config
     path = os.path.join(config.uniir_dir, ckpt.ckpt_dir, ckpt.ckpt_name)
     assert os.path.exists(path), f"Checkpoint file {path} does not exist."
-    print(f"loading CLIPScoreFusion checkpoint from {path}")
+    print(f"loading {name} checkpoint from {path}")
     model.load_state_dict(torch.load(path, map_location="cpu")["model"])
     return model

@@ -121,7 +121,8 @@ class NativeTrainer:
                  accumulation_steps=1):
         self.model = model
         self.clip = model.clip_model
-        self.opt = NativeAdamW(self.clip, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        extra = [model.t5_optimizer_group(lr=lr, weight_decay=weight_decay)] if hasattr(model, "t5_optimizer_group") else None
+        self.opt = NativeAdamW(self.clip, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, extra=extra)
         self.sched = CosineLR(self.opt, t_total)
         self.accum = accumulation_steps
         self.micro = 0
