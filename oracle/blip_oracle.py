@@ -75,12 +75,15 @@ def bert_forward(sd, ids, mask, enc_hidden, cfg, prefix=""):
         ctx = _attn(sd, b + "attention.self.", h, h, heads, add_mask)
         h = _ln(ctx @ sd[b + "attention.output.dense.weight"].t() + sd[b + "attention.output.dense.bias"] + h,
                 sd[b + "attention.output.LayerNorm.weight"], sd[b + "attention.output.LayerNorm.bias"], eps)
-        ctx = _attn(sd, b + "crossattention.self.", h, enc_hidden, heads, None)   # image attention mask is all ones
-        h = _ln(ctx @ sd[b + "crossattention.output.dense.weight"].t() + sd[b + "crossattention.output.dense.bias"] + h,
-                sd[b + "crossattention.output.LayerNorm.weight"], sd[b + "crossattention.output.LayerNorm.bias"], eps)
+        if enc_hidden is not None:      # mode "multimodal"; mode "text" (BLIP_SF) skips the cross-attention sublayer
+            ctx = _attn(sd, b + "crossattention.self.", h, enc_hidden, heads, None)   # image attention mask is all ones
+            h = _ln(ctx @ sd[b + "crossattention.output.dense.weight"].t() + sd[b + "crossattention.output.dense.bias"] + h,
+                    sd[b + "crossattention.output.LayerNorm.weight"], sd[b + "crossattention.output.LayerNorm.bias"], eps)
         f = F.gelu(h @ sd[b + "intermediate.dense.weight"].t() + sd[b + "intermediate.dense.bias"])
         h = _ln(f @ sd[b + "output.dense.weight"].t() + sd[b + "output.dense.bias"] + h,
                 sd[b + "output.LayerNorm.weight"], sd[b + "output.LayerNorm.bias"], eps)
+    if p + "pooler.dense.weight" not in sd:      # add_pooling_layer=False (BLIP_SF)
+        return h, None
     pooled = torch.tanh(h[:, 0] @ sd[p + "pooler.dense.weight"].t() + sd[p + "pooler.dense.bias"])
     return h, pooled
 
@@ -93,9 +96,19 @@ def encode_multimodal_input(sd, ids, mask, images, vit_cfg, med_cfg, momentum=Fa
     return bert_forward(sd, ids, mask, img, med_cfg, prefix=f"text_encoder{sfx}.")[1]
 
 
+def encode_multimodal_input_sf(sd, ids, mask, images, txt_mask, img_mask, vit_cfg, med_cfg, momentum=False):
+    """blip_scorefusion/blip_sf.py:97-172: text_proj(BERT mode "text" [:,0]) * txt_mask + vision_proj(ViT [:,0]) * img_mask"""
+    sfx = "_m" if momentum else ""
+    tfeat = bert_forward(sd, ids, mask, None, med_cfg, prefix=f"text_encoder{sfx}.")[0][:, 0]
+    temb = tfeat @ sd[f"text_proj{sfx}.weight"].t() + sd[f"text_proj{sfx}.bias"]
+    ifeat = vit_forward(sd, images, vit_cfg, prefix=f"visual_encoder{sfx}.")[:, 0]
+    iemb = ifeat @ sd[f"vision_proj{sfx}.weight"].t() + sd[f"vision_proj{sfx}.bias"]
+    return temb * txt_mask.unsqueeze(-1) + iemb * img_mask.unsqueeze(-1)
+
+
 def momentum_update(sd, m):
     for k in list(sd.keys()):
-        for enc in ("visual_encoder", "text_encoder"):
+        for enc in ("visual_encoder", "text_encoder", "vision_proj", "text_proj"):
             if k.startswith(enc + "."):
                 km = enc + "_m." + k[len(enc) + 1:]
                 if km in sd and sd[km].dtype.is_floating_point:
@@ -113,7 +126,11 @@ def contrastive_loss(sd, state, batch, alpha, vit_cfg, med_cfg, momentum):
     ids, mask, img = batch["ids"], batch["mask"], batch["img"]
     im = batch["index_mapping"]
     hard = "neg_cand_list" in im
-    emb = encode_multimodal_input(sd, ids, mask, img, vit_cfg, med_cfg)
+    if "tmask" in batch:     # BLIP_SF: score-level fusion of separately encoded text / image (same loss)
+        enc = lambda mom: encode_multimodal_input_sf(sd, ids, mask, img, batch["tmask"], batch["imask"], vit_cfg, med_cfg, mom)
+    else:
+        enc = lambda mom: encode_multimodal_input(sd, ids, mask, img, vit_cfg, med_cfg, mom)
+    emb = enc(False)
     qi = torch.tensor(im["query"]).flatten()
     pi = torch.tensor(im["pos_cand"]).flatten()
     q = F.normalize(emb[qi], dim=-1)
@@ -130,7 +147,7 @@ def contrastive_loss(sd, state, batch, alpha, vit_cfg, med_cfg, momentum):
     tgt = pos / pos.sum(1, keepdim=True)
     with torch.no_grad():
         momentum_update(sd, momentum)
-        emb_m = encode_multimodal_input(sd, ids, mask, img, vit_cfg, med_cfg, momentum=True)
+        emb_m = enc(True)
         q_m = F.normalize(emb_m[qi], dim=-1)
         p_m = F.normalize(emb_m[pi], dim=-1)
         q_m_all = torch.cat([q_m.t(), state["query_queue"].clone()], dim=1)

@@ -290,6 +290,79 @@ def g8h():
     print("g8h ok", steps)
 
 
+def g8s():
+    """BLIPScoreFusion (blip_scorefusion/blip_sf.py): ViT cls -> vision_proj, BERT mode="text" cls -> text_proj, masked
+    sum, then the same momentum / queue loss; two steps with a text-only and an image-only item in the batch"""
+    import torch.distributed as dist
+    from models.uniir_blip.backbone import med
+    from models.uniir_blip.backbone.vit import VisionTransformer
+    from models.uniir_blip.blip_scorefusion import blip_sf
+    med.BertPreTrainedModel.init_weights = lambda s: s.apply(s._init_weights)
+    med.BertPreTrainedModel.get_head_mask = lambda s, h, n, *a, **k: [None] * n
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29549")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    blip_sf.create_vit = lambda vit, image_size, *a, **k: (VisionTransformer(**TINY_VIT), TINY_VIT["embed_dim"])
+    blip_sf.init_tokenizer = lambda: None
+    cfg_path = os.path.join("/tmp", "tiny_med_config.json")
+    json.dump(TINY_MED, open(cfg_path, "w"))
+    torch.manual_seed(281)
+    E, K, b = 64, 16, 4
+    model = blip_sf.BLIPScoreFusion(med_config=cfg_path, image_size=32, vit="base", embed_dim=E, queue_size=K,
+                                    momentum=0.9, config=types.SimpleNamespace(tokenizer_max_length=20))
+    perturb(model.visual_encoder, 282)
+    perturb(model.text_encoder, 283)
+    perturb(model.vision_proj, 284)
+    perturb(model.text_proj, 285)
+    model.copy_params()
+    model.train()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    M = 2 * b
+    out = {}
+    steps = []
+    for step, alpha in enumerate([0.0, 0.4]):
+        ids, mask, _ = med_inputs(290 + step, n=M, L=20)
+        img = torch.randn(M, 3, 32, 32, generator=torch.Generator().manual_seed(295 + step))
+        tmask, imask = torch.ones(M, dtype=torch.long), torch.ones(M, dtype=torch.long)
+        tmask[3] = 0      # image-only item
+        imask[4] = 0      # text-only item
+        batch = {
+            "txt_batched": types.SimpleNamespace(input_ids=ids, attention_mask=mask),
+            "image_batched": img, "txt_mask_batched": tmask, "image_mask_batched": imask,
+            "p_did_list": torch.tensor([7, 8, 7, 9]) + 10 * step,
+            "index_mapping": {"query": [[2 * i] for i in range(b)], "pos_cand": [[2 * i + 1] for i in range(b)]},
+        }
+        model.zero_grad()
+        res = model(batch, alpha=alpha)
+        res["loss"].backward()
+        steps.append((res["loss"].item(), res["accuracy"].item()))
+        out.update({f"s{step}_ids": ids.numpy(), f"s{step}_mask": mask.numpy(), f"s{step}_img": img.numpy(),
+                    f"s{step}_tmask": tmask.numpy(), f"s{step}_imask": imask.numpy(),
+                    f"s{step}_pdid": batch["p_did_list"].numpy(), f"s{step}_alpha": alpha,
+                    f"s{step}_loss": res["loss"].item(), f"s{step}_acc": res["accuracy"].item(),
+                    f"s{step}_dtemp": model.temp.grad.numpy(),
+                    f"s{step}_g_vit_qkv0": model.visual_encoder.blocks[0].attn.qkv.weight.grad.numpy(),
+                    f"s{step}_g_txt_q0": model.text_encoder.encoder.layer[0].attention.self.query.weight.grad.numpy(),
+                    f"s{step}_g_vproj": model.vision_proj.weight.grad.numpy(), f"s{step}_g_tprojb": model.text_proj.bias.grad.numpy(),
+                    f"s{step}_query_queue": model.query_queue.numpy().copy(), f"s{step}_cand_queue": model.cand_queue.numpy().copy(),
+                    f"s{step}_idx_queue": model.idx_queue.numpy().copy(), f"s{step}_ptr": model.new_ptr_queue.numpy().copy(),
+                    f"s{step}_m_vproj": model.vision_proj_m.weight.detach().numpy().copy()})
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.grad is not None:
+                    p.add_(-0.05 * p.grad)
+    assert model.text_encoder.encoder.layer[0].crossattention.self.query.weight.grad is None
+    for k, v in sd0.items():
+        if "_m." in k:
+            continue
+        if v.dtype.is_floating_point or k.endswith("idx_queue") or k.endswith("new_ptr_queue"):
+            out[f"sd0::{k}"] = v.numpy()
+    out.update(med_cfg=json.dumps(TINY_MED), vit_cfg=json.dumps(TINY_VIT), queue_size=K, momentum=0.9, embed_dim=E)
+    np.savez_compressed(os.path.join(HERE, "g8s_blipsf.npz"), **out)
+    print("g8s ok", steps)
+
+
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
