@@ -198,3 +198,58 @@ def test_g8h_blip_ff_hard_negatives():
             for n, p in model._online_params():
                 if n != "temp":
                     p.add_(-0.05 * p.grad)
+
+
+def test_g8s_blip_sf_two_training_steps():
+    """BLIPScoreFusion against the reference golden G8s: projections, masked sum (one image-only and one text-only item),
+    momentum of the projection heads, frozen cross-attention untouched by AdamW"""
+    from uniir_amd.blip_model import BLIPScoreFusion
+    from uniir_amd.trainer import NativeAdamW
+    z = np.load(os.path.join(G, "g8s_blipsf.npz"))
+    med_cfg, vit_cfg = json.loads(str(z["med_cfg"])), json.loads(str(z["vit_cfg"]))
+    model = BLIPScoreFusion(med_config=med_cfg, vit_config=vit_cfg, embed_dim=int(z["embed_dim"]), queue_size=int(z["queue_size"]),
+                            momentum=float(z["momentum"]), config=types.SimpleNamespace(tokenizer_max_length=20))
+    load_sub(model, z, "sd0::", "")
+    model.copy_params()
+    model = model.cuda()
+    model.train()
+    frozen = "text_encoder.encoder.layer.0.crossattention.self.query.weight"
+    assert not model.get_parameter(frozen).requires_grad
+    for step in range(2):
+        b = len(z[f"s{step}_pdid"])
+        batch = {
+            "txt_batched": types.SimpleNamespace(input_ids=torch.from_numpy(z[f"s{step}_ids"]).cuda(),
+                                                 attention_mask=torch.from_numpy(z[f"s{step}_mask"]).cuda()),
+            "image_batched": torch.from_numpy(z[f"s{step}_img"]).cuda(),
+            "txt_mask_batched": torch.from_numpy(z[f"s{step}_tmask"]).cuda(),
+            "image_mask_batched": torch.from_numpy(z[f"s{step}_imask"]).cuda(),
+            "p_did_list": torch.from_numpy(z[f"s{step}_pdid"]),
+            "index_mapping": {"query": [[2 * i] for i in range(b)], "pos_cand": [[2 * i + 1] for i in range(b)]},
+        }
+        model.zero_grad()
+        out = model(batch, alpha=float(z[f"s{step}_alpha"]))
+        out["loss"].backward()
+        assert abs(out["loss"].item() - float(z[f"s{step}_loss"])) < 2e-2, (out["loss"].item(), float(z[f"s{step}_loss"]))
+        assert out["accuracy"].item() == float(z[f"s{step}_acc"])
+        assert rel(model.query_queue, z[f"s{step}_query_queue"]) < 2e-2
+        assert np.array_equal(model.idx_queue.cpu().numpy(), z[f"s{step}_idx_queue"])
+        # (step 1 averages weights that were nudged with the device gradients: bf16-level differences)
+        assert rel(model.get_parameter("vision_proj_m.weight"), z[f"s{step}_m_vproj"]) < 2e-4
+        for name, key in (("visual_encoder.blocks.0.attn.qkv.weight", "g_vit_qkv0"),
+                          ("text_encoder.encoder.layer.0.attention.self.query.weight", "g_txt_q0"),
+                          ("vision_proj.weight", "g_vproj"), ("text_proj.bias", "g_tprojb")):
+            r = rel(model.get_parameter(name).grad, z[f"s{step}_{key}"])
+            assert r < 8e-2, (step, name, r)
+        with torch.no_grad():   # the fixture nudges every parameter that received a gradient (temp included)
+            for n, p in model._online_params():
+                if n not in model._frozen:
+                    p.add_(-0.05 * p.grad)
+    # the optimizer must leave the frozen cross-attention (and its weight decay) alone
+    opt = NativeAdamW(model, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.5, allreduce=False)
+    w_frozen = model.get_parameter(frozen).detach().clone()
+    w_proj = model.get_parameter("text_proj.weight").detach().clone()
+    t0 = model.temp.detach().clone()
+    opt.step()
+    assert torch.equal(model.get_parameter(frozen).detach(), w_frozen)
+    assert (model.get_parameter("text_proj.weight").detach() - w_proj).abs().max().item() > 1e-4
+    assert model.temp.item() != t0.item()

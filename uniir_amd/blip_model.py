@@ -50,7 +50,7 @@ def vit_param_shapes(cfg, img_size):
     return out
 
 
-def bert_param_shapes(cfg, enc_width):
+def bert_param_shapes(cfg, enc_width, pooler=True):
     """flat order: query/key/value weights (and biases) adjacent, so one [3W,W] (self) / [2W,enc] (cross) GEMM serves them"""
     W, I = cfg["hidden_size"], cfg["intermediate_size"]
     out = [("embeddings.word_embeddings.weight", (cfg["vocab_size"], W)),
@@ -71,7 +71,8 @@ def bert_param_shapes(cfg, enc_width):
                 (b + "intermediate.dense.weight", (I, W)), (b + "intermediate.dense.bias", (I,)),
                 (b + "output.dense.weight", (W, I)), (b + "output.dense.bias", (W,)),
                 (b + "output.LayerNorm.weight", (W,)), (b + "output.LayerNorm.bias", (W,))]
-    out += [("pooler.dense.weight", (W, W)), ("pooler.dense.bias", (W,))]
+    if pooler:
+        out += [("pooler.dense.weight", (W, W)), ("pooler.dense.bias", (W,))]
     return out
 
 
@@ -181,9 +182,11 @@ def _ln2(st, x, wname, eps, R, W):
     return o32, o16
 
 
-def bert_forward(st, prefix, cfg, ids, key_len, img16, Ti, save):
+def bert_forward(st, prefix, cfg, ids, key_len, img16, Ti, save, cross=True, pool=True):
     """src/models/uniir_blip/backbone/med.py BertModel.forward(mode="multimodal") -> pooler_output fp32 [M,W] + stash.
-    ids int32 [M,L]; key_len int32 [M]; img16 bf16 [M*Ti, enc_width] (image attention mask all ones, blip_ff.py:98,108)"""
+    ids int32 [M,L]; key_len int32 [M]; img16 bf16 [M*Ti, enc_width] (image attention mask all ones, blip_ff.py:98,108).
+    cross=False: mode "text" (the cross-attention sublayer is skipped, BLIP_SF); pool=False: add_pooling_layer=False, the
+    class-token row of last_hidden_state is returned instead of the tanh pooler output."""
     W, I, eps = cfg["hidden_size"], cfg["intermediate_size"], cfg["layer_norm_eps"]
     heads, layers = cfg["num_attention_heads"], cfg["num_hidden_layers"]
     M, L = ids.shape
@@ -203,12 +206,16 @@ def bert_forward(st, prefix, cfg, ids, key_len, img16, Ti, save):
         t1 = ops.linear_fwd(ao, st.w16(b + "attention.output.dense.weight"), st.p(b + "attention.output.dense.bias"),
                             epilogue=ops.EPI_RESID_F32, resid=h32)
         a32, a16 = _ln2(st, t1, b + "attention.output.LayerNorm.", eps, R, W)
-        cq = ops.linear_fwd(a16, st.w16(c + "query.weight"), st.p(c + "query.bias"))
-        ckv = ops.linear_fwd(img16, st.w16(c + "key.weight", (2 * W, img16.shape[1])), st.p(c + "key.bias", (2 * W,)))
-        co, lse2 = ops.attention_fwd_ex(cq, W, ckv, ckv[:, W:], 2 * W, M, L, Ti, heads)
-        t2 = ops.linear_fwd(co, st.w16(b + "crossattention.output.dense.weight"),
-                            st.p(b + "crossattention.output.dense.bias"), epilogue=ops.EPI_RESID_F32, resid=a32)
-        c32, c16 = _ln2(st, t2, b + "crossattention.output.LayerNorm.", eps, R, W)
+        cq = ckv = co = lse2 = t2 = None
+        if cross:
+            cq = ops.linear_fwd(a16, st.w16(c + "query.weight"), st.p(c + "query.bias"))
+            ckv = ops.linear_fwd(img16, st.w16(c + "key.weight", (2 * W, img16.shape[1])), st.p(c + "key.bias", (2 * W,)))
+            co, lse2 = ops.attention_fwd_ex(cq, W, ckv, ckv[:, W:], 2 * W, M, L, Ti, heads)
+            t2 = ops.linear_fwd(co, st.w16(b + "crossattention.output.dense.weight"),
+                                st.p(b + "crossattention.output.dense.bias"), epilogue=ops.EPI_RESID_F32, resid=a32)
+            c32, c16 = _ln2(st, t2, b + "crossattention.output.LayerNorm.", eps, R, W)
+        else:
+            c32, c16 = a32, a16
         f = torch.empty(R, I, device=dev, dtype=torch.bfloat16)
         ops.linear_fwd(c16, st.w16(b + "intermediate.dense.weight"), st.p(b + "intermediate.dense.bias"), out=f,
                        epilogue=ops.EPI_BIAS_ACT, C2=g, act=ops.ACT_GELU_ERF)
@@ -220,6 +227,8 @@ def bert_forward(st, prefix, cfg, ids, key_len, img16, Ti, save):
         h32, h16 = _ln2(st, t3, b + "output.LayerNorm.", eps, R, W)
     rows = torch.empty(M, W, device=dev, dtype=torch.float32)
     ops.call("uniir_gather_rows", h32, None, rows, M, L, W)
+    if not pool:
+        return rows, stash
     rows16 = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
     ops.call("uniir_cast_f32_to_bf16", rows, rows16, rows.numel())
     pre = ops.linear_fwd(rows16, st.w16(prefix + "pooler.dense.weight"), st.p(prefix + "pooler.dense.bias"),
@@ -231,8 +240,9 @@ def bert_forward(st, prefix, cfg, ids, key_len, img16, Ti, save):
     return pooled, stash
 
 
-def bert_backward(st, prefix, cfg, dpooled, stash):
-    """returns d(img tokens) fp32 [M*Ti, enc_width]; parameter gradients accumulate into st.g32"""
+def bert_backward(st, prefix, cfg, dpooled, stash, cross=True, pool=True):
+    """returns d(img tokens) fp32 [M*Ti, enc_width] (None without cross-attention); parameter gradients accumulate into
+    st.g32.  dpooled: gradient of what bert_forward returned (pooler output, or the class-token rows with pool=False)"""
     W, I, eps = cfg["hidden_size"], cfg["intermediate_size"], cfg["layer_norm_eps"]
     heads, layers = cfg["num_attention_heads"], cfg["num_hidden_layers"]
     M, L, Ti, key_len, img16 = stash["M"], stash["L"], stash["Ti"], stash["key_len"], stash["img16"]
@@ -244,6 +254,22 @@ def bert_backward(st, prefix, cfg, dpooled, stash):
     def colsum(x, cols, name, shape=None):
         ops.call("uniir_colsum_bf16", x, cols, G(name, shape), x.shape[0], cols)
 
+    if not pool:
+        drows = dpooled.contiguous().float()
+    else:
+        drows = _pooler_backward(st, prefix, dpooled, stash, M, W, colsum)
+    do = torch.zeros(R, W, **f32)
+    ops.call("uniir_scatter_rows", drows, None, do, M, L, W)
+    dimg = torch.zeros(M * Ti, img16.shape[1], **f32) if cross else None
+    g = torch.empty(R, I, **b16)
+    return _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum)
+
+
+def _pooler_backward(st, prefix, dpooled, stash, M, W, colsum):
+    dev = dpooled.device
+    G = st.grad_view
+    f32 = dict(device=dev, dtype=torch.float32)
+    b16 = dict(device=dev, dtype=torch.bfloat16)
     # pooler: pooled = tanh(rows @ Wp^T + bp)
     dpre = torch.empty(M, W, **f32)
     ops.call("uniir_tanh_bwd", stash["pooled"], dpooled.contiguous(), dpre, dpre.numel())
@@ -253,10 +279,17 @@ def bert_backward(st, prefix, cfg, dpooled, stash):
     colsum(dpre16, W, prefix + "pooler.dense.bias")
     drows = torch.empty(M, W, **f32)
     ops.gemm(dpre16, st.w16(prefix + "pooler.dense.weight"), drows, M, W, W, W, W, W, b_tmaj=True, epilogue=ops.EPI_F32)
-    do = torch.zeros(R, W, **f32)
-    ops.call("uniir_scatter_rows", drows, None, do, M, L, W)
-    dimg = torch.zeros(M * Ti, img16.shape[1], **f32)
-    g = torch.empty(R, I, **b16)
+    return drows
+
+
+def _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum):
+    W, I, eps = cfg["hidden_size"], cfg["intermediate_size"], cfg["layer_norm_eps"]
+    heads, layers = cfg["num_attention_heads"], cfg["num_hidden_layers"]
+    M, L, Ti, key_len, img16 = stash["M"], stash["L"], stash["Ti"], stash["key_len"], stash["img16"]
+    R, dev = M * L, do.device
+    G = st.grad_view
+    f32 = dict(device=dev, dtype=torch.float32)
+    b16 = dict(device=dev, dtype=torch.bfloat16)
     for i in reversed(range(layers)):
         b = f"{prefix}encoder.layer.{i}."
         s, c = b + "attention.self.", b + "crossattention.self."
@@ -275,28 +308,31 @@ def bert_backward(st, prefix, cfg, dpooled, stash):
         dc = torch.empty(R, W, **f32)       # d c32 = df @ Wi + dt3 (the residual branch)
         ops.gemm(df, st.w16(b + "intermediate.dense.weight"), dc, R, W, I, I, W, W, b_tmaj=True,
                  epilogue=ops.EPI_RESID_F32, resid=dt3)
-        # ---- cross-attention sublayer: c = LN(co @ Wco^T + bco + a32)
-        dt2 = ops.layernorm_bwd(sv["t2"], st.p(b + "crossattention.output.LayerNorm.weight"), dc,
-                                G(b + "crossattention.output.LayerNorm.weight"),
-                                G(b + "crossattention.output.LayerNorm.bias"), eps, dx_bf16=d16, rows=R, width=W)
-        ops.linear_wgrad(d16, sv["co"], G(b + "crossattention.output.dense.weight"))
-        colsum(d16, W, b + "crossattention.output.dense.bias")
-        dco = ops.linear_dgrad(d16, st.w16(b + "crossattention.output.dense.weight"))
-        dcq = torch.empty(R, W, **b16)
-        dckv = torch.empty(M * Ti, 2 * W, **b16)
-        ckv = sv["ckv"]
-        ops.attention_bwd_ex(sv["cq"], W, ckv, ckv[:, W:], 2 * W, sv["co"], dco, sv["lse2"], dcq, W, dckv, dckv[:, W:],
-                             2 * W, M, L, Ti, heads)
-        Ew = img16.shape[1]
-        ops.linear_wgrad(dckv, img16, G(c + "key.weight", (2 * W, Ew)))
-        colsum(dckv, 2 * W, c + "key.bias", (2 * W,))
-        ops.gemm(dckv, st.w16(c + "key.weight", (2 * W, Ew)), dimg, M * Ti, Ew, 2 * W, 2 * W, Ew, Ew, b_tmaj=True,
-                 epilogue=ops.EPI_RESID_F32, resid=dimg)          # dimg += dckv @ Wkv (in place: same element r/w)
-        ops.linear_wgrad(dcq, sv["a16"], G(c + "query.weight"))
-        colsum(dcq, W, c + "query.bias")
-        da = torch.empty(R, W, **f32)       # d a32 = dcq @ Wcq + dt2
-        ops.gemm(dcq, st.w16(c + "query.weight"), da, R, W, W, W, W, W, b_tmaj=True, epilogue=ops.EPI_RESID_F32,
-                 resid=dt2)
+        if not cross:
+            da = dc                      # mode "text": c32 is a32
+        else:
+            # ---- cross-attention sublayer: c = LN(co @ Wco^T + bco + a32)
+            dt2 = ops.layernorm_bwd(sv["t2"], st.p(b + "crossattention.output.LayerNorm.weight"), dc,
+                                    G(b + "crossattention.output.LayerNorm.weight"),
+                                    G(b + "crossattention.output.LayerNorm.bias"), eps, dx_bf16=d16, rows=R, width=W)
+            ops.linear_wgrad(d16, sv["co"], G(b + "crossattention.output.dense.weight"))
+            colsum(d16, W, b + "crossattention.output.dense.bias")
+            dco = ops.linear_dgrad(d16, st.w16(b + "crossattention.output.dense.weight"))
+            dcq = torch.empty(R, W, **b16)
+            dckv = torch.empty(M * Ti, 2 * W, **b16)
+            ckv = sv["ckv"]
+            ops.attention_bwd_ex(sv["cq"], W, ckv, ckv[:, W:], 2 * W, sv["co"], dco, sv["lse2"], dcq, W, dckv, dckv[:, W:],
+                                 2 * W, M, L, Ti, heads)
+            Ew = img16.shape[1]
+            ops.linear_wgrad(dckv, img16, G(c + "key.weight", (2 * W, Ew)))
+            colsum(dckv, 2 * W, c + "key.bias", (2 * W,))
+            ops.gemm(dckv, st.w16(c + "key.weight", (2 * W, Ew)), dimg, M * Ti, Ew, 2 * W, 2 * W, Ew, Ew, b_tmaj=True,
+                     epilogue=ops.EPI_RESID_F32, resid=dimg)          # dimg += dckv @ Wkv (in place: same element r/w)
+            ops.linear_wgrad(dcq, sv["a16"], G(c + "query.weight"))
+            colsum(dcq, W, c + "query.bias")
+            da = torch.empty(R, W, **f32)       # d a32 = dcq @ Wcq + dt2
+            ops.gemm(dcq, st.w16(c + "query.weight"), da, R, W, W, W, W, W, b_tmaj=True, epilogue=ops.EPI_RESID_F32,
+                     resid=dt2)
         # ---- self-attention sublayer: a = LN(ao @ Wo^T + bo + h32)
         dt1 = ops.layernorm_bwd(sv["t1"], st.p(b + "attention.output.LayerNorm.weight"), da,
                                 G(b + "attention.output.LayerNorm.weight"), G(b + "attention.output.LayerNorm.bias"),
@@ -440,6 +476,8 @@ class _SoftTargetLossFn(torch.autograd.Function):
 
 
 class BLIPFeatureFusion(nn.Module):
+    SCORE_FUSION = False
+
     def __init__(self, med_config="backbone/configs/med_config.json", image_size=224, vit="base", vit_grad_ckpt=False,
                  vit_ckpt_layer=0, embed_dim=768, queue_size=57600, momentum=0.995, config=None, seed=0,
                  vit_config=None):
@@ -453,12 +491,22 @@ class BLIPFeatureFusion(nn.Module):
         W, D = self.med_cfg["hidden_size"], self.vit_cfg["embed_dim"]
         if W // self.med_cfg["num_attention_heads"] != 64 or D // self.vit_cfg["num_heads"] != 64 or W % 64 or D % 64:
             raise ValueError("the attention kernels are built for head_dim 64 (BLIP base / large both are)")
-        if embed_dim != W:
+        sf = self.SCORE_FUSION
+        if not sf and embed_dim != W:
             raise ValueError("BLIP_FF returns the BERT pooler output: embed_dim must equal the hidden size")
         self.med_cfg["encoder_width"] = D
         self.queue_size, self.momentum, self.embed_dim, self.config = queue_size, momentum, embed_dim, config
-        self._shapes = ([("visual_encoder." + n, s) for n, s in vit_param_shapes(self.vit_cfg, self.image_size)]
-                        + [("text_encoder." + n, s) for n, s in bert_param_shapes(self.med_cfg, D)])
+        vis = [("visual_encoder." + n, s) for n, s in vit_param_shapes(self.vit_cfg, self.image_size)]
+        txt = [("text_encoder." + n, s) for n, s in bert_param_shapes(self.med_cfg, D, pooler=not sf)]
+        if sf:     # blip_sf.py:35-47: no pooler, projection heads, cross-attention present but frozen -> kept at the END of
+            # the flat stores so that the optimizer range stops before it (a frozen tensor must not see weight decay)
+            proj = [("vision_proj.weight", (embed_dim, D)), ("vision_proj.bias", (embed_dim,)),
+                    ("text_proj.weight", (embed_dim, W)), ("text_proj.bias", (embed_dim,))]
+            self._frozen = {n for n, _ in txt if "crossattention" in n}
+            self._shapes = vis + [t for t in txt if t[0] not in self._frozen] + proj + [t for t in txt if t[0] in self._frozen]
+        else:
+            self._frozen = set()
+            self._shapes = vis + txt
         g = torch.Generator().manual_seed(seed)
         for n, shp in self._shapes:
             leaf = n.rsplit(".", 1)[-1]
@@ -468,7 +516,7 @@ class BLIPFeatureFusion(nn.Module):
                 v = torch.zeros(shp)
             else:
                 v = torch.randn(shp, generator=g) * 0.02
-            _attach(self, n, nn.Parameter(v))
+            _attach(self, n, nn.Parameter(v, requires_grad=n not in self._frozen))
         for n, shp in self._shapes:      # momentum encoders start as copies (blip_ff.py:280-285 copy_params)
             enc, rest = n.split(".", 1)
             _attach(self, f"{enc}_m.{rest}", nn.Parameter(self.get_parameter(n).detach().clone(), requires_grad=False))
@@ -523,7 +571,8 @@ class BLIPFeatureFusion(nn.Module):
         for n, p in self._online_params():
             online.p(n).copy_(p.data.float())
             p.data = online.p(n)
-            p.grad = online.grad_view(n)
+            if n not in self._frozen:
+                p.grad = online.grad_view(n)
         for n, _ in self._shapes:
             enc, rest = n.split(".", 1)
             pm = self.get_parameter(f"{enc}_m.{rest}")
@@ -540,13 +589,18 @@ class BLIPFeatureFusion(nn.Module):
         return self._flat_dict()
 
     def _flat_dict(self):
-        """what NativeAdamW reads: one weight-decay group over everything (uniir_blip/train.py:193-197)"""
+        """what NativeAdamW reads: one weight-decay group over everything trainable (uniir_blip/train.py:193-197); frozen
+        tensors (BLIP_SF's cross-attention) sit between the trainable range and temp and are skipped"""
         st = self._online
-        return dict(p32=st.p32, g32=st.g32, w16=st.w16_buf, total=st.total, split=0)
+        d = dict(p32=st.p32, g32=st.g32, w16=st.w16_buf, total=st.total, split=0)
+        if self._frozen:
+            first = min(st.off[n] for n in self._frozen)
+            d["ranges"] = [(0, first, 1), (st.off["temp"], st.total, 1)]
+        return d
 
     def optimizer_groups(self):
         """(no-decay params, decay params) for NativeAdamW: the reference applies weight decay to every parameter"""
-        return [], [p for _, p in self._online_params()]
+        return [], [p for n, p in self._online_params() if n not in self._frozen]
 
     def _refresh_conv(self, momentum_too=True):
         D, P = self.vit_cfg["embed_dim"], self.vit_cfg["patch_size"]
@@ -574,7 +628,7 @@ class BLIPFeatureFusion(nn.Module):
         if self._online is not None:
             self._online.g32.zero_()
             for n, p in self._online_params():
-                if p.grad is None or p.grad.data_ptr() != self._online.grad_view(n).data_ptr():
+                if n not in self._frozen and (p.grad is None or p.grad.data_ptr() != self._online.grad_view(n).data_ptr()):
                     p.grad = self._online.grad_view(n)
         else:
             super().zero_grad(set_to_none=set_to_none)
@@ -645,7 +699,8 @@ class BLIPFeatureFusion(nn.Module):
             self.temp.clamp_(0.001, 0.5)
         emb = self.encode_multimodal_input(txt, img, batch.get("txt_mask_batched"), batch.get("image_mask_batched"))
         self._momentum_update()
-        emb_m = self.encode_multimodal_input(txt, img, use_momentum=True)
+        emb_m = self.encode_multimodal_input(txt, img, batch.get("txt_mask_batched"), batch.get("image_mask_batched"),
+                                             use_momentum=True)
         loss, acc, q_m, p_m, nc_m = _SoftTargetLossFn.apply(emb, self.temp, self, emb_m, qi, pi, ids_row, alpha, ni, ids_neg)
         if hard and not bool(torch.rand(1) < 0.5):
             # blip_ff.py:233-246: a coin flip (same host generator as the reference) enqueues each query's FIRST negative
@@ -670,6 +725,94 @@ class BLIPFeatureFusion(nn.Module):
         if encode_mbeir_batch:
             return self.encode_mbeir_batch(batch)
         return self.compute_contrastive_loss(batch, alpha)
+
+
+class _EncodeSFFn(torch.autograd.Function):
+    """BLIP_SF encoder (blip_sf.py:97-172): text_proj(BERT mode "text" class token) * txt_mask + vision_proj(ViT class
+    token) * img_mask"""
+
+    @staticmethod
+    def forward(ctx, model, ids, key_len, images, tmask, imask, anchor):
+        save = bool(ctx.needs_input_grad[6])
+        emb, stash = model._encode_sf(model._online, model._conv16, ids, key_len, images, tmask, imask, save)
+        ctx.model, ctx.stash = model, stash
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        model, st, S = ctx.model, ctx.model._online, ctx.stash
+        ctx.stash = None
+        M, E = demb.shape
+        dev = demb.device
+        G = st.grad_view
+        dt, di = torch.empty(M, E, device=dev), torch.empty(M, E, device=dev)
+        ops.call("uniir_fuse_embeddings_bwd", demb.contiguous(), S["tmask"], S["imask"], dt, di, M, E)
+
+        def proj_bwd(dy, x16, name):
+            dy16 = torch.empty(M, E, device=dev, dtype=torch.bfloat16)
+            ops.call("uniir_cast_f32_to_bf16", dy, dy16, dy.numel())
+            ops.linear_wgrad(dy16, x16, G(name + ".weight"))
+            ops.call("uniir_colsum_bf16", dy16, E, G(name + ".bias"), M, E)
+            K = x16.shape[1]
+            dx = torch.empty(M, K, device=dev, dtype=torch.float32)
+            ops.gemm(dy16, st.w16(name + ".weight"), dx, M, K, E, E, K, K, b_tmaj=True, epilogue=ops.EPI_F32)
+            return dx
+
+        dtfeat = proj_bwd(dt, S["tfeat16"], "text_proj")
+        difeat = proj_bwd(di, S["ifeat16"], "vision_proj")
+        bert_backward(st, "text_encoder.", model.med_cfg, dtfeat, S["bst"], cross=False, pool=False)
+        T, D = S["T"], difeat.shape[1]
+        dtok = torch.zeros(M * T, D, device=dev, dtype=torch.float32)
+        ops.call("uniir_scatter_rows", difeat, None, dtok, M, T, D)
+        vit_backward(st, model._dconv, "visual_encoder.", model.vit_cfg, dtok, S["vst"])
+        return None, None, None, None, None, None, None
+
+
+class BLIPScoreFusion(BLIPFeatureFusion):
+    """src/models/uniir_blip/blip_scorefusion/blip_sf.py: the same momentum / queue loss as BLIP_FF on score-fused
+    embeddings; state-dict keys add vision_proj{,_m}.* / text_proj{,_m}.*, the BERT has no pooler, its cross-attention
+    parameters exist but are frozen (:66-69) and unused (mode "text")."""
+    SCORE_FUSION = True
+
+    def _encode_sf(self, st, conv16, ids, key_len, images, tmask, imask, save):
+        dev = ids.device
+        M = ids.shape[0]
+        E = self.embed_dim
+        tok, T, vst = vit_forward(st, conv16, "visual_encoder.", self.vit_cfg, self.image_size, images, save)
+        ifeat16 = tok.view(M, T, -1)[:, 0].contiguous()                     # class-token rows (a copy)
+        tfeat, bst = bert_forward(st, "text_encoder.", self.med_cfg, ids, key_len, None, 0, save, cross=False, pool=False)
+        tfeat16 = torch.empty(M, tfeat.shape[1], device=dev, dtype=torch.bfloat16)
+        ops.call("uniir_cast_f32_to_bf16", tfeat, tfeat16, tfeat.numel())
+        temb = ops.linear_fwd(tfeat16, st.w16("text_proj.weight"), st.p("text_proj.bias"), epilogue=ops.EPI_RESID_F32)
+        iemb = ops.linear_fwd(ifeat16, st.w16("vision_proj.weight"), st.p("vision_proj.bias"), epilogue=ops.EPI_RESID_F32)
+        emb = torch.empty(M, E, device=dev, dtype=torch.float32)
+        ops.call("uniir_fuse_embeddings", temb, iemb, tmask, imask, emb, M, E)
+        stash = dict(vst=vst, bst=bst, T=T, tfeat16=tfeat16, ifeat16=ifeat16, tmask=tmask, imask=imask) if save else None
+        return emb, stash
+
+    def encode_multimodal_input(self, txt_dict_batched, image_batched, txt_mask=None, img_mask=None, use_momentum=False):
+        self._sync()
+        ids, key_len = self._text_inputs(txt_dict_batched)
+        M = ids.shape[0]
+        dev = ids.device
+        ones = torch.ones(M, dtype=torch.int64, device=dev)
+        tmask = ones if txt_mask is None else txt_mask.to(dev).to(torch.int64).contiguous()
+        imask = ones if img_mask is None else img_mask.to(dev).to(torch.int64).contiguous()
+        if use_momentum:
+            with torch.no_grad():
+                return self._encode_sf(self._mom, self._conv16_m, ids, key_len, image_batched, tmask, imask, False)[0]
+        anchor = torch.zeros(1, device=dev, requires_grad=torch.is_grad_enabled())
+        return _EncodeSFFn.apply(self, ids, key_len, image_batched, tmask, imask, anchor)
+
+
+def blip_sf(pretrained="", **kwargs):
+    model = BLIPScoreFusion(**kwargs)
+    if pretrained:
+        sd = torch.load(pretrained, map_location="cpu")
+        msg = model.load_state_dict(sd.get("model", sd), strict=False)
+        print("missing keys:")
+        print(msg.missing_keys)
+    return model
 
 
 def blip_ff(pretrained="", **kwargs):

@@ -45,8 +45,11 @@ def load_runfile(filename, load_task_id=False):
 
 def build_model_from_config(config):
     name = config.model.name
-    if name == "BLIPFeatureFusion":
-        from models.uniir_blip.blip_featurefusion.blip_ff import BLIPFeatureFusion
+    if name in ("BLIPFeatureFusion", "BLIPScoreFusion"):
+        if name == "BLIPFeatureFusion":
+            from models.uniir_blip.blip_featurefusion.blip_ff import BLIPFeatureFusion
+        else:
+            from models.uniir_blip.blip_scorefusion.blip_sf import BLIPScoreFusion as BLIPFeatureFusion
         mc = config.model
         model = BLIPFeatureFusion(med_config=os.path.join("../models/uniir_blip", "backbone/configs/med_config.json"),
                                   image_size=mc.image_size, vit=mc.vit, vit_grad_ckpt=mc.vit_grad_ckpt,
@@ -55,12 +58,11 @@ def build_model_from_config(config):
         ckpt = mc.ckpt_config
         path = os.path.join(config.uniir_dir, ckpt.ckpt_dir, ckpt.ckpt_name)
         assert os.path.exists(path), f"Checkpoint file {path} does not exist."
-        print(f"loading BLIPFeatureFusion checkpoint from {path}")
+        print(f"loading {name} checkpoint from {path}")
         model.load_state_dict(torch.load(path, map_location="cpu")["model"])
         return model
     if name not in ("CLIPScoreFusion", "CLIPFeatureFusion"):
-        raise NotImplementedError(f"{name}: CLIPScoreFusion, CLIPFeatureFusion and BLIPFeatureFusion are on the MI355X "
-                                  "hot path (BLIP_SF is listed as next in DESIGN.md)")
+        raise NotImplementedError(f"Model {name} is not implemented.")
     if name == "CLIPFeatureFusion":
         from models.uniir_clip.clip_featurefusion.clip_ff import CLIPFeatureFusion as CLIPScoreFusion
     else:

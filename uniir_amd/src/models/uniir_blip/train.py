@@ -3,7 +3,7 @@ keys, checkpoint dictionary, one process per GPU under torch.distributed.run).
 
 Mirrors: save_checkpoint :46-61, train :64-141, main :144-309 (model factory :166-189, AdamW(model.parameters(),
 lr=init_lr, weight_decay) :193-197 -> NativeAdamW with one weight-decay group, CosineAnnealingLR(T_max=t_total) :283).
-Only BLIPFeatureFusion is built in this round (BLIPScoreFusion: DESIGN.md "next").  No DDP wrapper / GradScaler: the
+BLIPFeatureFusion and BLIPScoreFusion are both built.  No DDP wrapper / GradScaler: the
 gradient all-reduce is one RCCL call over the flat gradient buffer inside NativeAdamW.step().
 """
 import argparse
@@ -22,6 +22,7 @@ from common.config import OmegaConf
 from data.mbeir_dataset import MBEIRMainCollator, MBEIRMainDataset, Mode
 from models.uniir_blip.backbone.blip import load_checkpoint
 from models.uniir_blip.blip_featurefusion.blip_ff import blip_ff
+from models.uniir_blip.blip_scorefusion.blip_sf import blip_sf
 from models.uniir_blip.engine import eval_engine, train_one_epoch
 from uniir_amd.trainer import CosineLR, NativeAdamW
 
@@ -62,9 +63,10 @@ def main(config):
     set_seed(config.seed + utils.get_rank())
     mc = config.model
     ckpt = mc.ckpt_config
-    if mc.name != "BLIPFeatureFusion":
-        raise NotImplementedError(f"Model {mc.name} not implemented on the MI355X path (BLIPFeatureFusion is)")
-    model = blip_ff(pretrained=ckpt.get("pretrained_blip_url", ""), image_size=mc.image_size, vit=mc.vit,
+    if mc.name not in ("BLIPFeatureFusion", "BLIPScoreFusion"):
+        raise NotImplementedError(f"Model {mc.name} not implemented")
+    factory = blip_ff if mc.name == "BLIPFeatureFusion" else blip_sf
+    model = factory(pretrained=ckpt.get("pretrained_blip_url", ""), image_size=mc.image_size, vit=mc.vit,
                     vit_grad_ckpt=mc.vit_grad_ckpt, vit_ckpt_layer=mc.vit_ckpt_layer, embed_dim=mc.embed_dim,
                     queue_size=mc.queue_size, config=mc)
     tc = config.trainer_config

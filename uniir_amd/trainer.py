@@ -59,7 +59,10 @@ class NativeAdamW(torch.optim.Optimizer):
             comm.allreduce_sum_(fl["g32"])         # one RCCL all-reduce; the mean is folded into grad_scale
         self.opt_step += 1
         split, total = fl["split"], fl["total"]
-        for (lo, hi), group in zip(((0, split), (split, total)), self.param_groups):
+        # (lo, hi, param-group index); default: [0, split) without weight decay, [split, total) with
+        ranges = fl.get("ranges") or [(0, split, 0), (split, total, 1)]
+        for lo, hi, gi in ranges:
+            group = self.param_groups[gi]
             if hi > lo:
                 b1, b2 = group["betas"]
                 ops.call("uniir_adamw_step", fl["p32"][lo:hi], fl["g32"][lo:hi], self.m[lo:hi], self.v[lo:hi],
