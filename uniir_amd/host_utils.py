@@ -1,0 +1,249 @@
+"""Host-side bookkeeping shared by the reference-shaped trees under uniir_amd/src (one implementation instead of the
+reference's three copies): rank / world helpers and init_distributed_mode (reference src/common/dist_utils.py:62-91,
+src/models/uniir_{clip,blip}/utils.py:233-306), ContiguousDistributedSampler (dist_utils.py:94-115), SmoothedValue /
+MetricLogger (utils.py:44-200) and the epoch loops of src/models/uniir_{clip,blip}/engine.py.  No arithmetic of the hot
+path lives here."""
+import datetime
+import math
+import os
+import time
+from collections import defaultdict, deque
+from datetime import timedelta
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import Sampler
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def setup_for_distributed(is_master):
+    import builtins
+    builtin_print = builtins.print
+
+    def quiet_print(*args, **kwargs):
+        if is_master or kwargs.pop("force", False):
+            builtin_print(*args, **kwargs)
+
+    builtins.print = quiet_print
+
+
+def init_distributed_mode(args):
+    """reads RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run) or SLURM_PROCID; sets args.rank/.gpu/.distributed"""
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        args.rank = int(os.environ["RANK"])
+        args.world_size = int(os.environ["WORLD_SIZE"])
+        args.gpu = int(os.environ.get("LOCAL_RANK", 0))
+    elif "SLURM_PROCID" in os.environ:
+        args.rank = int(os.environ["SLURM_PROCID"])
+        args.gpu = args.rank % max(1, torch.cuda.device_count())
+        args.world_size = int(os.environ.get("SLURM_NTASKS", 1))
+    else:
+        print("Not using distributed mode")
+        args.distributed, args.gpu, args.rank, args.world_size = False, 0, 0, 1
+        return
+    args.distributed = True
+    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(args.gpu)
+    args.dist_backend = backend
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    print(f"| distributed init (rank {args.rank}): {getattr(args, 'dist_url', 'env://')}", flush=True)
+    dist.init_process_group(backend=backend, init_method=getattr(args, "dist_url", "env://"), world_size=args.world_size,
+                            rank=args.rank, timeout=timedelta(minutes=60))
+    dist.barrier()
+
+
+class ContiguousDistributedSampler(Sampler):
+    """rank r iterates [r*ceil(n/W), min((r+1)*ceil(n/W), n)) in order, no padding (ragged and empty shards allowed)"""
+
+    def __init__(self, dataset, num_replicas=None, rank=None):
+        self.dataset = dataset
+        self.num_replicas = num_replicas if num_replicas is not None else get_world_size()
+        self.rank = rank if rank is not None else get_rank()
+        self.epoch = 0
+        self.num_samples_per_replica = math.ceil(len(dataset) / self.num_replicas)
+        self.total_size = self.num_samples_per_replica * self.num_replicas
+
+    def __iter__(self):
+        n = len(self.dataset)
+        lo = min(self.rank * self.num_samples_per_replica, n)
+        return iter(range(lo, min(lo + self.num_samples_per_replica, n)))
+
+    def __len__(self):
+        return self.num_samples_per_replica
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+
+class SmoothedValue(object):
+    """windowed series (median / avg / max / last value) plus the global running average"""
+
+    def __init__(self, window_size=20, fmt=None):
+        self.deque = deque(maxlen=window_size)
+        self.total, self.count = 0.0, 0
+        self.fmt = fmt or "{median:.4f} ({global_avg:.4f})"
+
+    def update(self, value, n=1):
+        self.deque.append(value)
+        self.count += n
+        self.total += value * n
+
+    def synchronize_between_processes(self):
+        """sums count / total over ranks (one float64[2] all-reduce per meter per epoch); the window is local"""
+        if not is_dist_avail_and_initialized():
+            return
+        dev = "cuda" if torch.cuda.is_available() and dist.get_backend() != "gloo" else "cpu"
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        dist.barrier()
+        dist.all_reduce(t)
+        self.count, self.total = int(t[0].item()), t[1].item()
+
+    @property
+    def median(self):
+        return torch.tensor(list(self.deque)).median().item()
+
+    @property
+    def avg(self):
+        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+
+    @property
+    def global_avg(self):
+        return self.total / self.count
+
+    @property
+    def max(self):
+        return max(self.deque)
+
+    @property
+    def value(self):
+        return self.deque[-1]
+
+    def __str__(self):
+        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
+
+
+class MetricLogger(object):
+    def __init__(self, delimiter="\t"):
+        self.meters = defaultdict(SmoothedValue)
+        self.delimiter = delimiter
+
+    def update(self, **kwargs):
+        for k, v in kwargs.items():
+            if isinstance(v, torch.Tensor):
+                v = v.item()
+            assert isinstance(v, (float, int))
+            self.meters[k].update(v)
+
+    def __getattr__(self, attr):
+        if attr in self.__dict__.get("meters", {}):
+            return self.meters[attr]
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{attr}'")
+
+    def __str__(self):
+        return self.delimiter.join(f"{n}: {m}" for n, m in self.meters.items())
+
+    def global_avg(self):
+        return self.delimiter.join(f"{n}: {m.global_avg:.4f}" for n, m in self.meters.items())
+
+    def synchronize_between_processes(self):
+        for m in self.meters.values():
+            m.synchronize_between_processes()
+
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
+
+    def log_every(self, iterable, print_freq, header=None):
+        header = header or ""
+        start = end = time.time()
+        iter_time, data_time = SmoothedValue(fmt="{avg:.4f}"), SmoothedValue(fmt="{avg:.4f}")
+        n = len(iterable)
+        width = len(str(n))
+        for i, obj in enumerate(iterable):
+            data_time.update(time.time() - end)
+            yield obj
+            iter_time.update(time.time() - end)
+            if i % print_freq == 0 or i == n - 1:
+                eta = str(datetime.timedelta(seconds=int(iter_time.global_avg * (n - i))))
+                msg = [header, f"[{i:>{width}}/{n}]", f"eta: {eta}", str(self), f"time: {iter_time}", f"data: {data_time}"]
+                if torch.cuda.is_available():
+                    msg.append(f"max mem: {torch.cuda.max_memory_allocated() / (1024.0 * 1024.0):.0f}")
+                print(self.delimiter.join(msg))
+            end = time.time()
+        total = time.time() - start
+        print(f"{header} Total time: {datetime.timedelta(seconds=int(total))} ({total / max(1, n):.4f} s / it)")
+
+
+
+
+# ------------------------------------------------------------------------------------------------------------
+# epoch loops (reference src/models/uniir_clip/engine.py:7-84 and src/models/uniir_blip/engine.py:9-114): what the
+# two engines share; `step_fn(model, batch, i, n_batches)` is the only model-specific part (BLIP passes alpha)
+# ------------------------------------------------------------------------------------------------------------
+def batch_to_device(batch, gpu_id):
+    for key, value in batch.items():
+        if isinstance(value, torch.Tensor):
+            batch[key] = value.to(gpu_id, non_blocking=True)
+        elif hasattr(value, "input_ids") and hasattr(value, "items"):      # transformers BatchEncoding (BLIP tokenizer)
+            for k, v in value.items():
+                value[k] = v.to(gpu_id)
+    return batch
+
+
+def run_train_epoch(model, data_loader, optimizer, scheduler, config, gpu_id, epoch, step_fn):
+    """forward, loss / accumulation_steps, backward, optimizer + scheduler step every accumulation_steps micro-batches;
+    the logged lr is read after scheduler.step() and the logged loss is un-scaled, like the reference"""
+    model.train()
+    log = MetricLogger(delimiter="  ")
+    log.add_meter("lr", SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    log.add_meter("loss", SmoothedValue(window_size=1, fmt="{value:.4f}"))
+    log.add_meter("inbatch_accuracy", SmoothedValue(window_size=1, fmt="{value:.4f}"))
+    accum = config.trainer_config.gradient_accumulation_steps
+    pending, n = 0, len(data_loader)
+    for i, batch in enumerate(log.log_every(data_loader, config.trainer_config.print_freq, f"Train Epoch: [{epoch}]")):
+        outputs = step_fn(model, batch_to_device(batch, gpu_id), i, n)
+        scaled = outputs["loss"] / accum
+        scaled.backward()
+        pending += 1
+        if pending == accum:
+            optimizer.step()
+            model.zero_grad()
+            scheduler.step()
+            pending = 0
+        log.update(loss=scaled.item() * accum)                 # host sync, as in the reference's loop
+        log.update(lr=optimizer.param_groups[0]["lr"])
+        log.update(inbatch_accuracy=outputs["accuracy"].item())
+    log.synchronize_between_processes()
+    print("Averaged stats:", log.global_avg())
+    return {k: meter.global_avg for k, meter in log.meters.items()}
+
+
+@torch.no_grad()
+def run_eval_epoch(model, data_loader, config, gpu_id, step_fn):
+    model.eval()
+    log = MetricLogger(delimiter="  ")
+    log.add_meter("loss", SmoothedValue(window_size=1, fmt="{value:.4f}"))
+    log.add_meter("inbatch_accuracy", SmoothedValue(window_size=1, fmt="{value:.4f}"))
+    n = len(data_loader)
+    for i, batch in enumerate(log.log_every(data_loader, config.evaluator.print_freq, "Test:")):
+        outputs = step_fn(model, batch_to_device(batch, gpu_id), i, n)
+        log.update(loss=outputs["loss"].item())
+        log.update(inbatch_accuracy=outputs["accuracy"].item())
+    log.synchronize_between_processes()
+    print("Averaged stats:", log.global_avg())
+    return {k: meter.global_avg for k, meter in log.meters.items()}

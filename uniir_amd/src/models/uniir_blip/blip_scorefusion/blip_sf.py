@@ -12,8 +12,7 @@ _BLIP_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class BLIPScoreFusion(_Native):
     def __init__(self, med_config="backbone/configs/med_config.json", **kwargs):
         if isinstance(med_config, str) and not os.path.isfile(med_config):
-            tail = med_config.replace("\\", "/").split("uniir_blip/")[-1]
-            med_config = os.path.join(_BLIP_DIR, tail)
+            med_config = {}      # built-in BERT-base defaults (uniir_amd.blip_model.MED_DEFAULT); an existing file is honoured
         super().__init__(med_config=med_config, **kwargs)
 
 

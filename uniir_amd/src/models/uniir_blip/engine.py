@@ -1,67 +1,27 @@
-"""Train / eval epoch loops for the BLIP models (drop-in for UniIR src/models/uniir_blip/engine.py:
-train_one_epoch :9-66, eval_engine :69-114).  Same signatures, alpha ramp (epoch 0: alpha * min(1, i / len(loader))),
-gradient accumulation and logging.
+"""Drop-in module path for UniIR src/models/uniir_blip/engine.py (train_one_epoch, eval_engine: same signatures, the
+alpha ramp config.model.alpha * min(1, i / len(loader)) in epoch 0 and during eval).  Loops: uniir_amd/host_utils.py.
 
-Differences on MI355X (result-preserving): no autocast / GradScaler (bf16 MFMA compute, fp32 loss), the optimizer step is
-the fused AdamW over the flat buffer with one RCCL all-reduce (uniir_amd.trainer.NativeAdamW).
-
-eval_engine reproduces what the reference's save/restore really does: `state_dict()` aliases the live tensors, the
-queues are reset with in-place copies (so they stay reset) and `_momentum_update` rebinds `param_m.data` (so the
-momentum weights are what `load_state_dict(saved_state)` brings back).  Net effect after eval: online weights untouched,
-momentum weights restored, queues / pointer left as eval wrote them.  Here the momentum weights are updated in place, so
-they are snapshotted explicitly.
-"""
+eval_engine reproduces what the reference's save / restore really does: `state_dict()` aliases the live tensors, the
+queues are reset with in-place copies (so they stay reset) and `_momentum_update` rebinds `param_m.data` (so the momentum
+weights are what `load_state_dict(saved_state)` brings back).  Net effect after eval: online weights untouched, momentum
+weights restored, queues / pointer left as eval wrote them.  Here the momentum weights are updated in place, so they are
+snapshotted explicitly."""
 import torch
 
-from models.uniir_blip import utils
-
-
-def _to_device(batch, gpu_id):
-    for key, value in batch.items():
-        if isinstance(value, torch.Tensor):
-            batch[key] = value.to(gpu_id, non_blocking=True)
-        elif hasattr(value, "items") and not isinstance(value, dict):      # transformers BatchEncoding
-            for k, v in value.items():
-                value[k] = v.to(gpu_id)
-    return batch
+from uniir_amd.host_utils import run_eval_epoch, run_train_epoch
 
 
 def train_one_epoch(model, data_loader, optimizer, epoch, gpu_id, scheduler, global_step, scaler, config):
-    model.train()
-    logger = utils.MetricLogger(delimiter="  ")
-    logger.add_meter("lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
-    logger.add_meter("loss", utils.SmoothedValue(window_size=1, fmt="{value:.4f}"))
-    logger.add_meter("inbatch_accuracy", utils.SmoothedValue(window_size=1, fmt="{value:.4f}"))
-    accumulation_steps = config.trainer_config.gradient_accumulation_steps
-    pending = 0
-    n = len(data_loader)
-    for i, batch in enumerate(logger.log_every(data_loader, config.trainer_config.print_freq, f"Train Epoch: [{epoch}]")):
-        batch = _to_device(batch, gpu_id)
-        alpha = config.model.alpha if epoch > 0 else config.model.alpha * min(1, i / n)
-        outputs = model(batch=batch, alpha=alpha)
-        loss = outputs["loss"] / accumulation_steps
-        loss.backward()
-        pending += 1
-        if pending == accumulation_steps:
-            global_step += 1
-            optimizer.step()
-            model.zero_grad()
-            scheduler.step()
-            pending = 0
-        logger.update(loss=loss.item() * accumulation_steps)
-        logger.update(lr=optimizer.param_groups[0]["lr"])
-        logger.update(inbatch_accuracy=outputs["accuracy"].item())
-    logger.synchronize_between_processes()
-    print("Averaged stats:", logger.global_avg())
-    return {k: meter.global_avg for k, meter in logger.meters.items()}
+    full = config.model.alpha
+
+    def step(m, batch, i, n):
+        return m(batch=batch, alpha=full if epoch > 0 else full * min(1, i / n))
+
+    return run_train_epoch(model, data_loader, optimizer, scheduler, config, gpu_id, epoch, step)
 
 
 @torch.no_grad()
 def eval_engine(model_without_ddp, model, data_loader, gpu_id, config):
-    model.eval()
-    logger = utils.MetricLogger(delimiter="  ")
-    logger.add_meter("loss", utils.SmoothedValue(window_size=1, fmt="{value:.4f}"))
-    logger.add_meter("inbatch_accuracy", utils.SmoothedValue(window_size=1, fmt="{value:.4f}"))
     m = model_without_ddp
     m._sync()
     momentum_snapshot = m._mom.p32.clone()
@@ -71,16 +31,10 @@ def eval_engine(model_without_ddp, model, data_loader, gpu_id, config):
     m.new_ptr_queue.zero_()
     m._ptr_host = 0
     print("Cleared model queue states.")
-    n = len(data_loader)
-    for i, batch in enumerate(logger.log_every(data_loader, config.evaluator.print_freq, "Test:")):
-        batch = _to_device(batch, gpu_id)
-        outputs = model(batch=batch, alpha=config.model.alpha * min(1, i / n))
-        logger.update(loss=outputs["loss"].item())
-        logger.update(inbatch_accuracy=outputs["accuracy"].item())
-    logger.synchronize_between_processes()
-    print("Averaged stats:", logger.global_avg())
+    stats = run_eval_epoch(model, data_loader, config, gpu_id,
+                           lambda mm, batch, i, n: mm(batch=batch, alpha=config.model.alpha * min(1, i / n)))
     m._mom.p32.copy_(momentum_snapshot)
     m._mom.refresh_shadow()
     m._refresh_conv()
     print("Restored model queue states and model states from the saved variables.")
-    return {k: meter.global_avg for k, meter in logger.meters.items()}
+    return stats
