@@ -1,0 +1,75 @@
+"""Two ranks on ONE MI355X (backend gloo, both processes on cuda:0): the whole distributed CLIP_SF train step on the device
+path -- all-gather of p, targets offset by rank, reduce-scatter backward, flat-gradient all-reduce with the 1/W mean folded
+into AdamW -- must reproduce the single-process step on the concatenated batch (DDP semantics: the mean over ranks of the
+per-rank q->p cross-entropies equals the un-gathered loss over all 2b pairs).  The 8-GPU RCCL run itself belongs to the
+driver; this pins the exchange logic on real device tensors."""
+import os
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(gather):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "uniir_amd", "src"))
+    from oracle import clip_oracle as O
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd import clip_model
+    from uniir_amd.trainer import NativeTrainer
+    cfg = O.tiny_config()
+    clip_model.CLIP_CONFIGS["tiny-dist"] = cfg
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=gather), data_config=SimpleNamespace(in_batch_neg_num=0))
+    model = CLIPScoreFusion("tiny-dist", device="cuda:0", config=config)
+    model.clip_model.load_state_dict(O.init_state_dict(cfg, seed=9))
+    return O, cfg, model, NativeTrainer(model, lr=1e-3, t_total=10)
+
+
+def _rank_batch(O, cfg, rank, pairs):
+    full = O.synthetic_batch(cfg, 2 * pairs, seed=31)          # the global batch: 2 * pairs pairs
+    lo, hi = rank * 2 * pairs, (rank + 1) * 2 * pairs          # this rank's items (pairs are [query, candidate] couples)
+    out = {k: (v[lo:hi].cuda() if isinstance(v, torch.Tensor) else v) for k, v in full.items()}
+    out["index_mapping"] = {"query": [[2 * i] for i in range(pairs)], "pos_cand": [[2 * i + 1] for i in range(pairs)]}
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O, cfg, model, tr = _build(gather=True)
+    out = tr.train_step(_rank_batch(O, cfg, rank, 4))
+    torch.cuda.synchronize()
+    q.put((rank, float(out["loss"].detach()), model.clip_model.visual.proj.detach().cpu().numpy().copy(),
+           float(model.clip_model.logit_scale.detach())))       # plain numpy / floats: no torch shared-memory handles
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_device_step_equals_single_process_on_the_global_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29541, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (l, w, s) for r, l, w, s in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+    O, cfg, model, tr = _build(gather=False)
+    full = O.synthetic_batch(cfg, 8, seed=31)
+    dfull = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in full.items()}
+    out = tr.train_step(dfull)
+    ref_loss = float(out["loss"].detach())
+    assert abs(0.5 * (res[0][0] + res[1][0]) - ref_loss) < 2e-3 * max(1.0, abs(ref_loss))
+    import numpy as np
+    w_ref = model.clip_model.visual.proj.detach().cpu().numpy()
+    step = np.abs(w_ref - O.init_state_dict(cfg, seed=9)["visual.proj"].numpy()).max()
+    assert np.array_equal(res[0][1], res[1][1])        # replicas stay bit-identical
+    for r in range(2):        # ... and match the single-process update on the global batch
+        assert np.abs(res[r][1] - w_ref).max() < 0.05 * step + 1e-7, (np.abs(res[r][1] - w_ref).max(), step)
+        assert abs(res[r][2] - model.clip_model.logit_scale.item()) < 1e-4

@@ -24,6 +24,10 @@ def all_gather_rows(p):
     if W == 1:
         return p
     out = torch.empty(W * p.shape[0], p.shape[1], device=p.device, dtype=p.dtype)
+    if p.is_cuda and dist.get_backend() == "gloo":      # tests only (two ranks on one GPU): gloo gathers on the host
+        host = torch.empty(out.shape, dtype=p.dtype)
+        dist.all_gather_into_tensor(host, p.detach().cpu().contiguous())
+        return out.copy_(host)
     dist.all_gather_into_tensor(out, p.contiguous())
     return out
 
@@ -34,8 +38,8 @@ def reduce_scatter_rows(d_all, b):
     if W == 1:
         return d_all
     out = torch.empty(b, d_all.shape[1], device=d_all.device, dtype=d_all.dtype)
-    if dist.get_backend() == "gloo":   # gloo has no reduce_scatter: all_reduce then slice (tests only)
-        tmp = d_all.clone()
+    if dist.get_backend() == "gloo":   # gloo has no reduce_scatter: all_reduce (on the host) then slice (tests only)
+        tmp = d_all.detach().cpu().clone()
         dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
         out.copy_(tmp[rank() * b:(rank() + 1) * b])
     else:
@@ -50,7 +54,12 @@ def target_offset(b):
 
 def allreduce_sum_(flat):
     if world() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() == "gloo":   # tests only (two ranks on one GPU)
+            host = flat.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
