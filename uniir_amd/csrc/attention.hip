@@ -303,7 +303,7 @@ __global__ __launch_bounds__(ATT_THREADS, REL ? 2 : 4) void attn_bwd_kernel(Attn
                     const int q = qb * 32 + qt * 16 + 4 * g + r;
                     const int dg = min(max(key - q + Tq - 1, 0), Tq + Tk - 2);
                     float p = __builtin_amdgcn_exp2f(sa[r] * sl2 + (REL ? dbias[dg] : 0.f) - lse2[q]);
-                    if (key >= kvalid || (causal && key > q) || q >= Tq) p = 0.f;
+                    if (key >= kvalid || (causal && key > q) || (REL && q >= Tq)) p = 0.f;
                     pt[qt][r] = p;
                     dst[qt][r] = p * (dp[r] - Dq[q]);
                     // d bias = d logits; a wave-instruction touches ~28 distinct diagonals: cheap LDS atomics
