@@ -110,11 +110,14 @@ int uniir_attention_bwd(const void* qkv, const void* out, const void* dout, cons
  * lse is [batch][heads][tq].  bwd writes dq [batch*tq][dq_ld], dk / dv [batch*tk][dkv_ld]. */
 int uniir_attention_fwd_ex(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld, void* out,
                            int64_t out_ld, float* lse, const int32_t* key_len, int32_t batch, int32_t tq,
-                           int32_t tk, int32_t heads, int32_t causal, void* stream);
+                           int32_t tk, int32_t heads, int32_t causal, float drop_p, uint32_t drop_seed, void* stream);
 int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld,
                            const void* out, const void* dout, int64_t out_ld, const float* lse,
                            const int32_t* key_len, void* dq, int64_t dq_ld, void* dk, void* dv, int64_t dkv_ld,
-                           int32_t batch, int32_t tq, int32_t tk, int32_t heads, int32_t causal, void* stream);
+                           int32_t batch, int32_t tq, int32_t tk, int32_t heads, int32_t causal, float drop_p,
+                           uint32_t drop_seed, void* stream);
+/* drop_p > 0 (BERT attention_probs_dropout_prob in train mode): P V uses P * mask / (1 - drop_p), mask regenerated from
+ * (drop_seed, ((item * heads + head) * tq + query) * tk + key); backward must get the same pair. */
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] small fused pieces of the towers.
@@ -235,6 +238,21 @@ int uniir_sgemm_acc(const float* A, int64_t sam, int64_t sak, const float* B, in
                     float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * [DROPOUT] train-mode dropout / DropPath of the BLIP and T5 stacks.  Masks are counter based: element idx of a call
+ * with seed s is kept iff fmix32(idx * 0x9E3779B1 ^ s) >= p * 2^32 (kept values are scaled by 1 / (1 - p)); backward
+ * regenerates the mask from the same (seed, idx).  idx = row * cols + col of the logical [rows][cols] tensor.
+ *   dropout_f32 : y = (resid ? resid : 0) + x * mask [* rowscale[row / rows_per_scale]]  -> fp32 and / or bf16
+ *   dropout_bf16: y = x * mask [* rowscale[...]]  (bf16 rows of pitch ld; in place allowed)
+ *   dropout_mask: out[idx] = mask value (0 or 1 / (1 - p)); for tests
+ * rowscale (optional) is the per-item DropPath factor (0 or 1 / keep) of blip's ViT-large.
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_dropout_f32(const float* x, const float* resid, float* y_f32, void* y_bf16, int64_t rows, int32_t cols, float p,
+                      uint32_t seed, const float* rowscale, int32_t rows_per_scale, void* stream);
+int uniir_dropout_bf16(const void* x, void* y, int64_t rows, int32_t cols, int64_t ld, float p, uint32_t seed,
+                       const float* rowscale, int32_t rows_per_scale, void* stream);
+int uniir_dropout_mask(float* out, int64_t count, float p, uint32_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * [CLIP_FF] pieces of the feature-fusion stack of src/models/uniir_clip/clip_featurefusion/clip_ff.py:80-96,161-192
  * (transformers T5Stack, encoder mode): RMS norm (T5LayerNorm: y = gamma * x * rsqrt(mean(x^2) + eps), no bias; same
  * argument meaning as uniir_layernorm_*), self-attention with logits = scale * q.k + rel_emb[rel_bucket[key - query +
@@ -248,10 +266,11 @@ int uniir_rmsnorm_bwd(const float* x, int64_t x_stride, const float* gamma, cons
                       const float* dres, float* dx_f32, int64_t dx_stride, void* dx_bf16, float* dgamma, int32_t rows,
                       int32_t width, float eps, void* stream);
 int uniir_attention_rel_fwd(const void* qkv, void* out, float* lse, const float* rel_emb, const int32_t* rel_bucket,
-                            int32_t nbuckets, float scale, int32_t batch, int32_t seq, int32_t heads, void* stream);
+                            int32_t nbuckets, float scale, int32_t batch, int32_t seq, int32_t heads, float drop_p,
+                            uint32_t drop_seed, void* stream);
 int uniir_attention_rel_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                             const float* rel_emb, const int32_t* rel_bucket, int32_t nbuckets, float scale, float* drel,
-                            int32_t batch, int32_t seq, int32_t heads, void* stream);
+                            int32_t batch, int32_t seq, int32_t heads, float drop_p, uint32_t drop_seed, void* stream);
 int uniir_meanpool_fwd(const float* x, float* out, int32_t n, int32_t tokens, int32_t width, void* stream);
 int uniir_meanpool_bwd(const float* dout, float* dx, int32_t n, int32_t tokens, int32_t width, void* stream);
 

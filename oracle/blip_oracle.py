@@ -12,7 +12,10 @@ Restated from (paths relative to the UniIR reference tree):
   * src/models/uniir_blip/blip_featurefusion/blip_ff.py:82-116 (encode), :118-257 (loss), :288-310 (momentum, queues)
 PARITY PINNING: tests/golden/g6_med.npz, g7_vit.npz, g8_blipff.npz were produced by importing those reference files
 here (tests/golden/make_golden_blip.py); tests/test_oracle_blip.py holds this restatement to them.
-Dropout / DropPath are not restated (the fixtures run with probability 0).
+Dropout / DropPath: the fixtures run with probability 0.  The train-mode sites are restated as optional multiplicative
+masks (`masks(kind, shape)`, called in forward order; vit.py:79-80 DropPath, med.py:84,175,198,212,341 dropout) so that
+tests can hold the HIP path's masked forward / backward to the same arithmetic with the SAME masks; the random stream
+itself is the framework's, not torch's.
 """
 import math
 
@@ -25,8 +28,10 @@ def _ln(x, w, b, eps):
 
 
 # ------------------------------------------------------------------------------------------------ BLIP ViT
-def vit_forward(sd, x, cfg, prefix=""):
+def vit_forward(sd, x, cfg, prefix="", masks=None):
     """sd: state dict with timm-style keys under `prefix`; x [N,3,H,W] -> tokens [N, 1+g*g, D]"""
+    one = lambda kind, shape: 1.0
+    masks = masks or one
     p = prefix
     D, P, heads = cfg["embed_dim"], cfg["patch_size"], cfg["num_heads"]
     t = F.conv2d(x, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=P)
@@ -41,15 +46,15 @@ def vit_forward(sd, x, cfg, prefix=""):
         qkv = (h @ sd[b + "attn.qkv.weight"].t() + sd[b + "attn.qkv.bias"]).reshape(N, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
         a = torch.softmax((qkv[0] @ qkv[1].transpose(-2, -1)) * hd ** -0.5, dim=-1)
         o = (a @ qkv[2]).transpose(1, 2).reshape(N, L, D)
-        t = t + (o @ sd[b + "attn.proj.weight"].t() + sd[b + "attn.proj.bias"])
+        t = t + (o @ sd[b + "attn.proj.weight"].t() + sd[b + "attn.proj.bias"]) * masks("path", (N, 1, 1))
         h = _ln(t, sd[b + "norm2.weight"], sd[b + "norm2.bias"], 1e-6)
         h = F.gelu(h @ sd[b + "mlp.fc1.weight"].t() + sd[b + "mlp.fc1.bias"])
-        t = t + (h @ sd[b + "mlp.fc2.weight"].t() + sd[b + "mlp.fc2.bias"])
+        t = t + (h @ sd[b + "mlp.fc2.weight"].t() + sd[b + "mlp.fc2.bias"]) * masks("path", (N, 1, 1))
     return _ln(t, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
 
 
 # ------------------------------------------------------------------------------------------------ MED BERT
-def _attn(sd, pre, q_in, kv_in, heads, add_mask):
+def _attn(sd, pre, q_in, kv_in, heads, add_mask, pmask=1.0):
     """BertSelfAttention: q from q_in, k/v from kv_in; additive mask [N,1,1,Lk] or None"""
     N, Lq, W = q_in.shape
     hd = W // heads
@@ -59,28 +64,33 @@ def _attn(sd, pre, q_in, kv_in, heads, add_mask):
     s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
     if add_mask is not None:
         s = s + add_mask
-    return (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(N, Lq, W)
+    return ((torch.softmax(s, dim=-1) * pmask) @ v).transpose(1, 2).reshape(N, Lq, W)
 
 
-def bert_forward(sd, ids, mask, enc_hidden, cfg, prefix=""):
+def bert_forward(sd, ids, mask, enc_hidden, cfg, prefix="", masks=None):
     """BertModel(mode='multimodal'): -> (last_hidden_state [N,L,W], pooler_output [N,W])"""
     p = prefix
     eps, heads = cfg["layer_norm_eps"], cfg["num_attention_heads"]
-    L = ids.shape[1]
+    N, L = ids.shape
+    masks = masks or (lambda kind, shape: 1.0)
     h = sd[p + "embeddings.word_embeddings.weight"][ids] + sd[p + "embeddings.position_embeddings.weight"][:L]
     h = _ln(h, sd[p + "embeddings.LayerNorm.weight"], sd[p + "embeddings.LayerNorm.bias"], eps)
+    h = h * masks("hidden", h.shape)
     add_mask = (1.0 - mask[:, None, None, :].to(h.dtype)) * -10000.0
     for i in range(cfg["num_hidden_layers"]):
         b = f"{p}encoder.layer.{i}."
-        ctx = _attn(sd, b + "attention.self.", h, h, heads, add_mask)
-        h = _ln(ctx @ sd[b + "attention.output.dense.weight"].t() + sd[b + "attention.output.dense.bias"] + h,
+        ctx = _attn(sd, b + "attention.self.", h, h, heads, add_mask, masks("attn", (N, heads, L, L)))
+        dense = ctx @ sd[b + "attention.output.dense.weight"].t() + sd[b + "attention.output.dense.bias"]
+        h = _ln(dense * masks("hidden", h.shape) + h,
                 sd[b + "attention.output.LayerNorm.weight"], sd[b + "attention.output.LayerNorm.bias"], eps)
         if enc_hidden is not None:      # mode "multimodal"; mode "text" (BLIP_SF) skips the cross-attention sublayer
-            ctx = _attn(sd, b + "crossattention.self.", h, enc_hidden, heads, None)   # image attention mask is all ones
-            h = _ln(ctx @ sd[b + "crossattention.output.dense.weight"].t() + sd[b + "crossattention.output.dense.bias"] + h,
+            ctx = _attn(sd, b + "crossattention.self.", h, enc_hidden, heads, None,   # image attention mask is all ones
+                        masks("attn", (N, heads, L, enc_hidden.shape[1])))
+            dense = ctx @ sd[b + "crossattention.output.dense.weight"].t() + sd[b + "crossattention.output.dense.bias"]
+            h = _ln(dense * masks("hidden", h.shape) + h,
                     sd[b + "crossattention.output.LayerNorm.weight"], sd[b + "crossattention.output.LayerNorm.bias"], eps)
         f = F.gelu(h @ sd[b + "intermediate.dense.weight"].t() + sd[b + "intermediate.dense.bias"])
-        h = _ln(f @ sd[b + "output.dense.weight"].t() + sd[b + "output.dense.bias"] + h,
+        h = _ln((f @ sd[b + "output.dense.weight"].t() + sd[b + "output.dense.bias"]) * masks("hidden", h.shape) + h,
                 sd[b + "output.LayerNorm.weight"], sd[b + "output.LayerNorm.bias"], eps)
     if p + "pooler.dense.weight" not in sd:      # add_pooling_layer=False (BLIP_SF)
         return h, None

@@ -253,3 +253,68 @@ def test_g8s_blip_sf_two_training_steps():
     assert torch.equal(model.get_parameter(frozen).detach(), w_frozen)
     assert (model.get_parameter("text_proj.weight").detach() - w_proj).abs().max().item() > 1e-4
     assert model.temp.item() != t0.item()
+
+
+def test_blip_ff_train_mode_dropout_matches_masked_oracle():
+    """train mode with BERT hidden / attention dropout and ViT DropPath: the counter-based masks are exported
+    (uniir_dropout_mask, same seeds) and fed to the oracle's mask hooks -- forward and gradients must agree like the
+    dropout-free runs do; eval mode is deterministic and mask-free"""
+    from oracle import blip_oracle as bo
+    from uniir_amd import ops
+    z = np.load(os.path.join(G, "g8_blipff.npz"))
+    med_cfg, vit_cfg = json.loads(str(z["med_cfg"])), json.loads(str(z["vit_cfg"]))
+    med_cfg.update(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.2)
+    vit_cfg["drop_path_rate"] = 0.5
+    model = tiny_model(med_cfg, vit_cfg)
+    sd = load_sub(model, z, "sd0::", "")
+    model = model.cuda()
+    txt = types.SimpleNamespace(input_ids=torch.from_numpy(z["s0_ids"]).cuda(), attention_mask=torch.from_numpy(z["s0_mask"]).cuda())
+    img = torch.from_numpy(z["s0_img"]).cuda()
+    M = img.shape[0]
+    model.eval()
+    with torch.no_grad():
+        e0, e1 = model.encode_multimodal_input(txt, img), model.encode_multimodal_input(txt, img)
+    assert torch.equal(e0, e1)
+    ref_eval = bo.encode_multimodal_input({k: v for k, v in sd.items()}, torch.from_numpy(z["s0_ids"]),
+                                          torch.from_numpy(z["s0_mask"]), torch.from_numpy(z["s0_img"]), vit_cfg, med_cfg)
+    assert rel(e0, ref_eval) < 2e-2
+    model.train()
+    model.zero_grad()
+    torch.manual_seed(5)
+    emb = model.encode_multimodal_input(txt, img)
+    assert rel(emb, ref_eval) > 5e-2          # the masks did something
+    w = torch.randn(emb.shape, generator=torch.Generator().manual_seed(1))
+    (emb * w.cuda()).sum().backward()
+    with torch.no_grad():
+        torch.manual_seed(6)
+        assert not torch.equal(model.encode_multimodal_input(txt, img), emb.detach())
+    # the same draws, replayed for the oracle
+    torch.manual_seed(5)
+    seeds = ops.DropSeeds()
+    depth = vit_cfg["depth"]
+    keep = 1.0 - torch.linspace(0, 0.5, depth).view(depth, 1, 1)
+    rowscale = torch.floor(keep + torch.rand(depth, 2, M)) / keep
+    path_iter = iter([rowscale[i, j] for i in range(depth) for j in range(2)])
+
+    def masks(kind, shape):
+        if kind == "path":
+            return next(path_iter).view(shape)
+        p = med_cfg["hidden_dropout_prob"] if kind == "hidden" else med_cfg["attention_probs_dropout_prob"]
+        buf = torch.empty(int(np.prod(shape)), device="cuda")
+        ops.call("uniir_dropout_mask", buf, buf.numel(), p, seeds.next())
+        return buf.view(*shape).cpu()
+
+    sdg = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    tok = bo.vit_forward(sdg, torch.from_numpy(z["s0_img"]), vit_cfg, prefix="visual_encoder.", masks=masks)
+    ref = bo.bert_forward(sdg, torch.from_numpy(z["s0_ids"]), torch.from_numpy(z["s0_mask"]), tok, med_cfg,
+                          prefix="text_encoder.", masks=masks)[1]
+    assert rel(emb, ref) < 2e-2, rel(emb, ref)
+    (ref * w).sum().backward()
+    for name in ("visual_encoder.blocks.0.attn.qkv.weight", "visual_encoder.blocks.0.attn.proj.bias",
+                 "visual_encoder.blocks.1.mlp.fc2.bias", "visual_encoder.pos_embed",
+                 "text_encoder.embeddings.word_embeddings.weight", "text_encoder.encoder.layer.0.attention.self.query.weight",
+                 "text_encoder.encoder.layer.0.crossattention.self.key.weight",
+                 "text_encoder.encoder.layer.0.attention.output.dense.bias",
+                 "text_encoder.encoder.layer.1.output.dense.weight", "text_encoder.pooler.dense.weight"):
+        r = rel(model.get_parameter(name).grad, sdg[name].grad)
+        assert r < 8e-2, (name, r)

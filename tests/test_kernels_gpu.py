@@ -326,7 +326,7 @@ def test_attention_relative_bias_fwd_bwd(batch, seq, heads):
     table = ((offs > 0).long() * half + torch.where(on < 8, on, torch.min(olarge, torch.full_like(olarge, half - 1)))).to(torch.int32).to(DEV)
     out = torch.empty(batch * seq, W, device=DEV, dtype=torch.bfloat16)
     lse = torch.empty(batch, heads, seq, device=DEV)
-    ops.call("uniir_attention_rel_fwd", qkv, out, lse, emb, table, nb, 1.0, batch, seq, heads)
+    ops.call("uniir_attention_rel_fwd", qkv, out, lse, emb, table, nb, 1.0, batch, seq, heads, 0.0, 0)
     # reference
     embr = emb.clone().requires_grad_(True)
     x = qkv.float().view(batch, seq, 3, heads, 64).requires_grad_(True)
@@ -339,6 +339,77 @@ def test_attention_relative_bias_fwd_bwd(batch, seq, heads):
     ref.backward(dout.float())
     dqkv = torch.empty_like(qkv)
     drel = torch.zeros(nb, heads, device=DEV)
-    ops.call("uniir_attention_rel_bwd", qkv, out, dout, lse, dqkv, emb, table, nb, 1.0, drel, batch, seq, heads)
+    ops.call("uniir_attention_rel_bwd", qkv, out, dout, lse, dqkv, emb, table, nb, 1.0, drel, batch, seq, heads, 0.0, 0)
     assert rel_err(dqkv, x.grad.reshape(batch * seq, 3 * W)) < 2e-2, rel_err(dqkv, x.grad.reshape(batch * seq, 3 * W))
     assert rel_err(drel, embr.grad) < 2e-2, rel_err(drel, embr.grad)
+
+
+def test_dropout_masks_and_elementwise():
+    """counter-based dropout: keep rate, determinism, the same mask through the fp32 / bf16 / DropPath forms"""
+    ops = _ops()
+    rows, cols, p, seed = 513, 768, 0.1, 12345
+    mask = torch.empty(rows * cols, device=DEV)
+    ops.call("uniir_dropout_mask", mask, mask.numel(), p, seed)
+    keep = (mask > 0).float().mean().item()
+    assert abs(keep - 0.9) < 3e-3 and set(mask.unique().tolist()) <= {0.0, mask.max().item()}
+    assert abs(mask.max().item() - 1 / 0.9) < 1e-6
+    m2 = torch.empty_like(mask)
+    ops.call("uniir_dropout_mask", m2, m2.numel(), p, seed)
+    assert torch.equal(mask, m2)
+    ops.call("uniir_dropout_mask", m2, m2.numel(), p, seed + 1)
+    assert (mask != m2).float().mean().item() > 0.1
+    # adjacent elements / rows are not correlated (a cheap independence check)
+    mk = (mask > 0).float().view(rows, cols)
+    assert abs((mk[:, 1:] * mk[:, :-1]).mean().item() - 0.81) < 5e-3 and abs((mk[1:] * mk[:-1]).mean().item() - 0.81) < 5e-3
+    torch.manual_seed(3)
+    x, res = torch.randn(rows, cols, device=DEV), torch.randn(rows, cols, device=DEV)
+    rs = (torch.rand(rows // 19, device=DEV) > 0.3).float() / 0.7              # DropPath factors, 19 rows per item
+    y32, y16 = torch.empty_like(x), torch.empty(rows, cols, device=DEV, dtype=torch.bfloat16)
+    ops.call("uniir_dropout_f32", x, res, y32, y16, rows, cols, p, seed, rs, 19)
+    ref = res + x * mask.view(rows, cols) * rs.repeat_interleave(19)[:, None]
+    assert torch.allclose(y32, ref, atol=1e-6) and rel_err(y16, ref) < 4e-3
+    xb = bf(x)
+    yb = torch.empty_like(xb)
+    ops.call("uniir_dropout_bf16", xb, yb, rows, cols, cols, p, seed, None, 0)
+    assert rel_err(yb, xb.float() * mask.view(rows, cols)) < 4e-3
+    ops.call("uniir_dropout_f32", x, None, y32, None, rows, cols, 0.0, 0, None, 0)     # p = 0: identity
+    assert torch.equal(y32, x)
+
+
+@pytest.mark.parametrize("rel", [False, True])
+def test_attention_probability_dropout(rel):
+    """P V with P * mask / keep, softmax statistics of the full P; backward with the regenerated mask (both kernels)"""
+    ops = _ops()
+    torch.manual_seed(17)
+    batch, seq, heads, p, seed = 2, 77, 2, 0.1, 777
+    W = heads * 64
+    qkv = bf(torch.randn(batch * seq, 3 * W, device=DEV) * (0.35 if rel else 1.0))
+    mask = torch.empty(batch * heads * seq * seq, device=DEV)
+    ops.call("uniir_dropout_mask", mask, mask.numel(), p, seed)
+    mask = mask.view(batch, heads, seq, seq)
+    x = qkv.float().view(batch, seq, 3, heads, 64).requires_grad_(True)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    out = torch.empty(batch * seq, W, device=DEV, dtype=torch.bfloat16)
+    if rel:
+        emb = torch.randn(32, heads, device=DEV)
+        table = torch.randint(0, 32, (2 * seq - 1,), device=DEV, dtype=torch.int32)
+        lse = torch.empty(batch, heads, seq, device=DEV)
+        ops.call("uniir_attention_rel_fwd", qkv, out, lse, emb, table, 32, 1.0, batch, seq, heads, p, seed)
+        pos = torch.arange(seq, device=DEV)
+        bias = emb[table[(pos[None, :] - pos[:, None] + seq - 1)].long()].permute(2, 0, 1)
+        logits = q @ k.transpose(-1, -2) + bias[None]
+    else:
+        out, lse = ops.attention_fwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, batch, seq, seq, heads, drop_p=p, drop_seed=seed)
+        logits = q @ k.transpose(-1, -2) / 8.0
+    ref = ((torch.softmax(logits, dim=-1) * mask) @ v).transpose(1, 2).reshape(batch * seq, W)
+    assert rel_err(out, ref) < 8e-3, rel_err(out, ref)
+    dout = bf(torch.randn(batch * seq, W, device=DEV))
+    ref.backward(dout.float())
+    dqkv = torch.empty_like(qkv)
+    if rel:
+        drel = torch.zeros(32, heads, device=DEV)
+        ops.call("uniir_attention_rel_bwd", qkv, out, dout, lse, dqkv, emb, table, 32, 1.0, drel, batch, seq, heads, p, seed)
+    else:
+        ops.attention_bwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, out, dout, lse, dqkv, 3 * W, dqkv[:, W:],
+                             dqkv[:, 2 * W:], 3 * W, batch, seq, seq, heads, drop_p=p, drop_seed=seed)
+    assert rel_err(dqkv, x.grad.reshape(batch * seq, 3 * W)) < 2e-2, rel_err(dqkv, x.grad.reshape(batch * seq, 3 * W))

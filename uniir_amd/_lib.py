@@ -35,9 +35,10 @@ SIGNATURES = {
     "uniir_layernorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
     "uniir_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
-    "uniir_attention_fwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, P, c_int, c_int, c_int, c_int, c_int, S]),
+    "uniir_attention_fwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, P, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       C.c_uint32, S]),
     "uniir_attention_bwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, P, c_i64, P, P, P, c_i64, P, P, c_i64, c_int, c_int,
-                                       c_int, c_int, c_int, S]),
+                                       c_int, c_int, c_int, c_float, C.c_uint32, S]),
     "uniir_patchify": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_vit_assemble": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
     "uniir_vit_assemble_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
@@ -64,10 +65,13 @@ SIGNATURES = {
                                  c_float, S]),
     "uniir_rmsnorm_fwd": (c_int, [P, c_i64, P, P, P, c_int, c_int, c_float, S]),
     "uniir_rmsnorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, c_int, c_int, c_float, S]),
-    "uniir_attention_rel_fwd": (c_int, [P, P, P, P, P, c_int, c_float, c_int, c_int, c_int, S]),
-    "uniir_attention_rel_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_float, P, c_int, c_int, c_int, S]),
+    "uniir_attention_rel_fwd": (c_int, [P, P, P, P, P, c_int, c_float, c_int, c_int, c_int, c_float, C.c_uint32, S]),
+    "uniir_attention_rel_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_float, P, c_int, c_int, c_int, c_float, C.c_uint32, S]),
     "uniir_meanpool_fwd": (c_int, [P, P, c_int, c_int, c_int, S]),
     "uniir_meanpool_bwd": (c_int, [P, P, c_int, c_int, c_int, S]),
+    "uniir_dropout_f32": (c_int, [P, P, P, P, c_i64, c_int, c_float, C.c_uint32, P, c_int, S]),
+    "uniir_dropout_bf16": (c_int, [P, P, c_i64, c_int, c_i64, c_float, C.c_uint32, P, c_int, S]),
+    "uniir_dropout_mask": (c_int, [P, c_i64, c_float, C.c_uint32, S]),
     "uniir_tanh_fwd": (c_int, [P, P, c_i64, S]),
     "uniir_tanh_bwd": (c_int, [P, P, P, c_i64, S]),
     "uniir_ema_update": (c_int, [P, P, P, c_i64, c_float, S]),

@@ -8,8 +8,10 @@ All arithmetic is in libuniir_hip.so; this file is the launch sequence, the flat
 stash.  Differences from the reference, stated once:
   * bf16 MFMA GEMMs with fp32 accumulation / fp32 LayerNorm, softmax statistics, residual stream, loss (the reference
     runs fp16 autocast); no GradScaler is needed;
-  * dropout (BERT 0.1) and DropPath (ViT-large 0.1) are not applied: the forward is the reference's expectation
-    (its eval-mode forward); see DESIGN.md "BLIP_FF";
+  * train mode applies the reference's dropout sites -- BERT hidden / attention-probability dropout 0.1 (med.py:84,
+    175,198,212,341; online and momentum encoders alike, both are in train mode) and DropPath of ViT-large (vit.py:79-80,
+    blip.py:249-254) -- with counter-based masks regenerated in backward (ops.DropSeeds); the masks are a different random
+    stream than torch's, so only the distribution matches; eval mode (and a config with zero rates) is deterministic;
   * the BERT padding mask must be a prefix mask (tokenizer padding="max_length"), it travels as one key length per row;
   * hard negatives (blip_ff.py:127-131,159-170,233-246) are supported; like the reference their momentum features are
     used un-normalised and a host coin flip decides what is enqueued.
@@ -24,11 +26,12 @@ from . import comm, ops
 from .clip_model import ALIGN, _Blk, _tower_bwd, _tower_fwd
 
 VIT_CONFIGS = {   # src/models/uniir_blip/backbone/blip.py:229-255 (create_vit)
-    "base": dict(patch_size=16, embed_dim=768, depth=12, num_heads=12),
-    "large": dict(patch_size=16, embed_dim=1024, depth=24, num_heads=16),
+    "base": dict(patch_size=16, embed_dim=768, depth=12, num_heads=12, drop_path_rate=0.0),
+    "large": dict(patch_size=16, embed_dim=1024, depth=24, num_heads=16, drop_path_rate=0.1),
 }
 MED_DEFAULT = dict(hidden_size=768, intermediate_size=3072, layer_norm_eps=1e-12, max_position_embeddings=512,
-                   num_attention_heads=12, num_hidden_layers=12, vocab_size=30524)   # backbone/configs/med_config.json
+                   num_attention_heads=12, num_hidden_layers=12, vocab_size=30524, hidden_dropout_prob=0.1,
+                   attention_probs_dropout_prob=0.1)   # backbone/configs/med_config.json
 VIT_EPS = 1e-6
 
 
@@ -132,8 +135,10 @@ def _attach(root, dotted, param):
 # ------------------------------------------------------------------------------------------------------------
 # launch sequences
 # ------------------------------------------------------------------------------------------------------------
-def vit_forward(st, conv16, prefix, cfg, img_size, images, save):
-    """src/models/uniir_blip/backbone/vit.py:196-221 -> bf16 tokens [M*T, D] (after the final norm) + stash"""
+def vit_forward(st, conv16, prefix, cfg, img_size, images, save, drop=None):
+    """src/models/uniir_blip/backbone/vit.py:196-221 -> bf16 tokens [M*T, D] (after the final norm) + stash.
+    drop (ops.DropSeeds, train mode): DropPath with rates linspace(0, drop_path_rate, depth) (vit.py:167), one Bernoulli
+    draw per item and residual branch from torch's CPU generator"""
     D, P, depth = cfg["embed_dim"], cfg["patch_size"], cfg["depth"]
     M, dev = images.shape[0], images.device
     G = (img_size // P) ** 2
@@ -147,9 +152,14 @@ def vit_forward(st, conv16, prefix, cfg, img_size, images, save):
     ops.call("uniir_vit_assemble", po, st.p(prefix + "cls_token"), st.p(prefix + "pos_embed"), x0, M, T, D)
     del po
     blk = lambda i: _Blk(st, None, _vit_blk_names(prefix, i))
-    x, saved = _tower_fwd(st, None, depth, x0, M, T, D, heads, False, save, eps=VIT_EPS, act=ops.ACT_GELU_ERF, blk=blk)
+    rowscale = None
+    if drop is not None and cfg.get("drop_path_rate", 0.0) > 0 and depth > 1:
+        keep = 1.0 - torch.linspace(0, cfg["drop_path_rate"], depth).view(depth, 1, 1)
+        rowscale = (torch.floor(keep + torch.rand(depth, 2, M)) / keep).to(dev)
+    x, saved = _tower_fwd(st, None, depth, x0, M, T, D, heads, False, save, eps=VIT_EPS, act=ops.ACT_GELU_ERF, blk=blk,
+                          rowscale=rowscale)
     tok = ops.layernorm_fwd(x, st.p(prefix + "norm.weight"), st.p(prefix + "norm.bias"), VIT_EPS, rows=M * T, width=D)
-    stash = dict(patches=patches, x=x, saved=saved, M=M, T=T) if save else None
+    stash = dict(patches=patches, x=x, saved=saved, M=M, T=T, rowscale=rowscale) if save else None
     return tok, T, stash
 
 
@@ -163,7 +173,7 @@ def vit_backward(st, dconv, prefix, cfg, dtok, stash):
                            st.grad_view(prefix + "norm.bias"), VIT_EPS, dx_bf16=dxb, rows=R, width=D)
     blk = lambda i: _Blk(st, None, _vit_blk_names(prefix, i))
     dx = _tower_bwd(st, None, depth, dx, dxb, stash["saved"], M, T, D, heads, False, eps=VIT_EPS, act=ops.ACT_GELU_ERF,
-                    blk=blk)
+                    blk=blk, rowscale=stash["rowscale"])
     G = T - 1
     dpo = torch.empty(M * G, D, device=dev, dtype=torch.bfloat16)
     ops.call("uniir_vit_assemble_bwd", dx, dpo, st.grad_view(prefix + "cls_token"), st.grad_view(prefix + "pos_embed"),
@@ -182,11 +192,13 @@ def _ln2(st, x, wname, eps, R, W):
     return o32, o16
 
 
-def bert_forward(st, prefix, cfg, ids, key_len, img16, Ti, save, cross=True, pool=True):
+def bert_forward(st, prefix, cfg, ids, key_len, img16, Ti, save, cross=True, pool=True, drop=None):
     """src/models/uniir_blip/backbone/med.py BertModel.forward(mode="multimodal") -> pooler_output fp32 [M,W] + stash.
     ids int32 [M,L]; key_len int32 [M]; img16 bf16 [M*Ti, enc_width] (image attention mask all ones, blip_ff.py:98,108).
     cross=False: mode "text" (the cross-attention sublayer is skipped, BLIP_SF); pool=False: add_pooling_layer=False, the
-    class-token row of last_hidden_state is returned instead of the tanh pooler output."""
+    class-token row of last_hidden_state is returned instead of the tanh pooler output.
+    drop (ops.DropSeeds, train mode): hidden dropout after the embedding LayerNorm and after each of the three output
+    dense layers (before the residual add), attention-probability dropout inside both attention kernels."""
     W, I, eps = cfg["hidden_size"], cfg["intermediate_size"], cfg["layer_norm_eps"]
     heads, layers = cfg["num_attention_heads"], cfg["num_hidden_layers"]
     M, L = ids.shape
@@ -196,34 +208,52 @@ def bert_forward(st, prefix, cfg, ids, key_len, img16, Ti, save, cross=True, poo
     ops.call("uniir_text_embed", ids, st.p(prefix + "embeddings.word_embeddings.weight"),
              st.p(prefix + "embeddings.position_embeddings.weight"), e32, scratch, M, L, W, cfg["vocab_size"])
     h32, h16 = _ln2(st, e32, prefix + "embeddings.LayerNorm.", eps, R, W)
-    stash = dict(ids=ids, e32=e32, layers=[], M=M, L=L, Ti=Ti, key_len=key_len, img16=img16) if save else None
+    ph = cfg.get("hidden_dropout_prob", 0.0) if drop is not None else 0.0
+    pa = cfg.get("attention_probs_dropout_prob", 0.0) if drop is not None else 0.0
+    s_emb = drop.next() if ph else 0
+    if ph:
+        ops.dropout_f32(h32, ph, s_emb, out_f32=h32, out_bf16=h16)
+    stash = dict(ids=ids, e32=e32, layers=[], M=M, L=L, Ti=Ti, key_len=key_len, img16=img16, ph=ph, pa=pa,
+                 s_emb=s_emb) if save else None
+
+    def out_dense(x16, name, resid):
+        """dense -> dropout -> + residual (BertSelfOutput / BertOutput, med.py:196-200,339-343), pre-LayerNorm sum"""
+        if not ph:
+            return ops.linear_fwd(x16, st.w16(name + "weight"), st.p(name + "bias"), epilogue=ops.EPI_RESID_F32,
+                                  resid=resid), 0
+        t = ops.linear_fwd(x16, st.w16(name + "weight"), st.p(name + "bias"), epilogue=ops.EPI_RESID_F32)
+        sd = drop.next()
+        ops.dropout_f32(t, ph, sd, resid=resid, out_f32=t)
+        return t, sd
+
     g = torch.empty(R, I, device=dev, dtype=torch.bfloat16)
     for i in range(layers):
         b = f"{prefix}encoder.layer.{i}."
         s, c = b + "attention.self.", b + "crossattention.self."
         qkv = ops.linear_fwd(h16, st.w16(s + "query.weight", (3 * W, W)), st.p(s + "query.bias", (3 * W,)))
-        ao, lse1 = ops.attention_fwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, M, L, L, heads, key_len=key_len)
-        t1 = ops.linear_fwd(ao, st.w16(b + "attention.output.dense.weight"), st.p(b + "attention.output.dense.bias"),
-                            epilogue=ops.EPI_RESID_F32, resid=h32)
+        sa1 = drop.next() if pa else 0
+        ao, lse1 = ops.attention_fwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, M, L, L, heads, key_len=key_len,
+                                        drop_p=pa, drop_seed=sa1)
+        t1, so1 = out_dense(ao, b + "attention.output.dense.", h32)
         a32, a16 = _ln2(st, t1, b + "attention.output.LayerNorm.", eps, R, W)
         cq = ckv = co = lse2 = t2 = None
+        sa2 = so2 = 0
         if cross:
             cq = ops.linear_fwd(a16, st.w16(c + "query.weight"), st.p(c + "query.bias"))
             ckv = ops.linear_fwd(img16, st.w16(c + "key.weight", (2 * W, img16.shape[1])), st.p(c + "key.bias", (2 * W,)))
-            co, lse2 = ops.attention_fwd_ex(cq, W, ckv, ckv[:, W:], 2 * W, M, L, Ti, heads)
-            t2 = ops.linear_fwd(co, st.w16(b + "crossattention.output.dense.weight"),
-                                st.p(b + "crossattention.output.dense.bias"), epilogue=ops.EPI_RESID_F32, resid=a32)
+            sa2 = drop.next() if pa else 0
+            co, lse2 = ops.attention_fwd_ex(cq, W, ckv, ckv[:, W:], 2 * W, M, L, Ti, heads, drop_p=pa, drop_seed=sa2)
+            t2, so2 = out_dense(co, b + "crossattention.output.dense.", a32)
             c32, c16 = _ln2(st, t2, b + "crossattention.output.LayerNorm.", eps, R, W)
         else:
             c32, c16 = a32, a16
         f = torch.empty(R, I, device=dev, dtype=torch.bfloat16)
         ops.linear_fwd(c16, st.w16(b + "intermediate.dense.weight"), st.p(b + "intermediate.dense.bias"), out=f,
                        epilogue=ops.EPI_BIAS_ACT, C2=g, act=ops.ACT_GELU_ERF)
-        t3 = ops.linear_fwd(g, st.w16(b + "output.dense.weight"), st.p(b + "output.dense.bias"),
-                            epilogue=ops.EPI_RESID_F32, resid=c32)
+        t3, so3 = out_dense(g, b + "output.dense.", c32)
         if save:
             stash["layers"].append(dict(h16=h16, qkv=qkv, ao=ao, lse1=lse1, t1=t1, a16=a16, cq=cq, ckv=ckv, co=co,
-                                        lse2=lse2, t2=t2, c16=c16, f=f, t3=t3))
+                                        lse2=lse2, t2=t2, c16=c16, f=f, t3=t3, seeds=(sa1, so1, sa2, so2, so3)))
         h32, h16 = _ln2(st, t3, b + "output.LayerNorm.", eps, R, W)
     rows = torch.empty(M, W, device=dev, dtype=torch.float32)
     ops.call("uniir_gather_rows", h32, None, rows, M, L, W)
@@ -290,15 +320,19 @@ def _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum):
     G = st.grad_view
     f32 = dict(device=dev, dtype=torch.float32)
     b16 = dict(device=dev, dtype=torch.bfloat16)
+    ph, pa = stash["ph"], stash["pa"]
     for i in reversed(range(layers)):
         b = f"{prefix}encoder.layer.{i}."
         s, c = b + "attention.self.", b + "crossattention.self."
         sv = stash["layers"][i]
         stash["layers"][i] = None
+        sa1, so1, sa2, so2, so3 = sv["seeds"]
         # ---- feed-forward sublayer: o = LN(g @ Wout^T + bout + c32), g = gelu(c16 @ Wi^T + bi)
         d16 = torch.empty(R, W, **b16)
         dt3 = ops.layernorm_bwd(sv["t3"], st.p(b + "output.LayerNorm.weight"), do, G(b + "output.LayerNorm.weight"),
                                 G(b + "output.LayerNorm.bias"), eps, dx_bf16=d16, rows=R, width=W)
+        if ph:      # the dense branch sees the masked gradient, the residual branch (dt3, fp32) the full one
+            ops.dropout_bf16_(d16, ph, so3)
         df = torch.empty(R, I, **b16)
         ops.linear_dgrad(d16, st.w16(b + "output.dense.weight"), out=df, aux=sv["f"], act_out=g,
                          colsum=G(b + "intermediate.dense.bias"), act=ops.ACT_GELU_ERF)
@@ -315,6 +349,8 @@ def _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum):
             dt2 = ops.layernorm_bwd(sv["t2"], st.p(b + "crossattention.output.LayerNorm.weight"), dc,
                                     G(b + "crossattention.output.LayerNorm.weight"),
                                     G(b + "crossattention.output.LayerNorm.bias"), eps, dx_bf16=d16, rows=R, width=W)
+            if ph:
+                ops.dropout_bf16_(d16, ph, so2)
             ops.linear_wgrad(d16, sv["co"], G(b + "crossattention.output.dense.weight"))
             colsum(d16, W, b + "crossattention.output.dense.bias")
             dco = ops.linear_dgrad(d16, st.w16(b + "crossattention.output.dense.weight"))
@@ -322,7 +358,7 @@ def _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum):
             dckv = torch.empty(M * Ti, 2 * W, **b16)
             ckv = sv["ckv"]
             ops.attention_bwd_ex(sv["cq"], W, ckv, ckv[:, W:], 2 * W, sv["co"], dco, sv["lse2"], dcq, W, dckv, dckv[:, W:],
-                                 2 * W, M, L, Ti, heads)
+                                 2 * W, M, L, Ti, heads, drop_p=pa, drop_seed=sa2)
             Ew = img16.shape[1]
             ops.linear_wgrad(dckv, img16, G(c + "key.weight", (2 * W, Ew)))
             colsum(dckv, 2 * W, c + "key.bias", (2 * W,))
@@ -337,18 +373,22 @@ def _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum):
         dt1 = ops.layernorm_bwd(sv["t1"], st.p(b + "attention.output.LayerNorm.weight"), da,
                                 G(b + "attention.output.LayerNorm.weight"), G(b + "attention.output.LayerNorm.bias"),
                                 eps, dx_bf16=d16, rows=R, width=W)
+        if ph:
+            ops.dropout_bf16_(d16, ph, so1)
         ops.linear_wgrad(d16, sv["ao"], G(b + "attention.output.dense.weight"))
         colsum(d16, W, b + "attention.output.dense.bias")
         dao = ops.linear_dgrad(d16, st.w16(b + "attention.output.dense.weight"))
         qkv = sv["qkv"]
         dqkv = torch.empty(R, 3 * W, **b16)
         ops.attention_bwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, sv["ao"], dao, sv["lse1"], dqkv, 3 * W,
-                             dqkv[:, W:], dqkv[:, 2 * W:], 3 * W, M, L, L, heads, key_len=key_len)
+                             dqkv[:, W:], dqkv[:, 2 * W:], 3 * W, M, L, L, heads, key_len=key_len, drop_p=pa, drop_seed=sa1)
         ops.linear_wgrad(dqkv, sv["h16"], G(s + "query.weight", (3 * W, W)))
         colsum(dqkv, 3 * W, s + "query.bias", (3 * W,))
         do = torch.empty(R, W, **f32)       # d h32 = dqkv @ Wqkv + dt1
         ops.gemm(dqkv, st.w16(s + "query.weight", (3 * W, W)), do, R, W, 3 * W, 3 * W, W, W, b_tmaj=True,
                  epilogue=ops.EPI_RESID_F32, resid=dt1)
+    if ph:
+        ops.dropout_f32(do, ph, stash["s_emb"], out_f32=do)
     de = ops.layernorm_bwd(stash["e32"], st.p(prefix + "embeddings.LayerNorm.weight"), do,
                            G(prefix + "embeddings.LayerNorm.weight"), G(prefix + "embeddings.LayerNorm.bias"), eps,
                            rows=R, width=W)
@@ -365,8 +405,10 @@ class _EncodeFn(torch.autograd.Function):
     def forward(ctx, model, ids, key_len, images, anchor):
         save = bool(ctx.needs_input_grad[4])
         st = model._online
-        tok, Ti, vst = vit_forward(st, model._conv16, "visual_encoder.", model.vit_cfg, model.image_size, images, save)
-        pooled, bst = bert_forward(st, "text_encoder.", model.med_cfg, ids, key_len, tok, Ti, save)
+        drop = model._drop_seeds()
+        tok, Ti, vst = vit_forward(st, model._conv16, "visual_encoder.", model.vit_cfg, model.image_size, images, save,
+                                   drop=drop)
+        pooled, bst = bert_forward(st, "text_encoder.", model.med_cfg, ids, key_len, tok, Ti, save, drop=drop)
         ctx.model, ctx.vst, ctx.bst = model, vst, bst
         return pooled
 
@@ -639,6 +681,12 @@ class BLIPFeatureFusion(nn.Module):
         return out
 
     # ---- encoders ------------------------------------------------------------------------------------------
+    def _drop_seeds(self):
+        """train mode with a non-zero rate: a fresh seed stream for one encoder pass (else None: no dropout launches)"""
+        rates = (self.med_cfg.get("hidden_dropout_prob", 0.0), self.med_cfg.get("attention_probs_dropout_prob", 0.0),
+                 self.vit_cfg.get("drop_path_rate", 0.0))
+        return ops.DropSeeds() if self.training and any(r > 0 for r in rates) else None
+
     def _text_inputs(self, txt):
         ids = txt["input_ids"] if isinstance(txt, dict) else txt.input_ids
         mask = txt["attention_mask"] if isinstance(txt, dict) else txt.attention_mask
@@ -652,9 +700,10 @@ class BLIPFeatureFusion(nn.Module):
         ids, key_len = self._text_inputs(txt_dict_batched)
         if use_momentum:
             with torch.no_grad():
+                drop = self._drop_seeds()
                 tok, Ti, _ = vit_forward(self._mom, self._conv16_m, "visual_encoder.", self.vit_cfg, self.image_size,
-                                         image_batched, False)
-                return bert_forward(self._mom, "text_encoder.", self.med_cfg, ids, key_len, tok, Ti, False)[0]
+                                         image_batched, False, drop=drop)
+                return bert_forward(self._mom, "text_encoder.", self.med_cfg, ids, key_len, tok, Ti, False, drop=drop)[0]
         anchor = torch.zeros(1, device=ids.device, requires_grad=torch.is_grad_enabled())
         return _EncodeFn.apply(self, ids, key_len, image_batched, anchor)
 
@@ -778,9 +827,11 @@ class BLIPScoreFusion(BLIPFeatureFusion):
         dev = ids.device
         M = ids.shape[0]
         E = self.embed_dim
-        tok, T, vst = vit_forward(st, conv16, "visual_encoder.", self.vit_cfg, self.image_size, images, save)
+        drop = self._drop_seeds()
+        tok, T, vst = vit_forward(st, conv16, "visual_encoder.", self.vit_cfg, self.image_size, images, save, drop=drop)
         ifeat16 = tok.view(M, T, -1)[:, 0].contiguous()                     # class-token rows (a copy)
-        tfeat, bst = bert_forward(st, "text_encoder.", self.med_cfg, ids, key_len, None, 0, save, cross=False, pool=False)
+        tfeat, bst = bert_forward(st, "text_encoder.", self.med_cfg, ids, key_len, None, 0, save, cross=False, pool=False,
+                                  drop=drop)
         tfeat16 = torch.empty(M, tfeat.shape[1], device=dev, dtype=torch.bfloat16)
         ops.call("uniir_cast_f32_to_bf16", tfeat, tfeat16, tfeat.numel())
         temb = ops.linear_fwd(tfeat16, st.w16("text_proj.weight"), st.p("text_proj.bias"), epilogue=ops.EPI_RESID_F32)

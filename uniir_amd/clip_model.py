@@ -219,8 +219,11 @@ class _Blk:
         return self.m.grad_view(self.names[k])
 
 
-def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5, act=ops.ACT_QUICKGELU, blk=None):
-    """pre-LN residual blocks (CLIP resblocks; with eps / act / blk(i) overridden also the BLIP ViT blocks)"""
+def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5, act=ops.ACT_QUICKGELU, blk=None,
+               rowscale=None):
+    """pre-LN residual blocks (CLIP resblocks; with eps / act / blk(i) overridden also the BLIP ViT blocks).
+    rowscale fp32 [layers, 2, M]: DropPath factors (0 or 1/keep per item) of the two residual branches of each block
+    (BLIP ViT-large in train mode, backbone/vit.py:79-80); None = no DropPath (the residual add stays in the GEMM)"""
     blk = blk or (lambda i: _Blk(model, f"{prefix}.resblocks.{i}"))
     R = M * T
     dev = x.device
@@ -235,12 +238,20 @@ def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5,
         ops.layernorm_fwd(x, b.p32("ln1w"), b.p32("ln1b"), eps, out_bf16=h1, rows=R, width=W)
         qkv = ops.linear_fwd(h1, b.w16("wqkv"), b.p32("bqkv"))
         ao, lse = ops.attention_fwd(qkv, M, T, heads, causal)
-        x2 = ops.linear_fwd(ao, b.w16("wo"), b.p32("bo"), epilogue=ops.EPI_RESID_F32, resid=x)
+        if rowscale is None:
+            x2 = ops.linear_fwd(ao, b.w16("wo"), b.p32("bo"), epilogue=ops.EPI_RESID_F32, resid=x)
+        else:
+            x2 = ops.linear_fwd(ao, b.w16("wo"), b.p32("bo"), epilogue=ops.EPI_RESID_F32)
+            ops.dropout_f32(x2, 0.0, 0, resid=x, out_f32=x2, rowscale=rowscale[i, 0], rows_per_scale=T)
         h2 = torch.empty(R, W, device=dev, dtype=torch.bfloat16) if save else h
         ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), eps, out_bf16=h2, rows=R, width=W)
         f = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
         ops.linear_fwd(h2, b.w16("wfc"), b.p32("bfc"), out=f, epilogue=ops.EPI_BIAS_ACT, C2=g, act=act)
-        xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32, resid=x2)
+        if rowscale is None:
+            xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32, resid=x2)
+        else:
+            xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32)
+            ops.dropout_f32(xn, 0.0, 0, resid=x2, out_f32=xn, rowscale=rowscale[i, 1], rows_per_scale=T)
         if save:
             saved.append((x, qkv, ao, lse, x2, f, h1, h2))
         x = xn
@@ -248,8 +259,10 @@ def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5,
 
 
 def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, eps=1e-5, act=ops.ACT_QUICKGELU,
-               blk=None):
-    """dx fp32 [R,W] and its bf16 copy dxb: gradient w.r.t. the tower output.  Returns d(tower input) (fp32)."""
+               blk=None, rowscale=None):
+    """dx fp32 [R,W] and its bf16 copy dxb: gradient w.r.t. the tower output.  Returns d(tower input) (fp32).
+    With DropPath factors (rowscale, see _tower_fwd) the branch gradient is rowscale * dx: the bf16 copy is scaled in
+    place and the two bias gradients are its column sums (instead of the sums fused into the LayerNorm backward)."""
     blk = blk or (lambda i: _Blk(model, f"{prefix}.resblocks.{i}"))
     R = M * T
     dev = dx.device
@@ -258,11 +271,15 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
     dh = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
     # bias gradient of the last block's c_proj: column sums of the incoming gradient (the other blocks get theirs from
     # the LayerNorm backward that produces their incoming gradient)
-    ops.call("uniir_colsum_bf16", dxb, W, blk(layers - 1).g("bproj"), R, W)
+    if rowscale is None:
+        ops.call("uniir_colsum_bf16", dxb, W, blk(layers - 1).g("bproj"), R, W)
     for i in reversed(range(layers)):
         b = blk(i)
         x, qkv, ao, lse, x2, f, h1, h2 = saved[i]
         saved[i] = None
+        if rowscale is not None:
+            ops.dropout_bf16_(dxb, 0.0, 0, rowscale=rowscale[i, 1], rows_per_scale=T)
+            ops.call("uniir_colsum_bf16", dxb, W, b.g("bproj"), R, W)
         # d(mlp): df = (dx @ Wproj) * act'(f); the same epilogue re-materialises g = act(f) for dWproj and sums
         # df's columns into the c_fc bias gradient
         ops.linear_dgrad(dxb, b.w16("wproj"), out=df, aux=f, act_out=g, colsum=b.g("bfc"), act=act)
@@ -271,8 +288,12 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
         ops.linear_dgrad(df, b.w16("wfc"), out=dh)                               # dh := d ln_2 out
         dx2 = torch.empty(R, W, device=dev, dtype=torch.float32)
         ops.layernorm_bwd(x2, b.p32("ln2w"), dh, b.g("ln2w"), b.g("ln2b"), eps, dres=dx, dx=dx2, dx_bf16=dxb,
-                          rows=R, width=W, dx_colsum=b.g("bo"))                  # d x2 also is d(out_proj out): its bias grad
+                          rows=R, width=W, dx_colsum=(b.g("bo") if rowscale is None else None))   # d x2 also is
+        # d(out_proj out): its bias grad
         del x2, f, h2
+        if rowscale is not None:
+            ops.dropout_bf16_(dxb, 0.0, 0, rowscale=rowscale[i, 0], rows_per_scale=T)
+            ops.call("uniir_colsum_bf16", dxb, W, b.g("bo"), R, W)
         ops.linear_wgrad(dxb, ao, b.g("wo"))
         ops.linear_dgrad(dxb, b.w16("wo"), out=dh)                               # dh := d attn out
         dqkv = ops.attention_bwd(qkv, ao, dh, lse, M, T, heads, causal)
@@ -282,7 +303,7 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
         ops.linear_dgrad(dqkv, b.w16("wqkv"), out=dh)                            # dh := d ln_1 out
         del dqkv, h1
         ops.layernorm_bwd(x, b.p32("ln1w"), dh, b.g("ln1w"), b.g("ln1b"), eps, dres=dx2, dx=dx, dx_bf16=dxb,
-                          rows=R, width=W, dx_colsum=(blk(i - 1).g("bproj") if i > 0 else None))
+                          rows=R, width=W, dx_colsum=(blk(i - 1).g("bproj") if i > 0 and rowscale is None else None))
         del x, dx2
     return dx
 

@@ -76,7 +76,7 @@ def t5_forward(st, prefix, x, M, T, heads, layers, save):
         qkv = ops.linear_fwd(h1, st.w16(a + "SelfAttention.q.weight", (3 * inner, D)))
         ao = torch.empty(R, inner, device=dev, dtype=torch.bfloat16)
         lse = torch.empty(M, heads, T, device=dev, dtype=torch.float32)
-        ops.call("uniir_attention_rel_fwd", qkv, ao, lse, rel, table, T5_BUCKETS, 1.0, M, T, heads)
+        ops.call("uniir_attention_rel_fwd", qkv, ao, lse, rel, table, T5_BUCKETS, 1.0, M, T, heads, 0.0, 0)
         x2 = ops.linear_fwd(ao, st.w16(a + "SelfAttention.o.weight"), epilogue=ops.EPI_RESID_F32, resid=x)
         h2 = _rms(st, x2, f + "layer_norm.weight", R, D)
         wi = st.w16(f + "DenseReluDense.wi.weight")
@@ -130,7 +130,7 @@ def t5_backward(st, prefix, dpooled, stash, heads, layers):
         dao = ops.linear_dgrad(dxb, st.w16(a + "SelfAttention.o.weight"))
         dqkv = torch.empty_like(qkv)
         ops.call("uniir_attention_rel_bwd", qkv, ao, dao, lse, dqkv, st.p(rel_name), table, T5_BUCKETS, 1.0, G(rel_name), M, T,
-                 heads)
+                 heads, 0.0, 0)
         ops.linear_wgrad(dqkv, h1, G(a + "SelfAttention.q.weight", (3 * inner, D)))
         dh = ops.linear_dgrad(dqkv, st.w16(a + "SelfAttention.q.weight", (3 * inner, D)))
         ops.call("uniir_rmsnorm_bwd", x, D, st.p(a + "layer_norm.weight"), dh, 0, dx2, dx, D, dxb, G(a + "layer_norm.weight"),

@@ -112,9 +112,13 @@ struct AttnArgs {
     const int* rel_bucket;        // [Tq + Tk - 1] bucket of every key - query offset
     float* drel;                  // backward, optional: [buckets][H] += d loss / d rel_emb
     int nbuckets;
+    // attention-probability dropout (BERT attention_probs_dropout_prob, T5 dropout_rate): P V uses P * mask / keep with
+    // mask(seed, ((m H + h) Tq + q) Tk + key) (common.h drop_hash); the softmax statistics stay those of the full P
+    float drop_p;
+    unsigned drop_seed;
 };
 
-template <bool REL>
+template <bool REL, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tq = a.Tq, Tk = a.Tk, H = a.H, causal = a.causal;
@@ -128,6 +132,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     const unsigned short* vbase = a.v + (long)m * Tk * a.kv_ld + h * ATT_D;
     const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
     const float sl2 = REL ? a.scale * LOG2EF : SCALE_LOG2E;
+    const unsigned dth = DROP ? drop_threshold(a.drop_p) : 0u;
+    const float dks = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     float* dbias = reinterpret_cast<float*>(lds + 2 * Tkp * 128);    // bias of every diagonal key - query (x log2 e)
     if (REL)
         for (int d = tid; d < Tq + Tk - 1; d += ATT_THREADS) dbias[d] = a.rel_emb[a.rel_bucket[d] * H + h] * LOG2EF;
@@ -192,6 +198,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
             sum = group_sum(sum);
             l_run = l_run * alpha + sum;
             m_run = m_new;
+            if (DROP) {
+                const unsigned rowbase = (unsigned)((((long)m * H + h) * Tq + q) * Tk);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        st[kt][r] *= drop_scale(rowbase + (unsigned)(kb * 32 + kt * 16 + 4 * g + r), a.drop_seed, dth, dks);
+            }
             const bf16x8_t pf = pack8(st[0], st[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -215,8 +229,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 
 // Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
 // Phase 2 (per 16-query tile): dQ^T += K^T dS^T with S^T = K Q^T oriented [key][q].
-template <bool REL>
-__global__ __launch_bounds__(ATT_THREADS, REL ? 2 : 4) void attn_bwd_kernel(AttnArgs a) {
+template <bool REL, bool DROP>
+__global__ __launch_bounds__(ATT_THREADS, (REL || DROP) ? 2 : 4) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tq = a.Tq, Tk = a.Tk, H = a.H, causal = a.causal;
     const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
@@ -229,8 +243,11 @@ __global__ __launch_bounds__(ATT_THREADS, REL ? 2 : 4) void attn_bwd_kernel(Attn
     float* ddiag = dbias + (Tq + Tk);      // [Tq + Tk - 1] gradient per diagonal
     const float sl2 = REL ? a.scale * LOG2EF : SCALE_LOG2E;
     const float oscale = REL ? a.scale : ATT_SCALE;
+    const unsigned dth = DROP ? drop_threshold(a.drop_p) : 0u;
+    const float dks = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = blockIdx.x / H, h = blockIdx.x % H;
+    const unsigned headbase = (unsigned)((((long)m * H + h) * Tq) * Tk);
     const unsigned short* qbase = a.q + (long)m * Tq * a.q_ld + h * ATT_D;
     const unsigned short* kbase = a.k + (long)m * Tk * a.kv_ld + h * ATT_D;
     const unsigned short* vbase = a.v + (long)m * Tk * a.kv_ld + h * ATT_D;
@@ -304,8 +321,9 @@ __global__ __launch_bounds__(ATT_THREADS, REL ? 2 : 4) void attn_bwd_kernel(Attn
                     const int dg = min(max(key - q + Tq - 1, 0), Tq + Tk - 2);
                     float p = __builtin_amdgcn_exp2f(sa[r] * sl2 + (REL ? dbias[dg] : 0.f) - lse2[q]);
                     if (key >= kvalid || (causal && key > q) || (REL && q >= Tq)) p = 0.f;
-                    pt[qt][r] = p;
-                    dst[qt][r] = p * (dp[r] - Dq[q]);
+                    const float mk = DROP ? drop_scale(headbase + (unsigned)q * (unsigned)Tk + (unsigned)key, a.drop_seed, dth, dks) : 1.0f;
+                    pt[qt][r] = p * mk;
+                    dst[qt][r] = p * (dp[r] * mk - Dq[q]);
                     // d bias = d logits; a wave-instruction touches ~28 distinct diagonals: cheap LDS atomics
                     if (REL && a.drel && key < Tk && q < Tq) atomicAdd(&ddiag[dg], dst[qt][r]);
                 }
@@ -365,7 +383,8 @@ __global__ __launch_bounds__(ATT_THREADS, REL ? 2 : 4) void attn_bwd_kernel(Attn
                     float p = __builtin_amdgcn_exp2f(
                         sa[r] * sl2 + (REL ? dbias[min(max(key - q + Tq - 1, 0), Tq + Tk - 2)] : 0.f) - my_lse);
                     if (key >= kvalid || (causal && key > q)) p = 0.f;
-                    dst[kt][r] = p * (dp[r] - my_D);
+                    const float mk = DROP ? drop_scale(headbase + (unsigned)q * (unsigned)Tk + (unsigned)key, a.drop_seed, dth, dks) : 1.0f;
+                    dst[kt][r] = p * (dp[r] * mk - my_D);
                 }
             }
             const bf16x8_t dsf = pack8(dst[0], dst[1]);
@@ -399,13 +418,19 @@ static int launch_attn_fwd(const AttnArgs& a, int batch, hipStream_t st) {
     const int sm = 2 * Tkp * 128 + (a.rel_emb ? (a.Tq + a.Tk) * 4 : 0);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * 512 * 128 + 1024 * 4);
+        const int big = 2 * 512 * 128 + 1024 * 4;
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         attr = true;
     }
-    if (a.rel_emb) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
+    const dim3 g(batch * a.H), b(ATT_THREADS);
+    const bool drop = a.drop_p > 0.f;
+    if (a.rel_emb && drop) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), g, b, sm, st, a);
+    else if (a.rel_emb) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), g, b, sm, st, a);
+    else if (drop) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), g, b, sm, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), g, b, sm, st, a);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -415,14 +440,19 @@ static int launch_attn_bwd(const AttnArgs& a, int batch, hipStream_t st) {
     const int sm = 2 * Tmax * 128 + 2 * Tqp * 4 + (a.rel_emb ? 2 * (a.Tq + a.Tk) * 4 : 0);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * 512 * 128 + 2 * 512 * 4);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * 512 * 128 + 2 * 512 * 4 + 2 * 1024 * 4);
+        const int big = 2 * 512 * 128 + 2 * 512 * 4 + 2 * 1024 * 4;
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         attr = true;
     }
-    if (a.rel_emb) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
-    else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(batch * a.H), dim3(ATT_THREADS), sm, st, a);
+    const dim3 g(batch * a.H), b(ATT_THREADS);
+    const bool drop = a.drop_p > 0.f;
+    if (a.rel_emb && drop) hipLaunchKernelGGL((attn_bwd_kernel<true, true>), g, b, sm, st, a);
+    else if (a.rel_emb) hipLaunchKernelGGL((attn_bwd_kernel<true, false>), g, b, sm, st, a);
+    else if (drop) hipLaunchKernelGGL((attn_bwd_kernel<false, true>), g, b, sm, st, a);
+    else hipLaunchKernelGGL((attn_bwd_kernel<false, false>), g, b, sm, st, a);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -465,7 +495,8 @@ extern "C" int uniir_attention_bwd(const void* qkv, const void* out, const void*
 // general form: separate Q and K/V tensors (cross-attention), optional per-item key length (padding mask)
 extern "C" int uniir_attention_fwd_ex(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld,
                                       void* out, int64_t out_ld, float* lse, const int32_t* key_len, int32_t batch,
-                                      int32_t tq, int32_t tk, int32_t heads, int32_t causal, void* stream) {
+                                      int32_t tq, int32_t tk, int32_t heads, int32_t causal, float drop_p,
+                                      uint32_t drop_seed, void* stream) {
     if (!q || !k || !v || !out || !lse || batch < 0 || heads <= 0) return UNIIR_EINVAL;
     if (batch == 0) return UNIIR_OK;
     if (tq < 1 || tk < 1 || tq > 512 || tk > 512) return UNIIR_ESHAPE;
@@ -476,6 +507,8 @@ extern "C" int uniir_attention_fwd_ex(const void* q, int64_t q_ld, const void* k
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
     a.q_ld = q_ld; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = out_ld; a.lse = lse; a.klen = key_len;
     a.Tq = tq; a.Tk = tk; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
+    if (drop_p < 0.f || drop_p >= 1.f) return UNIIR_EINVAL;
+    a.drop_p = drop_p; a.drop_seed = drop_seed;
     return launch_attn_fwd(a, batch, (hipStream_t)stream);
 }
 
@@ -483,7 +516,7 @@ extern "C" int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k
                                       const void* out, const void* dout, int64_t out_ld, const float* lse,
                                       const int32_t* key_len, void* dq, int64_t dq_ld, void* dk, void* dv,
                                       int64_t dkv_ld, int32_t batch, int32_t tq, int32_t tk, int32_t heads,
-                                      int32_t causal, void* stream) {
+                                      int32_t causal, float drop_p, uint32_t drop_seed, void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || batch < 0 || heads <= 0) return UNIIR_EINVAL;
     if (batch == 0) return UNIIR_OK;
     if (tq < 1 || tk < 1 || tq > 512 || tk > 512) return UNIIR_ESHAPE;
@@ -497,6 +530,8 @@ extern "C" int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k
     a.dout = (const unsigned short*)dout;
     a.dq = (unsigned short*)dq; a.dk = (unsigned short*)dk; a.dv = (unsigned short*)dv;
     a.dq_ld = dq_ld; a.dkv_ld = dkv_ld;
+    if (drop_p < 0.f || drop_p >= 1.f) return UNIIR_EINVAL;
+    a.drop_p = drop_p; a.drop_seed = drop_seed;
     return launch_attn_bwd(a, batch, (hipStream_t)stream);
 }
 
@@ -505,7 +540,7 @@ extern "C" int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k
 // uniir_attention_fwd.  bwd adds d loss / d rel_emb into drel (fp32 [buckets][heads], zero it once per step).
 extern "C" int uniir_attention_rel_fwd(const void* qkv, void* out, float* lse, const float* rel_emb,
                                        const int32_t* rel_bucket, int32_t nbuckets, float scale, int32_t batch,
-                                       int32_t seq, int32_t heads, void* stream) {
+                                       int32_t seq, int32_t heads, float drop_p, uint32_t drop_seed, void* stream) {
     if (!qkv || !out || !lse || !rel_emb || !rel_bucket || batch < 0 || heads <= 0 || nbuckets <= 0 || nbuckets > 64)
         return UNIIR_EINVAL;
     if (batch == 0) return UNIIR_OK;
@@ -516,12 +551,15 @@ extern "C" int uniir_attention_rel_fwd(const void* qkv, void* out, float* lse, c
     a.q_ld = a.kv_ld = 3 * W; a.out = (unsigned short*)out; a.out_ld = W; a.lse = lse;
     a.Tq = a.Tk = seq; a.H = heads; a.causal = 0; a.scale = scale;
     a.rel_emb = rel_emb; a.rel_bucket = rel_bucket; a.nbuckets = nbuckets;
+    if (drop_p < 0.f || drop_p >= 1.f) return UNIIR_EINVAL;
+    a.drop_p = drop_p; a.drop_seed = drop_seed;
     return launch_attn_fwd(a, batch, (hipStream_t)stream);
 }
 
 extern "C" int uniir_attention_rel_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                                        const float* rel_emb, const int32_t* rel_bucket, int32_t nbuckets, float scale,
-                                       float* drel, int32_t batch, int32_t seq, int32_t heads, void* stream) {
+                                       float* drel, int32_t batch, int32_t seq, int32_t heads, float drop_p,
+                                       uint32_t drop_seed, void* stream) {
     if (!qkv || !out || !dout || !lse || !dqkv || !rel_emb || !rel_bucket || batch < 0 || heads <= 0 || nbuckets <= 0 ||
         nbuckets > 64)
         return UNIIR_EINVAL;
@@ -535,5 +573,7 @@ extern "C" int uniir_attention_rel_bwd(const void* qkv, const void* out, const v
     a.dq = (unsigned short*)dqkv; a.dk = a.dq + W; a.dv = a.dq + 2 * W; a.dq_ld = a.dkv_ld = 3 * W;
     a.Tq = a.Tk = seq; a.H = heads; a.causal = 0; a.scale = scale;
     a.rel_emb = rel_emb; a.rel_bucket = rel_bucket; a.nbuckets = nbuckets; a.drel = drel;
+    if (drop_p < 0.f || drop_p >= 1.f) return UNIIR_EINVAL;
+    a.drop_p = drop_p; a.drop_seed = drop_seed;
     return launch_attn_bwd(a, batch, (hipStream_t)stream);
 }

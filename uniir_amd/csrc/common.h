@@ -64,3 +64,19 @@ DEVINL int xcd_remap(int bid, int nwg) {
         hipError_t e__ = hipGetLastError();                        \
         if (e__ != hipSuccess) return UNIIR_ELAUNCH;               \
     } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// Dropout masks: counter-based (no state): element idx of a call with seed s is kept iff fmix32(idx * golden ^ s) >= p * 2^32.
+// The same (seed, idx) regenerates the mask in backward.  keep_scale = 1 / (1 - p) for kept elements, 0 otherwise.
+// ------------------------------------------------------------------------------------------------------------
+DEVINL unsigned drop_hash(unsigned idx, unsigned seed) {
+    unsigned h = idx * 0x9E3779B1u ^ seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+DEVINL unsigned drop_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967040.0f); }
+DEVINL float drop_scale(unsigned idx, unsigned seed, unsigned thresh, float keep_scale) {
+    return drop_hash(idx, seed) >= thresh ? keep_scale : 0.0f;
+}

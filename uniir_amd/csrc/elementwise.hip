@@ -740,3 +740,90 @@ extern "C" int uniir_meanpool_bwd(const float* dout, float* dx, int32_t n, int32
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// [DROPOUT] train-mode dropout of the BLIP MED BERT (hidden_dropout_prob / attention_probs_dropout_prob 0.1,
+// backbone/configs/med_config.json), the T5 fusion stack (dropout_rate 0.1) and DropPath of BLIP's ViT-large
+// (backbone/blip.py:245-254).  Element masks are regenerated from (seed, element index) -- see common.h.
+//   dropout_f32 : y = (resid ? resid : 0) + x * mask(idx) [* rowscale[row / div]]   -> fp32 and / or bf16 copies
+//   dropout_bf16: y = x * mask(idx) [* rowscale[row / div]]  (bf16 -> bf16; the masked gradient fed to wgrad / dgrad)
+//   dropout_mask: out[idx] = mask value (tests)
+// idx = row * cols + col of the logical [rows][cols] tensor (ld = row pitch of x / y in elements).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, const float* __restrict__ resid,
+                                                          float* __restrict__ y32, unsigned short* __restrict__ y16,
+                                                          long rows, int cols, float p, unsigned seed,
+                                                          const float* __restrict__ rowscale, int div) {
+    const unsigned th = drop_threshold(p);
+    const float ks = 1.0f / (1.0f - p);
+    const long nv = rows * (cols / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        const long row = i / (cols / 4);
+        const int c = (int)(i - row * (cols / 4)) * 4;
+        const long e = row * cols + c;
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + e);
+        const float rs = rowscale ? rowscale[row / div] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= (p > 0.f ? drop_scale((unsigned)(e + k), seed, th, ks) : 1.0f) * rs;
+        if (resid) v += *reinterpret_cast<const f32x4_t*>(resid + e);
+        if (y32) *reinterpret_cast<f32x4_t*>(y32 + e) = v;
+        if (y16) {
+            const u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(y16 + e) = pk;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                           long rows, int cols, long ld, float p, unsigned seed,
+                                                           const float* __restrict__ rowscale, int div) {
+    const unsigned th = drop_threshold(p);
+    const float ks = 1.0f / (1.0f - p);
+    const long nv = rows * (cols / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        const long row = i / (cols / 4);
+        const int c = (int)(i - row * (cols / 4)) * 4;
+        const long e = row * cols + c;
+        const u32x2_t a = *reinterpret_cast<const u32x2_t*>(x + row * ld + c);
+        float v[4] = {__uint_as_float(a[0] << 16), __uint_as_float(a[0] & 0xffff0000u), __uint_as_float(a[1] << 16),
+                      __uint_as_float(a[1] & 0xffff0000u)};
+        const float rs = rowscale ? rowscale[row / div] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= (p > 0.f ? drop_scale((unsigned)(e + k), seed, th, ks) : 1.0f) * rs;
+        const u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2_t*>(y + row * ld + c) = pk;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long count, float p, unsigned seed) {
+    const unsigned th = drop_threshold(p);
+    const float ks = 1.0f / (1.0f - p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256)
+        out[i] = drop_scale((unsigned)i, seed, th, ks);
+}
+extern "C" int uniir_dropout_f32(const float* x, const float* resid, float* y_f32, void* y_bf16, int64_t rows, int32_t cols,
+                                 float p, uint32_t seed, const float* rowscale, int32_t rows_per_scale, void* stream) {
+    if (!x || (!y_f32 && !y_bf16) || rows < 0 || cols <= 0 || cols % 4 || p < 0.f || p >= 1.f) return UNIIR_EINVAL;
+    if (rowscale && rows_per_scale <= 0) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid_for(rows * (cols / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                       resid, y_f32, (unsigned short*)y_bf16, (long)rows, cols, p, seed, rowscale, rows_per_scale > 0 ? rows_per_scale : 1);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+extern "C" int uniir_dropout_bf16(const void* x, void* y, int64_t rows, int32_t cols, int64_t ld, float p, uint32_t seed,
+                                  const float* rowscale, int32_t rows_per_scale, void* stream) {
+    if (!x || !y || rows < 0 || cols <= 0 || cols % 4 || ld % 4 || p < 0.f || p >= 1.f) return UNIIR_EINVAL;
+    if (rowscale && rows_per_scale <= 0) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid_for(rows * (cols / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, (unsigned short*)y, (long)rows, cols, (long)ld, p, seed, rowscale,
+                       rows_per_scale > 0 ? rows_per_scale : 1);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+extern "C" int uniir_dropout_mask(float* out, int64_t count, float p, uint32_t seed, void* stream) {
+    if (!out || count < 0 || p < 0.f || p >= 1.f) return UNIIR_EINVAL;
+    if (count == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(count, 256, 16384)), dim3(256), 0, (hipStream_t)stream, out, (long)count, p, seed);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}

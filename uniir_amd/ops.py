@@ -178,20 +178,49 @@ def attention_bwd(qkv, out, dout, lse, batch, seq, heads, causal, *, dqkv=None):
     return dqkv
 
 
-def attention_fwd_ex(q, q_ld, k, v, kv_ld, batch, tq, tk, heads, *, key_len=None, causal=False):
+def attention_fwd_ex(q, q_ld, k, v, kv_ld, batch, tq, tk, heads, *, key_len=None, causal=False, drop_p=0.0, drop_seed=0):
     """separate Q / K / V views (head h at column h*64 of rows with the given leading dimension); out [batch*tq, heads*64]"""
     out = torch.empty(batch * tq, heads * 64, device=q.device, dtype=torch.bfloat16)
     lse = torch.empty(batch, heads, tq, device=q.device, dtype=torch.float32)
     check(_lib.load().uniir_attention_fwd_ex(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), heads * 64, _p(lse), _p(key_len),
-                                             batch, tq, tk, heads, int(causal), _stream()), "attention_fwd_ex")
+                                             batch, tq, tk, heads, int(causal), float(drop_p), int(drop_seed), _stream()),
+          "attention_fwd_ex")
     return out, lse
 
 
 def attention_bwd_ex(q, q_ld, k, v, kv_ld, out, dout, lse, dq, dq_ld, dk, dv, dkv_ld, batch, tq, tk, heads, *,
-                     key_len=None, causal=False):
+                     key_len=None, causal=False, drop_p=0.0, drop_seed=0):
     check(_lib.load().uniir_attention_bwd_ex(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), _p(dout), heads * 64, _p(lse),
                                              _p(key_len), _p(dq), dq_ld, _p(dk), _p(dv), dkv_ld, batch, tq, tk, heads,
-                                             int(causal), _stream()), "attention_bwd_ex")
+                                             int(causal), float(drop_p), int(drop_seed), _stream()), "attention_bwd_ex")
+
+
+class DropSeeds:
+    """Seeds of the counter-based dropout masks of one forward pass (csrc/common.h drop_hash): one draw from torch's CPU
+    generator per forward (torch.manual_seed pins the masks), one derived 32-bit seed per dropout site; backward reuses
+    the seeds kept in the activation stash."""
+
+    def __init__(self):
+        self.base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        self.n = 0
+
+    def next(self):
+        self.n += 1
+        return (self.base + self.n * 0x9E3779B1) & 0xFFFFFFFF
+
+
+def dropout_f32(x, p, seed, *, resid=None, out_f32=None, out_bf16=None, rowscale=None, rows_per_scale=0):
+    """(resid +) x * mask [* rowscale[row // rows_per_scale]] of an fp32 [rows, cols] tensor -> fp32 and / or bf16"""
+    rows, cols = x.shape
+    check(_lib.load().uniir_dropout_f32(_p(x), _p(resid), _p(out_f32), _p(out_bf16), rows, cols, float(p), int(seed),
+                                        _p(rowscale), int(rows_per_scale), _stream()), "dropout_f32")
+
+
+def dropout_bf16_(x, p, seed, *, rowscale=None, rows_per_scale=0):
+    """in place x *= mask [* rowscale[row // rows_per_scale]] of a contiguous bf16 [rows, cols] gradient"""
+    rows, cols = x.shape
+    check(_lib.load().uniir_dropout_bf16(_p(x), _p(x), rows, cols, cols, float(p), int(seed), _p(rowscale),
+                                         int(rows_per_scale), _stream()), "dropout_bf16")
 
 
 def call(name, *args):
