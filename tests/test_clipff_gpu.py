@@ -33,7 +33,7 @@ def deep_ok(a, b, what):
     assert cos(a, b) > 0.985 and rel(a, b) < 0.2, (what, cos(a, b), rel(a, b))
 
 
-def _model(cfg, t5_cfg, seed=0):
+def _model(cfg, t5_cfg, seed=0, dropout_rate=0.0):
     from oracle import clip_oracle as O
     from models.uniir_clip.clip_featurefusion.clip_ff import CLIPFeatureFusion
     from uniir_amd import clip_model
@@ -41,7 +41,7 @@ def _model(cfg, t5_cfg, seed=0):
     config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=False), data_config=SimpleNamespace(in_batch_neg_num=0))
     m = CLIPFeatureFusion("tiny-ff", device="cuda", config=config,
                           t5_config=dict(d_model=t5_cfg["d_model"], num_heads=t5_cfg["num_heads"], d_ff=t5_cfg["d_ff"],
-                                         num_layers=t5_cfg["num_layers"]))
+                                         num_layers=t5_cfg["num_layers"], dropout_rate=dropout_rate))
     sd = O.init_state_dict(cfg, seed=seed)
     sd.pop("text_projection")
     m.clip_model.load_state_dict(sd, strict=True)
@@ -121,3 +121,61 @@ def test_clipff_model_matches_oracle_and_trains():
         dbatch["did_list"] = list(range(2 * pairs))
         emb, ids = m(dbatch, encode_mbeir_batch=True)
     assert emb.shape == (2 * pairs, 128) and torch.isfinite(emb).all()
+
+
+def test_t5_train_mode_dropout_matches_masked_oracle():
+    """the six T5 dropout sites with exported counter-based masks fed to the oracle's hooks: forward, input gradient and
+    weight gradients; plus the module switch (eval deterministic and mask-free, train mode stochastic)"""
+    from oracle import clip_oracle as O
+    from oracle import clipff_oracle as FF
+    from uniir_amd import clipff_model as FM
+    from uniir_amd import ops
+    z = np.load(os.path.join(G, "g13_clipff.npz"))
+    t5_cfg = json.loads(str(z["cfg"]))
+    cfg = O.tiny_config(embed_dim=t5_cfg["d_model"], transformer_width=t5_cfg["d_model"], transformer_heads=2)
+    m, _ = _model(cfg, t5_cfg, dropout_rate=0.1)
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    m.t5_layers.load_state_dict(sd, strict=True)
+    st = m._ensure_t5()
+    m.zero_grad()
+    txt, img = torch.from_numpy(z["txt_feat"]), torch.from_numpy(z["img_feat"])
+    M, Tt, D = txt.shape
+    T = Tt + img.shape[1]
+    x = torch.cat([txt, img], dim=1).view(M * T, D).contiguous().cuda()
+    p = 0.1
+    torch.manual_seed(11)
+    pooled, stash = FM.t5_forward(st, "", x.clone(), M, T, m.t5_heads, m.t5_layers_n, True, drop=ops.DropSeeds(), p=p)
+    w = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(2))
+    dx = FM.t5_backward(st, "", w.cuda(), stash, m.t5_heads, m.t5_layers_n).view(M, T, D)
+    torch.manual_seed(11)
+    seeds = ops.DropSeeds()
+
+    def masks(kind, shape):
+        buf = torch.empty(int(np.prod(shape)), device="cuda")
+        ops.call("uniir_dropout_mask", buf, buf.numel(), p, seeds.next())
+        return buf.view(*shape).cpu()
+
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = torch.cat([txt, img], dim=1).clone().requires_grad_(True)
+    ref = FF.t5_stack(sdg, xo, t5_cfg, masks=masks).mean(dim=1)
+    assert rel(pooled, ref) < 2e-2, rel(pooled, ref)
+    assert rel(pooled, z["emb"]) > 5e-2
+    (ref * w).sum().backward()
+    deep_ok(dx, xo.grad, "dx")
+    for name in ("block.0.layer.0.SelfAttention.q.weight", "block.0.layer.0.SelfAttention.o.weight",
+                 "block.1.layer.1.DenseReluDense.wi.weight", "block.1.layer.1.DenseReluDense.wo.weight",
+                 "block.0.layer.0.SelfAttention.relative_attention_bias.weight", "final_layer_norm.weight"):
+        deep_ok(st.grad_view(name), sdg[name].grad, name)
+    # module switch
+    batch = O.synthetic_batch(cfg, 2, seed=3)
+    t, im = batch["txt_batched"].cuda(), batch["image_batched"].cuda()
+    with torch.no_grad():
+        m.eval()
+        e0, e1 = m.encode_multimodal_input(t, im), m.encode_multimodal_input(t, im)
+        m.train()
+        torch.manual_seed(1)
+        d0 = m.encode_multimodal_input(t, im)
+        torch.manual_seed(1)
+        d1 = m.encode_multimodal_input(t, im)
+        d2 = m.encode_multimodal_input(t, im)
+    assert torch.equal(e0, e1) and torch.equal(d0, d1) and not torch.equal(d0, d2) and rel(d0, e0) > 1e-2

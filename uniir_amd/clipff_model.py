@@ -4,7 +4,9 @@ all tokens, no EOT pooling / projection), the token concat, the 2-layer T5 encod
 un-scaled attention with bucketed relative position bias, ReLU feed-forward, no biases) and the mean over tokens (:161-192).
 
 All arithmetic is in libuniir_hip.so; this file is the launch sequence + the flat store of the T5 parameters (state-dict
-keys `t5_layers.block.{i}.layer.{0,1}...` of transformers).  T5 dropout (0.1 in train mode) is not applied."""
+keys `t5_layers.block.{i}.layer.{0,1}...` of transformers).  In train mode the T5 dropout sites (dropout_rate 0.1: stack
+input, attention probabilities, attention output, after the ReLU, feed-forward output, after the final norm) are applied
+with counter-based masks regenerated in backward (ops.DropSeeds); the CLIP towers have no dropout."""
 import math
 
 import torch
@@ -14,6 +16,7 @@ from .blip_model import FlatStore
 from .clip_model import _tower_bwd, _tower_fwd
 
 T5_EPS = 1e-6
+T5_DROPOUT = 0.1      # transformers T5Config default dropout_rate (clip_ff.py:82,90 build T5Config() without overriding it)
 T5_BUCKETS, T5_MAXDIST = 32, 128
 
 
@@ -62,35 +65,58 @@ def _rms(st, x, name, R, D, out_f32=False):
     return y32 if out_f32 else y16
 
 
-def t5_forward(st, prefix, x, M, T, heads, layers, save):
-    """x fp32 [M*T, D] (the concatenated tokens) -> pooled fp32 [M, D] (+ stash)"""
+def t5_forward(st, prefix, x, M, T, heads, layers, save, drop=None, p=T5_DROPOUT):
+    """x fp32 [M*T, D] (the concatenated tokens; overwritten by its dropped version in train mode) -> pooled fp32 [M, D]
+    (+ stash).  drop: ops.DropSeeds in train mode, None in eval mode"""
     R, D = x.shape
     inner = heads * 64
     dev = x.device
     table = _table(T, dev)
     rel = st.p(prefix + "block.0.layer.0.SelfAttention.relative_attention_bias.weight")
     saved = []
+    p = p if drop is not None else 0.0
+    nxt = (lambda: drop.next()) if p else (lambda: 0)
+    s_in = nxt()
+    if p:
+        ops.dropout_f32(x, p, s_in, out_f32=x)
+
+    def branch(x16, w, resid):
+        """resid + dropout(x16 @ w^T)"""
+        if not p:
+            return ops.linear_fwd(x16, w, epilogue=ops.EPI_RESID_F32, resid=resid), 0
+        t = ops.linear_fwd(x16, w, epilogue=ops.EPI_RESID_F32)
+        sd = nxt()
+        ops.dropout_f32(t, p, sd, resid=resid, out_f32=t)
+        return t, sd
+
     for i in range(layers):
         a, f = f"{prefix}block.{i}.layer.0.", f"{prefix}block.{i}.layer.1."
         h1 = _rms(st, x, a + "layer_norm.weight", R, D)
         qkv = ops.linear_fwd(h1, st.w16(a + "SelfAttention.q.weight", (3 * inner, D)))
         ao = torch.empty(R, inner, device=dev, dtype=torch.bfloat16)
         lse = torch.empty(M, heads, T, device=dev, dtype=torch.float32)
-        ops.call("uniir_attention_rel_fwd", qkv, ao, lse, rel, table, T5_BUCKETS, 1.0, M, T, heads, 0.0, 0)
-        x2 = ops.linear_fwd(ao, st.w16(a + "SelfAttention.o.weight"), epilogue=ops.EPI_RESID_F32, resid=x)
+        sa = nxt()
+        ops.call("uniir_attention_rel_fwd", qkv, ao, lse, rel, table, T5_BUCKETS, 1.0, M, T, heads, p, sa)
+        x2, so = branch(ao, st.w16(a + "SelfAttention.o.weight"), x)
         h2 = _rms(st, x2, f + "layer_norm.weight", R, D)
         wi = st.w16(f + "DenseReluDense.wi.weight")
         ff = torch.empty(R, wi.shape[0], device=dev, dtype=torch.bfloat16)
         g = torch.empty(R, wi.shape[0], device=dev, dtype=torch.bfloat16)
         ops.linear_fwd(h2, wi, out=ff, epilogue=ops.EPI_BIAS_ACT, C2=g, act=ops.ACT_RELU)
-        xn = ops.linear_fwd(g, st.w16(f + "DenseReluDense.wo.weight"), epilogue=ops.EPI_RESID_F32, resid=x2)
+        sg = nxt()
+        if p:
+            ops.dropout_bf16_(g, p, sg)
+        xn, sf = branch(g, st.w16(f + "DenseReluDense.wo.weight"), x2)
         if save:
-            saved.append((x, h1, qkv, ao, lse, x2, h2, ff))
+            saved.append((x, h1, qkv, ao, lse, x2, h2, ff, (sa, so, sg, sf)))
         x = xn
     y = _rms(st, x, prefix + "final_layer_norm.weight", R, D, out_f32=True)
+    s_fin = nxt()
+    if p:
+        ops.dropout_f32(y, p, s_fin, out_f32=y)
     pooled = torch.empty(M, D, device=dev, dtype=torch.float32)
     ops.call("uniir_meanpool_fwd", y, pooled, M, T, D)
-    stash = dict(saved=saved, xf=x, M=M, T=T) if save else None
+    stash = dict(saved=saved, xf=x, M=M, T=T, p=p, s_in=s_in, s_fin=s_fin) if save else None
     return pooled, stash
 
 
@@ -106,6 +132,9 @@ def t5_backward(st, prefix, dpooled, stash, heads, layers):
     rel_name = prefix + "block.0.layer.0.SelfAttention.relative_attention_bias.weight"
     dy = torch.empty(R, D, device=dev, dtype=torch.float32)
     ops.call("uniir_meanpool_bwd", dpooled.contiguous(), dy, M, T, D)
+    p = stash["p"]
+    if p:
+        ops.dropout_f32(dy, p, stash["s_fin"], out_f32=dy)
     dx = torch.empty(R, D, device=dev, dtype=torch.float32)
     dxb = torch.empty(R, D, device=dev, dtype=torch.bfloat16)
     ops.call("uniir_rmsnorm_bwd", xf, D, st.p(prefix + "final_layer_norm.weight"), dy, 1, None, dx, D, dxb,
@@ -113,12 +142,17 @@ def t5_backward(st, prefix, dpooled, stash, heads, layers):
     del dy
     for i in reversed(range(layers)):
         a, f = f"{prefix}block.{i}.layer.0.", f"{prefix}block.{i}.layer.1."
-        x, h1, qkv, ao, lse, x2, h2, ff = stash["saved"][i]
+        x, h1, qkv, ao, lse, x2, h2, ff, (sa, so, sg, sf) = stash["saved"][i]
         stash["saved"][i] = None
+        if p:       # the feed-forward branch sees the masked gradient; dx (fp32) keeps the residual one
+            ops.dropout_bf16_(dxb, p, sf)
         wi, wo = st.w16(f + "DenseReluDense.wi.weight"), st.w16(f + "DenseReluDense.wo.weight")
         g = torch.empty_like(ff)
         df = torch.empty_like(ff)
         ops.linear_dgrad(dxb, wo, out=df, aux=ff, act_out=g, act=ops.ACT_RELU)        # df = (dx @ Wo) * relu'(ff), g = relu(ff)
+        if p:       # the ReLU-output mask: on the re-materialised activation and (it commutes with relu') on its gradient
+            ops.dropout_bf16_(g, p, sg)
+            ops.dropout_bf16_(df, p, sg)
         ops.linear_wgrad(dxb, g, G(f + "DenseReluDense.wo.weight"))
         ops.linear_wgrad(df, h2, G(f + "DenseReluDense.wi.weight"))
         dh = ops.linear_dgrad(df, wi)
@@ -126,16 +160,20 @@ def t5_backward(st, prefix, dpooled, stash, heads, layers):
         ops.call("uniir_rmsnorm_bwd", x2, D, st.p(f + "layer_norm.weight"), dh, 0, dx, dx2, D, dxb, G(f + "layer_norm.weight"),
                  R, D, T5_EPS)
         del ff, g, df, h2, x2
+        if p:
+            ops.dropout_bf16_(dxb, p, so)
         ops.linear_wgrad(dxb, ao, G(a + "SelfAttention.o.weight"))
         dao = ops.linear_dgrad(dxb, st.w16(a + "SelfAttention.o.weight"))
         dqkv = torch.empty_like(qkv)
         ops.call("uniir_attention_rel_bwd", qkv, ao, dao, lse, dqkv, st.p(rel_name), table, T5_BUCKETS, 1.0, G(rel_name), M, T,
-                 heads, 0.0, 0)
+                 heads, p, sa)
         ops.linear_wgrad(dqkv, h1, G(a + "SelfAttention.q.weight", (3 * inner, D)))
         dh = ops.linear_dgrad(dqkv, st.w16(a + "SelfAttention.q.weight", (3 * inner, D)))
         ops.call("uniir_rmsnorm_bwd", x, D, st.p(a + "layer_norm.weight"), dh, 0, dx2, dx, D, dxb, G(a + "layer_norm.weight"),
                  R, D, T5_EPS)
         del qkv, ao, lse, h1, x, dx2
+    if p:
+        ops.dropout_f32(dx, p, stash["s_in"], out_f32=dx)
     return dx
 
 
@@ -239,7 +277,9 @@ class FusionFn(torch.autograd.Function):
         M, D = text.shape[0], ttok.shape[1]
         x = torch.cat([ttok.view(M, Tt, D), itok.view(M, Ti, D)], dim=1).view(M * (Tt + Ti), D)     # a copy, no arithmetic
         del ttok, itok
-        pooled, fst = t5_forward(st, "", x, M, Tt + Ti, owner.t5_heads, owner.t5_layers_n, save)
+        drop = ops.DropSeeds() if owner.training and owner.t5_dropout > 0 else None
+        pooled, fst = t5_forward(st, "", x, M, Tt + Ti, owner.t5_heads, owner.t5_layers_n, save, drop=drop,
+                                 p=owner.t5_dropout)
         ctx.owner, ctx.stashes, ctx.dims = owner, (tst, ist, fst), (M, Tt, Ti, D)
         return pooled
 

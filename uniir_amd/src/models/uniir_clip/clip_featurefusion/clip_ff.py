@@ -35,8 +35,9 @@ class CLIPFeatureFusion(nn.Module):
         self.clip_model, self.img_preprocess_fn = clip_front.load(model_name, device, jit, download_root=download_root)
         self.tokenizer = clip_front.tokenize
         self.loss_function = nn.CrossEntropyLoss()  # attribute parity; the fused kernel computes the CE
-        t5 = dict(d_model=_T5_DMODEL.get(model_name), num_heads=12, d_ff=2048, num_layers=2)
+        t5 = dict(d_model=_T5_DMODEL.get(model_name), num_heads=12, d_ff=2048, num_layers=2, dropout_rate=0.1)
         t5.update(t5_config or {})
+        self.t5_dropout = float(t5["dropout_rate"])     # T5Config() default; active in train mode only
         if t5["d_model"] is None:
             raise NotImplementedError("Only ViT-B/32 and ViT-L/14 are supported.")
         self.t5_heads, self.t5_layers_n, self._t5_cfg = t5["num_heads"], t5["num_layers"], t5
