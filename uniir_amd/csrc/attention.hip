@@ -230,7 +230,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 // Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
 // Phase 2 (per 16-query tile): dQ^T += K^T dS^T with S^T = K Q^T oriented [key][q].
 template <bool REL, bool DROP>
-__global__ __launch_bounds__(ATT_THREADS, (REL || DROP) ? 2 : 4) void attn_bwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tq = a.Tq, Tk = a.Tk, H = a.H, causal = a.causal;
     const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;

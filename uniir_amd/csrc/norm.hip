@@ -6,7 +6,7 @@
 
 #define LN_MAXC 8  // float4 chunks per lane -> width <= 64*4*8 = 2048 (kernels are instantiated for NC = 2,3,4,8)
 
-template <int NC>
+template <int NC, bool EXACT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long x_stride,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) {
+            if (EXACT || c < nchunk) {
                 v[i] = *reinterpret_cast<const f32x4_t*>(xr + 4 * c);
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) {
+            if (EXACT || c < nchunk) {
                 const f32x4_t d = v[i] - mean;
                 q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) {
+            if (EXACT || c < nchunk) {
                 const f32x4_t g = *reinterpret_cast<const f32x4_t*>(gamma + 4 * c);
                 const f32x4_t b = rms ? f32x4_t{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4_t*>(beta + 4 * c);
                 const f32x4_t o = (v[i] - mean) * rstd * g + b;
@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy * gamma;  dgamma += dy*xhat; dbeta += dy
-template <int NC, bool DY_F32>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, long x_stride,
+// EXACT: width == 256 * NC (every production width: 512 / 768 / 1024) -- no chunk predication, which is worth 50 VGPRs
+// (202 -> 152 at NC = 4: 3 waves / SIMD instead of 2).  The residual-gradient row is loaded with x and dy at the top of the
+// row (one exposed memory latency per row instead of two).
+template <int NC, bool DY_F32, bool EXACT>
+__global__ __launch_bounds__(256, (EXACT && NC <= 4) ? 3 : 1) void ln_bwd_kernel(const float* __restrict__ x, long x_stride,
                                                      const float* __restrict__ gamma,
                                                      const void* __restrict__ dy_,
                                                      const float* __restrict__ dres,
@@ -82,13 +85,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
     for (long row = (long)blockIdx.x * 4 + w; row < rows; row += (long)gridDim.x * 4) {
         const float* xr = x + row * x_stride;
-        f32x4_t v[NC], d[NC];
+        f32x4_t v[NC], d[NC], rs[NC];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) {
+            if (EXACT || c < nchunk) {
                 v[i] = *reinterpret_cast<const f32x4_t*>(xr + 4 * c);
+                if (dres) rs[i] = *reinterpret_cast<const f32x4_t*>(dres + row * dx_stride + 4 * c);
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
                 if (DY_F32) {
                     d[i] = *reinterpret_cast<const f32x4_t*>((const float*)dy_ + row * width + 4 * c);
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) {
+            if (EXACT || c < nchunk) {
                 v[i] = v[i] - mean;
                 q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
             }
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) {
+            if (EXACT || c < nchunk) {
                 v[i] = v[i] * rstd;  // xhat
                 const f32x4_t g = d[i] * *reinterpret_cast<const f32x4_t*>(gamma + 4 * c);
                 ag[i] += d[i] * v[i];
@@ -129,9 +133,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) {
+            if (EXACT || c < nchunk) {
                 f32x4_t o = (d[i] - c1 - v[i] * c2) * rstd;
-                if (dres) o += *reinterpret_cast<const f32x4_t*>(dres + row * dx_stride + 4 * c);
+                if (dres) o += rs[i];
                 *reinterpret_cast<f32x4_t*>(dx + row * dx_stride + 4 * c) = o;
                 if (dx_colsum) ac[i] += o;
                 if (dx_bf16) {
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) *reinterpret_cast<f32x4_t*>(mine + 4 * c) = pass == 0 ? ag[i] : (pass == 1 ? ab[i] : ac[i]);
+            if (EXACT || c < nchunk) *reinterpret_cast<f32x4_t*>(mine + 4 * c) = pass == 0 ? ag[i] : (pass == 1 ? ab[i] : ac[i]);
         }
         __syncthreads();
         float* dst = pass == 0 ? dgamma : (pass == 1 ? dbeta : dx_colsum);
@@ -168,17 +172,44 @@ static inline int ln_grid(int rows) {
 template <int NC>
 static void launch_ln_fwd(const float* x, long x_stride, const float* gamma, const float* beta, unsigned short* yb,
                           float* yf, int rows, int width, float eps, hipStream_t st, int rms = 0) {
-    hipLaunchKernelGGL(ln_fwd_kernel<NC>, dim3(ln_grid(rows)), dim3(256), 0, st, x, x_stride, gamma, beta, yb, yf, rows,
-                       width, eps, rms);
+    static int resident[2] = {0, 0};
+    const bool exact = width == 256 * NC;
+    if (!resident[exact]) {
+        int per_cu = 0;
+        const void* fn = exact ? (const void*)ln_fwd_kernel<NC, true> : (const void*)ln_fwd_kernel<NC, false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        resident[exact] = per_cu * 256;
+    }
+    int g = (rows + 3) / 4;
+    if (g > resident[exact]) g = resident[exact];
+    if (exact)
+        hipLaunchKernelGGL((ln_fwd_kernel<NC, true>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, beta, yb, yf, rows, width,
+                           eps, rms);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<NC, false>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, beta, yb, yf, rows, width,
+                           eps, rms);
 }
 template <int NC, bool F32>
 static void launch_ln_bwd(const float* x, long x_stride, const float* gamma, const void* dy, const float* dres,
                           float* dx, long dx_stride, unsigned short* dxb, float* dgamma, float* dbeta, float* dxsum,
                           int rows, int width, float eps, hipStream_t st, int rms = 0) {
-    int g = ln_grid(rows);
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL((ln_bwd_kernel<NC, F32>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
-                       dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms);
+    // persistent rows: one resident wave of workgroups (occupancy x 256 CUs), no tail wave
+    static int resident[2] = {0, 0};
+    const bool exact = width == 256 * NC;
+    if (!resident[exact]) {
+        int per_cu = 0;
+        const void* fn = exact ? (const void*)ln_bwd_kernel<NC, F32, true> : (const void*)ln_bwd_kernel<NC, F32, false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        resident[exact] = per_cu * 256;
+    }
+    int g = (rows + 3) / 4;
+    if (g > resident[exact]) g = resident[exact];
+    if (exact)
+        hipLaunchKernelGGL((ln_bwd_kernel<NC, F32, true>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
+                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms);
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<NC, F32, false>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
+                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms);
 }
 static inline int ln_nc(int width) {
     const int c = (width / 4 + 63) / 64;
