@@ -80,13 +80,20 @@ DEVINL bf16x8_t pack8(const f32x4_t a, const f32x4_t b) {
 DEVINL f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-DEVINL float group_max(float v) {  // across the 4 lane groups (same lane&15)
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+// reductions across the 4 lane groups (same lane&15) with the gfx950 row-swap instructions (VALU, no LDS round trip):
+// v_permlane32_swap(x, x) leaves {x[lane % 32], x[lane % 32 + 32]} in the two results, v_permlane16_swap(x, x) the two
+// rows of each 32-lane half
+DEVINL float group_max(float v) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 DEVINL float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // Generalised argument block: self-attention on the packed in_proj layout (q|k|v per token, CLIP / BLIP ViT / BERT self)
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     const int Tkp = (Tk + 31) & ~31;
     char* ldsK = lds;
     char* ldsV = lds + Tkp * 128;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar loop control
     const int m = blockIdx.x / H, h = blockIdx.x % H;
     const unsigned short* qbase = a.q + (long)m * Tq * a.q_ld + h * ATT_D;
     const unsigned short* kbase = a.k + (long)m * Tk * a.kv_ld + h * ATT_D;
@@ -142,7 +149,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
     const int nqt = (Tq + 15) >> 4;
     const int qi = lane & 15, g = lane >> 4;
-    for (int qt = w; qt < nqt; qt += ATT_WAVES) {
+    // tile -> wave mapping rotated per workgroup: with 257 tokens there are 17 tiles for 8 waves, and the two workgroups
+    // sharing a CU would otherwise both put their third tile on SIMD 0 (the softmax is VALU-bound per SIMD)
+    const int rot = 0;
+    for (int qt = (w - rot) & (ATT_WAVES - 1); qt < nqt; qt += ATT_WAVES) {
         const int q0 = qt * 16, q = q0 + qi;
         bf16x8_t qf[2];
         qf[0] = frag_rows_global(qbase, a.q_ld, q0, 0, lane, Tq);
@@ -153,51 +163,64 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         float m_run = -1e30f, l_run = 0.f;
         const int kmax = causal ? min(kvalid, q0 + 16) : kvalid;
         const int nkb = max(1, (kmax + 31) >> 5);
-        f32x4_t sn[2];   // S^T of the NEXT key block, computed one iteration ahead so its MFMAs overlap this softmax
+        // S^T of a key block is computed one block ahead (its MFMAs overlap the previous block's softmax); the loop is
+        // unrolled by two with the two logit buffers swapping roles, so nothing is copied between iterations
+        auto s_block = [&](int kb, f32x4_t (&sx)[2]) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            sn[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < 2; ++kt) {
+                sx[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) sn[kt] = mfma16(frag_rows(ldsK, kt * 16, s, lane), qf[s], sn[kt]);
-        }
-        for (int kb = 0; kb < nkb; ++kb) {
-            f32x4_t st[2] = {sn[0], sn[1]};
-            if (kb + 1 < nkb) {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    sn[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        sn[kt] = mfma16(frag_rows(ldsK, (kb + 1) * 32 + kt * 16, s, lane), qf[s], sn[kt]);
-                }
+                for (int s = 0; s < 2; ++s) sx[kt] = mfma16(frag_rows(ldsK, kb * 32 + kt * 16, s, lane), qf[s], sx[kt]);
             }
+        };
+        auto softmax_pv = [&](int kb, f32x4_t (&st)[2]) {
+            // The softmax is VALU-bound (4 waves share a SIMD): logits stay raw (the 1/8 log2 e scale is folded into the
+            // exp2 argument with one fma), masks are applied only on blocks that touch a boundary (wave-uniform
+            // test), and the running output is rescaled only when some row's maximum moved.
+            const bool edge = kb * 32 + 32 > kvalid || (causal && kb * 32 + 31 > q0);
             float mx = -1e30f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb * 32 + kt * 16 + 4 * g + r;
-                    float v = st[kt][r] * sl2;
-                    if (REL) v += dbias[min(max(key - q + Tq - 1, 0), Tq + Tk - 2)];
-                    if (key >= kvalid || (causal && key > q)) v = -1e30f;
-                    st[kt][r] = v;
-                    mx = fmaxf(mx, v);
+                    if (REL) st[kt][r] = st[kt][r] * sl2 + dbias[min(max(key - q + Tq - 1, 0), Tq + Tk - 2)];
                 }
+            if (edge) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kb * 32 + kt * 16 + 4 * g + r;
+                        if (key >= kvalid || (causal && key > q)) st[kt][r] = -1e30f;
+                    }
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
             mx = group_max(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            const float es = REL ? 1.0f : sl2;
+            const float m_new = fmaxf(m_run, mx * es);
+            if (__any(m_new > m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * alpha;
+                m_run = m_new;
+            }
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = (st[kt][r] <= -1e29f) ? 0.f : __builtin_amdgcn_exp2f(st[kt][r] - m_new);
+                    // masked logits (-1e30) underflow to exactly 0; key 0 is valid for every row (klen >= 1, causal
+                    // includes the diagonal), so m_run is finite from the first block on
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], es, -m_run));
                     st[kt][r] = p;
                     sum += p;
                 }
-            sum = group_sum(sum);
-            l_run = l_run * alpha + sum;
-            m_run = m_new;
+            l_run += sum;      // per-lane partial of the row sum (alpha is uniform across the 4 lanes of a row)
             if (DROP) {
                 const unsigned rowbase = (unsigned)((((long)m * H + h) * Tq + q) * Tk);
 #pragma unroll
@@ -208,11 +231,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
             }
             const bf16x8_t pf = pack8(st[0], st[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                o[dt] = o[dt] * alpha;
-                o[dt] = mfma16(frag_cols_tr(ldsV, kb * 32, dt, lane), pf, o[dt]);
-            }
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_cols_tr(ldsV, kb * 32, dt, lane), pf, o[dt]);
+        };
+        f32x4_t sa[2], sb[2];
+        s_block(0, sa);
+        for (int kb = 0; kb < nkb; kb += 2) {
+            if (kb + 1 < nkb) s_block(kb + 1, sb);
+            softmax_pv(kb, sa);
+            if (kb + 1 >= nkb) break;
+            if (kb + 2 < nkb) s_block(kb + 2, sa);
+            softmax_pv(kb + 1, sb);
         }
+        l_run = group_sum(l_run);
         if (q < Tq) {
             const float inv = 1.0f / l_run;
             unsigned short* orow = a.out + ((long)m * Tq + q) * a.out_ld + h * ATT_D;
@@ -229,10 +259,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 
 // Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
 // Phase 2 (per 16-query tile): dQ^T += K^T dS^T with S^T = K Q^T oriented [key][q].
-template <bool REL, bool DROP>
+// CAUSAL (CLIP text tower, 77 tokens): compile-time; its short loops are mostly boundary tiles, so masks are always on
+template <bool REL, bool DROP, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int Tq = a.Tq, Tk = a.Tk, H = a.H, causal = a.causal;
+    const int Tq = a.Tq, Tk = a.Tk, H = a.H;
+    constexpr bool causal = CAUSAL;
     const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
     const int Tmax = max(Tqp, Tkp);
     char* bufA = lds;                 // Q, later K
@@ -245,7 +277,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     const float oscale = REL ? a.scale : ATT_SCALE;
     const unsigned dth = DROP ? drop_threshold(a.drop_p) : 0u;
     const float dks = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar loop control
     const int m = blockIdx.x / H, h = blockIdx.x % H;
     const unsigned headbase = (unsigned)((((long)m * H + h) * Tq) * Tk);
     const unsigned short* qbase = a.q + (long)m * Tq * a.q_ld + h * ATT_D;
@@ -288,6 +320,29 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     const int li = lane & 15, g = lane >> 4;
     const int nktile = (Tk + 15) >> 4, nqtile = (Tq + 15) >> 4;
     const int nqblk = Tqp >> 5;
+    // The loops below are issue-bound (VALU + LDS + MFMA of 4 waves share a SIMD), so: the lane parts of the swizzled LDS
+    // fragment addresses are computed once (row0 is a multiple of 16 / 32, so (row & 7) is a lane constant and the block
+    // offset is a scalar add with immediate sub-offsets); masks are applied only on tiles that touch a boundary
+    // (wave-uniform test); the per-query statistics are read as 16-byte vectors.
+    int offR[2], offT[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) offR[s] = li * 128 + (((s * 4 + g) ^ (li & 7)) << 4);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int row = 4 * g + (li >> 2), col = 16 * dt + 4 * (li & 3);
+        offT[dt] = row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1));
+    }
+    const char* rA[2] = {bufA + offR[0], bufA + offR[1]};
+    const int dAB = Tmax * 128;      // bufB - bufA (scalar): the dO / V fragments sit at the same lane offsets
+    const char* tA[4] = {bufA + offT[0], bufA + offT[1], bufA + offT[2], bufA + offT[3]};
+    auto rows_frag = [&](const char* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(p)); };
+    auto cols_frag = [&](const char* p) {     // 32-row block: rows 4g.., 16 + 4g.. of one column tile
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lds_read_tr16(p));
+        const u32x2_t h2 = __builtin_bit_cast(u32x2_t, lds_read_tr16(p + 2048));
+        const u32x4_t r = {l2[0], l2[1], h2[0], h2[1]};
+        return __builtin_bit_cast(bf16x8_t, r);
+    };
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
     // ---------------- phase 1: dK, dV ----------------
     for (int kt = w; kt < nktile; kt += ATT_WAVES) {
         const int k0 = kt * 16, key = k0 + li;
@@ -300,30 +355,48 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
         f32x4_t dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dv[dt] = zero4;
+            dk[dt] = zero4;
         }
+        const bool kedge = k0 + 16 > kvalid;
         const int qb0 = causal ? (k0 >> 5) : 0;
         for (int qb = qb0; qb < nqblk; ++qb) {
+            const int blk = qb * 4096;
+            const bool edge = CAUSAL || kedge || (REL && qb * 32 + 32 > Tq);
             f32x4_t pt[2], dst[2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                f32x4_t sa = zero4, dp = zero4;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    sa = mfma16(frag_rows(bufA, qb * 32 + qt * 16, s, lane), kf[s], sa);
-                    dp = mfma16(frag_rows(bufB, qb * 32 + qt * 16, s, lane), vf[s], dp);
+                    sa = mfma16(rows_frag(rA[s] + blk + qt * 2048), kf[s], sa);
+                    dp = mfma16(rows_frag(rA[s] + dAB + blk + qt * 2048), vf[s], dp);
                 }
                 // A rows = queries, B cols = keys -> acc[r] = S[q = 4g + r][key = li]
+                const int qv = qb * 32 + qt * 16 + 4 * g;
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse2 + qv);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(Dq + qv);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = qb * 32 + qt * 16 + 4 * g + r;
+                    const int q = qv + r;
                     const int dg = min(max(key - q + Tq - 1, 0), Tq + Tk - 2);
-                    float p = __builtin_amdgcn_exp2f(sa[r] * sl2 + (REL ? dbias[dg] : 0.f) - lse2[q]);
-                    if (key >= kvalid || (causal && key > q) || (REL && q >= Tq)) p = 0.f;
+                    float p = REL ? __builtin_amdgcn_exp2f(sa[r] * sl2 + dbias[dg] - l4[r])
+                                  : __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], sl2, -l4[r]));
+                    pt[qt][r] = p;
+                }
+                if (edge) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key >= kvalid || (causal && key > qv + r) || (REL && qv + r >= Tq)) pt[qt][r] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qv + r;
+                    const int dg = min(max(key - q + Tq - 1, 0), Tq + Tk - 2);
+                    const float p = pt[qt][r];
                     const float mk = DROP ? drop_scale(headbase + (unsigned)q * (unsigned)Tk + (unsigned)key, a.drop_seed, dth, dks) : 1.0f;
-                    pt[qt][r] = p * mk;
-                    dst[qt][r] = p * (dp[r] * mk - Dq[q]);
+                    pt[qt][r] = DROP ? p * mk : p;
+                    dst[qt][r] = p * ((DROP ? dp[r] * mk : dp[r]) - d4[r]);
                     // d bias = d logits; a wave-instruction touches ~28 distinct diagonals: cheap LDS atomics
                     if (REL && a.drel && key < Tk && q < Tq) atomicAdd(&ddiag[dg], dst[qt][r]);
                 }
@@ -331,8 +404,8 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
             const bf16x8_t pf = pack8(pt[0], pt[1]), dsf = pack8(dst[0], dst[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = mfma16(frag_cols_tr(bufB, qb * 32, dt, lane), pf, dv[dt]);
-                dk[dt] = mfma16(frag_cols_tr(bufA, qb * 32, dt, lane), dsf, dk[dt]);
+                dv[dt] = mfma16(cols_frag(tA[dt] + dAB + blk), pf, dv[dt]);
+                dk[dt] = mfma16(cols_frag(tA[dt] + blk), dsf, dk[dt]);
             }
         }
         if (key < Tk) {
@@ -364,32 +437,45 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
         const float my_lse = lse2[q0 + li], my_D = Dq[q0 + li];
         f32x4_t dq[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = zero4;
         const int kmax = causal ? min(kvalid, q0 + 16) : kvalid;
         const int nkb = (kmax + 31) >> 5;
         for (int kb = 0; kb < nkb; ++kb) {
+            const int blk = kb * 4096;
+            const bool edge = CAUSAL || kb * 32 + 32 > kvalid;
             f32x4_t dst[2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                f32x4_t sa = zero4, dp = zero4;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    sa = mfma16(frag_rows(bufA, kb * 32 + kt * 16, s, lane), qf[s], sa);
-                    dp = mfma16(frag_rows(bufB, kb * 32 + kt * 16, s, lane), dof[s], dp);
+                    sa = mfma16(rows_frag(rA[s] + blk + kt * 2048), qf[s], sa);
+                    dp = mfma16(rows_frag(rA[s] + dAB + blk + kt * 2048), dof[s], dp);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb * 32 + kt * 16 + 4 * g + r;
-                    float p = __builtin_amdgcn_exp2f(
-                        sa[r] * sl2 + (REL ? dbias[min(max(key - q + Tq - 1, 0), Tq + Tk - 2)] : 0.f) - my_lse);
-                    if (key >= kvalid || (causal && key > q)) p = 0.f;
+                    float p = REL ? __builtin_amdgcn_exp2f(sa[r] * sl2 + dbias[min(max(key - q + Tq - 1, 0), Tq + Tk - 2)] - my_lse)
+                                  : __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], sl2, -my_lse));
+                    dst[kt][r] = p;
+                }
+                if (edge) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kb * 32 + kt * 16 + 4 * g + r;
+                        if (key >= kvalid || (causal && key > q)) dst[kt][r] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb * 32 + kt * 16 + 4 * g + r;
                     const float mk = DROP ? drop_scale(headbase + (unsigned)q * (unsigned)Tk + (unsigned)key, a.drop_seed, dth, dks) : 1.0f;
-                    dst[kt][r] = p * (dp[r] * mk - my_D);
+                    dst[kt][r] = dst[kt][r] * ((DROP ? dp[r] * mk : dp[r]) - my_D);
                 }
             }
             const bf16x8_t dsf = pack8(dst[0], dst[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(frag_cols_tr(bufA, kb * 32, dt, lane), dsf, dq[dt]);
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(cols_frag(tA[dt] + blk), dsf, dq[dt]);
         }
         if (q < Tq) {
             unsigned short* qrow = dqbase + (long)q * a.dq_ld;
@@ -441,18 +527,23 @@ static int launch_attn_bwd(const AttnArgs& a, int batch, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         const int big = 2 * 512 * 128 + 2 * 512 * 4 + 2 * 1024 * 4;
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         attr = true;
     }
     const dim3 g(batch * a.H), b(ATT_THREADS);
     const bool drop = a.drop_p > 0.f;
-    if (a.rel_emb && drop) hipLaunchKernelGGL((attn_bwd_kernel<true, true>), g, b, sm, st, a);
-    else if (a.rel_emb) hipLaunchKernelGGL((attn_bwd_kernel<true, false>), g, b, sm, st, a);
-    else if (drop) hipLaunchKernelGGL((attn_bwd_kernel<false, true>), g, b, sm, st, a);
-    else hipLaunchKernelGGL((attn_bwd_kernel<false, false>), g, b, sm, st, a);
+    if (a.causal && a.rel_emb) return UNIIR_ESHAPE;
+    if (a.causal && drop) hipLaunchKernelGGL((attn_bwd_kernel<false, true, true>), g, b, sm, st, a);
+    else if (a.causal) hipLaunchKernelGGL((attn_bwd_kernel<false, false, true>), g, b, sm, st, a);
+    else if (a.rel_emb && drop) hipLaunchKernelGGL((attn_bwd_kernel<true, true, false>), g, b, sm, st, a);
+    else if (a.rel_emb) hipLaunchKernelGGL((attn_bwd_kernel<true, false, false>), g, b, sm, st, a);
+    else if (drop) hipLaunchKernelGGL((attn_bwd_kernel<false, true, false>), g, b, sm, st, a);
+    else hipLaunchKernelGGL((attn_bwd_kernel<false, false, false>), g, b, sm, st, a);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
