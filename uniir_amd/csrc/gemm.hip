@@ -381,6 +381,15 @@ DEVINL void epilogue_atomic_pp(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
     }
 }
 
+#if defined(UNIIR_EXP_BUILD) && defined(PP_TS)   // per-workgroup s_memtime stamps (100 MHz): start, main loop done, end
+__device__ unsigned long long g_pp_ts[3 * 65536];
+extern "C" int uniir_debug_read_ts(void* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_ts), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#define PP_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 65536) g_pp_ts[3 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define PP_STAMP(i)
+#endif
 // LOOP: 0 = compiler-scheduled loop, 1 = counted-lgkmcnt asm loop, 2 = ping-pong 8-phase loop (gemm_core_pp.h)
 template <typename Elem, bool A_TMAJ, bool B_TMAJ, int WM, int WN, int BK, int LOOP>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p) {
@@ -405,6 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    PP_STAMP(0);
     constexpr bool PP = (WM == 2 && WN == 4 && BK == 64 && LOOP == 2);
     if (PP)
         glds_mainloop_pp<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
@@ -412,6 +422,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
         glds_mainloop_asm<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
     else
         glds_mainloop<Elem, A_TMAJ, B_TMAJ, WM, WN, BK>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
+    PP_STAMP(1);
     const int w = threadIdx.x >> 6;
     const int wm = (w / WN) * 128, wn = (w % WN) * 64;
     if (WM * WN == 8) {   // 256x256 tile: LDS-staged, fully coalesced epilogue
@@ -427,6 +438,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
         } else {
             epilogue256_staged<PP>(p, acc, m0, n0, wm, wn, lds, p.epilogue);
         }
+        PP_STAMP(2);
         return;
     }
     if (p.slab) {
