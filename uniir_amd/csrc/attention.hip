@@ -149,10 +149,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
     const int nqt = (Tq + 15) >> 4;
     const int qi = lane & 15, g = lane >> 4;
-    // tile -> wave mapping rotated per workgroup: with 257 tokens there are 17 tiles for 8 waves, and the two workgroups
-    // sharing a CU would otherwise both put their third tile on SIMD 0 (the softmax is VALU-bound per SIMD)
-    const int rot = 0;
-    for (int qt = (w - rot) & (ATT_WAVES - 1); qt < nqt; qt += ATT_WAVES) {
+    for (int qt = w; qt < nqt; qt += ATT_WAVES) {
         const int q0 = qt * 16, q = q0 + qi;
         bf16x8_t qf[2];
         qf[0] = frag_rows_global(qbase, a.q_ld, q0, 0, lane, Tq);

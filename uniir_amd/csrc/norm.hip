@@ -164,11 +164,6 @@ __global__ __launch_bounds__(256, (EXACT && NC <= 4) ? 3 : 1) void ln_bwd_kernel
     }
 }
 
-static inline int ln_grid(int rows) {
-    int g = (rows + 3) / 4;
-    return g > 2048 ? 2048 : (g < 1 ? 1 : g);
-}
-
 template <int NC>
 static void launch_ln_fwd(const float* x, long x_stride, const float* gamma, const float* beta, unsigned short* yb,
                           float* yf, int rows, int width, float eps, hipStream_t st, int rms = 0) {
