@@ -80,22 +80,6 @@ DEVINL bf16x8_t pack8(const f32x4_t a, const f32x4_t b) {
 DEVINL f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-// reductions across the 4 lane groups (same lane&15) with the gfx950 row-swap instructions (VALU, no LDS round trip):
-// v_permlane32_swap(x, x) leaves {x[lane % 32], x[lane % 32 + 32]} in the two results, v_permlane16_swap(x, x) the two
-// rows of each 32-lane half
-DEVINL float group_max(float v) {
-    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-DEVINL float group_sum(float v) {
-    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 // Generalised argument block: self-attention on the packed in_proj layout (q|k|v per token, CLIP / BLIP ViT / BERT self)
 // and rectangular cross-attention (BLIP MED: Tq text tokens attending to Tk image tokens) share the kernels.
 struct AttnArgs {

@@ -65,6 +65,22 @@ DEVINL int xcd_remap(int bid, int nwg) {
         if (e__ != hipSuccess) return UNIIR_ELAUNCH;               \
     } while (0)
 
+// Reductions across the 4 rows of a wave (lanes sharing lane & 15) with the gfx950 row-swap instructions (VALU, no LDS
+// crossbar round trip like __shfl_xor(.., 16 / 32)): v_permlane32_swap(x, x) leaves {x[lane % 32], x[lane % 32 + 32]} in the
+// two results, v_permlane16_swap(x, x) the two rows of each 32-lane half.  The result is in every lane.
+DEVINL float group_max(float v) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+DEVINL float group_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Dropout masks: counter-based (no state): element idx of a call with seed s is kept iff fmix32(idx * golden ^ s) >= p * 2^32.
 // The same (seed, idx) regenerates the mask in backward.  keep_scale = 1 / (1 - p) for kept elements, 0 otherwise.

@@ -499,8 +499,7 @@ __global__ __launch_bounds__(512, 2) void topk_gmax_pp_kernel(const unsigned sho
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n0r + r < rows) x = fmaxf(x, v[r]);
             }
-            x = fmaxf(x, __shfl_xor(x, 16, 64));
-            x = fmaxf(x, __shfl_xor(x, 32, 64));
+            x = group_max(x);
             if (lg == 0) stage[ql * 16 + (rl >> 4)] = x;
         }
     }
@@ -585,8 +584,7 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
                 float m = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) m = fmaxf(m, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                m = group_max(m);
                 if (lg == 0) stage[(j * 16 + li) * TKS_CH + t] = m;
             }
         };
