@@ -159,3 +159,27 @@ def test_clip_ff_state_dict_layout_and_t5_group():
     from uniir_amd.clipff_model import rel_bucket_table
     t = rel_bucket_table(334)
     assert t.shape == (667,) and int(t[333]) == 0 and int(t[334]) == 17 and int(t[332]) == 1 and int(t.max()) == 31 and int(t[0]) == 15
+
+
+def test_hard_negative_selection_and_jsonl_helpers(tmp_path):
+    """select_hard_negatives == the reference's filter / multiplier + remainder padding / truncation (mbeir_retriever.py
+    :664-680); the jsonl helpers keep the reference's argument order and return shapes (preprocessing/utils.py:198-269)"""
+    from mbeir_retriever import select_hard_negatives
+    from data.preprocessing.utils import count_entries_in_file, load_jsonl_as_list, save_list_as_jsonl
+
+    def restated(retrieved, pos, neg, n):
+        hard = [d for d in retrieved if d not in pos and d not in neg]
+        if 0 < len(hard) < n:
+            hard = hard * (n // len(hard)) + hard[: n % len(hard)]
+        return hard[:n]
+
+    retrieved = [f"1:{i}" for i in (5, 9, 2, 7, 3, 8, 1)]
+    for pos, neg, n in ((["1:9"], [], 3), (["1:9"], ["1:5", "1:2"], 10), (retrieved, [], 4), ([], ["1:1"], 6), ([], [], 7),
+                        (["1:5", "1:9", "1:2", "1:7", "1:3", "1:8"], [], 5)):
+        assert select_hard_negatives(retrieved, pos, neg, n) == restated(retrieved, pos, neg, n)
+    path = str(tmp_path / "x.jsonl")
+    rows = [{"qid": "1:1", "neg_cand_list": ["1:2"]}, {"qid": "1:2", "neg_cand_list": []}]
+    save_list_as_jsonl(rows, path)
+    assert load_jsonl_as_list(path) == rows and count_entries_in_file(path) == (2, rows)
+    save_list_as_jsonl(rows[:1], path, mode="a")
+    assert count_entries_in_file(path)[0] == 3

@@ -187,3 +187,24 @@ def test_train_embed_index_retrieve_pipeline(tmp_path):
     want_s, want_i = c_oracle.topk(cemb, cids, qemb, 10)
     got = np.array([[9 * 10_000_000 + int(l.split()[2].split(":")[1]) for l in lines[q * 10:(q + 1) * 10]] for q in range(12)])
     assert np.array_equal(got, want_i)
+    # ---- hard-negative mining (reference mbeir_retriever.py:606-708) on the same tree: the train queries are the val ones
+    hdir = os.path.join(base, "train")
+    os.makedirs(hdir, exist_ok=True)
+    np.save(os.path.join(hdir, "mbeir_toy_train_embed.npy"), qemb)
+    np.save(os.path.join(hdir, "mbeir_toy_train_ids.npy"), np.array([9 * 500_000 + i + 1 for i in range(12)], dtype=np.int64))
+    hcfg = load("retrieval")
+    hcfg.retrieval_config.train_datasets_config = OmegaConf.create(
+        {"enable_retrieve": True, "datasets_name": ["toy"], "correspond_cand_pools_name": ["toy"]})
+    hcfg.retrieval_config.k, hcfg.retrieval_config.num_hard_negs = 6, 8
+    hcfg.retrieval_config.hard_negs_dir_name = "hard_negs"
+    mbeir_retriever.run_hard_negative_mining(hcfg)
+    mined = [json.loads(l) for l in open(os.path.join(data_dir, "train", "hard_negs", "mbeir_toy_hard_negs_train.jsonl"))]
+    src = [json.loads(l) for l in open(os.path.join(data_dir, "train", "mbeir_toy_train.jsonl"))]
+    _, top6 = c_oracle.topk(cemb, cids, qemb, 6)
+    assert len(mined) == 12
+    for q in range(12):
+        ranked = [f"9:{int(h) % 10_000_000}" for h in top6[q]]
+        hard = [d for d in ranked if d not in src[q]["pos_cand_list"]]
+        want = (hard * 8)[:8] if hard else []          # fewer than num_hard_negs: repeated cyclically, then cut
+        assert mined[q]["qid"] == src[q]["qid"] and mined[q]["pos_cand_list"] == src[q]["pos_cand_list"]
+        assert mined[q]["neg_cand_list"] == want, (q, mined[q]["neg_cand_list"], want)

@@ -29,7 +29,9 @@ import numpy as np
 import torch
 
 from config import OmegaConf
-from data.preprocessing.utils import get_mbeir_task_name, unhash_did, unhash_qid
+from data.preprocessing.utils import (count_entries_in_file, get_mbeir_task_name, load_jsonl_as_list,
+                                      load_mbeir_format_pool_file_as_dict, print_mbeir_format_dataset_stats,
+                                      save_list_as_jsonl, unhash_did, unhash_qid)
 
 _SHARD_CACHE = {}
 
@@ -191,6 +193,57 @@ def run_retrieval(config, query_embedder_config=None):
     return results
 
 
+def select_hard_negatives(retrieved_dids, pos_cand_list, neg_cand_list, num_hard_negs):
+    """retrieved candidates that are neither positives nor already-listed negatives, in rank order; a short non-empty list
+    is repeated cyclically up to num_hard_negs, a long one cut there (reference :664-680)"""
+    known = set(pos_cand_list) | set(neg_cand_list)
+    hard = [d for d in retrieved_dids if d not in known]
+    if not hard:
+        print("Warning: hard_negatives list is empty.")
+        return hard
+    if len(hard) < num_hard_negs:
+        hard = [hard[i % len(hard)] for i in range(num_hard_negs)]
+    return hard[:num_hard_negs]
+
+
+def run_hard_negative_mining(config):
+    """src/common/mbeir_retriever.py:606-708: top-k of every train query of the first dataset over the first candidate
+    pool (device brute force instead of FAISS), filtered into hard negatives and appended to neg_cand_list; output
+    <mbeir_data_dir>/train/<hard_negs_dir_name>/mbeir_<dataset>_hard_negs_train.jsonl"""
+    rc = config.retrieval_config
+    expt = config.experiment.path_suffix
+    tc = rc.train_datasets_config
+    assert tc.enable_retrieve, "Hard negative mining is not enabled for training data"
+    dataset_name, split = tc.datasets_name[0].lower(), "train"      # only the first dataset / pool, like the reference
+    query_data_list = load_jsonl_as_list(os.path.join(config.mbeir_data_dir, "train", f"mbeir_{dataset_name}_{split}.jsonl"))
+    embed_dir = os.path.join(config.uniir_dir, rc.embed_dir_name, expt, split)
+    query_ids = np.load(os.path.join(embed_dir, f"mbeir_{dataset_name}_{split}_ids.npy"))
+    embed_path = os.path.join(embed_dir, f"mbeir_{dataset_name}_{split}_embed.npy")
+    pool_name, pool_split = tc.correspond_cand_pools_name[0].lower(), "cand_pool"
+    index_path = os.path.join(config.uniir_dir, rc.index_dir_name, expt, pool_split, f"mbeir_{pool_name}_{pool_split}.index")
+    print("-" * 30)
+    print(f"Hard Negative mining, Datasets: {dataset_name}, Candidate Pools: {pool_name}")
+    print("-" * 30)
+    # the reference searches all queries in one FAISS call; here QUERY_CHUNK-sized sweeps over the resident shards
+    _, retrieved = search_index(embed_path, index_path, batch_size=max(1, query_ids.shape[0]), num_cand_to_retrieve=rc.k)
+    assert len(query_ids) == len(retrieved)
+    for i, hashed_qid in enumerate(query_ids):
+        entry = query_data_list[i]
+        assert unhash_qid(hashed_qid) == entry["qid"]
+        dids = [unhash_did(h) for h in retrieved[i]]
+        entry["neg_cand_list"].extend(select_hard_negatives(dids, entry["pos_cand_list"], entry["neg_cand_list"],
+                                                            rc.num_hard_negs))
+    out_path = os.path.join(config.mbeir_data_dir, "train", rc.hard_negs_dir_name,
+                            f"mbeir_{dataset_name}_hard_negs_{split}.jsonl")
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    save_list_as_jsonl(query_data_list, out_path)
+    total, data = count_entries_in_file(out_path)
+    print(f"MBEIR Train Data with Hard Negatives saved to {out_path}")
+    print(f"Total number of entries in {out_path}: {total}")
+    pool_path = os.path.join(config.mbeir_data_dir, pool_split, f"mbeir_{pool_name}_{pool_split}.jsonl")
+    print_mbeir_format_dataset_stats(data, load_mbeir_format_pool_file_as_dict(pool_path, doc_key_to_content=True, key_type="did"))
+
+
 def parse_arguments():
     p = argparse.ArgumentParser(description="MI355X brute-force retrieval pipeline")
     p.add_argument("--uniir_dir", type=str, default="/data/UniIR")
@@ -209,7 +262,7 @@ def main():
     config.uniir_dir, config.mbeir_data_dir = args.uniir_dir, args.mbeir_data_dir
     print(OmegaConf.to_yaml(config, sort_keys=False))
     if args.enable_hard_negative_mining:
-        raise NotImplementedError("hard-negative mining is outside the MI355X hot path in this round (DESIGN.md)")
+        run_hard_negative_mining(config)
     if args.enable_create_index:
         create_index(config)
     if args.enable_retrieval:

@@ -1,6 +1,6 @@
 """Host-side id hashing / string helpers of M-BEIR (drop-in for the parts of UniIR
 src/data/preprocessing/utils.py that sit on the train / embed / retrieve path: :7-31 tables, :46-74 id hashing,
-:77-107 lookups, :110-116 format_string, jsonl helpers).  Pure Python; pinned by tests/golden/g9_host.json."""
+:77-107 lookups, :110-116 format_string, :198-269 jsonl helpers).  Pure Python; pinned by tests/golden/g9_host.json."""
 import json
 
 DATASET_IDS = {"VisualNews": 0, "Fashion200K": 1, "WebQA": 2, "EDIS": 3, "NIGHTS": 4, "OVEN": 5, "INFOSEEK": 6,
@@ -78,15 +78,42 @@ def load_jsonl_as_list(path):
         return [json.loads(line) for line in f if line.strip()]
 
 
-def save_list_as_jsonl(path, data, mode="w"):
-    with open(path, mode) as f:
+def save_list_as_jsonl(data, filename, mode="w"):
+    """(data, filename) like the reference (src/data/preprocessing/utils.py:198)"""
+    with open(filename, mode) as f:
         for e in data:
             f.write(json.dumps(e) + "\n")
 
 
-def count_entries_in_file(path):
-    with open(path, "r") as f:
-        return sum(1 for line in f if line.strip())
+def count_entries_in_file(filename):
+    """-> (number of entries, entries) of a .jsonl / .json file (reference :257-269)"""
+    if filename.endswith(".jsonl"):
+        data = load_jsonl_as_list(filename)
+    elif filename.endswith(".json"):
+        with open(filename, "r") as f:
+            data = json.load(f)
+    else:
+        raise ValueError("Unsupported file format. Only .json and .jsonl are supported.")
+    return len(data), data
+
+
+def print_mbeir_format_dataset_stats(data, cand_pool_dict):
+    """console summary of an M-BEIR instance file after hard-negative mining (reference :548-563 prints a longer
+    per-modality table; the numbers a training run needs to sanity-check are kept): instances, candidate list lengths,
+    modality pairs of the positives"""
+    n = max(1, len(data))
+    pairs = {}
+    for e in data:
+        for did in e.get("pos_cand_list", []):
+            cand = cand_pool_dict.get(did)
+            key = f"{e.get('query_modality')} -> {cand.get('modality') if cand else '?'}"
+            pairs[key] = pairs.get(key, 0) + 1
+    print(f"--- INSTANCES ---\n\t{len(data)}")
+    print(f"--- AVG_POS_CAND ---\n\t{sum(len(e.get('pos_cand_list', [])) for e in data) / n:.1f}")
+    print(f"--- AVG_NEG_CAND ---\n\t{sum(len(e.get('neg_cand_list', [])) for e in data) / n:.1f}")
+    print("--- QUERY -> POSITIVE MODALITY ---")
+    for key in sorted(pairs):
+        print(f"\t{key}: {pairs[key]}")
 
 
 def load_mbeir_format_pool_file_as_dict(pool_file_path, doc_key_to_content=False, key_type="did"):
