@@ -73,3 +73,48 @@ def test_two_rank_device_step_equals_single_process_on_the_global_batch():
     for r in range(2):        # ... and match the single-process update on the global batch
         assert np.abs(res[r][1] - w_ref).max() < 0.05 * step + 1e-7, (np.abs(res[r][1] - w_ref).max(), step)
         assert abs(res[r][2] - model.clip_model.logit_scale.item()) < 1e-4
+
+
+def _resident_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from uniir_amd import comm, retrieval
+    g = np.random.default_rng(5)
+    pool = g.standard_normal((3001, 128)).astype(np.float16)
+    ids = (g.permutation(3001) + 7_000_000).astype(np.int64)
+    queries = g.standard_normal((37, 128)).astype(np.float16)
+    lo, hi = comm.contiguous_shard(3001)                       # the sampler's slice of the pool for this rank
+    shard = retrieval.PoolShard(torch.from_numpy(pool[lo:hi]).cuda(), torch.from_numpy(ids[lo:hi]))
+    qlo, qhi = (0, 30) if rank == 0 else (30, 37)              # uneven query counts per rank
+    s, i = retrieval.search_resident(shard, torch.from_numpy(queries[qlo:qhi]).cuda(), 10)
+    torch.cuda.synchronize()
+    q.put((rank, s.cpu().numpy().copy(), i.cpu().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_resident_shards_give_the_single_pool_topk():
+    """embedder <-> retriever fusion: every rank keeps its slice of the pool in HBM, queries are exchanged, the merged
+    result equals the C oracle's exact top-k over the whole pool (scores bit-exact, ids identical)"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import c_oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_resident_worker, args=(r, 2, 29547, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (s, i) for r, s, i in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+    g = np.random.default_rng(5)
+    pool = g.standard_normal((3001, 128)).astype(np.float16)
+    ids = (g.permutation(3001) + 7_000_000).astype(np.int64)
+    queries = g.standard_normal((37, 128)).astype(np.float16)
+    want_s, want_i = c_oracle.topk(pool, ids, queries, 10)
+    got_s = np.concatenate([res[0][0], res[1][0]])
+    got_i = np.concatenate([res[0][1], res[1][1]])
+    assert got_s.shape == (37, 10)
+    assert np.array_equal(got_i, want_i) and np.array_equal(got_s, want_s)

@@ -56,6 +56,9 @@ def _worker(rank, world, port, q):
     s, i = comm.gather_topk(torch.full((3, 2), float(rank)), torch.full((3, 2), rank, dtype=torch.int64))
     res["gs"], res["gi"] = s.numpy(), i.numpy()
     res["shard"] = comm.contiguous_shard(9)
+    # uneven query counts per rank (3 rows on rank 0, 1 row on rank 1) -> rank-ordered concatenation everywhere
+    rows, sizes = comm.all_gather_varlen(torch.full((3 - 2 * rank, 4), float(10 + rank), dtype=torch.float16))
+    res["var"], res["sizes"] = rows.float().numpy(), sizes
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -80,6 +83,9 @@ def test_two_rank_exchange_matches_reference_golden():
         assert np.allclose(res[r]["flat"], 1.5)
         assert res[r]["gs"].shape == (2, 3, 2) and res[r]["gi"][1, 0, 0] == 1
     assert res[0]["shard"] == (0, 5) and res[1]["shard"] == (5, 9)
+    for r in range(2):
+        assert res[r]["sizes"] == [3, 1] and res[r]["var"].shape == (4, 4)
+        assert np.array_equal(res[r]["var"][:, 0], np.array([10, 10, 10, 11], dtype=np.float32))
 
 
 def _blip_queue_worker(rank, world, port, q):

@@ -1,6 +1,7 @@
 """GPU parity of the brute-force top-k against a torch fp32 restatement of FAISS IDMap,Flat IP semantics
 (normalize rows, exact inner product, top-k descending).  Ids must be identical wherever the reference's own
 score gap exceeds fp32 noise; planted neighbours make that explicit."""
+import numpy as np
 import pytest
 import torch
 
@@ -74,3 +75,28 @@ def test_topk_duplicates_tiebreak():
     dup_ids = sorted(ids[[50, 100, 101, 102, 103, 104, 105]].tolist())
     assert i[0, :7].tolist() == dup_ids
     assert (s[0, :7] == s[0, 0]).all()
+
+
+def test_embed_resident_then_search_without_leaving_hbm():
+    """embedder <-> retriever fusion on one rank: the embedder loop keeps fp16 rows + hashed ids on the device, the shard is
+    searched in place; equals the C oracle on the same fp16 rows"""
+    from oracle import c_oracle
+    from uniir_amd import retrieval
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(500, 128, generator=g)
+
+    class Fake(torch.nn.Module):
+        def forward(self, batch, encode_mbeir_batch=False):
+            assert encode_mbeir_batch and batch["x"].is_cuda
+            return batch["x"] * 1.5, batch["did_list"]
+
+    loader = [{"x": table[lo:lo + 64], "did_list": list(range(9_000_001 + lo, 9_000_001 + min(500, lo + 64)))}
+              for lo in range(0, 500, 64)]
+    emb, ids = retrieval.embed_resident(Fake(), loader, torch.device("cuda"))
+    assert emb.dtype == torch.float16 and emb.is_cuda and emb.shape == (500, 128) and ids.dtype == torch.int64
+    assert ids.tolist() == list(range(9_000_001, 9_000_501))
+    shard = retrieval.PoolShard(emb, ids)
+    queries = torch.randn(21, 128, generator=g).half().cuda()
+    s, i = retrieval.search_resident(shard, queries, 10)
+    want_s, want_i = c_oracle.topk(emb.cpu().numpy(), ids.cpu().numpy(), queries.cpu().numpy(), 10)
+    assert np.array_equal(i.cpu().numpy(), want_i) and np.array_equal(s.cpu().numpy(), want_s)

@@ -69,11 +69,34 @@ def gather_topk(scores, ids):
     if W == 1:
         return scores.unsqueeze(0), ids.unsqueeze(0)
     q, k = scores.shape
-    s = torch.empty(W * q, k, device=scores.device, dtype=scores.dtype)      # concatenation form (works on gloo too)
-    i = torch.empty(W * q, k, device=ids.device, dtype=ids.dtype)
-    dist.all_gather_into_tensor(s, scores.contiguous())
-    dist.all_gather_into_tensor(i, ids.contiguous())
-    return s.view(W, q, k), i.view(W, q, k)
+    dev = scores.device
+    host = scores.is_cuda and dist.get_backend() == "gloo"      # tests only (ranks sharing one GPU)
+    s = torch.empty(W * q, k, device="cpu" if host else dev, dtype=scores.dtype)   # concatenation form (works on gloo too)
+    i = torch.empty(W * q, k, device="cpu" if host else dev, dtype=ids.dtype)
+    dist.all_gather_into_tensor(s, scores.contiguous().to(s.device))
+    dist.all_gather_into_tensor(i, ids.contiguous().to(i.device))
+    return s.view(W, q, k).to(dev), i.view(W, q, k).to(dev)
+
+
+def all_gather_varlen(rows):
+    """[n_r, ...] per rank (n_r may differ) -> (concatenation over ranks in rank order, list of n_r).  Used to hand every
+    rank's queries to every pool shard; two small collectives (sizes, padded rows)."""
+    W = world()
+    if W == 1:
+        return rows, [rows.shape[0]]
+    gloo = dist.get_backend() == "gloo"          # tests only (ranks sharing one GPU): stage through the host
+    dev = rows.device
+    sizes = torch.zeros(W, dtype=torch.int64, device="cpu" if gloo else dev)
+    mine = torch.tensor([rows.shape[0]], dtype=torch.int64, device=sizes.device)
+    dist.all_gather_into_tensor(sizes, mine)
+    sizes = [int(x) for x in sizes.tolist()]
+    cap = max(max(sizes), 1)
+    pad = torch.zeros((cap,) + tuple(rows.shape[1:]), dtype=rows.dtype, device="cpu" if gloo else dev)
+    pad[: rows.shape[0]] = rows.detach().to(pad.device)
+    out = torch.empty((W * cap,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=pad.device)
+    dist.all_gather_into_tensor(out, pad)
+    out = out.view((W, cap) + tuple(rows.shape[1:]))
+    return torch.cat([out[r, : sizes[r]] for r in range(W)], dim=0).to(dev), sizes
 
 
 def contiguous_shard(n, W=None, r=None):

@@ -82,3 +82,42 @@ def merge_shards(scores, ids):
     out_i = torch.empty(nq, k, device=scores.device, dtype=torch.int64)
     ops.call("uniir_topk_merge", scores.contiguous(), ids.contiguous(), nshard, nq, k, out_s, out_i)
     return out_s, out_i
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Embedder <-> retriever fusion.  The reference gathers every rank's embeddings on rank 0,
+# writes .npy, re-reads them into a FAISS index file and re-uploads that file for every search
+# (src/common/mbeir_embedder.py:63-116, mbeir_retriever.py:69-117,197-206).  Here each rank keeps the fp16 rows it
+# encoded (its ContiguousDistributedSampler slice) in HBM as its pool shard; queries travel, the pool never does.
+# ------------------------------------------------------------------------------------------------------------
+def embed_resident(model, data_loader, device):
+    """the embedder loop of mbeir_embedder.generate_embeds_and_ids_for_dataset_with_gather without the gather:
+    -> (fp16 [n, d] on `device`, hashed ids int64 [n] on `device`) of this rank's slice"""
+    chunks, ids = [], []
+    with torch.no_grad():
+        for batch in data_loader:
+            for key, v in batch.items():
+                if isinstance(v, torch.Tensor):
+                    batch[key] = v.to(device, non_blocking=True)
+                elif hasattr(v, "input_ids") and hasattr(v, "items"):     # BLIP: transformers BatchEncoding
+                    for kk, vv in v.items():
+                        v[kk] = vv.to(device)
+            emb, batch_ids = model(batch, encode_mbeir_batch=True)
+            chunks.append(emb.half())          # the reference stores fp16 too (use_fp16=True)
+            ids.extend(int(i) for i in batch_ids)
+    emb = torch.cat(chunks, dim=0) if chunks else torch.zeros(0, 64, dtype=torch.float16, device=device)
+    return emb.contiguous(), torch.tensor(ids, dtype=torch.int64, device=device)
+
+
+def search_resident(shard: PoolShard, queries_f16: torch.Tensor, k: int):
+    """Exact global top-k of this rank's queries over the union of all ranks' resident shards:
+    all-gather the queries (small) -> every rank searches its own shard -> all-gather the per-shard top-k ->
+    k-way merge on (score desc, id asc) -> each rank keeps the rows of its own queries.  Identical to the single-shard
+    search over the concatenated pool (ids are unique across shards)."""
+    from . import comm
+    all_q, sizes = comm.all_gather_varlen(queries_f16.contiguous())
+    s, i = search_shard(shard, all_q, k)
+    gs, gi = comm.gather_topk(s, i)
+    ms, mi = (gs[0], gi[0]) if gs.shape[0] == 1 else merge_shards(gs, gi)
+    lo = sum(sizes[: comm.rank()])
+    return ms[lo:lo + sizes[comm.rank()]], mi[lo:lo + sizes[comm.rank()]]
