@@ -302,6 +302,22 @@ int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_norm, const i
 int uniir_topk_merge(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k,
                      float* out_scores, int64_t* out_ids, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * [IMAGE] device-side image transform (input pipeline).  Replaces, for a decoded RGB uint8
+ * image [h][w][3] already in HBM, the CPU chain of upstream clip._transform (preprocess returned by clip.load, used at
+ * src/models/uniir_clip/clip_scorefusion/clip_sf.py:25-26 and applied in src/data/mbeir_dataset.py:92-100) and of BLIP's
+ * eval transform (src/models/uniir_blip/backbone/transform/blip_transform.py:41-48):
+ *   PIL resize to (oh, ow) with BICUBIC -> crop rows [top, top+n) x columns [left, left+n) -> x / 255 ->
+ *   (v - mean[c]) / std[c] -> out fp32 [3][n][n].
+ * The resize is bit-exact with Pillow's 8-bit resample; mean3 / std3 are HOST pointers to 3 floats (read at call time).
+ * (oh, ow, top, left) are the caller's geometry (torchvision Resize + CenterCrop: short side n, long side
+ * int(n * long / short), offsets round-half-even((size - n) / 2); BLIP: oh = ow = n, no crop).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t uniir_image_workspace_bytes(int32_t h, int32_t w, int32_t oh, int32_t ow, int32_t n);
+int uniir_image_preprocess(const void* rgb_u8, int32_t h, int32_t w, int32_t oh, int32_t ow, int32_t top, int32_t left,
+                           int32_t n, const float* mean3, const float* std3, float* out, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,3 +54,34 @@ def topk(pool_f16, ids, queries_f16, k):
     lib().oracle_topk(pool.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), C.c_int64(n), d,
                       qs.ctypes.data_as(C.c_void_p), nq, k, s.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p))
     return s, i
+
+
+def resize_geometry(h, w, n_px):
+    """torchvision Resize(n_px) + CenterCrop(n_px) on a PIL image (third-party, restated from its published behaviour):
+    the short side becomes n_px, the long side int(n_px * long / short) (truncation); the crop offsets are
+    int(round((size - n_px) / 2.0)) with Python's round-half-to-even.  -> (oh, ow, top, left)"""
+    if w <= h:
+        ow, oh = n_px, int(n_px * h / w)
+    else:
+        oh, ow = n_px, int(n_px * w / h)
+    return oh, ow, int(round((oh - n_px) / 2.0)), int(round((ow - n_px) / 2.0))
+
+
+def resize_bicubic(img_u8, oh, ow):
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w, _ = img.shape
+    out = np.empty((oh, ow, 3), dtype=np.uint8)
+    lib().oracle_resize_bicubic_rgb8(img.ctypes.data_as(C.c_void_p), h, w, out.ctypes.data_as(C.c_void_p), oh, ow)
+    return out
+
+
+def clip_preprocess(img_u8, n_px, mean, std):
+    """uint8 [h, w, 3] -> fp32 [3, n_px, n_px]: upstream clip._transform"""
+    h, w, _ = img_u8.shape
+    oh, ow, top, left = resize_geometry(h, w, n_px)
+    r = resize_bicubic(img_u8, oh, ow)
+    out = np.empty((3, n_px, n_px), dtype=np.float32)
+    m, s = _f32(mean), _f32(std)
+    lib().oracle_crop_normalize(r.ctypes.data_as(C.c_void_p), oh, ow, top, left, n_px, m.ctypes.data_as(C.c_void_p),
+                                s.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out

@@ -118,3 +118,110 @@ void oracle_topk(const uint16_t* pool, const int64_t* ids, int64_t n, int dim, c
     }
     free(pinv); free(qinv); free(qn); free(e);
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Image preprocessing of the encoders' input pipeline: upstream clip._transform, reached
+ * from src/models/uniir_clip/clip_scorefusion/clip_sf.py:25-26 (clip.load -> preprocess) and applied per item in
+ * src/data/mbeir_dataset.py:92-100; BLIP's eval transform (backbone/transform/blip_transform.py:41-48) is the same chain
+ * with a square resize and no crop.  The arithmetic lives in third-party code that is NOT in /root/reference:
+ * Pillow (Image.resize(BICUBIC) = libImaging/Resample.c, 8-bit path) and torchvision (Resize / CenterCrop / ToTensor /
+ * Normalize).  Restated here from their published behaviour and pinned against Pillow 12.2.0 run in the build
+ * container (tests/golden/g14_image.npz, made by tests/golden/make_golden_image.py).
+ *   resample: per output coordinate a window [xmin, xmin + n) of source pixels around center = (x + 0.5) * scale with
+ *   support 2 * max(scale, 1), Keys cubic (a = -0.5) weights evaluated at (i + xmin - center + 0.5) / max(scale, 1),
+ *   normalised in double, rounded half away from zero to 22-bit fixed point; horizontal pass first, each pass
+ *   accumulates ints from 2^21, arithmetic-shifts by 22 and clamps to 0..255 into a uint8 intermediate.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define RS_BITS 22
+static double cubic_keys(double x) {
+    const double a = -0.5;
+    if (x < 0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+/* -> window size; bounds[2*o] = first source index, bounds[2*o+1] = count; kk[o*ksize + i] fixed-point weights */
+int oracle_resample_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk, int kk_cap) {
+    const double scale = (double)in_size / out_size;
+    const double fscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * fscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    if (!bounds || !kk) return ksize;
+    if ((long)ksize * out_size > kk_cap) return -1;
+    double* w = (double*)malloc(sizeof(double) * ksize);
+    for (int o = 0; o < out_size; ++o) {
+        const double center = (o + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        const int n = xmax - xmin;
+        double ww = 0.0;
+        for (int i = 0; i < n; ++i) {
+            w[i] = cubic_keys((i + xmin - center + 0.5) * (1.0 / fscale));
+            ww += w[i];
+        }
+        for (int i = 0; i < ksize; ++i) {
+            double v = i < n ? (ww != 0.0 ? w[i] / ww : w[i]) : 0.0;
+            kk[(long)o * ksize + i] = v < 0 ? (int32_t)(-0.5 + v * (1 << RS_BITS)) : (int32_t)(0.5 + v * (1 << RS_BITS));
+        }
+        bounds[2 * o] = xmin;
+        bounds[2 * o + 1] = n;
+    }
+    free(w);
+    return ksize;
+}
+static uint8_t rs_clip8(int32_t acc) {
+    const int32_t v = acc >> RS_BITS;      /* arithmetic shift: floor */
+    return v < 0 ? 0 : (v > 255 ? 255 : (uint8_t)v);
+}
+/* src uint8 [h][w][3] -> dst uint8 [oh][ow][3] (PIL Image.resize((ow, oh), BICUBIC) of an RGB image) */
+int oracle_resize_bicubic_rgb8(const uint8_t* src, int h, int w, uint8_t* dst, int oh, int ow) {
+    const int kx = oracle_resample_coeffs(w, ow, 0, 0, 0), ky = oracle_resample_coeffs(h, oh, 0, 0, 0);
+    int32_t* bx = (int32_t*)malloc(sizeof(int32_t) * 2 * ow);
+    int32_t* by = (int32_t*)malloc(sizeof(int32_t) * 2 * oh);
+    int32_t* cx = (int32_t*)malloc(sizeof(int32_t) * (size_t)kx * ow);
+    int32_t* cy = (int32_t*)malloc(sizeof(int32_t) * (size_t)ky * oh);
+    oracle_resample_coeffs(w, ow, bx, cx, kx * ow);
+    oracle_resample_coeffs(h, oh, by, cy, ky * oh);
+    const uint8_t* hsrc = src;
+    uint8_t* tmp = 0;
+    if (ow != w) {                       /* horizontal pass (skipped when the width is unchanged, like Pillow) */
+        tmp = (uint8_t*)malloc((size_t)h * ow * 3);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < ow; ++x)
+                for (int c = 0; c < 3; ++c) {
+                    int32_t acc = 1 << (RS_BITS - 1);
+                    for (int i = 0; i < bx[2 * x + 1]; ++i)
+                        acc += (int32_t)src[((size_t)y * w + bx[2 * x] + i) * 3 + c] * cx[(size_t)x * kx + i];
+                    tmp[((size_t)y * ow + x) * 3 + c] = rs_clip8(acc);
+                }
+        hsrc = tmp;
+    }
+    if (oh != h) {
+        for (int y = 0; y < oh; ++y)
+            for (int x = 0; x < ow; ++x)
+                for (int c = 0; c < 3; ++c) {
+                    int32_t acc = 1 << (RS_BITS - 1);
+                    for (int i = 0; i < by[2 * y + 1]; ++i)
+                        acc += (int32_t)hsrc[((size_t)(by[2 * y] + i) * ow + x) * 3 + c] * cy[(size_t)y * ky + i];
+                    dst[((size_t)y * ow + x) * 3 + c] = rs_clip8(acc);
+                }
+    } else {
+        memcpy(dst, hsrc, (size_t)oh * ow * 3);
+    }
+    free(bx); free(by); free(cx); free(cy); free(tmp);
+    return 0;
+}
+/* crop [top, top + n) x [left, left + n) of uint8 [h][w][3], ToTensor (x / 255 in fp32) and Normalize ((v - mean) / std):
+ * out fp32 [3][n][n] */
+void oracle_crop_normalize(const uint8_t* img, int h, int w, int top, int left, int n, const float* mean, const float* std,
+                           float* out) {
+    (void)h;
+    for (int c = 0; c < 3; ++c)
+        for (int y = 0; y < n; ++y)
+            for (int x = 0; x < n; ++x) {
+                const float v = (float)img[((size_t)(top + y) * w + left + x) * 3 + c] / 255.0f;
+                out[((size_t)c * n + y) * n + x] = (v - mean[c]) / std[c];
+            }
+}

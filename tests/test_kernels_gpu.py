@@ -413,3 +413,32 @@ def test_attention_probability_dropout(rel):
         ops.attention_bwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, out, dout, lse, dqkv, 3 * W, dqkv[:, W:],
                              dqkv[:, 2 * W:], 3 * W, batch, seq, seq, heads, drop_p=p, drop_seed=seed)
     assert rel_err(dqkv, x.grad.reshape(batch * seq, 3 * W)) < 2e-2, rel_err(dqkv, x.grad.reshape(batch * seq, 3 * W))
+
+
+def test_device_image_transform_is_bit_exact():
+    """uniir_image_preprocess == Pillow's BICUBIC resize (golden G14, made by Pillow) + crop + (x / 255 - mean) / std of
+    the C oracle, bit for bit: down- / up-scaling, one unchanged axis, identity, saturated patterns, BLIP's square resize"""
+    import os
+    import numpy as np
+    from oracle import c_oracle
+    from uniir_amd import clip_front
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g14_image.npz"))
+    mean, std = clip_front._MEAN, clip_front._STD
+    imgs, wants = [], []
+    for c in range(int(z["n_cases"])):
+        img, res = z[f"c{c}_img"], z[f"c{c}_res"]
+        n, oh, ow, top, left = (int(v) for v in z[f"c{c}_geom"])
+        assert clip_front.resize_geometry(img.shape[0], img.shape[1], n) == (oh, ow, top, left)
+        crop = res[top:top + n, left:left + n].astype(np.float32) / np.float32(255.0)        # from PILLOW's own output
+        want = (crop.transpose(2, 0, 1) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]
+        got = clip_front.preprocess_on_device([img], n, DEV)[0].cpu().numpy()
+        assert np.array_equal(got, want.astype(np.float32)), (c, np.abs(got - want).max())
+        assert np.array_equal(got, c_oracle.clip_preprocess(img, n, mean, std))
+    # a batch of differently sized images in one call, and BLIP's square resize without crop against the oracle
+    batch = [z["c0_img"], z["c1_img"], z["c3_img"]]
+    out = clip_front.preprocess_on_device(batch, 32, DEV).cpu().numpy()
+    for i, img in enumerate(batch):
+        assert np.array_equal(out[i], c_oracle.clip_preprocess(img, 32, mean, std))
+    sq = clip_front.preprocess_on_device([z["c4_img"]], 48, DEV, center_crop=False)[0].cpu().numpy()
+    r = c_oracle.resize_bicubic(z["c4_img"], 48, 48).astype(np.float32) / np.float32(255.0)
+    assert np.array_equal(sq, ((r.transpose(2, 0, 1) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]))

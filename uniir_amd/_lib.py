@@ -80,6 +80,8 @@ SIGNATURES = {
     "uniir_pool_inv_norms": (c_int, [P, c_i64, c_int, P, S]),
     "uniir_topk_workspace_bytes": (c_i64, [c_int, c_int, c_i64]),
     "uniir_topk_ncand": (c_int, [c_int, c_int]),
+    "uniir_image_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
+    "uniir_image_preprocess": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_i64, S]),
     "uniir_topk_coarse": (c_int, [P, P, c_i64, c_int, P, c_int, c_int, P, P, P, c_i64, S]),
     "uniir_topk_rescore": (c_int, [P, P, P, c_i64, c_int, P, P, c_int, P, c_int, c_int, P, P, P, S]),
     "uniir_topk_merge": (c_int, [P, P, c_int, c_int, c_int, P, P, S]),

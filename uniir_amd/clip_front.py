@@ -24,15 +24,57 @@ def _preprocess(n_px):
         CLIP mean/std normalisation (upstream clip._transform)."""
         from PIL import Image
         w, h = image.size
-        s = n_px / min(w, h)
-        nw, nh = max(n_px, round(w * s)), max(n_px, round(h * s))
+        nh, nw, top, left = resize_geometry(h, w, n_px)          # torchvision Resize + CenterCrop integers
         image = image.resize((nw, nh), Image.BICUBIC)
-        left, top = (nw - n_px) // 2, (nh - n_px) // 2
         image = image.crop((left, top, left + n_px, top + n_px)).convert("RGB")
         a = torch.from_numpy(np.asarray(image, dtype=np.float32) / 255.0).permute(2, 0, 1)
         return (a - torch.tensor(_MEAN).view(3, 1, 1)) / torch.tensor(_STD).view(3, 1, 1)
 
     return fn
+
+
+def resize_geometry(h, w, n_px, center_crop=True):
+    """integer geometry of the transform: torchvision Resize(n_px) (short side n_px, long side int(n_px * long / short)) +
+    CenterCrop (offsets round-half-even((size - n_px) / 2)) as upstream clip._transform composes them; center_crop=False
+    is BLIP's square Resize((n_px, n_px)) (blip_transform.py:41-48).  -> (oh, ow, top, left)"""
+    if not center_crop:
+        return n_px, n_px, 0, 0
+    if w <= h:
+        ow, oh = n_px, int(n_px * h / w)
+    else:
+        oh, ow = n_px, int(n_px * w / h)
+    return oh, ow, int(round((oh - n_px) / 2.0)), int(round((ow - n_px) / 2.0))
+
+
+def preprocess_on_device(images, n_px, device, mean=_MEAN, std=_STD, center_crop=True, out=None):
+    """Decoded RGB images (PIL images or uint8 [h, w, 3] arrays / tensors, any sizes) -> fp32 [M, 3, n_px, n_px] on the
+    device through libuniir_hip's uniir_image_preprocess: the resize / crop / normalise chain of the reference's CPU
+    workers, bit-exact with Pillow's BICUBIC for the integer stage (include/uniir_hip.h [IMAGE])."""
+    import ctypes
+
+    from . import _lib, ops
+    lib = _lib.load()
+    M = len(images)
+    if out is None:
+        out = torch.empty(M, 3, n_px, n_px, device=device, dtype=torch.float32)
+    mean_c, std_c = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    ws = None
+    for i, img in enumerate(images):
+        if not isinstance(img, (torch.Tensor, np.ndarray)):
+            img = np.asarray(img.convert("RGB"), dtype=np.uint8)
+        t = torch.as_tensor(img)
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+            raise ValueError("images must be RGB uint8 [h, w, 3]")
+        t = t.contiguous().to(device, non_blocking=True)
+        h, w = int(t.shape[0]), int(t.shape[1])
+        oh, ow, top, left = resize_geometry(h, w, n_px, center_crop)
+        need = lib.uniir_image_workspace_bytes(h, w, oh, ow, n_px)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, device=device, dtype=torch.uint8)
+        ops.check(lib.uniir_image_preprocess(t.data_ptr(), h, w, oh, ow, top, left, n_px, mean_c, std_c, out[i].data_ptr(),
+                                             ws.data_ptr(), ws.numel(), stream), "image_preprocess")
+    return out
 
 
 def load(name="ViT-B/32", device="cuda", jit=False, download_root=None, seed=0):
