@@ -208,3 +208,29 @@ def test_train_embed_index_retrieve_pipeline(tmp_path):
         want = (hard * 8)[:8] if hard else []          # fewer than num_hard_negs: repeated cyclically, then cut
         assert mined[q]["qid"] == src[q]["qid"] and mined[q]["pos_cand_list"] == src[q]["pos_cand_list"]
         assert mined[q]["neg_cand_list"] == want, (q, mined[q]["neg_cand_list"], want)
+
+
+def test_device_prefetcher_same_batches_same_order():
+    from uniir_amd.host_utils import DevicePrefetcher
+
+    class Enc(dict):                      # stands in for transformers' BatchEncoding (has .input_ids and .items())
+        @property
+        def input_ids(self):
+            return self["input_ids"]
+
+    g = torch.Generator().manual_seed(0)
+    batches = [{"image_batched": torch.randn(4, 3, 8, 8, generator=g), "txt_batched": torch.randint(0, 99, (4, 7), generator=g),
+                "enc": Enc(input_ids=torch.randint(0, 9, (4, 5), generator=g), attention_mask=torch.ones(4, 5, dtype=torch.long)),
+                "index_mapping": {"query": [[0]]}, "n": i} for i in range(5)]
+    want = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in batches]
+    feed = DevicePrefetcher(batches, 0)
+    assert len(feed) == 5
+    seen = 0
+    for i, b in enumerate(feed):
+        assert b["n"] == i and b["image_batched"].is_cuda and b["enc"]["input_ids"].is_cuda
+        acc = b["image_batched"].double().sum() + b["txt_batched"].sum()        # consume on the compute stream
+        assert torch.equal(b["image_batched"].cpu(), want[i]["image_batched"])
+        assert torch.equal(b["txt_batched"].cpu(), want[i]["txt_batched"])
+        assert abs(acc.item() - (want[i]["image_batched"].double().sum() + want[i]["txt_batched"].sum()).item()) < 1e-6
+        seen += 1
+    assert seen == 5 and list(DevicePrefetcher([], 0)) == []
