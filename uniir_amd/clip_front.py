@@ -4,8 +4,10 @@ Reference call sites: src/models/uniir_clip/clip_scorefusion/clip_sf.py:25-26 (c
 clip.tokenize).  Upstream downloads weights / ships a BPE vocabulary; neither exists offline, so:
   * load(): builds the architecture for `name` (random init, upstream std choices) and, when
     <download_root>/<name>.pt (a state dict, or a checkpoint with a "state_dict"/"model" entry) exists, loads it;
-  * tokenize(): needs <UNIIR_BPE_PATH or download_root>/bpe_simple_vocab_16e6.txt.gz; without the file it raises
-    (tokenizer parity is unpinned offline, SURVEY.md section 7 'No network').
+  * tokenize(): the byte-level BPE of clip/simple_tokenizer.py (BPETokenizer below, pinned on a synthetic merge list
+    against an independent implementation: tests/golden/g15_bpe.json); it needs OpenAI's bpe_simple_vocab_16e6.txt.gz
+    at $UNIIR_BPE_PATH, $UNIIR_CLIP_ROOT or ~/.cache/clip and raises without it (parity on the REAL vocabulary is
+    unpinned offline, SURVEY.md section 7 'No network').
 """
 import os
 
@@ -93,7 +95,115 @@ def load(name="ViT-B/32", device="cuda", jit=False, download_root=None, seed=0):
     return model, _preprocess(CLIP_CONFIGS[name]["image_resolution"])
 
 
+class BPETokenizer:
+    """Byte-level BPE of openai/CLIP (clip/simple_tokenizer.py, third-party: restated from its published behaviour, pinned
+    in tests against transformers' CLIPTokenizer on a synthetic vocabulary -- the real 16e6 vocabulary is not available
+    offline).  Vocabulary order: the 256 byte symbols, the same with the end-of-word marker, one entry per merge rule of
+    the file (lines 1 .. 49152 - 256 - 2), then <|startoftext|>, <|endoftext|>."""
+    EOW = "</w>"
+
+    def __init__(self, bpe_path):
+        import gzip
+        import regex
+        opener = gzip.open if bpe_path.endswith(".gz") else open
+        with opener(bpe_path, "rt", encoding="utf-8") as f:
+            lines = f.read().split("\n")
+        rules = [tuple(ln.split()) for ln in lines[1:49152 - 256 - 2 + 1] if ln.strip()]
+        # printable bytes stand for themselves, the other 68 get code points from 256 upwards (no whitespace / control symbols)
+        keep = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+        self.byte_sym, extra = {}, 0
+        for b in range(256):
+            if b in keep:
+                self.byte_sym[b] = chr(b)
+            else:
+                self.byte_sym[b] = chr(256 + extra)
+                extra += 1
+        base = [self.byte_sym[b] for b in keep] + [self.byte_sym[b] for b in range(256) if b not in keep]
+        vocab = base + [v + self.EOW for v in base] + ["".join(r) for r in rules] + ["<|startoftext|>", "<|endoftext|>"]
+        self.encoder = {tok: i for i, tok in enumerate(vocab)}
+        self.rank = {r: i for i, r in enumerate(rules)}
+        self.cache = {"<|startoftext|>": ("<|startoftext|>",), "<|endoftext|>": ("<|endoftext|>",)}
+        self.splitter = regex.compile(
+            r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+", regex.IGNORECASE)
+        self.sot, self.eot = self.encoder["<|startoftext|>"], self.encoder["<|endoftext|>"]
+
+    def _merge_word(self, token):
+        if token in self.cache:
+            return self.cache[token]
+        parts = list(token[:-1]) + [token[-1] + self.EOW]
+        while len(parts) > 1:
+            best = min(((self.rank.get((a, b), float("inf")), i) for i, (a, b) in enumerate(zip(parts, parts[1:]))))
+            if best[0] == float("inf"):
+                break
+            first, second = parts[best[1]], parts[best[1] + 1]
+            merged, i = [], 0
+            while i < len(parts):          # every occurrence of the best-ranked pair, left to right
+                if i + 1 < len(parts) and parts[i] == first and parts[i + 1] == second:
+                    merged.append(first + second)
+                    i += 2
+                else:
+                    merged.append(parts[i])
+                    i += 1
+            parts = merged
+        self.cache[token] = tuple(parts)
+        return self.cache[token]
+
+    @staticmethod
+    def clean(text):
+        import html
+        import re
+        try:
+            import ftfy
+            text = ftfy.fix_text(text)
+        except ImportError:          # upstream repairs mojibake first; without ftfy well-formed text passes unchanged
+            pass
+        text = html.unescape(html.unescape(text)).strip()
+        return re.sub(r"\s+", " ", text).strip().lower()
+
+    def encode(self, text):
+        ids = []
+        for tok in self.splitter.findall(self.clean(text)):
+            sym = "".join(self.byte_sym[b] for b in tok.encode("utf-8"))
+            ids.extend(self.encoder[p] for p in self._merge_word(sym))
+        return ids
+
+
+_TOKENIZER = None
+
+
+def _bpe_path():
+    cands = [os.environ.get("UNIIR_BPE_PATH", "")]
+    for root in (os.environ.get("UNIIR_CLIP_ROOT", ""), os.path.expanduser("~/.cache/clip")):
+        cands.append(os.path.join(root, "bpe_simple_vocab_16e6.txt.gz"))
+    for c in cands:
+        if c and os.path.isdir(c):
+            c = os.path.join(c, "bpe_simple_vocab_16e6.txt.gz")
+        if c and os.path.isfile(c):
+            return c
+    return None
+
+
 def tokenize(texts, context_length=77, truncate=False):
-    raise RuntimeError(
-        "clip.tokenize needs OpenAI's bpe_simple_vocab_16e6.txt.gz, which is not available offline; feed token ids "
-        "(int32 [n, 77], SOT=49406 ... EOT=49407, zero padded) or install the vocabulary (see INTEGRATION.md)")
+    """clip.tokenize: [SOT] + BPE ids + [EOT], zero padded to context_length -> int32 [n, context_length]; too long inputs
+    raise unless truncate (then cut and the last id forced to EOT)."""
+    global _TOKENIZER
+    if _TOKENIZER is None:
+        path = _bpe_path()
+        if path is None:
+            raise RuntimeError(
+                "clip.tokenize needs OpenAI's bpe_simple_vocab_16e6.txt.gz, which is not available offline; set "
+                "UNIIR_BPE_PATH to the file (or feed token ids: int32 [n, 77], SOT=49406 ... EOT=49407, zero padded)")
+        _TOKENIZER = BPETokenizer(path)
+    tk = _TOKENIZER
+    if isinstance(texts, str):
+        texts = [texts]
+    out = torch.zeros(len(texts), context_length, dtype=torch.int32)
+    for i, text in enumerate(texts):
+        ids = [tk.sot] + tk.encode(text) + [tk.eot]
+        if len(ids) > context_length:
+            if not truncate:
+                raise RuntimeError(f"Input {text} is too long for context length {context_length}")
+            ids = ids[:context_length]
+            ids[-1] = tk.eot
+        out[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+    return out
