@@ -183,3 +183,38 @@ def test_hard_negative_selection_and_jsonl_helpers(tmp_path):
     assert load_jsonl_as_list(path) == rows and count_entries_in_file(path) == (2, rows)
     save_list_as_jsonl(rows[:1], path, mode="a")
     assert count_entries_in_file(path)[0] == 3
+
+
+def test_clip_load_reads_torchscript_archives_and_plain_state_dicts(tmp_path):
+    """the published CLIP files are TorchScript archives whose state_dict carries a few extra entries; a plain state dict
+    (or a checkpoint with a "state_dict" entry) must load the same way"""
+    import torch
+    from oracle import clip_oracle as O
+    from uniir_amd import clip_front, clip_model
+    cfg = O.tiny_config()
+    clip_model.CLIP_CONFIGS["tiny-load"] = cfg
+    sd = O.init_state_dict(cfg, seed=4)
+
+    class Node(torch.nn.Module):
+        def forward(self):
+            return 0
+
+    root = Node()
+    for name, value in list(sd.items()) + [("input_resolution", torch.tensor(cfg["image_resolution"]))]:
+        node, parts = root, name.split(".")
+        for part in parts[:-1]:
+            if not hasattr(node, part):
+                node.add_module(part, Node())
+            node = getattr(node, part)
+        if value.is_floating_point():
+            node.register_parameter(parts[-1], torch.nn.Parameter(value.clone()))
+        else:
+            node.register_buffer(parts[-1], value.clone())
+    torch.jit.script(root).save(str(tmp_path / "tiny-load.pt"))
+    model, _ = clip_front.load("tiny-load", device=None, download_root=str(tmp_path))
+    got = model.state_dict()
+    assert all(torch.equal(got[k], sd[k].float()) for k in sd)
+    os.remove(str(tmp_path / "tiny-load.pt"))
+    torch.save({"state_dict": sd}, str(tmp_path / "tiny-load.pt"))
+    model2, _ = clip_front.load("tiny-load", device=None, download_root=str(tmp_path))
+    assert all(torch.equal(model2.state_dict()[k], sd[k].float()) for k in sd)

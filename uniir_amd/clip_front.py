@@ -86,7 +86,10 @@ def load(name="ViT-B/32", device="cuda", jit=False, download_root=None, seed=0):
     if download_root:
         path = os.path.join(os.path.expanduser(download_root), name.replace("/", "-") + ".pt")
         if os.path.exists(path):
-            sd = torch.load(path, map_location="cpu")
+            try:            # the published files are TorchScript archives (upstream clip.load falls back the other way)
+                sd = torch.jit.load(path, map_location="cpu").state_dict()
+            except RuntimeError:
+                sd = torch.load(path, map_location="cpu", weights_only=False)
             sd = sd.get("state_dict", sd.get("model", sd)) if isinstance(sd, dict) else sd.state_dict()
             sd = {k: v.float() for k, v in sd.items() if k in model.state_dict()}
             model.load_state_dict(sd, strict=True)
