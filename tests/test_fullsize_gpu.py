@@ -1,0 +1,115 @@
+"""BASELINE.json's full sizes on the MI355X, checked through properties that do not need a CPU run of the whole problem
+(SURVEY.md section 8c / the task's parity bar):
+  * InfoNCE at config 2's per-rank shape (512 queries x 4096 gathered candidates x 768): the C oracle still finishes in
+    seconds here, so the logits are compared bit for bit;
+  * brute-force top-10 over one GPU's 700 k x 768 fp16 shard: order, id validity, planted neighbours at rank 1, every
+    returned score re-derived bit-exactly by the C oracle on just the returned rows, shard-split + merge == single search;
+  * the CLIP_SF ViT-L/14 encoder at 1024 items: row independence (a permuted batch gives the permuted embeddings, a
+    64-item slice gives the same rows), unit norms after the loss's normalisation, and gradient linearity in the loss."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_infonce_full_rank_shape_bit_exact():
+    from oracle import c_oracle
+    from uniir_amd import ops
+    b, B, E, toff = 512, 4096, 768, 1024          # rank 2 of 8: targets offset by rank * b
+    rng = np.random.default_rng(7)
+    q = rng.standard_normal((b, E)).astype(np.float32)
+    p = rng.standard_normal((B, E)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    scale = float(np.float32(1 / 0.07))
+    score = torch.empty(b, B, device=DEV)
+    stats = torch.empty(3 * b, device=DEV)
+    loss, acc = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+    ops.call("uniir_infonce_fwd", torch.tensor(q, device=DEV), torch.tensor(p, device=DEV), torch.tensor([scale], device=DEV),
+             b, B, E, toff, score, stats, loss, acc)
+    want = c_oracle.infonce_scores(q, p, scale)
+    assert np.array_equal(score.cpu().numpy(), want)
+    l, a, _ = c_oracle.infonce_loss(want, toff)
+    assert abs(loss.item() - l) < 2e-6 * max(1.0, abs(l)) and acc.item() == a
+
+
+@pytest.mark.parametrize("nq", [64, 1024])
+def test_topk_full_shard_properties(nq):
+    from oracle import c_oracle
+    from uniir_amd import retrieval
+    n, d, k = 700_000, 768, 10
+    g = torch.Generator(device=DEV).manual_seed(11 + nq)
+    pool = torch.randn(n, d, device=DEV, generator=g).half()
+    queries = torch.randn(nq, d, device=DEV, generator=g).half()
+    where = torch.randperm(n, device=DEV, generator=g)[:nq]
+    pool[where] = (queries.float() * 3.0).half()              # planted: same direction, another norm -> cosine 1
+    ids = torch.randperm(n, device=DEV, generator=g).to(torch.int64) + 5_000_000
+    shard = retrieval.PoolShard(pool, ids)
+    s, i = retrieval.search_shard(shard, queries, k)
+    sc, ic = s.cpu().numpy(), i.cpu().numpy()
+    assert (np.diff(sc, axis=1) <= 0).all()                                        # sorted, best first
+    assert (ic >= 5_000_000).all() and all(len(set(r)) == k for r in ic.tolist())  # valid, unique
+    assert np.array_equal(ic[:, 0], ids[where].cpu().numpy())                      # the planted row wins
+    assert np.abs(sc[:, 0] - 1.0).max() < 1e-3
+    # every returned (query, row) score is the oracle's exact fp32 value: re-run the oracle on the returned rows only
+    row_of = torch.empty(n + 5_000_000, dtype=torch.int32, device=DEV)
+    row_of[ids] = torch.arange(n, dtype=torch.int32, device=DEV)
+    for qi in range(0, nq, max(1, nq // 16)):
+        rows = row_of[i[qi]].long()
+        ws, wi = c_oracle.topk(pool[rows].cpu().numpy(), ids[rows].cpu().numpy(), queries[qi:qi + 1].cpu().numpy(), k)
+        assert np.array_equal(wi[0], ic[qi]) and np.array_equal(ws[0], sc[qi])
+    # two half shards + merge == the single search, bit for bit
+    h = n // 2
+    a = retrieval.search_shard(retrieval.PoolShard(pool[:h], ids[:h]), queries, k)
+    b = retrieval.search_shard(retrieval.PoolShard(pool[h:], ids[h:]), queries, k)
+    ms, mi = retrieval.merge_shards(torch.stack([a[0], b[0]]), torch.stack([a[1], b[1]]))
+    assert torch.equal(ms, s) and torch.equal(mi, i)
+
+
+def test_vit_l14_encoder_row_independence_and_gradient_linearity():
+    import os
+    import sys
+    from types import SimpleNamespace
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "uniir_amd", "src"))
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    cfg = CLIP_CONFIGS["ViT-L/14"]
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=False), data_config=SimpleNamespace(in_batch_neg_num=0))
+    torch.manual_seed(5)
+    model = CLIPScoreFusion(model_name="ViT-L/14", device=DEV, config=config)
+    model.float()
+    M = 1024
+    g = torch.Generator().manual_seed(9)
+    txt = torch.randint(1, cfg["vocab_size"] - 2, (M, 77), generator=g, dtype=torch.int32)
+    eot = torch.randint(3, 77, (M,), generator=g)
+    txt[torch.arange(M), eot] = cfg["vocab_size"] - 1                      # EOT = arg-max token id
+    for r in range(M):
+        txt[r, eot[r] + 1:] = 0
+    img = torch.randn(M, 3, 224, 224, generator=torch.Generator(device=DEV).manual_seed(9), device=DEV)
+    txt = txt.to(DEV)
+    ones = torch.ones(M, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        emb = model.encode_multimodal_input(txt, img, ones, ones)
+        assert emb.shape == (M, 768) and torch.isfinite(emb).all()
+        perm = torch.randperm(M, generator=g).to(DEV)
+        emb_p = model.encode_multimodal_input(txt[perm], img[perm], ones, ones)
+        assert torch.equal(emb_p, emb[perm])                               # rows do not see each other
+        emb_s = model.encode_multimodal_input(txt[:64], img[:64], ones[:64], ones[:64])
+        assert (emb_s - emb[:64]).abs().max().item() <= 1e-6 * emb.abs().max().item()
+    # gradient linearity: d(2 L) = 2 dL (powers of two commute with every rounding; fp32 atomics reorder -> 1e-5)
+    batch = {"txt_batched": txt[:128], "image_batched": img[:128], "txt_mask_batched": ones[:128], "image_mask_batched": ones[:128],
+             "index_mapping": {"query": [[2 * j] for j in range(64)], "pos_cand": [[2 * j + 1] for j in range(64)]}}
+    grads = []
+    for scale in (1.0, 2.0):
+        model.zero_grad()
+        out = model(batch)
+        (out["loss"] * scale).backward()
+        grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    for name in ("clip_model.visual.proj", "clip_model.visual.transformer.resblocks.0.attn.in_proj_weight",
+                 "clip_model.transformer.resblocks.11.mlp.c_fc.weight", "clip_model.token_embedding.weight",
+                 "clip_model.visual.transformer.resblocks.23.ln_2.weight"):
+        a, b = grads[0][name], grads[1][name]
+        assert a.abs().max().item() > 0 and (b - 2 * a).abs().max().item() <= 1e-5 * b.abs().max().item(), name
