@@ -13,8 +13,8 @@ from uniir_amd import _lib, ops  # noqa: E402
 
 dev = "cuda"
 lib = _lib.load()
-for (M, N, K, what) in ((65792, 3072, 1024, "qkv fwd"), (65792, 1024, 1024, "out fwd"), (65792, 4096, 1024, "fc fwd"),
-                        (65792, 1024, 4096, "proj fwd")):
+for (M, N, K, what) in ((263168, 3072, 1024, "qkv fwd"), (263168, 1024, 1024, "out fwd"), (263168, 4096, 1024, "fc fwd"),
+                        (263168, 1024, 4096, "proj fwd")):
     x = torch.randn(M, K, device=dev).bfloat16()
     w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
     b = torch.randn(N, device=dev)
