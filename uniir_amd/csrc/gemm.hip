@@ -22,6 +22,7 @@ struct GemmKArgs {
     float* slab;  // split-K slabs [k_splits][M][N] (plain stores) or nullptr (atomics)
     int asm_loop;   // 1 counted-lgkmcnt double-buffer loop, 2 ping-pong loop
     float* colsum;  // optional [N]: += column sums of the fp32 result (bias gradient), 256-tile staged epilogue only
+    int raster_gm, raster_cw;   // 2-D tile rasterisation block (row panels x column panels), 0 = row-major
 };
 
 DEVINL float act_fwd(float x, int act) {
@@ -404,17 +405,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
     // panels per XCD-L2 working set instead of 9 MB at N = 4096 (fc forward / proj dgrad +4 ... 5 %).  With <= 4 column
     // panels the plain row-major order already is that block.
     int mt, nt;
-    if (p.tiles_n > 4) {
-        constexpr int GM = 8;
+    if (p.raster_gm > 0 && p.tiles_n > p.raster_cw) {
+        const int GM = p.raster_gm, CW = p.raster_cw;
         const int gwidth = GM * p.tiles_n;
         const int gfirst = (id / gwidth) * GM;
         const int gsize = min(p.tiles_m - gfirst, GM);
         const int idg = id % gwidth;                     // position inside the group of gsize row panels
-        const int chunk = idg / (gsize * 4);             // column chunk of (up to) 4 panels
-        const int cw = min(4, p.tiles_n - chunk * 4);
-        const int r = idg - chunk * gsize * 4;
+        const int chunk = idg / (gsize * CW);            // column chunk of (up to) CW panels
+        const int cw = min(CW, p.tiles_n - chunk * CW);
+        const int r = idg - chunk * gsize * CW;
         mt = gfirst + r / cw;
-        nt = chunk * 4 + r % cw;
+        nt = chunk * CW + r % cw;
     } else {
         mt = id / p.tiles_n;
         nt = id - mt * p.tiles_n;
@@ -476,6 +477,13 @@ static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
     using S = GldsShape<WM, WN, BK>;
     a.tiles_m = (a.M + S::BM - 1) / S::BM;
     a.tiles_n = (a.N + S::BN - 1) / S::BN;
+    {
+        static const char* env = getenv("UNIIR_GEMM_RASTER");      // "GM,CW" (tuning); default 8 x 4, "0" = row-major
+        int gm = 8, cw = 4;
+        if (env && sscanf(env, "%d,%d", &gm, &cw) < 2) cw = 4;
+        a.raster_gm = gm;
+        a.raster_cw = cw > 0 ? cw : 4;
+    }
     const int grid = a.tiles_m * a.tiles_n * a.k_splits;
     dim3 g(grid), b(S::T);
     const size_t sm = S::LDS_BYTES;
