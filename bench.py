@@ -19,8 +19,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "uniir_amd", "src"))
 
 FLOP_PER_PAIR = {"ViT-L/14": 1.052e12, "ViT-B/32": 88.7e9}
-# measured offline with rocprofv3 PMC passes of this very command (profiles/r01_pmc_step_v5.txt); null for other configs
-PMC_GEMM_TRAFFIC = {("ViT-L/14", 512): 3.77e9}
+# measured offline with rocprofv3 PMC passes of this very command (profiles/r01_pmc_step_v8.txt); null for other configs
+PMC_GEMM_TRAFFIC = {("ViT-L/14", 512): 3.25e9}
 MFMA_PEAK_BF16 = 2.5e15
 HBM_PEAK = 8.0e12
 
@@ -153,7 +153,7 @@ def main():
                 "unit": "TFLOP/s", "frac": round(gflop / gtime / MFMA_PEAK_BF16, 4) if gtime > 0 else None,
                 "traffic": PMC_GEMM_TRAFFIC.get((args.model, args.pairs)),
                 "traffic_note": "bytes per GEMM launch (mean over the step's 441 launches), rocprofv3 --pmc FETCH_SIZE (x2, "
-                                "gfx950 correction) + WRITE_SIZE in separate passes: profiles/r01_pmc_step_v5.txt; L2<->fabric "
+                                "gfx950 correction) + WRITE_SIZE in separate passes: profiles/r01_pmc_step_v8.txt; L2<->fabric "
                                 "requests, MALL hits included (upper bound of HBM bytes); algorithmic mean 2.6e9",
                 "launches_timed": len(timing), "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} GEMM launches bracketed by HIP events",
                 "end_to_end_frac": round(value * FLOP_PER_PAIR[args.model] / (world * MFMA_PEAK_BF16), 4)}
