@@ -24,7 +24,6 @@ def rel(a, b):
 def _build(cfg, seed=0):
     from oracle import clip_oracle as O
     from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
-    from uniir_amd.clip_model import CLIP
     from uniir_amd import clip_model
     clip_model.CLIP_CONFIGS["tiny-test"] = cfg
     sd = O.init_state_dict(cfg, seed=seed)

@@ -1,5 +1,5 @@
 """Per-kernel timing on the GPU box (dev tool): prints TF/s and GB/s per kernel; not part of the shipped path."""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from uniir_amd import ops, retrieval

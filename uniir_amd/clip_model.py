@@ -9,7 +9,6 @@ fp32 LayerNorm, fused attention, fp32 residual stream.  This file is host plumbi
 backward, and the activation stash.  There is no torch fallback.
 """
 import math
-from collections import OrderedDict
 
 import torch
 from torch import nn
