@@ -234,3 +234,30 @@ def test_device_prefetcher_same_batches_same_order():
         assert abs(acc.item() - (want[i]["image_batched"].double().sum() + want[i]["txt_batched"].sum()).item()) < 1e-6
         seen += 1
     assert seen == 5 and list(DevicePrefetcher([], 0)) == []
+
+
+def test_deferred_device_image_transform_through_dataset_collator_prefetcher(tmp_path):
+    """img_preprocess_fn = RawImageTransform: the workers only decode, the collator keeps uint8 images, the prefetcher
+    transforms them on the GPU -- the batch tensor is bit-identical to the CPU (Pillow + torch) transform, image-less items
+    stay black"""
+    from PIL import Image
+    from data.mbeir_dataset import MBEIRCandidatePoolCollator, MBEIRCandidatePoolDataset
+    from uniir_amd import clip_front
+    from uniir_amd.host_utils import DevicePrefetcher
+    root = str(tmp_path)
+    _make_tree(root, n_cand=9, n_query=3)
+    pool = os.path.join("cand_pool", "mbeir_toy_cand_pool.jsonl")
+    n_px = 32
+    batches = {}
+    for mode, fn in (("cpu", clip_front._preprocess(n_px)), ("gpu", clip_front.RawImageTransform(n_px))):
+        ds = MBEIRCandidatePoolDataset(root, pool, fn, print_config=False)
+        col = MBEIRCandidatePoolCollator(tokenizer=_toy_tokenize, image_size=(n_px, n_px))
+        if mode == "gpu":
+            col.raw_transform = fn
+        batch = col([ds[i] for i in range(len(ds))])
+        batches[mode] = next(iter(DevicePrefetcher([batch], 0)))
+    a, b = batches["cpu"]["image_batched"], batches["gpu"]["image_batched"]
+    assert a.is_cuda and b.is_cuda and a.shape == b.shape == (9, 3, n_px, n_px)
+    assert torch.equal(batches["cpu"]["image_mask_batched"], batches["gpu"]["image_mask_batched"])
+    assert torch.equal(a, b)
+    assert (b[batches["gpu"]["image_mask_batched"] == 0] == 0).all() and batches["gpu"]["image_mask_batched"].sum().item() == 6

@@ -79,6 +79,51 @@ def preprocess_on_device(images, n_px, device, mean=_MEAN, std=_STD, center_crop
     return out
 
 
+class RawImage:
+    """a decoded RGB image waiting for the device transform (uint8 [h, w, 3], shareable between loader workers)"""
+    __slots__ = ("data",)
+
+    def __init__(self, data):
+        self.data = data
+
+
+class RawImageTransform:
+    """Drop-in `img_preprocess_fn` that defers resize / crop / normalise to the GPU: the dataset worker only decodes, the
+    collator builds a RawImageBatch, and the batch is transformed by `preprocess_on_device` when it is moved to the device
+    (host_utils.DevicePrefetcher / batch_to_device).  Bit-identical tensors to the CPU transform `_preprocess(n_px)`."""
+
+    def __init__(self, n_px, mean=_MEAN, std=_STD, center_crop=True):
+        self.n_px, self.mean, self.std, self.center_crop = n_px, tuple(mean), tuple(std), center_crop
+
+    def __call__(self, image):
+        return RawImage(torch.from_numpy(np.array(image.convert("RGB"), dtype=np.uint8)))
+
+
+class RawImageBatch:
+    """what a collator stacks instead of a float tensor when its items are RawImages (None = the black padding image of
+    items without an image, which the reference builds as zeros AFTER normalisation)"""
+
+    def __init__(self, images, transform):
+        self.images, self.transform = list(images), transform
+
+    def size(self, dim=0):
+        n = self.transform.n_px
+        return (len(self.images), 3, n, n)[dim]
+
+    def pin_memory(self):
+        self.images = [im if im is None else im.pin_memory() for im in self.images]
+        return self
+
+    def to_device(self, device):
+        t = self.transform
+        out = torch.zeros(len(self.images), 3, t.n_px, t.n_px, device=device, dtype=torch.float32)
+        have = [i for i, im in enumerate(self.images) if im is not None]
+        if have:
+            got = preprocess_on_device([self.images[i] for i in have], t.n_px, device, t.mean, t.std, t.center_crop)
+            out[torch.tensor(have, device=device)] = got
+        return out
+
+
 def load(name="ViT-B/32", device="cuda", jit=False, download_root=None, seed=0):
     if name not in CLIP_CONFIGS:
         raise RuntimeError(f"Model {name} not found; available models = {list(CLIP_CONFIGS)}")

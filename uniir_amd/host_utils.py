@@ -199,6 +199,8 @@ def batch_to_device(batch, gpu_id):
     for key, value in batch.items():
         if isinstance(value, torch.Tensor):
             batch[key] = value.to(gpu_id, non_blocking=True)
+        elif hasattr(value, "to_device"):                                   # clip_front.RawImageBatch: transform on the GPU
+            batch[key] = value.to_device(torch.device("cuda", gpu_id) if isinstance(gpu_id, int) else torch.device(gpu_id))
         elif hasattr(value, "input_ids") and hasattr(value, "items"):      # transformers BatchEncoding (BLIP tokenizer)
             for k, v in value.items():
                 value[k] = v.to(gpu_id)
@@ -229,6 +231,8 @@ class DevicePrefetcher:
             for key, value in batch.items():
                 if isinstance(value, torch.Tensor):
                     batch[key] = self._move(value)
+                elif hasattr(value, "to_device"):                                   # clip_front.RawImageBatch
+                    batch[key] = value.pin_memory().to_device(self.dev)
                 elif hasattr(value, "input_ids") and hasattr(value, "items"):      # transformers BatchEncoding (BLIP)
                     for k, v in value.items():
                         value[k] = self._move(v)

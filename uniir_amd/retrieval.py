@@ -99,6 +99,8 @@ def embed_resident(model, data_loader, device):
             for key, v in batch.items():
                 if isinstance(v, torch.Tensor):
                     batch[key] = v.to(device, non_blocking=True)
+                elif hasattr(v, "to_device"):                              # deferred device image transform
+                    batch[key] = v.to_device(torch.device(device))
                 elif hasattr(v, "input_ids") and hasattr(v, "items"):     # BLIP: transformers BatchEncoding
                     for kk, vv in v.items():
                         v[kk] = vv.to(device)

@@ -39,6 +39,8 @@ def generate_embeds_and_ids_for_dataset_with_gather(model, data_loader, device, 
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 batch[k] = v.to(device, non_blocking=True)
+            elif hasattr(v, "to_device"):                              # deferred device image transform (RawImageBatch)
+                batch[k] = v.to_device(torch.device(device))
             elif hasattr(v, "input_ids") and hasattr(v, "items"):     # BLIP: transformers BatchEncoding
                 for kk, vv in v.items():
                     v[kk] = vv.to(device)

@@ -188,6 +188,7 @@ class MBEIRCollatorBase(object):
         self.H, self.W = (image_size, image_size) if isinstance(image_size, int) else image_size
         self.padded_image = torch.zeros((3, self.H, self.W))   # black image for image-less items
         self.padded_txt = ""                                    # empty string for text-less items
+        self.raw_transform = None          # set to the RawImageTransform used as img_preprocess_fn to defer to the GPU
 
     def _pack(self, items):
         """items: list of {"txt","img"} -> the four flat tensors; missing modalities are padded and masked out"""
@@ -199,7 +200,14 @@ class MBEIRCollatorBase(object):
             imgs.append(it["img"] if has_img else self.padded_image)
             tmask.append(int(has_txt))
             imask.append(int(has_img))
-        out = {"txt_batched": self.tokenizer(txts), "image_batched": torch.stack(imgs, dim=0),
+        raw = [im for im in imgs if hasattr(im, "data") and not isinstance(im, torch.Tensor)]
+        if raw:      # deferred device transform (uniir_amd.clip_front.RawImageTransform): keep the decoded bytes
+            from uniir_amd.clip_front import RawImageBatch
+            images = RawImageBatch([im.data if hasattr(im, "data") and not isinstance(im, torch.Tensor) else None for im in imgs],
+                                   self.raw_transform)
+        else:
+            images = torch.stack(imgs, dim=0)
+        out = {"txt_batched": self.tokenizer(txts), "image_batched": images,
                "txt_mask_batched": torch.tensor(tmask, dtype=torch.long),
                "image_mask_batched": torch.tensor(imask, dtype=torch.long)}
         tb = out["txt_batched"]
