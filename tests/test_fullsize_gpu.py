@@ -113,3 +113,57 @@ def test_vit_l14_encoder_row_independence_and_gradient_linearity():
                  "clip_model.visual.transformer.resblocks.23.ln_2.weight"):
         a, b = grads[0][name], grads[1][name]
         assert a.abs().max().item() > 0 and (b - 2 * a).abs().max().item() <= 1e-5 * b.abs().max().item(), name
+
+
+def test_config1_vit_b32_step_against_the_oracle():
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case): real CLIP ViT-B/32 dimensions, a few pairs so
+    that the fp32 oracle's forward + backward finishes in seconds on the host; embeddings, loss and every parameter
+    gradient against the oracle at the bf16 tolerances of the tiny-model tests (2e-2 / 3e-2 / 8e-2 relative L2,
+    gradient cosine > 0.999)"""
+    import os
+    import sys
+    from types import SimpleNamespace
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "uniir_amd", "src"))
+    from oracle import clip_oracle as O
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    cfg = CLIP_CONFIGS["ViT-B/32"]
+    sd = O.init_state_dict(cfg, seed=1)
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=False), data_config=SimpleNamespace(in_batch_neg_num=0))
+    model = CLIPScoreFusion("ViT-B/32", device=DEV, config=config)
+    model.float()
+    model.clip_model.load_state_dict(sd, strict=True)
+    oracle = O.OracleCLIP(cfg, sd)
+    pairs = 4
+    batch = O.synthetic_batch(cfg, pairs, seed=21)
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    emb_o = O.encode_multimodal_input(oracle.sd(), cfg, batch["txt_batched"], batch["image_batched"],
+                                      batch["txt_mask_batched"], batch["image_mask_batched"])
+    out_o = O.inbatch_contrastive_loss(emb_o, batch["index_mapping"], oracle.logit_scale.exp())
+    out_o["loss"].backward()
+    model.train()
+    model.zero_grad()
+    emb_d = model.encode_multimodal_input(dbatch["txt_batched"], dbatch["image_batched"], dbatch["txt_mask_batched"],
+                                          dbatch["image_mask_batched"])
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+        return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+    assert rel(emb_d, emb_o) < 2e-2, rel(emb_d, emb_o)
+    out_d = model(dbatch)
+    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 3e-2 * max(1.0, abs(out_o["loss"].item()))
+    assert out_d["accuracy"].item() == out_o["accuracy"].item()
+    out_d["loss"].backward()
+    errs, gd, go = {}, [], []
+    for n, p in model.clip_model.named_parameters():
+        g = getattr(oracle, n.replace(".", "__")).grad
+        if g is None:
+            continue
+        errs[n] = rel(p.grad, g)
+        gd.append(p.grad.flatten().cpu())
+        go.append(g.flatten())
+    big = {n: e for n, e in errs.items() if e > 8e-2}
+    assert not big, big
+    assert torch.nn.functional.cosine_similarity(torch.cat(gd), torch.cat(go), dim=0).item() > 0.999
