@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels of uniir_amd (wave64, MFMA 16x16x32, LDS tr-reads).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -64,6 +65,19 @@ DEVINL int xcd_remap(int bid, int nwg) {
         hipError_t e__ = hipGetLastError();                        \
         if (e__ != hipSuccess) return UNIIR_ELAUNCH;               \
     } while (0)
+
+// max over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane: four DPP steps, no LDS crossbar
+DEVINL float row16_max(float x) {
+    auto step = [](float v, auto ctrl) {
+        const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true);
+        return fmaxf(v, __builtin_bit_cast(float, o));
+    };
+    x = step(x, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    x = step(x, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    x = step(x, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    x = step(x, std::integral_constant<int, 0x140>{});   // row_mirror
+    return x;
+}
 
 // Reductions across the 4 rows of a wave (lanes sharing lane & 15) with the gfx950 row-swap instructions (VALU, no LDS
 // crossbar round trip like __shfl_xor(.., 16 / 32)): v_permlane32_swap(x, x) leaves {x[lane % 32], x[lane % 32 + 32]} in the

@@ -307,7 +307,11 @@ __global__ __launch_bounds__(128 * WM, 2) void topk_gmax_kernel(const unsigned s
 //   pass 2: groups >= tau0 are collected in LDS (a few dozen), ranked exactly, the best gcap kept.
 // If the collection overflows (massive exact ties) the kernel falls back to one-extraction-per-round selection.
 #define TK_SELCAP 1024
-template <int BS>   // threads per query (256: many queries; 1024: <= 64 queries, where one block per query leaves CUs idle)
+#define TK_SELREG 24    // float2 loads per thread of the register-resident variant: ngroups <= 1024 * 2 * 24
+// REG (the interactive <= 64-query path, one 1024-thread block per query): the query's group maxima are read ONCE, as
+// back-to-back 8-byte loads that all stay in flight, and both passes (thread maxima, collection above the threshold) run
+// on registers -- the two dependent strided passes over global memory were 40 of the kernel's 62 us at 700 k rows.
+template <int BS, bool REG = false>   // threads per query (256: many queries; 1024: <= 64 queries)
 __global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__ gmax, long ngroups, long rows, int nq,
                                                         int kc, int gcap, int* __restrict__ cand_idx) {
     __shared__ float tmax[BS];
@@ -324,11 +328,38 @@ __global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__
     int* out = cand_idx + (long)q * gcap * TK_G;
     for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
     float mx = -INFINITY;
-    for (long e = tid; e < ngroups; e += BS) mx = fmaxf(mx, g[e]);
-    tmax[tid] = mx;
+    f32x2_t rv[REG ? TK_SELREG : 1];
+    if (REG) {
+#pragma unroll
+        for (int it = 0; it < TK_SELREG; ++it) {
+            const long e = 2L * (it * BS + tid);
+            rv[it] = e < ngroups ? *reinterpret_cast<const f32x2_t*>(g + e) : f32x2_t{-INFINITY, -INFINITY};   // ngroups is even
+        }
+#pragma unroll
+        for (int it = 0; it < TK_SELREG; ++it) mx = fmaxf(mx, fmaxf(rv[it][0], rv[it][1]));
+    } else {
+        for (long e = tid; e < ngroups; e += BS) mx = fmaxf(mx, g[e]);
+    }
     if (tid == 0) { bcnt = 0; tau0 = -INFINITY; tau = -INFINITY; }
-    __syncthreads();
-    {
+    if (BS == 1024) {
+        // threshold = the kc-th largest of the 64 quarter-wave maxima (disjoint subsets, so at least kc entries reach it;
+        // ~20-30 entries do at kc = 18).  Ranking all 1024 thread maxima against each other was 1 M compares per block
+        // -- 40 of the kernel's 50 us.
+        const float qm = row16_max(mx);
+        if ((tid & 15) == 0) tmax[tid >> 4] = qm;
+        __syncthreads();
+        if (tid < 64) {
+            const float v = tmax[tid];
+            int rank = 0;
+            for (int t = 0; t < 64; ++t) {
+                const float o = tmax[t];
+                rank += (o > v || (o == v && t < tid)) ? 1 : 0;
+            }
+            if (rank == min(kc, 64) - 1) tau0 = v;
+        }
+    } else {
+        tmax[tid] = mx;
+        __syncthreads();
         int rank = 0;
         for (int t = 0; t < BS; ++t) {
             const float o = tmax[t];
@@ -338,11 +369,24 @@ __global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__
     }
     __syncthreads();
     const float t0 = tau0;
-    for (long e = tid; e < ngroups; e += BS) {
-        const float v = g[e];
-        if (v >= t0 && v > -INFINITY) {
-            const int pos = atomicAdd(&bcnt, 1);
-            if (pos < TK_SELCAP) { bval[pos] = v; bgrp[pos] = (int)e; }
+    if (REG) {
+#pragma unroll
+        for (int it = 0; it < TK_SELREG; ++it)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float v = rv[it][h];
+                if (v >= t0 && v > -INFINITY) {
+                    const int pos = atomicAdd(&bcnt, 1);
+                    if (pos < TK_SELCAP) { bval[pos] = v; bgrp[pos] = (int)(2L * (it * BS + tid) + h); }
+                }
+            }
+    } else {
+        for (long e = tid; e < ngroups; e += BS) {
+            const float v = g[e];
+            if (v >= t0 && v > -INFINITY) {
+                const int pos = atomicAdd(&bcnt, 1);
+                if (pos < TK_SELCAP) { bval[pos] = v; bgrp[pos] = (int)e; }
+            }
         }
     }
     __syncthreads();
@@ -439,18 +483,6 @@ struct ElemF16Direct {   // operands in the order the main loop hands them over 
     }
 };
 
-// max over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane: four DPP steps, no LDS crossbar
-DEVINL float row16_max(float x) {
-    auto step = [](float v, auto ctrl) {
-        const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true);
-        return fmaxf(v, __builtin_bit_cast(float, o));
-    };
-    x = step(x, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
-    x = step(x, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
-    x = step(x, std::integral_constant<int, 0x141>{});   // row_half_mirror
-    x = step(x, std::integral_constant<int, 0x140>{});   // row_mirror
-    return x;
-}
 
 // -------------------------------------------------------------------------------------------------------------
 // Group-max scan for many queries (129 .. 1024 per call: the MFMA-bound regime): one 256-candidate x 256-query tile per
@@ -645,8 +677,12 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
                 hipLaunchKernelGGL(topk_stream_kernel<16>, dim3(grid), dim3(512), sms, st0, (const unsigned short*)pool_f16,
                                    pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, nchunks);
             }
-            hipLaunchKernelGGL(topk_gsel_kernel<1024>, dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq, kc,
-                               TK_GMULT * kc, cand_idx);
+            if (ngroups % 2 == 0 && ngroups <= 1024L * 2 * TK_SELREG)
+                hipLaunchKernelGGL((topk_gsel_kernel<1024, true>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
+                                   kc, TK_GMULT * kc, cand_idx);
+            else
+                hipLaunchKernelGGL((topk_gsel_kernel<1024, false>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
+                                   kc, TK_GMULT * kc, cand_idx);
             HIP_LAUNCH_CHECK();
             return UNIIR_OK;
         }
@@ -759,10 +795,28 @@ __global__ __launch_bounds__(256) void final_sort_kernel(const float* __restrict
     const int* ci = cand_idx + (long)q * ncand;
     float last_s = INFINITY;
     long long last_id = -1;
+    // the thread's shortlist entries live in registers for all k rounds (ncand <= 2048 = 8 per thread; more fall back to
+    // re-reading): the rounds were re-fetching score / row / id from L2 every time
+    float rs[8];
+    long long rid[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int c = tid + 256 * u;
+        const bool ok = c < ncand && ci[c] >= 0;
+        rs[u] = ok ? es[c] : -INFINITY;
+        rid[u] = ok ? (ids ? ids[ci[c]] : (long long)ci[c]) : 0x7fffffffffffffffLL;
+    }
     for (int j = 0; j < k; ++j) {
         float bs = -INFINITY;
         long long bid = 0x7fffffffffffffffLL;
-        for (int c = tid; c < ncand; c += 256) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float s = rs[u];
+            const long long id = rid[u];
+            const bool after = id != 0x7fffffffffffffffLL && ((s < last_s) || (s == last_s && id > last_id));
+            if (after && (s > bs || (s == bs && id < bid))) { bs = s; bid = id; }
+        }
+        for (int c = tid + 2048; c < ncand; c += 256) {
             if (ci[c] < 0) continue;
             const float s = es[c];
             const long long id = ids ? ids[ci[c]] : (long long)ci[c];

@@ -42,10 +42,11 @@ def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None
     queries_f16 = queries_f16.contiguous()
     nq = queries_f16.shape[0]
     dev = queries_f16.device
-    out_s = torch.full((nq, k), float("-inf"), device=dev, dtype=torch.float32)
-    out_i = torch.full((nq, k), -1, device=dev, dtype=torch.int64)
-    if nq == 0 or shard.n == 0:
-        return out_s, out_i
+    if nq == 0 or shard.n == 0:          # FAISS pads missing results with -inf / -1
+        return (torch.full((nq, k), float("-inf"), device=dev, dtype=torch.float32),
+                torch.full((nq, k), -1, device=dev, dtype=torch.int64))
+    out_s = torch.empty(nq, k, device=dev, dtype=torch.float32)       # every slot is written by the final sort (padding included)
+    out_i = torch.empty(nq, k, device=dev, dtype=torch.int64)
     if nq > QUERY_CHUNK:      # many queries (the reference hands over all of them at once): sweep the shard per 1024-query
         ws = workspace        # chunk on the MFMA group-max path, reusing one workspace
         for lo in range(0, nq, QUERY_CHUNK):
