@@ -780,6 +780,66 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned short* __re
     }
     exact[t] = s;
 }
+// Same arithmetic, coalesced gathers (dim % 64 == 0): a wave owns 64 (query, candidate) pairs.  The candidate rows are
+// fetched 128 B at a time by 8 lanes per row (8 rows per load instruction instead of 64 rows x 16 B), parked in LDS
+// ([64 rows][128 B + 16 pad] per wave) and each lane then walks ITS row's 64 elements in order: the sum is still one
+// sequential fp32 chain per pair, in the oracle's order.  The next 128-B slice is already in flight during the walk.
+#define RSC_PITCH 144
+__global__ __launch_bounds__(256) void rescore_coalesced_kernel(const unsigned short* __restrict__ pool,
+                                                                const float* __restrict__ pinv,
+                                                                const unsigned short* __restrict__ queries,
+                                                                const float* __restrict__ qinv, int nq, int dim,
+                                                                const int* __restrict__ cand_idx, int ncand,
+                                                                float* __restrict__ exact) {
+    __shared__ __attribute__((aligned(16))) char stage[4][64 * RSC_PITCH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long pairs = (long)nq * ncand;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < pairs;
+    const int q = live ? (int)(t / ncand) : 0;
+    const int ci = live ? cand_idx[t] : -1;
+    const unsigned short* qr = queries + (long)q * dim;
+    const float iq = qinv[q], ic = ci >= 0 ? pinv[ci] : 0.f;
+    // lane -> (row r = 8 i + lane / 8 of the wave's 64 rows, 16-B piece lane % 8) for the cooperative loads
+    int rows8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rows8[i] = __shfl(ci, 8 * i + (lane >> 3), 64);
+    const int piece = lane & 7;
+    char* mine = &stage[w][0];
+    u32x4_t pre[8];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            pre[i] = rows8[i] >= 0 ? *reinterpret_cast<const u32x4_t*>(pool + (long)rows8[i] * dim + c0 + piece * 8) : z;
+        }
+    };
+    float s = 0.f;
+    fetch(0);
+    for (int c0 = 0; c0 < dim; c0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<u32x4_t*>(mine + (8 * i + (lane >> 3)) * RSC_PITCH + piece * 16) = pre[i];
+        __syncthreads();
+        if (c0 + 64 < dim) fetch(c0 + 64);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u32x4_t a = *reinterpret_cast<const u32x4_t*>(qr + c0 + 8 * u);
+            const u32x4_t b = *reinterpret_cast<const u32x4_t*>(mine + lane * RSC_PITCH + u * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float qa = f16_to_f32((unsigned short)(a[e] & 0xffffu)), ca = f16_to_f32((unsigned short)(b[e] & 0xffffu));
+                float qb = f16_to_f32((unsigned short)(a[e] >> 16)), cb = f16_to_f32((unsigned short)(b[e] >> 16));
+                if (iq != 0.f) { qa = __fmul_rn(qa, iq); qb = __fmul_rn(qb, iq); }
+                if (ic != 0.f) { ca = __fmul_rn(ca, ic); cb = __fmul_rn(cb, ic); }
+                s = __fadd_rn(s, __fmul_rn(qa, ca));
+                s = __fadd_rn(s, __fmul_rn(qb, cb));
+            }
+        }
+        __syncthreads();
+    }
+    if (live) exact[t] = ci >= 0 ? s : -INFINITY;
+}
 __global__ __launch_bounds__(256) void final_sort_kernel(const float* __restrict__ exact,
                                                          const int* __restrict__ cand_idx,
                                                          const long long* __restrict__ ids, int nq, int ncand,
@@ -857,9 +917,14 @@ extern "C" int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_no
     if (dim % 8) return UNIIR_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     const long pairs = (long)nq * ncand;
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
-                       (const unsigned short*)pool_f16, pool_inv_norm, (const unsigned short*)queries_f16,
-                       query_inv_norm, nq, dim, cand_idx, ncand, exact_ws);
+    if (dim % 64 == 0)
+        hipLaunchKernelGGL(rescore_coalesced_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned short*)pool_f16, pool_inv_norm, (const unsigned short*)queries_f16,
+                           query_inv_norm, nq, dim, cand_idx, ncand, exact_ws);
+    else
+        hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned short*)pool_f16, pool_inv_norm, (const unsigned short*)queries_f16,
+                           query_inv_norm, nq, dim, cand_idx, ncand, exact_ws);
     hipLaunchKernelGGL(final_sort_kernel, dim3(nq), dim3(256), 0, st, exact_ws, cand_idx,
                        (const long long*)pool_ids, nq, ncand, k, out_scores, (long long*)out_ids);
     HIP_LAUNCH_CHECK();
