@@ -698,8 +698,12 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
             hipLaunchKernelGGL(topk_gmax_pp_kernel, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
                                (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
                                (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
-            hipLaunchKernelGGL(topk_gsel_kernel<256>, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
-                               TK_GMULT * kc, cand_idx);
+            if (ngroups % 2 == 0 && ngroups <= 1024L * 2 * TK_SELREG)      // register-resident selection (see above)
+                hipLaunchKernelGGL((topk_gsel_kernel<1024, true>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
+                                   kc, TK_GMULT * kc, cand_idx);
+            else
+                hipLaunchKernelGGL(topk_gsel_kernel<256>, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
+                                   TK_GMULT * kc, cand_idx);
             HIP_LAUNCH_CHECK();
             return UNIIR_OK;
         }
