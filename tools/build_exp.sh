@@ -4,7 +4,8 @@
 set -e
 cd "$(dirname "$0")/../uniir_amd/csrc"
 name=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DUNIIR_EXP_BUILD "$@" -c gemm.hip -o build/gemm_exp_$name.o
+mkdir -p build/exp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DUNIIR_EXP_BUILD "$@" -c gemm.hip -o build/exp/gemm_exp_$name.o
 objs=$(ls build/*.o | grep -v "gemm" )
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libuniir_exp_$name.so build/gemm_exp_$name.o $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libuniir_exp_$name.so build/exp/gemm_exp_$name.o $objs
 echo built ../libuniir_exp_$name.so
