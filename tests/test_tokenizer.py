@@ -47,3 +47,23 @@ def test_tokenize_contract(bpe_file, monkeypatch):
     monkeypatch.setenv("HOME", os.path.dirname(path) + "/nohome")
     with pytest.raises(RuntimeError):                                                     # no vocabulary: loud, not silent
         clip_front.tokenize("a photo")
+
+
+def test_blip_tokenizer_offline_with_a_vocabulary_dir(tmp_path, monkeypatch):
+    """blip.init_tokenizer (backbone/blip.py:221-226): BertTokenizer + "[DEC]" / "[ENC]" from a local vocabulary
+    directory (UNIIR_BERT_VOCAB_DIR), and the model-side wrapper's max_length padding gives the prefix masks the BERT
+    kernels take as one key length per row; without a vocabulary the call fails loudly"""
+    from uniir_amd import blip_front
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "a", "photo", "of", "red", "dog", "##s", "running", "."]
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n")
+    monkeypatch.setenv("UNIIR_BERT_VOCAB_DIR", str(tmp_path))
+    tok = blip_front.init_tokenizer()
+    assert tok.bos_token == "[DEC]" and tok.enc_token_id == tok.convert_tokens_to_ids("[ENC]") and tok.enc_token_id >= len(vocab)
+    out = tok(["a photo of red dogs running.", "dog"], padding="max_length", truncation=True, max_length=12, return_tensors="pt")
+    ids, mask = out["input_ids"], out["attention_mask"]
+    assert ids.shape == (2, 12) and ids[0, 0].item() == 2          # [CLS] first
+    assert ids[0, :10].tolist() == [2, 5, 6, 7, 8, 9, 10, 11, 12, 3]     # wordpiece "dog" + "##s", then [SEP]
+    assert bool((mask[:, :-1] >= mask[:, 1:]).all()) and mask.sum(1).tolist() == [10, 3]
+    monkeypatch.setenv("UNIIR_BERT_VOCAB_DIR", str(tmp_path / "missing"))
+    with pytest.raises(RuntimeError):
+        blip_front.init_tokenizer()

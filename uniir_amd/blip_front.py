@@ -32,8 +32,8 @@ def init_tokenizer():
         raise RuntimeError("bert-base-uncased vocabulary not found offline; set UNIIR_BERT_VOCAB_DIR to a directory "
                            "holding vocab.txt, or feed input_ids / attention_mask directly") from e
     tokenizer.add_special_tokens({"bos_token": "[DEC]"})
-    tokenizer.add_special_tokens({"additional_special_tokens": ["[ENC]"]})
-    tokenizer.enc_token_id = tokenizer.additional_special_tokens_ids[0]
+    tokenizer.add_tokens(["[ENC]"], special_tokens=True)      # == add_special_tokens({"additional_special_tokens": [...]}),
+    tokenizer.enc_token_id = tokenizer.convert_tokens_to_ids("[ENC]")   # spelled so that transformers 4.x and 5.x both take it
     return tokenizer
 
 
