@@ -218,3 +218,30 @@ def test_clip_load_reads_torchscript_archives_and_plain_state_dicts(tmp_path):
     torch.save({"state_dict": sd}, str(tmp_path / "tiny-load.pt"))
     model2, _ = clip_front.load("tiny-load", device=None, download_root=str(tmp_path))
     assert all(torch.equal(model2.state_dict()[k], sd[k].float()) for k in sd)
+
+
+def test_checkpoint_loader_survives_pickled_config_objects(tmp_path):
+    """published UniIR checkpoints carry an omegaconf DictConfig under "config"; torch >= 2.6 rejects unknown globals by
+    default and omegaconf is not installed: the loader must still hand back the weights (and plain checkpoints as is)"""
+    import sys
+    import types
+    import torch
+    from uniir_amd.host_utils import load_checkpoint_file
+    mod = types.ModuleType("omegaconf_like.dictconfig")
+    pkg = types.ModuleType("omegaconf_like")
+
+    class DictConfig(dict):
+        pass
+
+    DictConfig.__module__, DictConfig.__qualname__ = "omegaconf_like.dictconfig", "DictConfig"
+    mod.DictConfig = DictConfig
+    sys.modules["omegaconf_like"], sys.modules["omegaconf_like.dictconfig"] = pkg, mod
+    try:
+        ckpt = {"model": {"w": torch.arange(6.0).view(2, 3)}, "config": DictConfig(a=1), "epoch": 3}
+        torch.save(ckpt, str(tmp_path / "published.pth"))
+    finally:
+        del sys.modules["omegaconf_like"], sys.modules["omegaconf_like.dictconfig"]
+    got = load_checkpoint_file(str(tmp_path / "published.pth"))          # the class is not importable any more
+    assert torch.equal(got["model"]["w"], torch.arange(6.0).view(2, 3)) and got["epoch"] == 3
+    torch.save({"model": {"w": torch.ones(2)}, "epoch": 0}, str(tmp_path / "plain.pth"))
+    assert torch.equal(load_checkpoint_file(str(tmp_path / "plain.pth"))["model"]["w"], torch.ones(2))

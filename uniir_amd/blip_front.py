@@ -92,7 +92,8 @@ def load_checkpoint(model, filename):
     load non-strictly, return (model, missing/unexpected report)"""
     if not os.path.isfile(filename):
         raise RuntimeError("checkpoint url or path is invalid")
-    state_dict = torch.load(filename, map_location="cpu")["model"]
+    from .host_utils import load_checkpoint_file
+    state_dict = load_checkpoint_file(filename)["model"]
     own = model.state_dict()
     n_patches = own["visual_encoder.pos_embed"].shape[-2] - 1
     for key in ("visual_encoder.pos_embed", "visual_encoder_m.pos_embed"):

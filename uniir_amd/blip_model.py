@@ -859,7 +859,8 @@ class BLIPScoreFusion(BLIPFeatureFusion):
 def blip_sf(pretrained="", **kwargs):
     model = BLIPScoreFusion(**kwargs)
     if pretrained:
-        sd = torch.load(pretrained, map_location="cpu")
+        from .host_utils import load_checkpoint_file
+        sd = load_checkpoint_file(pretrained)
         msg = model.load_state_dict(sd.get("model", sd), strict=False)
         print("missing keys:")
         print(msg.missing_keys)
@@ -869,7 +870,8 @@ def blip_sf(pretrained="", **kwargs):
 def blip_ff(pretrained="", **kwargs):
     model = BLIPFeatureFusion(**kwargs)
     if pretrained:
-        sd = torch.load(pretrained, map_location="cpu")
+        from .host_utils import load_checkpoint_file
+        sd = load_checkpoint_file(pretrained)
         msg = model.load_state_dict(sd.get("model", sd), strict=False)
         print("missing keys:")
         print(msg.missing_keys)

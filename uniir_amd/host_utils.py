@@ -195,6 +195,45 @@ class MetricLogger(object):
 # epoch loops (reference src/models/uniir_clip/engine.py:7-84 and src/models/uniir_blip/engine.py:9-114): what the
 # two engines share; `step_fn(model, batch, i, n_batches)` is the only model-specific part (BLIP passes alpha)
 # ------------------------------------------------------------------------------------------------------------
+def load_checkpoint_file(path):
+    """torch.load for UniIR checkpoints ({"model", "optimizer", "scheduler", "config", "epoch", "scaler"}).  The published
+    files pickle their `config` as an omegaconf DictConfig; torch >= 2.6 refuses such globals by default and omegaconf is
+    not a dependency here (common/config.py replaces it), so: plain tensors-only load first, then a permissive unpickler
+    that turns classes it cannot import into inert placeholders (the weights are what is read; a local, trusted file)."""
+    import pickle
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:      # noqa: BLE001  (pickle.UnpicklingError and friends)
+        pass
+
+    class _Placeholder(dict):          # accepts whatever the pickle stream does to the object it stands for
+        def __init__(self, *a, **k):
+            dict.__init__(self)
+
+        def __setstate__(self, state):
+            self["_state"] = state
+
+        def append(self, item):
+            self.setdefault("_items", []).append(item)
+
+        def extend(self, items):
+            self.setdefault("_items", []).extend(items)
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except Exception:      # noqa: BLE001
+                return type(name, (_Placeholder,), {"__module__": module})
+
+    class _Module:
+        Unpickler = _Unpickler
+        load = staticmethod(lambda f, **kw: _Unpickler(f, **kw).load())
+        __name__ = "pickle"
+
+    return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_Module)
+
+
 def batch_to_device(batch, gpu_id):
     for key, value in batch.items():
         if isinstance(value, torch.Tensor):

@@ -6,6 +6,8 @@ import random
 import numpy as np
 import torch
 
+from uniir_amd.host_utils import load_checkpoint_file
+
 
 def set_seed(seed):
     random.seed(seed)
@@ -59,7 +61,7 @@ def build_model_from_config(config):
         path = os.path.join(config.uniir_dir, ckpt.ckpt_dir, ckpt.ckpt_name)
         assert os.path.exists(path), f"Checkpoint file {path} does not exist."
         print(f"loading {name} checkpoint from {path}")
-        model.load_state_dict(torch.load(path, map_location="cpu")["model"])
+        model.load_state_dict(load_checkpoint_file(path)["model"])
         return model
     if name not in ("CLIPScoreFusion", "CLIPFeatureFusion"):
         raise NotImplementedError(f"Model {name} is not implemented.")
@@ -75,5 +77,5 @@ def build_model_from_config(config):
     path = os.path.join(config.uniir_dir, ckpt.ckpt_dir, ckpt.ckpt_name)
     assert os.path.exists(path), f"Checkpoint file {path} does not exist."
     print(f"loading {name} checkpoint from {path}")
-    model.load_state_dict(torch.load(path, map_location="cpu")["model"])
+    model.load_state_dict(load_checkpoint_file(path)["model"])
     return model

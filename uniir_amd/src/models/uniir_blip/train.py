@@ -24,6 +24,7 @@ from models.uniir_blip.backbone.blip import load_checkpoint
 from models.uniir_blip.blip_featurefusion.blip_ff import blip_ff
 from models.uniir_blip.blip_scorefusion.blip_sf import blip_sf
 from models.uniir_blip.engine import eval_engine, train_one_epoch
+from uniir_amd.host_utils import load_checkpoint_file
 from uniir_amd.trainer import CosineLR, NativeAdamW
 
 logger = logging.getLogger()
@@ -79,7 +80,7 @@ def main(config):
         model, msg = load_checkpoint(model, path)
         print("missing keys:")
         print(msg.missing_keys)
-        checkpoint = torch.load(path, map_location="cpu")
+        checkpoint = load_checkpoint_file(path)
     model.train()
     model = model.to(gpu)
     optimizer = NativeAdamW(model, lr=tc.init_lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=tc.weight_decay)

@@ -23,6 +23,7 @@ from common.config import OmegaConf
 from data.mbeir_dataset import MBEIRMainCollator, MBEIRMainDataset, Mode
 from models.uniir_clip.clip_featurefusion.clip_ff import CLIPFeatureFusion
 from models.uniir_clip.engine import eval_engine, train_one_epoch
+from uniir_amd.host_utils import load_checkpoint_file
 from uniir_amd.trainer import CosineLR, NativeAdamW
 
 logger = logging.getLogger()
@@ -71,7 +72,7 @@ def main(config):
         path = os.path.join(config.uniir_dir, ckpt.ckpt_dir, ckpt.ckpt_name)
         assert os.path.exists(path), f"Checkpoint file {path} does not exist."
         logger.info(f"loading CLIPFeatureFusion checkpoint from {path}")
-        checkpoint = torch.load(path, map_location="cpu")
+        checkpoint = load_checkpoint_file(path)
         model.load_state_dict(checkpoint["model"])
     model.train()
     model = model.to(gpu)
