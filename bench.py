@@ -5,10 +5,20 @@ A "step" is one in-batch contrastive train step (forward + backward + gradient a
 ViT-L/14 on synthetic 224x224 images + 77-token texts (BASELINE.json configs[1]).  Per-GPU work is fixed
 (weak scaling): --pairs query+candidate pairs per rank, global batch = pairs * n_gpus (4096 at 8 GPUs with the
 default 512).  Prints ONE JSON line on rank 0.
+
+Launch (the reference: run_inbatch.sh:50-53, `python -m torch.distributed.run --nproc_per_node=$NPROC train.py`):
+  * `python bench.py --gpus N` with no RANK in the environment re-executes itself under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`;
+  * under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE set, the driver's N>1 form) it is one rank of N.
+One process per GPU, backend "nccl" (= RCCL over xGMI).  `--dry-run` exercises the same launcher / rendezvous /
+collective / reporting code on CPU ranks (gloo) with a stand-in step: that is what tests/test_bench_launcher.py runs.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -19,10 +29,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "uniir_amd", "src"))
 
 FLOP_PER_PAIR = {"ViT-L/14": 1.052e12, "ViT-B/32": 88.7e9}
-# measured offline with rocprofv3 PMC passes of this very command (profiles/r01_pmc_step_v8.txt); null for other configs
-PMC_GEMM_TRAFFIC = {("ViT-L/14", 512): 3.25e9}
+FLOP_PER_ITEM_FWD = {"ViT-L/14": 175.33e9, "ViT-B/32": 14.78e9}
+BLIP_FF_FLOP_PER_PAIR = 1.212e12
 MFMA_PEAK_BF16 = 2.5e15
 HBM_PEAK = 8.0e12
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_gemm_traffic.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes
 
 
 def synth_batch(cfg, pairs, seed, device):
@@ -47,40 +58,307 @@ def synth_batch(cfg, pairs, seed, device):
     }
 
 
-def cpu_baseline(model_name, budget_s=25.0):
-    """The oracle (CPU restatement of the reference path, oracle/clip_oracle.py) timed on the host cores on a
-    bounded sample of the same workload: same architecture, same synthetic inputs, b=2 pairs per step."""
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baselines (oracle = "port"; bounded samples, rank 0 at N = 1 only, after the timed region)
+# ------------------------------------------------------------------------------------------------------------------
+def _oracle_step_timer(model_name, pairs, threads, warmup, timed, budget_s):
+    """oracle/clip_oracle.py train step (fp32 fwd + bwd + AdamW, the reference's two weight-decay groups) on `threads` host
+    threads; returns (median seconds per step, steps timed)"""
     from oracle import clip_oracle as O
     torch.manual_seed(0)
-    cfg = O.CLIP_CONFIGS[model_name]
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        cfg = O.CLIP_CONFIGS[model_name]
+        model = O.OracleCLIP(cfg, seed=0)
+        nd, d = O.weight_decay_groups(model.named_parameters())
+        opt = torch.optim.AdamW([{"params": [p for _, p in nd], "weight_decay": 0.0},
+                                 {"params": [p for _, p in d], "weight_decay": 0.2}], lr=1e-5, betas=(0.9, 0.98), eps=1e-6)
+        batch = O.synthetic_batch(cfg, pairs, seed=2023)
+
+        def step():
+            t0 = time.perf_counter()
+            emb = O.encode_multimodal_input(model.sd(), cfg, batch["txt_batched"], batch["image_batched"],
+                                            batch["txt_mask_batched"], batch["image_mask_batched"])
+            out = O.inbatch_contrastive_loss(emb, batch["index_mapping"], model.logit_scale.exp())
+            opt.zero_grad()
+            out["loss"].backward()
+            opt.step()
+            return time.perf_counter() - t0
+
+        t_all = time.perf_counter()
+        times = []
+        for i in range(warmup + timed):
+            dt = step()
+            if i >= warmup:
+                times.append(dt)
+            if time.perf_counter() - t_all > budget_s and times:
+                break
+        if not times:          # the warm-up alone ate the budget: it is the only sample there is
+            times = [dt]
+        return statistics.median(times), len(times)
+    finally:
+        torch.set_num_threads(prev)
+
+
+def cpu_baseline(model_name):
+    """The oracle (CPU restatement of the reference path) timed on the host cores on bounded samples of the workload:
+    the headline architecture at 8 pairs/step on all cores (primary), and BASELINE.json configs[0] as written
+    (CLIP_SF ViT-B/32, batch 32, fp32, 1 process) on all cores -- median of 3 after 1 warm-up -- and on 1 core."""
+    cores = os.cpu_count() or 1
     threads = torch.get_num_threads()
-    model = O.OracleCLIP(cfg, seed=0)
-    nd, d = O.weight_decay_groups(model.named_parameters())
-    opt = torch.optim.AdamW([{"params": [p for _, p in nd], "weight_decay": 0.0},
-                             {"params": [p for _, p in d], "weight_decay": 0.2}], lr=1e-5, betas=(0.9, 0.98), eps=1e-6)
-    pairs = 2
-    batch = O.synthetic_batch(cfg, pairs, seed=2023)
-    steps, t_used = 0, 0.0
-    t_all0 = time.time()
-    while True:
-        t0 = time.time()
-        emb = O.encode_multimodal_input(model.sd(), cfg, batch["txt_batched"], batch["image_batched"],
-                                        batch["txt_mask_batched"], batch["image_mask_batched"])
-        out = O.inbatch_contrastive_loss(emb, batch["index_mapping"], model.logit_scale.exp())
+    t_l, n_l = _oracle_step_timer(model_name, 8, threads, 1, 2, 40.0)
+    t_b, n_b = _oracle_step_timer("ViT-B/32", 32, threads, 1, 3, 40.0)
+    t_1, n_1 = _oracle_step_timer("ViT-B/32", 4, 1, 0, 1, 30.0)
+    return {"value": round(8 / t_l, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/clip_oracle.py CLIP_SF {model_name} fp32 fwd+bwd+AdamW, 8 pairs/step, median of {n_l} step(s) "
+                      f"after 1 warm-up on {threads} host threads ({cores} logical cores)",
+            "config1": {"value": round(32 / t_b, 3), "unit": "pairs/s", "cores": threads,
+                        "sample": f"BASELINE configs[0] as written: CLIP_SF ViT-B/32, batch 32, fp32, 1 process, median of {n_b} "
+                                  f"steps after 1 warm-up"},
+            "config1_one_core": {"value": round(4 / t_1, 3), "unit": "pairs/s", "cores": 1,
+                                 "sample": "CLIP_SF ViT-B/32, 4 pairs/step (bounded: a 32-pair step takes ~1 min on one core), "
+                                           "1 step, torch.set_num_threads(1)"}}
+
+
+def cpu_retrieval_baseline(d=768, k=10):
+    """fp32 normalise -> Q @ C^T -> top-k on the host cores (FAISS IndexFlatIP's arithmetic; FAISS itself is
+    not in the image), bounded sample of config 4: 1024 queries x 262144 candidates, median of 3 after 1 warm-up"""
+    nq, n = 1024, 262144
+    g = torch.Generator().manual_seed(2023)
+    pool = torch.randn(n, d, generator=g).half()
+    q = torch.randn(nq, d, generator=g).half()
+    times = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        pn = torch.nn.functional.normalize(pool.float(), dim=1, eps=0)
+        qn = torch.nn.functional.normalize(q.float(), dim=1, eps=0)
+        s, idx = (qn @ pn.t()).topk(k, dim=1)
+        dt = time.perf_counter() - t0
+        if i:
+            times.append(dt)
+    t = statistics.median(times)
+    return {"value": round(nq * n / t / 1e6, 1), "unit": "M scored pairs/s", "M_candidates_per_s": round(n / t / 1e6, 2),
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"torch CPU fp32 normalize + matmul + topk({k}), {nq} queries x {n} x {d} candidates (pool normalised "
+                      f"inside the timed region like create_index + search_index), median of 3 after 1 warm-up"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# secondary device blocks (N = 1): retrieval (config 4), embedding extraction (config 3), BLIP_FF large (config 5), CLIP_FF
+# ------------------------------------------------------------------------------------------------------------------
+def bench_retrieval(dev, n=700_000, d=768, k=10, full=True):
+    """brute-force top-10 over one GPU's 700k x 768 fp16 shard of the 5.6M pool (configs[3]); whole search incl. the exact
+    re-score.  q64: interactive / HBM-bound; q1024: one MFMA sweep; q100000: config 4's per-GPU work (98 sweeps)"""
+    from uniir_amd import retrieval
+    g = torch.Generator(device=dev).manual_seed(2023)
+    pool = torch.randn(n, d, generator=g, device=dev).half()
+    shard = retrieval.PoolShard(pool, torch.arange(n, device=dev))
+    out = {}
+    for nq in ((64, 1024, 16384, 100_000) if full else (64, 1024)):
+        q = torch.randn(nq, d, generator=g, device=dev).half()
+        retrieval.search_shard(shard, q, k)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 10 if nq <= 1024 else (2 if nq <= 16384 else 1)
+        e0.record()
+        for _ in range(iters):
+            retrieval.search_shard(shard, q, k)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / iters
+        sweeps = -(-nq // retrieval.QUERY_CHUNK)      # the pool shard is read once per query chunk
+        out[f"q{nq}"] = {"M_candidates_per_s": round(n / t / 1e6, 1), "M_scores_per_s": round(nq * n / t / 1e6, 1),
+                         "ms": round(t * 1e3, 3), "sweeps": sweeps, "queries_per_sweep": min(nq, retrieval.QUERY_CHUNK),
+                         "hbm": {"achieved": round(sweeps * n * d * 2 / t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                 "frac": round(sweeps * n * d * 2 / t / HBM_PEAK, 4)},
+                         "mfma": {"achieved": round(2.0 * nq * n * d / t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,
+                                  "unit": "TFLOP/s", "frac": round(2.0 * nq * n * d / t / MFMA_PEAK_BF16, 4)}}
+    out["workload"] = (f"top-{k} of {n} x {d} fp16 candidates (one GPU's shard of the 5.6M pool), exact fp32 re-score; "
+                       "recall on M-BEIR itself cannot be shown offline (no dataset / checkpoint in the image): exactness is "
+                       "pinned against the C oracle instead")
+    return out
+
+
+def bench_embed(dev, model_name="ViT-L/14", items=2048, steps=3):
+    """config 3: forward-only embedding extraction through the reference's `model(batch, encode_mbeir_batch=True)` entry +
+    `.half()` per batch (mbeir_embedder.py:54-60), 2048 synthetic items per batch resident in HBM"""
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    model = CLIPScoreFusion(model_name=model_name, device=dev).float().eval()
+    batch = synth_batch(CLIP_CONFIGS[model_name], items // 2, 2023, dev)
+    batch["did_list"] = list(range(items))
+    with torch.no_grad():
+        model(batch, encode_mbeir_batch=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            emb, _ids = model(batch, encode_mbeir_batch=True)
+            out = emb.half()
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"metric": "embedding items/s (CLIP_SF-L forward only, fp16 out)", "value": round(items / dt, 1), "unit": "items/s",
+            "ms_per_batch": round(dt * 1e3, 2), "items_per_batch": items, "out_shape": list(out.shape),
+            "mfma_frac": round(items / dt * FLOP_PER_ITEM_FWD[model_name] / MFMA_PEAK_BF16, 4)}
+
+
+def _blip_synth(pairs, L, vocab, seed, device):
+    import types
+    g = torch.Generator().manual_seed(seed)
+    M = 2 * pairs
+    ids = torch.randint(1000, vocab - 2, (M, L), generator=g)
+    ids[:, 0] = 101
+    valid = torch.randint(5, L + 1, (M,), generator=g)
+    mask = (torch.arange(L).unsqueeze(0) < valid.unsqueeze(1)).long()
+    ids = ids * mask
+    img = torch.randn(M, 3, 224, 224, generator=torch.Generator(device=device).manual_seed(seed), device=device)
+    return {"txt_batched": types.SimpleNamespace(input_ids=ids.to(device), attention_mask=mask.to(device)),
+            "image_batched": img, "p_did_list": torch.arange(pairs) + 1000 * seed,
+            "index_mapping": {"query": [[2 * i] for i in range(pairs)], "pos_cand": [[2 * i + 1] for i in range(pairs)]}}
+
+
+def bench_blip_ff(dev, pairs=256, steps=3, warmup=1, queue=57344, length=100):
+    """config 5: BLIP_FF large (ViT-L/16 @224 + MED BERT-base cross-attention) train step, b = 256 pairs / GPU (global 2048
+    at 8 GPUs), queue 57344, 100 text tokens, alpha 0.4, train-mode dropout + DropPath on (blip_ff.py:118-257)"""
+    import types
+    from uniir_amd.blip_model import BLIPFeatureFusion
+    from uniir_amd.trainer import NativeAdamW
+    model = BLIPFeatureFusion(med_config={}, vit="large", queue_size=queue, momentum=0.995,
+                              config=types.SimpleNamespace(tokenizer_max_length=length)).to(dev)
+    model.check_masks = False
+    opt = NativeAdamW(model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, allreduce=False)
+    batches = [_blip_synth(pairs, length, 30524, s, dev) for s in range(2)]
+
+    def step(i):
         opt.zero_grad()
+        out = model(batches[i % 2], alpha=0.4)
         out["loss"].backward()
         opt.step()
-        dt = time.time() - t0
-        if steps > 0 or dt > budget_s / 2:   # first step is warm-up unless it already eats the budget
-            t_used += dt
-            steps_timed = steps if steps > 0 else 1
-        steps += 1
-        if time.time() - t_all0 > budget_s or steps >= 4:
-            break
-    timed = max(1, steps - 1) if steps > 1 else 1
-    return {"value": pairs * timed / t_used, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/clip_oracle.py CLIP_SF {model_name} fp32 fwd+bwd+AdamW, {pairs} pairs/step, "
-                      f"{timed} timed step(s) on {threads} host threads"}
+        return out
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"metric": "query+cand pairs/sec in-batch contrastive (BLIP_FF large)", "value": round(pairs / dt, 1),
+            "unit": "pairs/s", "ms_per_step": round(dt * 1e3, 2), "pairs_per_gpu": pairs, "queue_size": queue,
+            "text_len": length, "dropout": "train mode (BERT 0.1, DropPath <= 0.1)",
+            "mfma_frac": round(pairs / dt * BLIP_FF_FLOP_PER_PAIR / MFMA_PEAK_BF16, 4), "final_loss": round(float(out["loss"]), 4)}
+
+
+def bench_clip_ff(dev, pairs=256, steps=3, warmup=1):
+    """CLIP_FF ViT-L/14 train step (towers without pooling -> 2-layer T5 fusion over 334 tokens -> mean pool -> InfoNCE;
+    clip_ff.py:161-192), T5 dropout on"""
+    from types import SimpleNamespace
+    from models.uniir_clip.clip_featurefusion.clip_ff import CLIPFeatureFusion
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    from uniir_amd.trainer import NativeTrainer
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=True), data_config=SimpleNamespace(in_batch_neg_num=0))
+    model = CLIPFeatureFusion("ViT-L/14", device=dev, config=config)
+    tr = NativeTrainer(model, lr=1e-5, t_total=1000)
+    batch = synth_batch(CLIP_CONFIGS["ViT-L/14"], pairs, 2023, dev)
+    for _ in range(warmup):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.train_step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # the towers' FLOPs per pair are those of CLIP_SF-L; the 2-layer T5 stack (d_model 768, 334 tokens) adds ~2 %, not counted
+    return {"metric": "query+cand pairs/sec in-batch contrastive (CLIP_FF ViT-L/14)", "value": round(pairs / dt, 1),
+            "unit": "pairs/s", "ms_per_step": round(dt * 1e3, 2), "pairs_per_gpu": pairs,
+            "mfma_frac": round(pairs / dt * FLOP_PER_PAIR["ViT-L/14"] / MFMA_PEAK_BF16, 4),
+            "mfma_frac_note": "tower FLOPs only (T5 fusion stack not counted)", "final_loss": round(float(out["loss"].detach()), 4)}
+
+
+def _secondary(name, fn, *a, **kw):
+    try:
+        r = fn(*a, **kw)
+    except Exception as e:      # a secondary block must never take the headline line down with it
+        r = {"error": f"{type(e).__name__}: {e}"[:300]}
+    torch.cuda.empty_cache()
+    return r
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher / distributed plumbing
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside a launcher: become `torch.distributed.run` with N ranks of this script"""
+    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def time_collectives(dist, dev, world, b, E, flat):
+    """the step's three exchanges timed alone (barrier + sync bracketed, mean of 3 after 1 warm-up), in ms"""
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        dist.barrier()
+
+    def timed(fn):
+        fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        sync()
+        return round((time.perf_counter() - t0) / 3 * 1e3, 3)
+
+    p = torch.randn(b, E, device=dev)
+    all_p = torch.empty(world * b, E, device=dev)
+    d_all = torch.randn(world * b, E, device=dev)
+    out = {"all_gather_p_ms": timed(lambda: dist.all_gather_into_tensor(all_p, p))}
+    if dist.get_backend() != "gloo":
+        dp = torch.empty(b, E, device=dev)
+        out["reduce_scatter_dp_ms"] = timed(lambda: dist.reduce_scatter_tensor(dp, d_all, op=dist.ReduceOp.SUM))
+    else:   # gloo (dry run) has no reduce_scatter: comm.reduce_scatter_rows falls back to all_reduce + slice
+        out["reduce_scatter_dp_ms"] = timed(lambda: dist.all_reduce(d_all, op=dist.ReduceOp.SUM))
+    out["all_reduce_grads_ms"] = timed(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM))
+    out["all_reduce_grads_GB"] = round(flat.numel() * flat.element_size() / 1e9, 3)
+    return out
+
+
+class _DryRunTrainer:
+    """CPU stand-in for NativeTrainer (dry run only): the same collective sequence per step -- all-gather of p,
+    reduce-scatter of d all_p, block-wise overlapped gradient all-reduce through comm.GradReducer -- around trivial math"""
+
+    def __init__(self, pairs, E=64, blocks=6, block_elems=50_000):
+        from uniir_amd import comm
+        self.comm, self.pairs, self.E = comm, pairs, E
+        self.blocks, self.block_elems = blocks, block_elems
+        self.g32 = torch.zeros(1000 + blocks * block_elems)
+        self.reducer = comm.GradReducer(self.g32, bucket_bytes=4 * block_elems * 2)
+        self.last_collectives = 0
+
+    def train_step(self, batch):
+        comm = self.comm
+        p = torch.full((self.pairs, self.E), float(comm.rank() + 1))
+        all_p = comm.all_gather_rows(p)
+        d_p = comm.reduce_scatter_rows(torch.ones_like(all_p), self.pairs)
+        self.g32.fill_(1.0)
+        for i in reversed(range(self.blocks)):
+            self.reducer.ready(1000 + i * self.block_elems, 1000 + (i + 1) * self.block_elems)
+        self.last_collectives = self.reducer.finish()
+        ok = bool((self.g32 == comm.world()).all()) and bool((d_p == comm.world()).all())
+        return {"loss": torch.tensor(0.0 if ok else float("nan"))}
 
 
 def main():
@@ -92,50 +370,72 @@ def main():
     ap.add_argument("--model", default="ViT-L/14")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-retrieval", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the embed / BLIP_FF / CLIP_FF blocks")
+    ap.add_argument("--dry-run", action="store_true", help="CPU ranks over gloo with a stand-in step (launcher test)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if "RANK" in os.environ and args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU product path); --dry-run only tests the launcher")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from types import SimpleNamespace
-    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
-    from uniir_amd import ops
-    from uniir_amd.clip_model import CLIP_CONFIGS
-    from uniir_amd.trainer import NativeTrainer
-
-    cfg = CLIP_CONFIGS[args.model]
-    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=True), data_config=SimpleNamespace(in_batch_neg_num=0))
-    torch.manual_seed(2023 + rank)
-    model = CLIPScoreFusion(model_name=args.model, device=dev, config=config)
-    model.float()
-    trainer = NativeTrainer(model, lr=1e-5, t_total=10000)
-    batch = synth_batch(cfg, args.pairs, 2023 + rank, dev)
+        if args.dry_run:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    if args.dry_run:
+        E = 64
+        trainer = _DryRunTrainer(args.pairs, E)
+        batch, timing, model, ops = None, [], None, None
+        flat = trainer.g32
+    else:
+        from types import SimpleNamespace
+        from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+        from uniir_amd import ops
+        from uniir_amd.clip_model import CLIP_CONFIGS
+        from uniir_amd.trainer import NativeTrainer
+        cfg = CLIP_CONFIGS[args.model]
+        E = cfg["embed_dim"]
+        config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=True), data_config=SimpleNamespace(in_batch_neg_num=0))
+        torch.manual_seed(2023 + rank)
+        model = CLIPScoreFusion(model_name=args.model, device=dev, config=config)
+        model.float()
+        trainer = NativeTrainer(model, lr=1e-5, t_total=10000)
+        batch = synth_batch(cfg, args.pairs, 2023 + rank, dev)
 
     for _ in range(args.warmup):
         out = trainer.train_step(batch)
     barrier()
-    ops.GEMM_TIMING = [] if rank == 0 else None
+    if ops is not None:
+        ops.GEMM_TIMING = [] if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = trainer.train_step(batch)
     barrier()
     dt = time.perf_counter() - t0
-    timing = ops.GEMM_TIMING
-    ops.GEMM_TIMING = None
+    if ops is not None:
+        timing = ops.GEMM_TIMING or []
+        ops.GEMM_TIMING = None
     loss = float(out["loss"].detach())
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -144,72 +444,72 @@ def main():
     global_pairs = args.pairs * world
     value = global_pairs * args.steps / dt
 
+    rccl = None
+    if world > 1:
+        if not args.dry_run:
+            flat = model.clip_model._flat["g32"]
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        opt = trainer if args.dry_run else trainer.opt
+        rccl = {"backend": dist.get_backend(), "ranks_seen": int(seen.item()),
+                "grad_allreduce": {"overlapped_with_backward": True, "collectives_per_step": int(opt.last_collectives),
+                                   "bucket_MB": round((opt.reducer.bucket_elems * 4) / 2**20, 1) if opt.reducer else None}}
+        rccl.update(time_collectives(dist, dev, world, args.pairs, E, flat))
+
     result = None
     if rank == 0:
-        gflop = sum(f for f, _, _ in timing)
-        gtime = sum(e0.elapsed_time(e1) for _, e0, e1 in timing) * 1e-3
-        roof = {"bound": "mfma", "kernel": "gemm_kernel<bf16> (NT/NN/TN MFMA GEMMs of the towers)",
-                "achieved": round(gflop / gtime / 1e12, 2) if gtime > 0 else None, "peak": MFMA_PEAK_BF16 / 1e12,
-                "unit": "TFLOP/s", "frac": round(gflop / gtime / MFMA_PEAK_BF16, 4) if gtime > 0 else None,
-                "traffic": PMC_GEMM_TRAFFIC.get((args.model, args.pairs)),
-                "traffic_note": "bytes per GEMM launch (mean over the step's 441 launches), rocprofv3 --pmc FETCH_SIZE (x2, "
-                                "gfx950 correction) + WRITE_SIZE in separate passes: profiles/r01_pmc_step_v8.txt; L2<->fabric "
-                                "requests, MALL hits included (upper bound of HBM bytes); algorithmic mean 2.6e9",
-                "launches_timed": len(timing), "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} GEMM launches bracketed by HIP events",
-                "end_to_end_frac": round(value * FLOP_PER_PAIR[args.model] / (world * MFMA_PEAK_BF16), 4)}
+        if args.dry_run:
+            roof = None
+        else:
+            gflop = sum(f for f, _, _ in timing)
+            gtime = sum(e0.elapsed_time(e1) for _, e0, e1 in timing) * 1e-3
+            traffic, traffic_note = None, "no rocprofv3 --pmc record for this configuration under profiles/"
+            if os.path.exists(PMC_FILE):
+                rec = json.load(open(PMC_FILE))
+                if rec.get("model") == args.model and rec.get("pairs") == args.pairs:
+                    traffic, traffic_note = rec["bytes_per_launch"], rec["note"]
+            roof = {"bound": "mfma",
+                    "kernel": "gemm_glds_kernel<ElemBF16, {NT,NN,TN}, 2, 4, 64, 2> (256x256x64 ping-pong LDS-DMA MFMA GEMM: "
+                              "forward, dgrad and wgrad of the towers' linear layers)",
+                    "achieved": round(gflop / gtime / 1e12, 2) if gtime > 0 else None, "peak": MFMA_PEAK_BF16 / 1e12,
+                    "unit": "TFLOP/s", "frac": round(gflop / gtime / MFMA_PEAK_BF16, 4) if gtime > 0 else None,
+                    "traffic": traffic, "traffic_note": traffic_note, "launches_timed": len(timing),
+                    "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} GEMM launches of the timed region bracketed by HIP events on the "
+                                "launch stream (2 event records per sampled launch; < 0.1 % of the step)",
+                    "end_to_end_frac": round(value * FLOP_PER_PAIR[args.model] / (world * MFMA_PEAK_BF16), 4)}
         result = {
             "metric": "query+cand pairs/sec in-batch contrastive (CLIP_SF-L)", "value": round(value, 2),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"CLIP_SF {args.model} in-batch contrastive train step (fwd+bwd+allreduce+AdamW), "
-                                   f"{args.pairs} pairs/GPU, global batch {global_pairs}, 224x224 images + 77-token text",
+            "vs_baseline": None, "dtype": "bf16" if not args.dry_run else "f32", "data": "synthetic",
+            "config": {"workload": (f"CLIP_SF {args.model} in-batch contrastive train step (fwd+bwd+allreduce+AdamW), "
+                                    f"{args.pairs} pairs/GPU, global batch {global_pairs}, 224x224 images + 77-token text")
+                       if not args.dry_run else "DRY RUN: launcher / collective plumbing only, not a measurement",
                        "pairs_per_gpu": args.pairs, "global_batch": global_pairs, "parallelism": f"dp{world}",
                        "final_loss": round(loss, 4)},
             "roofline": roof,
         }
+        if rccl is not None:
+            result["rccl"] = rccl
     del trainer, model, batch, out
-    torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_retrieval:
-        result["retrieval"] = bench_retrieval(dev)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.model)
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.dry_run:
+        if not args.no_retrieval:
+            result["retrieval"] = _secondary("retrieval", bench_retrieval, dev)
+        if not args.no_secondary:
+            result["embed"] = _secondary("embed", bench_embed, dev, args.model)
+            result["blip_ff_large"] = _secondary("blip_ff_large", bench_blip_ff, dev)
+            result["clip_ff"] = _secondary("clip_ff", bench_clip_ff, dev)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.model)
+            if not args.no_retrieval and isinstance(result.get("retrieval"), dict):
+                result["retrieval"]["cpu_baseline"] = cpu_retrieval_baseline()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def bench_retrieval(dev, n=700_000, d=768, k=10):
-    """Secondary metric: brute-force top-10 over one GPU's 700k x 768 fp16 shard of the 5.6M pool (configs[3])."""
-    from uniir_amd import retrieval
-    g = torch.Generator(device=dev).manual_seed(2023)
-    pool = torch.randn(n, d, generator=g, device=dev).half()
-    shard = retrieval.PoolShard(pool, torch.arange(n, device=dev))
-    out = {}
-    for nq in (64, 1024, 16384):    # interactive (HBM-bound), one MFMA sweep, many sweeps (SURVEY 8d config 4 regime)
-        q = torch.randn(nq, d, generator=g, device=dev).half()
-        retrieval.search_shard(shard, q, k)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 5 if nq <= 1024 else 2
-        e0.record()
-        for _ in range(iters):
-            retrieval.search_shard(shard, q, k)
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) * 1e-3 / iters
-        sweeps = -(-nq // retrieval.QUERY_CHUNK)      # the pool shard is read once per 1024-query chunk
-        out[f"q{nq}"] = {"M_candidates_per_s": round(n / t / 1e6, 1), "M_scores_per_s": round(nq * n / t / 1e6, 1),
-                         "ms": round(t * 1e3, 3),
-                         "sweeps": sweeps,
-                         "hbm": {"achieved": round(sweeps * n * d * 2 / t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                 "frac": round(sweeps * n * d * 2 / t / HBM_PEAK, 4)},
-                         "mfma": {"achieved": round(2.0 * nq * n * d / t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,
-                                  "unit": "TFLOP/s", "frac": round(2.0 * nq * n * d / t / MFMA_PEAK_BF16, 4)}}
-    out["workload"] = f"top-{k} of {n} x {d} fp16 candidates (one GPU shard of the 5.6M pool), exact re-score"
-    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,52 @@
+"""bench.py's N>1 path without GPUs: `python bench.py --gpus 2 --dry-run` must re-execute itself under
+torch.distributed.run with 2 ranks (free port, 127.0.0.1), form the process group, run the step's collective sequence
+(all-gather p, reduce-scatter, bucketed gradient all-reduce through comm.GradReducer), take the max-over-ranks time and
+print ONE JSON line from rank 0 with n_gpus = 2 and the rccl block.  The reference launches the same way:
+run_inbatch.sh:50-53 (python -m torch.distributed.run --nproc_per_node=$NPROC train.py)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env_extra=None):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "2"
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=300)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, lines
+
+
+def test_gpus_flag_spawns_that_many_ranks_and_reports_them():
+    p, lines = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--pairs", "8"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout          # exactly one JSON line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 16 and r["config"]["pairs_per_gpu"] == 8 and r["config"]["parallelism"] == "dp2"
+    assert r["config"]["final_loss"] == 0.0            # the stand-in step checks every collective's result (nan otherwise)
+    assert r["value"] > 0 and abs(r["value"] - 16 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-2 * r["value"]
+    rc = r["rccl"]
+    assert rc["ranks_seen"] == 2 and rc["backend"] == "gloo"
+    assert rc["grad_allreduce"]["overlapped_with_backward"] and rc["grad_allreduce"]["collectives_per_step"] >= 3
+    for k in ("all_gather_p_ms", "reduce_scatter_dp_ms", "all_reduce_grads_ms"):
+        assert rc[k] > 0
+
+
+def test_single_rank_dry_run_needs_no_launcher():
+    p, lines = _run(["--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0", "--pairs", "4"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and "rccl" not in r and r["config"]["global_batch"] == 4
+
+
+def test_world_size_mismatch_is_an_error():
+    p, _ = _run(["--gpus", "4", "--dry-run"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                             "MASTER_PORT": "29999"})
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)

@@ -121,3 +121,61 @@ def test_two_rank_blip_queue_update_is_rank_major_and_identical_on_every_rank():
     for r in range(2):
         assert np.array_equal(res[r]["qq"], want_q) and np.array_equal(res[r]["cq"], -want_q)
         assert np.array_equal(res[r]["idx"], want_idx) and res[r]["ptr"] == 4
+
+
+def _reducer_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uniir_amd import comm
+    g = torch.Generator().manual_seed(100 + rank)
+    n = 10_000
+    grads = torch.randn(n, generator=g) * torch.logspace(-6, 3, n)       # wide dynamic range: any re-association would show
+    flat_ref = grads.clone()
+    comm.allreduce_sum_(flat_ref)                                        # the round-1 path: one all-reduce of everything
+    flat = grads.clone()
+    red = comm.GradReducer(flat, bucket_bytes=4 * 1500)
+    # "backward": blocks announced last-to-first like _tower_bwd does (adjacent ranges, to be coalesced), a second tower,
+    # one stray range; [0, 1000) and [9000, 10000) are never announced and must be picked up by finish()
+    for lo in range(4000, 1000, -500):
+        red.ready(lo, lo + 500)
+    for lo in range(8000, 4500, -700):
+        red.ready(lo, lo + 700)
+    red.ready(8700, 9000)
+    launched_before_finish = red.n_collectives
+    ncoll = red.finish()
+    # a second step on the same reducer (state re-armed)
+    flat2 = flat.clone()
+    red2_in = flat2.clone()
+    comm.allreduce_sum_(red2_in)
+    red.flat = flat2
+    red.ready(0, 5000)
+    red.finish()
+    q.put((rank, torch.equal(flat, flat_ref), torch.equal(flat2, red2_in), launched_before_finish, ncoll))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_gradient_allreduce_equals_flat_allreduce_bit_for_bit():
+    """DDP-style buckets (comm.GradReducer, fed per finished block by clip_model._tower_bwd) == one all-reduce of the
+    flat gradient buffer, bit for bit, including the never-announced remainder and re-use across steps"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, 29536, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, same, same2, early, ncoll in res:
+        assert same and same2
+        assert early >= 2            # buckets really left before finish() (overlap), not one blocking call at the end
+        assert ncoll > early
+
+
+def test_reducer_rejects_overlapping_ranges():
+    from uniir_amd import comm
+    import pytest
+    with pytest.raises(RuntimeError):
+        comm.GradReducer._coalesce([(0, 10), (5, 20)])
+    assert comm.GradReducer._coalesce([(10, 20), (0, 10), (30, 40)]) == [(0, 20), (30, 40)]

@@ -162,6 +162,18 @@ class CLIP(nn.Module):
         o = fl["off"][name]
         return fl["g32"][o:o + math.prod(fl["shapes"][name])].view(fl["shapes"][name])
 
+    def layer_grad_range(self, prefix, i):
+        """[lo, hi) of the flat buffers that holds the four weight matrices of residual block i (adjacent: the weight-decay
+        section keeps named_parameters() order and the block's gains / biases live in the other section)"""
+        fl = self._flat
+        names = [f"{prefix}.resblocks.{i}.{n}" for n in ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight",
+                                                         "mlp.c_proj.weight")]
+        lo = min(fl["off"][n] for n in names)
+        hi = max(fl["off"][n] + (math.prod(fl["shapes"][n]) + ALIGN - 1) // ALIGN * ALIGN for n in names)
+        if hi - lo != sum((math.prod(fl["shapes"][n]) + ALIGN - 1) // ALIGN * ALIGN for n in names):
+            raise RuntimeError("flat layout: block weights are not adjacent")
+        return lo, hi
+
     def zero_grad(self, set_to_none=False):
         """Gradients live in one flat buffer; zeroing it is one memset (they are never set to None)."""
         if self._flat is not None:
@@ -262,6 +274,9 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
     """dx fp32 [R,W] and its bf16 copy dxb: gradient w.r.t. the tower output.  Returns d(tower input) (fp32).
     With DropPath factors (rowscale, see _tower_fwd) the branch gradient is rowscale * dx: the bf16 copy is scaled in
     place and the two bias gradients are its column sums (instead of the sums fused into the LayerNorm backward)."""
+    # DDP overlap: with a reducer armed (trainer.NativeAdamW.arm_overlap) a finished block's weight gradients go to the
+    # collective stream while the remaining blocks still run (only the stock CLIP block naming has a range lookup)
+    reducer = getattr(model, "_grad_reducer", None) if blk is None else None
     blk = blk or (lambda i: _Blk(model, f"{prefix}.resblocks.{i}"))
     R = M * T
     dev = dx.device
@@ -304,6 +319,8 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
         ops.layernorm_bwd(x, b.p32("ln1w"), dh, b.g("ln1w"), b.g("ln1b"), eps, dres=dx2, dx=dx, dx_bf16=dxb,
                           rows=R, width=W, dx_colsum=(blk(i - 1).g("bproj") if i > 0 and rowscale is None else None))
         del x, dx2
+        if reducer is not None:
+            reducer.ready(*model.layer_grad_range(prefix, i))
     return dx
 
 

@@ -2,7 +2,9 @@
 the CPU tests).  Only collectives the path really has:
   * all_gather_rows / reduce_scatter_rows: forward and backward of clip_sf.py:102-103
     (torch.distributed.nn.all_gather of p_embeds; its autograd backward is a reduce-scatter SUM);
-  * allreduce_mean_: DDP's gradient averaging (clip_scorefusion/train.py:218) on one flat buffer;
+  * allreduce_sum_ / GradReducer: DDP's gradient averaging (clip_scorefusion/train.py:218) on the flat fp32 gradient
+    buffer -- GradReducer is DDP's bucketed, backward-overlapped form: ranges of the buffer are reduced on the
+    collective stream as soon as backward has produced them;
   * gather_topk: per-shard (score, id) lists to every rank for the k-way merge (FAISS shard=True semantics,
     mbeir_retriever.py:98-100).
 """
@@ -61,6 +63,79 @@ def allreduce_sum_(flat):
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+class GradReducer:
+    """DDP's bucketed gradient all-reduce overlapped with backward (torch DistributedDataParallel as wrapped at
+    clip_scorefusion/train.py:218), on the flat fp32 gradient buffer of this build.
+
+    Backward calls ready(lo, hi) when the kernels that produce flat[lo:hi] have been enqueued on the compute stream;
+    adjacent ranges are coalesced and, once `bucket_bytes` have piled up, all-reduced (SUM) with async_op=True: on RCCL
+    the collective runs on the process group's own stream, ordered after the compute stream's position at the call, so it
+    overlaps the rest of backward.  finish() reduces whatever has not been announced (the complement of the announced
+    ranges) and makes the compute stream wait for every collective.  Every element is reduced exactly once, so the result
+    is bit-identical with one all-reduce of the whole buffer whenever the backend's sum is order-independent per element
+    (2 ranks: a+b; the 2-rank test checks it).  The 1/world mean stays folded into the AdamW kernel."""
+
+    def __init__(self, flat, bucket_bytes=64 << 20):
+        self.flat = flat
+        self.bucket_elems = max(1, bucket_bytes // flat.element_size())
+        self.pending, self.launched, self.works = [], [], []
+        self.n_collectives = 0
+
+    def _sync_backend(self):
+        # tests only (two gloo ranks sharing one GPU): gloo cannot reduce device memory -> staged through the host
+        return self.flat.is_cuda and dist.get_backend() == "gloo"
+
+    def ready(self, lo, hi):
+        if hi <= lo or world() == 1:
+            return
+        self.pending.append((lo, hi))
+        if sum(h - l for l, h in self.pending) >= self.bucket_elems:
+            self.flush()
+
+    @staticmethod
+    def _coalesce(ranges):
+        out = []
+        for lo, hi in sorted(ranges):
+            if out and lo <= out[-1][1]:
+                if lo < out[-1][1]:
+                    raise RuntimeError("GradReducer: overlapping gradient ranges announced")
+                out[-1] = (out[-1][0], hi)
+            else:
+                out.append((lo, hi))
+        return out
+
+    def flush(self):
+        for lo, hi in self._coalesce(self.pending):
+            view = self.flat[lo:hi]
+            if self._sync_backend():
+                allreduce_sum_(view)
+            else:
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            self.launched.append((lo, hi))
+            self.n_collectives += 1
+        self.pending = []
+
+    def finish(self):
+        """reduce the not-yet-announced remainder, wait for everything, re-arm for the next step"""
+        if world() > 1:
+            self.flush()
+            done = self._coalesce(self.launched)
+            cur, rest = 0, []
+            for lo, hi in done:
+                if lo > cur:
+                    rest.append((cur, lo))
+                cur = hi
+            if cur < self.flat.numel():
+                rest.append((cur, self.flat.numel()))
+            self.pending = rest
+            self.flush()
+            for w in self.works:
+                w.wait()          # RCCL: the current stream waits for the collective (no host block); gloo: host wait
+        n = self.n_collectives
+        self.pending, self.launched, self.works, self.n_collectives = [], [], [], 0
+        return n
 
 
 def gather_topk(scores, ids):

@@ -322,6 +322,8 @@ def run_train_epoch(model, data_loader, optimizer, scheduler, config, gpu_id, ep
     for i, batch in enumerate(log.log_every(feed, config.trainer_config.print_freq, f"Train Epoch: [{epoch}]")):
         outputs = step_fn(model, batch, i, n)
         scaled = outputs["loss"] / accum
+        if hasattr(optimizer, "arm_overlap"):          # overlapped gradient all-reduce only on the window's last backward
+            optimizer.arm_overlap(pending == accum - 1)
         scaled.backward()
         pending += 1
         if pending == accum:

@@ -12,7 +12,7 @@ EPI_BF16, EPI_BIAS_ACT, EPI_RESID_F32, EPI_DACT, EPI_F32, EPI_ATOMIC_F32 = range
 ACT_QUICKGELU, ACT_GELU_ERF, ACT_RELU = range(3)
 DT_BF16, DT_F16 = 0, 1
 GEMM_TIMING = None  # bench.py sets this to a list to collect (flops, start_event, end_event) of sampled GEMM launches
-GEMM_TIMING_STRIDE = 17   # HIP events around every launch would stall the queue (~50 us each): sample 1 in 17
+GEMM_TIMING_STRIDE = 53   # 2 event records per sampled launch; 441 GEMM launches per step and 441 % 53 = 17, so every shape is sampled over a few steps
 _GEMM_COUNTER = [0]
 
 

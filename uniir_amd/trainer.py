@@ -5,8 +5,9 @@ accumulation_steps, scheduler.step) and clip_scorefusion/train.py:52-61,195-199,
 (0.9,0.98) eps 1e-6, weight decay 0 for gains / biases / logit_scale and 0.2 for the rest,
 CosineAnnealingLR(T_max, eta_min=0)).  Differences, all result-preserving:
   * bf16 MFMA compute needs no GradScaler (the reference's fp16 autocast does);
-  * gradients live in one flat fp32 buffer: DDP's bucketed all-reduce(mean) becomes one RCCL all-reduce(sum) of that
-    buffer with the 1/world factor folded into the fused AdamW kernel;
+  * gradients live in one flat fp32 buffer: DDP's bucketed all-reduce(mean) becomes RCCL all-reduce(sum) of ranges of
+    that buffer, launched per finished residual block while backward still runs (comm.GradReducer; one blocking
+    all-reduce of the remainder at step()), with the 1/world factor folded into the fused AdamW kernel;
   * AdamW is one fused kernel per weight-decay group and refreshes the bf16 weight shadow in the same pass.
 """
 import math
@@ -20,7 +21,8 @@ class NativeAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics over the CLIP module's flat parameter buffer (two groups: [0, split) without weight
     decay, [split, total) with).  It is a real torch Optimizer (param_groups / lr schedulers / state_dict work)."""
 
-    def __init__(self, clip_model, lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2, allreduce=True, extra=None):
+    def __init__(self, clip_model, lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2, allreduce=True, extra=None,
+                 overlap=True, bucket_bytes=64 << 20):
         """extra: further flat parameter stores, each one param group of its own -- objects with .params (list of
         nn.Parameter), .store() (-> FlatStore with p32 / g32 / w16_buf / total), .weight_decay and .lr (CLIP_FF's T5
         stack: clip_featurefusion/train.py:52-61 gives it weight decay 0.2 on everything and its own learning rate)"""
@@ -38,6 +40,9 @@ class NativeAdamW(torch.optim.Optimizer):
         groups += [{"params": e.params, "weight_decay": e.weight_decay, "lr": e.lr} for e in self.extra]
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.allreduce = allreduce
+        self.overlap, self.bucket_bytes = overlap, bucket_bytes
+        self.reducer = None
+        self.last_collectives = 0
         self.m = self.v = None
         self.opt_step = 0
 
@@ -49,14 +54,30 @@ class NativeAdamW(torch.optim.Optimizer):
                 m.copy_(self.m)
                 v.copy_(self.v)
             self.m, self.v = m, v
+        if self.allreduce and self.overlap and comm.world() > 1:
+            if self.reducer is None or self.reducer.flat.data_ptr() != fl["g32"].data_ptr():
+                self.reducer = comm.GradReducer(fl["g32"], self.bucket_bytes)
+        else:
+            self.reducer = None
         return fl
+
+    def arm_overlap(self, last_micro_batch=True):
+        """call before backward(): on the LAST micro-batch of an accumulation window the tower backward hands every finished
+        residual block's weight gradients to the reducer (DDP's no_sync() on the earlier micro-batches)"""
+        self._buffers()
+        self.clip._grad_reducer = self.reducer if last_micro_batch else None
 
     @torch.no_grad()
     def step(self, closure=None):
         fl = self._buffers()
         world = comm.world() if self.allreduce else 1
         if world > 1:
-            comm.allreduce_sum_(fl["g32"])         # one RCCL all-reduce; the mean is folded into grad_scale
+            if self.reducer is not None:           # blocks already reduced during backward; now the remainder + wait
+                self.last_collectives = self.reducer.finish()
+            else:
+                comm.allreduce_sum_(fl["g32"])     # one RCCL all-reduce; the mean is folded into grad_scale
+                self.last_collectives = 1
+        self.clip._grad_reducer = None
         self.opt_step += 1
         split, total = fl["split"], fl["total"]
         # (lo, hi, param-group index); default: [0, split) without weight decay, [split, total) with
@@ -73,6 +94,8 @@ class NativeAdamW(torch.optim.Optimizer):
             st = e.store()
             if self.extra_mv[i] is None or self.extra_mv[i][0].numel() != st.total:
                 self.extra_mv[i] = (torch.zeros_like(st.p32), torch.zeros_like(st.p32))
+            elif self.extra_mv[i][0].device != st.p32.device:     # resumed from a checkpoint mapped to the CPU
+                self.extra_mv[i] = tuple(t.to(st.p32.device) for t in self.extra_mv[i])
             if world > 1:
                 comm.allreduce_sum_(st.g32)
             b1, b2 = group["betas"]
@@ -136,6 +159,7 @@ class NativeTrainer:
             self.opt.zero_grad()
         self.model.train()
         out = self.model(batch)
+        self.opt.arm_overlap(self.micro == self.accum - 1)
         (out["loss"] / self.accum).backward()
         self.micro += 1
         if self.micro == self.accum:
