@@ -245,3 +245,36 @@ def test_checkpoint_loader_survives_pickled_config_objects(tmp_path):
     assert torch.equal(got["model"]["w"], torch.arange(6.0).view(2, 3)) and got["epoch"] == 3
     torch.save({"model": {"w": torch.ones(2)}, "epoch": 0}, str(tmp_path / "plain.pth"))
     assert torch.equal(load_checkpoint_file(str(tmp_path / "plain.pth"))["model"]["w"], torch.ones(2))
+
+
+def test_checkpoint_loader_does_not_resolve_arbitrary_globals(tmp_path):
+    """the fallback unpickler must not import whatever a file names (os.system ...): such globals become inert
+    placeholders, the tensors still load"""
+    import pickle
+    import torch
+    from uniir_amd.host_utils import load_checkpoint_file
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("touch " + str(tmp_path / "pwned"),))
+
+    path = str(tmp_path / "evil.pth")
+    torch.save({"model": {"w": torch.arange(4.0)}, "config": Evil()}, path)
+    sd = load_checkpoint_file(path)
+    assert torch.equal(sd["model"]["w"], torch.arange(4.0))
+    assert not (tmp_path / "pwned").exists()
+
+
+def test_clip_load_refuses_missing_pretrained_weights(tmp_path, monkeypatch):
+    """a wrong pretrained_clip_model_dir must not silently train from random weights"""
+    import pytest
+    from oracle import clip_oracle as O
+    from uniir_amd import clip_front, clip_model
+    clip_model.CLIP_CONFIGS["tiny-missing"] = O.tiny_config()
+    monkeypatch.delenv("UNIIR_ALLOW_RANDOM_INIT", raising=False)
+    with pytest.raises(FileNotFoundError):
+        clip_front.load("tiny-missing", device=None, download_root=str(tmp_path))
+    monkeypatch.setenv("UNIIR_ALLOW_RANDOM_INIT", "1")
+    with pytest.warns(UserWarning):
+        clip_front.load("tiny-missing", device=None, download_root=str(tmp_path))

@@ -154,6 +154,9 @@ def test_train_embed_index_retrieve_pipeline(tmp_path):
     data_dir, uniir_dir = str(tmp_path / "mbeir"), str(tmp_path / "uniir")
     _make_tree(data_dir)
     cfgs = _configs(str(tmp_path), uniir_dir)
+    # the "pretrained" weights where run_inbatch.sh's config points (pretrained_clip_model_dir): a missing file is an error
+    os.makedirs(os.path.join(uniir_dir, "checkpoint/CLIP"), exist_ok=True)
+    torch.save({"state_dict": O.init_state_dict(O.tiny_config(), seed=4)}, os.path.join(uniir_dir, "checkpoint/CLIP/tiny-test.pt"))
 
     def load(name):
         c = OmegaConf.load(cfgs[name])

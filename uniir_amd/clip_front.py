@@ -138,6 +138,14 @@ def load(name="ViT-B/32", device="cuda", jit=False, download_root=None, seed=0):
             sd = sd.get("state_dict", sd.get("model", sd)) if isinstance(sd, dict) else sd.state_dict()
             sd = {k: v.float() for k, v in sd.items() if k in model.state_dict()}
             model.load_state_dict(sd, strict=True)
+        elif os.environ.get("UNIIR_ALLOW_RANDOM_INIT") != "1":
+            # upstream clip.load downloads the file or fails; silently fine-tuning from random weights would produce
+            # plausible-looking checkpoints and embeddings
+            raise FileNotFoundError(f"pretrained CLIP weights not found: {path} (there is no network to download them from; "
+                                    "put the openai/CLIP .pt file there, or set UNIIR_ALLOW_RANDOM_INIT=1 for a dry run)")
+        else:
+            import warnings
+            warnings.warn(f"{path} is missing: CLIP {name} stays RANDOMLY INITIALISED (UNIIR_ALLOW_RANDOM_INIT=1)")
     if device is not None and str(device) != "cpu":
         model = model.to(device)
     return model, _preprocess(CLIP_CONFIGS[name]["image_resolution"])

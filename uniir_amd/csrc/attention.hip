@@ -483,14 +483,13 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
 static int launch_attn_fwd(const AttnArgs& a, int batch, hipStream_t st) {
     const int Tkp = (a.Tk + 31) & ~31;
     const int sm = 2 * Tkp * 128 + (a.rel_emb ? (a.Tq + a.Tk) * 4 : 0);
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         const int big = 2 * 512 * 128 + 1024 * 4;
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        attr = true;
     }
     const dim3 g(batch * a.H), b(ATT_THREADS);
     const bool drop = a.drop_p > 0.f;
@@ -505,8 +504,8 @@ static int launch_attn_bwd(const AttnArgs& a, int batch, hipStream_t st) {
     const int Tqp = (a.Tq + 31) & ~31, Tkp = (a.Tk + 31) & ~31;
     const int Tmax = Tqp > Tkp ? Tqp : Tkp;
     const int sm = 2 * Tmax * 128 + 2 * Tqp * 4 + (a.rel_emb ? 2 * (a.Tq + a.Tk) * 4 : 0);
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         const int big = 2 * 512 * 128 + 2 * 512 * 4 + 2 * 1024 * 4;
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -514,7 +513,6 @@ static int launch_attn_bwd(const AttnArgs& a, int batch, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        attr = true;
     }
     const dim3 g(batch * a.H), b(ATT_THREADS);
     const bool drop = a.drop_p > 0.f;

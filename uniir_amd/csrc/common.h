@@ -60,6 +60,20 @@ DEVINL int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// hipFuncSetAttribute (dynamic LDS opt-in) is a PER-DEVICE setting: one process may launch on every visible GPU
+// (mbeir_retriever's single-process shards), so the "done" memo of a call site is kept per device
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        d &= 63;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 #define HIP_LAUNCH_CHECK()                                         \
     do {                                                           \
         hipError_t e__ = hipGetLastError();                        \

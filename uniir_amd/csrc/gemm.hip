@@ -489,11 +489,10 @@ static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
     const size_t sm = S::LDS_BYTES;
 #define LAUNCHG(AT, BT)                                                                           \
     do {                                                                                          \
-        static bool attr_set = false;                                                             \
-        if (!attr_set) {                                                                          \
+        static PerDeviceOnce attr_set;                                                            \
+        if (attr_set.first()) {                                                                   \
             (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<Elem, AT, BT, WM, WN, BK, ASM>,    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);       \
-            attr_set = true;                                                                      \
         }                                                                                         \
         hipLaunchKernelGGL((gemm_glds_kernel<Elem, AT, BT, WM, WN, BK, ASM>), g, b, sm, st, a);        \
     } while (0)
@@ -538,11 +537,10 @@ static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t s
     const size_t sm = GEMM_LDS_BYTES;
 #define LAUNCH(AT, BT)                                                                            \
     do {                                                                                          \
-        static bool attr_set = false;                                                             \
-        if (!attr_set) {                                                                          \
+        static PerDeviceOnce attr_set;                                                            \
+        if (attr_set.first()) {                                                                   \
             (void)hipFuncSetAttribute((const void*)gemm_kernel<Elem, AT, BT>,                           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);             \
-            attr_set = true;                                                                      \
         }                                                                                         \
         hipLaunchKernelGGL((gemm_kernel<Elem, AT, BT>), g, b, sm, st, a);                         \
     } while (0)

@@ -690,11 +690,9 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
         if (nq > 128 && dim % 64 == 0 && dim >= 192 && !(env_pp && env_pp[0] == '0')) {
             const int tiles_q = (nq + 255) / 256;
             const long tiles_c = (rows + 255) / 256;
-            static bool attr_pp = false;
-            if (!attr_pp) {
+            static PerDeviceOnce attr_pp;
+            if (attr_pp.first())
                 (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-                attr_pp = true;
-            }
             hipLaunchKernelGGL(topk_gmax_pp_kernel, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
                                (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
                                (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
@@ -738,11 +736,9 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
     TkEntry* bufs = (TkEntry*)workspace;
     TkEntry* partial = bufs + (long)nqt * nsl * TK_QT * TK_CAP;
     const size_t sm = TkShape::LDS_BYTES + 1024 + 64;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first())
         (void)hipFuncSetAttribute((const void*)topk_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        attr = true;
-    }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(topk_coarse_kernel, dim3(nsl, nqt), dim3(256), sm, st, (const unsigned short*)pool_f16,
                        pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, kc, rps, bufs, partial);

@@ -198,13 +198,16 @@ class MetricLogger(object):
 def load_checkpoint_file(path):
     """torch.load for UniIR checkpoints ({"model", "optimizer", "scheduler", "config", "epoch", "scaler"}).  The published
     files pickle their `config` as an omegaconf DictConfig; torch >= 2.6 refuses such globals by default and omegaconf is
-    not a dependency here (common/config.py replaces it), so: plain tensors-only load first, then a permissive unpickler
-    that turns classes it cannot import into inert placeholders (the weights are what is read; a local, trusted file)."""
+    not a dependency here (common/config.py replaces it), so: plain tensors-only load first; only when that is refused
+    for an unknown global, a second read with an unpickler that resolves torch / numpy / collections globals and turns
+    every other class into an inert placeholder (the weights are what is read).  Other failures propagate."""
     import pickle
+    import warnings
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:      # noqa: BLE001  (pickle.UnpicklingError and friends)
-        pass
+    except pickle.UnpicklingError as e:      # a global the tensors-only loader refuses (the pickled config object)
+        warnings.warn(f"{path}: tensors-only load refused ({str(e).splitlines()[0][:120]}); re-reading with the placeholder "
+                      "unpickler (only torch / numpy / collections globals are resolved)")
 
     class _Placeholder(dict):          # accepts whatever the pickle stream does to the object it stands for
         def __init__(self, *a, **k):
@@ -219,12 +222,20 @@ def load_checkpoint_file(path):
         def extend(self, items):
             self.setdefault("_items", []).extend(items)
 
+    allowed = ("torch", "numpy", "collections", "_codecs", "builtins")
+
     class _Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
-            try:
-                return super().find_class(module, name)
-            except Exception:      # noqa: BLE001
-                return type(name, (_Placeholder,), {"__module__": module})
+            # only what tensors / containers need is resolved; every other global (config classes, and anything a hostile
+            # file might name: os.system, subprocess ...) becomes an inert placeholder instead of being imported
+            root = module.split(".")[0]
+            if root in allowed and not (root == "builtins" and name in ("eval", "exec", "compile", "open", "__import__",
+                                                                         "getattr", "setattr", "delattr", "input")):
+                try:
+                    return super().find_class(module, name)
+                except Exception:      # noqa: BLE001
+                    pass
+            return type(name, (_Placeholder,), {"__module__": module})
 
     class _Module:
         Unpickler = _Unpickler
