@@ -138,7 +138,11 @@ def _attn_ref(qkv, batch, seq, heads, causal):
     return o, lse
 
 
-@pytest.mark.parametrize("batch,seq,heads,causal", [(3, 257, 4, 0), (5, 77, 3, 1), (4, 50, 2, 0), (2, 33, 1, 1), (2, 16, 1, 0)])
+# 257 / 50 / 129 / 273: leftover tiles split over the waves (1 tile 8 ways, 4 tiles 2 ways, 1 tile causal, 2 tiles 4 ways) and
+# a last block of 1 / 18 / 1 / 17 live rows; 197 (BLIP ViT, 13 tiles), 512 (the maximum), 1 and 17 (degenerate)
+@pytest.mark.parametrize("batch,seq,heads,causal", [(3, 257, 4, 0), (5, 77, 3, 1), (4, 50, 2, 0), (2, 33, 1, 1), (2, 16, 1, 0),
+                                                    (2, 197, 3, 0), (2, 129, 2, 1), (2, 273, 2, 0), (1, 512, 2, 0),
+                                                    (3, 1, 1, 0), (2, 17, 2, 1), (2, 145, 1, 0)])
 def test_attention_fwd_bwd(batch, seq, heads, causal):
     ops = _ops()
     torch.manual_seed(5)
@@ -157,6 +161,40 @@ def test_attention_fwd_bwd(batch, seq, heads, causal):
     for i, name in enumerate("qkv"):
         e = rel_err(d[:, i], g[:, i])
         assert e < 1.5e-2, (name, e)
+
+
+@pytest.mark.parametrize("batch,tq,tk,heads,enc", [(3, 100, 197, 12, 1024), (2, 35, 257, 2, 128), (2, 197, 100, 3, 192)])
+def test_cross_attention_with_key_lengths(batch, tq, tk, heads, enc):
+    """BLIP MED cross-attention at its real shapes (med.py:160-232): 100 text queries x 197 image keys, separate Q and
+    [K|V] tensors with their own leading dimensions, per-item key length (the padding mask as exact exclusion); fwd and
+    bwd against fp32 torch"""
+    ops = _ops()
+    torch.manual_seed(21)
+    W = heads * 64
+    q = bf(torch.randn(batch * tq, W, device=DEV))
+    kv = bf(torch.randn(batch * tk, 2 * W, device=DEV))
+    klen = torch.tensor([tk, max(1, tk // 3), 17][:batch], device=DEV, dtype=torch.int32)
+    out, lse = ops.attention_fwd_ex(q, W, kv, kv[:, W:], 2 * W, batch, tq, tk, heads, key_len=klen)
+    qr = q.float().requires_grad_(True)
+    kvr = kv.float().requires_grad_(True)
+    qq = qr.view(batch, tq, heads, 64).transpose(1, 2)
+    kk = kvr[:, :W].reshape(batch, tk, heads, 64).transpose(1, 2)
+    vv = kvr[:, W:].reshape(batch, tk, heads, 64).transpose(1, 2)
+    s = (qq @ kk.transpose(-1, -2)) * 0.125
+    dead = torch.arange(tk, device=DEV)[None, :] >= klen[:, None].long()
+    s = s.masked_fill(dead[:, None, None, :], float("-inf"))
+    oref = (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(batch * tq, W)
+    assert rel_err(out, oref) < 8e-3, rel_err(out, oref)
+    assert (lse - torch.logsumexp(s, -1)).abs().max() < 2e-3
+    do = bf(torch.randn(batch * tq, W, device=DEV))
+    oref.backward(do.float())
+    dq = torch.empty_like(q)
+    dkv = torch.full_like(kv, 7.0)          # rows >= key_len must come back as zeros, not stay untouched
+    ops.attention_bwd_ex(q, W, kv, kv[:, W:], 2 * W, out, do, lse, dq, W, dkv, dkv[:, W:], 2 * W, batch, tq, tk, heads,
+                         key_len=klen)
+    assert rel_err(dq, qr.grad) < 1.5e-2, rel_err(dq, qr.grad)
+    assert rel_err(dkv, kvr.grad) < 1.5e-2, rel_err(dkv, kvr.grad)
+    assert (dkv.float().view(batch, tk, 2 * W)[dead] == 0).all()
 
 
 def test_attention_softmax_spike():

@@ -20,10 +20,34 @@ def timeit(fn, iters=10, warm=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+def attn_only(items):
+    for (T, H, causal, b) in [(257, 16, 0, items), (197, 16, 0, items), (50, 12, 0, items), (77, 12, 1, items)]:
+        qkv = torch.randn(b * T, 3 * H * 64, device=dev).bfloat16()
+        out, lse = ops.attention_fwd(qkv, b, T, H, causal)
+        t = timeit(lambda: ops.attention_fwd(qkv, b, T, H, causal, out=out, lse=lse), iters=20)
+        fl = 4 * b * H * T * T * 64
+        do = torch.randn_like(out)
+        dqkv = torch.empty_like(qkv)
+        t2 = timeit(lambda: ops.attention_bwd(qkv, out, do, lse, b, T, H, causal, dqkv=dqkv), iters=20)
+        print(f"attn T={T} H={H} b={b} causal={causal}: fwd {t*1e3:.3f} ms {fl/t/1e12:.1f} TF/s | bwd {t2*1e3:.3f} ms {2.5*fl/t2/1e12:.1f} TF/s "
+              f"(split={os.environ.get('UNIIR_ATTN_SPLIT', '1')})")
+    # BLIP MED cross-attention: 100 text queries x 197 image keys, 12 heads
+    b, tq, tk, H = items, 100, 197, 12
+    W = H * 64
+    q = torch.randn(b * tq, W, device=dev).bfloat16()
+    kv = torch.randn(b * tk, 2 * W, device=dev).bfloat16()
+    out, lse = ops.attention_fwd_ex(q, W, kv, kv[:, W:], 2 * W, b, tq, tk, H)
+    t = timeit(lambda: ops.attention_fwd_ex(q, W, kv, kv[:, W:], 2 * W, b, tq, tk, H), iters=20)
+    print(f"cross attn 100x197 fwd: {t*1e3:.3f} ms {4*b*H*tq*tk*64/t/1e12:.1f} TF/s")
+
+
 def main():
     items = int(os.environ.get("MB_ITEMS", "256"))
     R = items * 257
     print(f"rows={R}")
+    only = os.environ.get("MB_ONLY", "")
+    if only == "attn":
+        return attn_only(items)
     for (N, K, name) in ([] if os.environ.get("MB_SKIP_GEMM") else [(3072, 1024, "qkv"), (1024, 1024, "out"), (4096, 1024, "fc"), (1024, 4096, "proj")]):
         x = torch.randn(R, K, device=dev).bfloat16()
         w = torch.randn(N, K, device=dev).bfloat16()
