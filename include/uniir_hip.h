@@ -206,6 +206,22 @@ int uniir_sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_
                 float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * [FP32] forward path of the encoders in fp32 ("model.float()" of the reference: clip_sf.py:25-26 keeps fp32 weights,
+ * the embedder only autocasts when use_fp16 is set).  Linear layers = uniir_sgemm (exact fp32 MFMA) followed by
+ * uniir_bias_act_f32: y = (resid ? resid : 0) + act(y + bias) in place (act < 0: none, else UNIIR_ACT_*);
+ * uniir_vit_assemble_f32 = uniir_vit_assemble on an fp32 patch projection; uniir_attention_f32_fwd = softmax(scale q k^T
+ * [causal / key_len masks]) v with separate Q / K / V views like uniir_attention_fwd_ex, fp32 in and out, any seq.
+ * Forward only; 157 TFLOP/s peak -- reference precision, not throughput.
+ * ---------------------------------------------------------------------------------------------- */
+int uniir_bias_act_f32(float* y, const float* bias, const float* resid, int64_t rows, int32_t cols, int32_t act,
+                       void* stream);
+int uniir_vit_assemble_f32(const float* patch_out, const float* class_emb, const float* pos_emb, float* x, int32_t n,
+                           int32_t tokens, int32_t width, void* stream);
+int uniir_attention_f32_fwd(const float* q, int64_t q_ld, const float* k, const float* v, int64_t kv_ld, float* out,
+                            int64_t out_ld, const int32_t* key_len, int32_t batch, int32_t tq, int32_t tk,
+                            int32_t heads, int32_t causal, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * [OPT] fused AdamW over one flat fp32 parameter group (torch.optim.AdamW semantics, no amsgrad):
  *   p *= 1 - lr*wd ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
  *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
@@ -298,9 +314,21 @@ int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_norm, const i
                        int64_t rows, int32_t dim, const void* queries_f16, const float* query_inv_norm,
                        int32_t nq, const int32_t* cand_idx, int32_t ncand, int32_t k, float* exact_ws,
                        float* out_scores, int64_t* out_ids, void* stream);
+/* The whole search of one pool shard in ONE call -- what the reference's FFI for this path would bind
+ * (mbeir_retriever.py:188-232 search_index: faiss.normalize_L2(queries); index.search(queries, k)):
+ * query inverse norms, then per chunk of <= 1024 queries one sweep of the shard (MFMA group-max scan) and one fused
+ * selection + exact re-score + sort launch.  k <= 56.  Same results as coarse + rescore, bit for bit.
+ * workspace: uniir_topk_ip_workspace_bytes(nq, k, rows) bytes, 256-B aligned. */
+int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows);
+int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
+                  int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
+                  int64_t* out_ids, void* workspace, int64_t workspace_bytes, void* stream);
 /* k-way merge of per-shard results (score desc, id asc): in [nshard][nq][k] -> out [nq][k] */
 int uniir_topk_merge(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k,
                      float* out_scores, int64_t* out_ids, void* stream);
+/* the same for lists of k_in entries per shard merged into the k_out best (k_out may exceed k_in) */
+int uniir_topk_merge_ex(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k_in,
+                        int32_t k_out, float* out_scores, int64_t* out_ids, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [IMAGE] device-side image transform (input pipeline).  Replaces, for a decoded RGB uint8

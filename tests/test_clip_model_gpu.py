@@ -57,8 +57,10 @@ def test_forward_backward_matches_oracle(cfgkw):
     model.clip_model.zero_grad()
     emb_d = model.encode_multimodal_input(dbatch["txt_batched"], dbatch["image_batched"], dbatch["txt_mask_batched"],
                                           dbatch["image_mask_batched"])
+    print("OBS tiny emb rel", rel(emb_d, emb_o))
     assert rel(emb_d, emb_o) < 2e-2, rel(emb_d, emb_o)
     out_d = model(dbatch)
+    print("OBS tiny loss diff", abs(out_d["loss"].item() - out_o["loss"].item()))
     assert abs(out_d["loss"].item() - out_o["loss"].item()) < 3e-2 * max(1.0, abs(out_o["loss"].item()))
     out_d["loss"].backward()
     errs = {}
@@ -68,13 +70,14 @@ def test_forward_backward_matches_oracle(cfgkw):
             continue
         errs[n] = rel(p.grad, go)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
-    print("worst grad rel errs:", worst)
+    print("OBS tiny worst grad rel errs:", worst[:3])
     big = {n: e for n, e in errs.items() if e > 8e-2}
     assert not big, big
     # global gradient direction
     gd = torch.cat([p.grad.flatten().cpu() for n, p in model.clip_model.named_parameters() if n in errs])
     go = torch.cat([getattr(oracle, n.replace(".", "__")).grad.flatten() for n, _ in model.clip_model.named_parameters() if n in errs])
     cos = torch.nn.functional.cosine_similarity(gd, go, dim=0).item()
+    print("OBS tiny cos", cos)
     assert cos > 0.999, cos
 
 
@@ -103,12 +106,13 @@ def test_train_steps_track_oracle():
         sched.step()
         lo.append(out["loss"].item())
         ld.append(tr.train_step(dbatch)["loss"].item())
-    print("oracle losses", lo, "device losses", ld)
+    print("OBS traj oracle losses", lo, "device losses", ld)
     for a, b in zip(ld, lo):
         assert abs(a - b) < 5e-2 * max(1.0, abs(b))
     assert ld[-1] < ld[0]
     # weights after 3 steps
     e = rel(model.clip_model.visual.proj, getattr(oracle, "visual__proj"))
+    print("OBS traj weight rel", e)
     assert e < 2e-2, e
 
 
@@ -125,6 +129,7 @@ def test_no_grad_embedding_path():
     emb_o = O.encode_multimodal_input(oracle.sd(), cfg, batch["txt_batched"], batch["image_batched"],
                                       batch["txt_mask_batched"], batch["image_mask_batched"])
     assert ids == dbatch["did_list"]
+    print("OBS nograd emb rel", rel(emb, emb_o))
     assert rel(emb, emb_o) < 2e-2
 
 
@@ -158,4 +163,5 @@ def test_hard_negative_batch_through_the_model():
     assert abs(out_d["loss"].item() - out_o["loss"].item()) < 3e-2 * max(1.0, abs(out_o["loss"].item()))
     g_d = model.clip_model.visual.proj.grad
     g_o = oracle.visual__proj.grad
+    print("OBS hardneg loss diff", abs(out_d["loss"].item() - out_o["loss"].item()), "grad rel", rel(g_d, g_o))
     assert rel(g_d, g_o) < 8e-2, rel(g_d, g_o)

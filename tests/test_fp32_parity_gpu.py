@@ -1,0 +1,178 @@
+"""The north-star parity bar, end to end: "results match the reference PyTorch path on the same inputs (fp32 logits within
+1e-3, identical top-k candidate ids)" (BASELINE.json).  The bf16 MFMA towers cannot meet 1e-3 on logits of magnitude ~14
+(bf16 has 8 mantissa bits), so the bar is demonstrated on the fp32 forward path of the same module surface
+(`clip_model.precision = "fp32"`: exact-fp32 MFMA GEMMs, fp32 attention and LayerNorm, csrc/fp32_path.hip) -- what the
+reference computes after model.float() -- at BASELINE configs[0] AS WRITTEN: CLIP_SF ViT-B/32, batch 32, against the
+oracle (pinned to the reference by goldens G1-G5).  Reference entry point: clip_sf.py:53-63,88-97,134-144."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "uniir_amd", "src"))
+
+
+def test_fp32_kernels_against_torch():
+    from uniir_amd import ops
+    torch.manual_seed(3)
+    # attention: self (causal and not), cross with key lengths, sequence > 256 rows per pass
+    for (b, tq, tk, h, causal, klen) in [(2, 50, 50, 2, 0, None), (2, 77, 77, 3, 1, None), (1, 300, 300, 1, 0, None),
+                                         (3, 20, 45, 2, 0, [45, 7, 1])]:
+        W = h * 64
+        q = torch.randn(b * tq, W, device=DEV)
+        kv = torch.randn(b * tk, 2 * W, device=DEV)
+        out = torch.empty(b * tq, W, device=DEV)
+        kl = None if klen is None else torch.tensor(klen, device=DEV, dtype=torch.int32)
+        ops.call("uniir_attention_f32_fwd", q, W, kv, kv[:, W:], 2 * W, out, W, kl, b, tq, tk, h, causal, 0.125)
+        qq = q.double().view(b, tq, h, 64).transpose(1, 2)
+        kk = kv[:, :W].double().reshape(b, tk, h, 64).transpose(1, 2)
+        vv = kv[:, W:].double().reshape(b, tk, h, 64).transpose(1, 2)
+        s = qq @ kk.transpose(-1, -2) * 0.125
+        if causal:
+            s = s + torch.full((tq, tk), float("-inf"), device=DEV, dtype=torch.float64).triu_(1)
+        if klen is not None:
+            dead = torch.arange(tk, device=DEV)[None, :] >= kl[:, None].long()
+            s = s.masked_fill(dead[:, None, None, :], float("-inf"))
+        ref = (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(b * tq, W)
+        assert (out.double() - ref).abs().max().item() < 2e-6
+    # bias + activation + residual
+    y = torch.randn(37, 96, device=DEV)
+    bias, resid = torch.randn(96, device=DEV), torch.randn(37, 96, device=DEV)
+    for act, fn in ((-1, lambda t: t), (ops.ACT_QUICKGELU, lambda t: t * torch.sigmoid(1.702 * t)),
+                    (ops.ACT_GELU_ERF, torch.nn.functional.gelu), (ops.ACT_RELU, torch.relu)):
+        z = y.clone()
+        ops.call("uniir_bias_act_f32", z, bias, resid, 37, 96, act)
+        assert (z - (resid + fn(y + bias))).abs().max().item() < 2e-6
+    z = y.clone()
+    ops.call("uniir_bias_act_f32", z, None, None, 37, 96, ops.ACT_QUICKGELU)
+    assert (z - y * torch.sigmoid(1.702 * y)).abs().max().item() < 2e-6
+
+
+def _build(name, seed):
+    from oracle import clip_oracle as O
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    cfg = CLIP_CONFIGS[name]
+    sd = O.init_state_dict(cfg, seed=seed)
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=False), data_config=SimpleNamespace(in_batch_neg_num=0))
+    model = CLIPScoreFusion(name, device=DEV, config=config)
+    model.float()
+    model.clip_model.load_state_dict(sd, strict=True)
+    return O, cfg, sd, model
+
+
+def test_config1_as_written_fp32_logits_within_1e_3_and_identical_top10():
+    from oracle import c_oracle
+    from uniir_amd import retrieval
+    from uniir_amd.losses import InBatchNCEFn
+    O, cfg, sd, model = _build("ViT-B/32", seed=1)
+    pairs = 32                                                              # BASELINE configs[0]: batch 32
+    batch = O.synthetic_batch(cfg, pairs, seed=2023)
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    oracle = O.OracleCLIP(cfg, sd)
+    with torch.no_grad():
+        emb_o = O.encode_multimodal_input(oracle.sd(), cfg, batch["txt_batched"], batch["image_batched"],
+                                          batch["txt_mask_batched"], batch["image_mask_batched"])
+        out_o = O.inbatch_contrastive_loss(emb_o, batch["index_mapping"], oracle.logit_scale.exp())
+    model.eval()
+    model.clip_model.precision = "fp32"
+    with torch.no_grad():
+        emb_d = model.encode_multimodal_input(dbatch["txt_batched"], dbatch["image_batched"], dbatch["txt_mask_batched"],
+                                              dbatch["image_mask_batched"])
+        idx_q = torch.arange(0, 2 * pairs, 2, device=DEV, dtype=torch.int32)
+        idx_p = idx_q + 1
+        loss_d, acc_d, score_d = InBatchNCEFn.apply(emb_d, idx_q, idx_p, model.get_logit_scale(), False)
+        out_d = model(dbatch)                                               # the module's own entry point, same numbers
+    scale = float(emb_o.abs().max())
+    emb_err = (emb_d.cpu() - emb_o).abs().max().item()
+    assert emb_err < 2e-5 * max(1.0, scale), (emb_err, scale)
+    logit_err = (score_d.cpu() - out_o["score"]).abs().max().item()
+    assert out_o["score"].abs().max().item() > 1.0                          # logits are O(10): 1e-3 is a real constraint
+    assert logit_err < 1e-3, logit_err                                      # the north-star tolerance
+    assert abs(loss_d.item() - out_o["loss"].item()) < 1e-4 and acc_d.item() == out_o["accuracy"].item()
+    assert abs(out_d["loss"].item() - loss_d.item()) < 1e-6
+    # identical top-10 candidate ids: the 64 item embeddings as the pool (fp16, as the embedder stores them), the 32
+    # queries searched on the device path vs the C oracle on the oracle's embeddings
+    ids = (np.arange(2 * pairs) * 7 + 9_000_001).astype(np.int64)
+    pool_o = emb_o.numpy().astype(np.float16)
+    want_s, want_i = c_oracle.topk(pool_o, ids, pool_o[0::2], 10)
+    pool_d = emb_d.half()
+    got_s, got_i = retrieval.search_shard(retrieval.PoolShard(pool_d, torch.from_numpy(ids)), pool_d[0::2].contiguous(), 10)
+    gaps = np.abs(np.diff(want_s, axis=1)).min()
+    assert gaps > 1e-5                                                      # no near ties in the oracle's own ranking
+    assert np.array_equal(got_i.cpu().numpy(), want_i)
+    assert np.abs(got_s.cpu().numpy() - want_s).max() < 1e-3
+    # the bf16 production towers on the same batch, for the record: same top-10 ids here too, logits within bf16 noise
+    model.clip_model.precision = "bf16"
+    with torch.no_grad():
+        emb_b = model.encode_multimodal_input(dbatch["txt_batched"], dbatch["image_batched"], dbatch["txt_mask_batched"],
+                                              dbatch["image_mask_batched"])
+        _l, _a, score_b = InBatchNCEFn.apply(emb_b, idx_q, idx_p, model.get_logit_scale(), False)
+    assert (score_b.cpu() - out_o["score"]).abs().max().item() < 0.25
+    rel = ((emb_b.cpu() - emb_o).norm() / emb_o.norm()).item()
+    assert rel < 1e-2, rel
+
+
+def test_fp32_precision_refuses_backward():
+    O, cfg, sd, model = _build("ViT-B/32", seed=2)
+    model.clip_model.precision = "fp32"
+    batch = O.synthetic_batch(cfg, 2, seed=5)
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    model.train()
+    with pytest.raises(RuntimeError):
+        model(dbatch)
+
+
+def test_vit_l14_two_pairs_bf16_against_the_oracle():
+    """the headline architecture itself (ViT-L/14: patch K 588 -> 640 padding, 257-token attention inside the tower, 16
+    heads, width-1024 LayerNorm) against the fp32 oracle on 2 pairs: embeddings, loss, accuracy, every parameter
+    gradient, gradient cosine -- gates at ~2x the observed bf16 error"""
+    O, cfg, sd, model = _build("ViT-L/14", seed=3)
+    oracle = O.OracleCLIP(cfg, sd)
+    pairs = 2
+    batch = O.synthetic_batch(cfg, pairs, seed=77)
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    emb_o = O.encode_multimodal_input(oracle.sd(), cfg, batch["txt_batched"], batch["image_batched"],
+                                      batch["txt_mask_batched"], batch["image_mask_batched"])
+    out_o = O.inbatch_contrastive_loss(emb_o, batch["index_mapping"], oracle.logit_scale.exp())
+    out_o["loss"].backward()
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+        return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+    model.train()
+    model.zero_grad()
+    emb_d = model.encode_multimodal_input(dbatch["txt_batched"], dbatch["image_batched"], dbatch["txt_mask_batched"],
+                                          dbatch["image_mask_batched"])
+    assert rel(emb_d, emb_o) < 1e-2, rel(emb_d, emb_o)
+    out_d = model(dbatch)
+    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 1e-2 * max(1.0, abs(out_o["loss"].item()))
+    assert out_d["accuracy"].item() == out_o["accuracy"].item()
+    out_d["loss"].backward()
+    errs, gd, go = {}, [], []
+    for n, p in model.clip_model.named_parameters():
+        g = getattr(oracle, n.replace(".", "__")).grad
+        if g is None or g.abs().max() == 0:
+            continue
+        errs[n] = rel(p.grad, g)
+        gd.append(p.grad.flatten().cpu())
+        go.append(g.flatten())
+    worst = max(errs.values())
+    print(f"ViT-L/14 2 pairs: emb rel {rel(emb_d, emb_o):.2e}, worst grad rel {worst:.2e}")
+    big = {n: e for n, e in errs.items() if e > 4e-2}
+    assert not big, big
+    assert torch.nn.functional.cosine_similarity(torch.cat(gd), torch.cat(go), dim=0).item() > 0.9995
+    # and the fp32 forward of the same architecture: 257-token fp32 attention, K = 588 patch GEMM
+    model.eval()
+    model.clip_model.precision = "fp32"
+    with torch.no_grad():
+        emb_f = model.encode_multimodal_input(dbatch["txt_batched"], dbatch["image_batched"], dbatch["txt_mask_batched"],
+                                              dbatch["image_mask_batched"])
+    assert (emb_f.cpu() - emb_o.detach()).abs().max().item() < 2e-5 * max(1.0, float(emb_o.abs().max()))

@@ -151,8 +151,10 @@ def test_config1_vit_b32_step_against_the_oracle():
         a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
         return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
+    print("OBS b32 emb rel", rel(emb_d, emb_o))
     assert rel(emb_d, emb_o) < 2e-2, rel(emb_d, emb_o)
     out_d = model(dbatch)
+    print("OBS b32 loss diff", abs(out_d["loss"].item() - out_o["loss"].item()))
     assert abs(out_d["loss"].item() - out_o["loss"].item()) < 3e-2 * max(1.0, abs(out_o["loss"].item()))
     assert out_d["accuracy"].item() == out_o["accuracy"].item()
     out_d["loss"].backward()
@@ -164,6 +166,7 @@ def test_config1_vit_b32_step_against_the_oracle():
         errs[n] = rel(p.grad, g)
         gd.append(p.grad.flatten().cpu())
         go.append(g.flatten())
+    print("OBS b32 worst grad", max(errs.values()), "cos", torch.nn.functional.cosine_similarity(torch.cat(gd), torch.cat(go), dim=0).item())
     big = {n: e for n, e in errs.items() if e > 8e-2}
     assert not big, big
     assert torch.nn.functional.cosine_similarity(torch.cat(gd), torch.cat(go), dim=0).item() > 0.999

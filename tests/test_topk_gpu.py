@@ -100,3 +100,68 @@ def test_embed_resident_then_search_without_leaving_hbm():
     s, i = retrieval.search_resident(shard, queries, 10)
     want_s, want_i = c_oracle.topk(emb.cpu().numpy(), ids.cpu().numpy(), queries.cpu().numpy(), 10)
     assert np.array_equal(i.cpu().numpy(), want_i) and np.array_equal(s.cpu().numpy(), want_s)
+
+
+def _two_call_search(shard, queries, k):
+    """the round-1 call sequence (uniir_topk_coarse -> gsel / rescore_coalesced / final_sort kernels) through the C ABI"""
+    from uniir_amd import _lib, ops, retrieval
+    nq, dev = queries.shape[0], queries.device
+    kc = k + retrieval.COARSE_MARGIN
+    ws = torch.empty(_lib.load().uniir_topk_workspace_bytes(nq, kc, shard.n), device=dev, dtype=torch.uint8)
+    ncand = _lib.load().uniir_topk_ncand(nq, kc)
+    cand = torch.empty(nq, ncand, device=dev, dtype=torch.int32)
+    cs = torch.empty(nq, kc, device=dev)
+    ops.call("uniir_topk_coarse", shard.emb, shard.inv_norm, shard.n, shard.dim, queries, nq, kc, cand, cs, ws, ws.numel())
+    exact = torch.empty(nq, ncand, device=dev)
+    out_s, out_i = torch.empty(nq, k, device=dev), torch.empty(nq, k, device=dev, dtype=torch.int64)
+    ops.call("uniir_topk_rescore", shard.emb, shard.inv_norm, shard.ids, shard.n, shard.dim, queries,
+             retrieval.query_inv_norms(queries), nq, cand, ncand, k, exact, out_s, out_i)
+    return out_s, out_i
+
+
+@pytest.mark.parametrize("n,nq,d,k", [(70001, 64, 768, 10), (30000, 7, 512, 50), (9000, 300, 256, 10), (40, 5, 64, 10),
+                                      (70000, 1100, 768, 10)])
+def test_single_call_search_equals_the_three_kernel_tail_bit_for_bit(n, nq, d, k):
+    """uniir_topk_ip (fused select + re-score + sort per query) == coarse + rescore, scores and ids, incl. zero rows,
+    duplicate ties, a ragged last group and -1 padding"""
+    from uniir_amd import retrieval
+    torch.manual_seed(11)
+    pool = torch.randn(n, d, device=DEV).half()
+    pool[3] = 0
+    if n > 200:
+        pool[100:104] = pool[50]
+    queries = torch.randn(nq, d, device=DEV).half()
+    queries[0] = pool[50] if n > 200 else queries[0]
+    queries[1] = 0
+    ids = (torch.randperm(n, device=DEV) * 3 + 17).long()
+    shard = retrieval.PoolShard(pool, ids)
+    s1, i1 = retrieval.search_shard(shard, queries, k)
+    s2, i2 = _two_call_search(shard, queries[:1024].contiguous(), k)
+    assert torch.equal(i1[:1024], i2) and torch.equal(s1[:1024], s2)
+
+
+@pytest.mark.parametrize("k", [57, 100, 200])
+def test_large_k_is_exact_also_when_one_slice_holds_most_of_the_top_k(k):
+    """k > 56 (FAISS accepts up to 2048): assembled from row slices with the hide-check; a planted cluster of 150
+    near-duplicates of query 0 inside one slice forces the refinement loop.  Bit-exact against the C oracle."""
+    from oracle import c_oracle
+    from uniir_amd import retrieval
+    g = np.random.default_rng(3)
+    n, d, nq = 6000, 128, 9
+    pool = g.standard_normal((n, d)).astype(np.float16)
+    queries = g.standard_normal((nq, d)).astype(np.float16)
+    pool[1000:1150] = (queries[0].astype(np.float32) * 1.5 + 0.05 * g.standard_normal((150, d))).astype(np.float16)
+    ids = (g.permutation(n) + 10_000).astype(np.int64)
+    want_s, want_i = c_oracle.topk(pool, ids, queries, k)
+    shard = retrieval.PoolShard(torch.from_numpy(pool).to(DEV), torch.from_numpy(ids))
+    s, i = retrieval.search_shard(shard, torch.from_numpy(queries).to(DEV), k)
+    assert np.array_equal(i.cpu().numpy(), want_i) and np.array_equal(s.cpu().numpy(), want_s)
+
+
+def test_large_k_beyond_the_pool_pads_like_faiss():
+    from uniir_amd import retrieval
+    torch.manual_seed(4)
+    pool = torch.randn(70, 64, device=DEV).half()
+    s, i = retrieval.search_shard(retrieval.PoolShard(pool, torch.arange(70)), torch.randn(3, 64, device=DEV).half(), 90)
+    assert (i[:, :70] >= 0).all() and (i[:, 70:] == -1).all() and torch.isinf(s[:, 70:]).all()
+    assert all(sorted(r.tolist()) == list(range(70)) for r in i[:, :70])

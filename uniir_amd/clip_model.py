@@ -96,6 +96,9 @@ class CLIP(nn.Module):
         # flat storage (built lazily on the device)
         self._flat = None
         self.kpad = (3 * P * P + 63) // 64 * 64
+        # "bf16": MFMA towers, forward + backward (training / fast extraction).  "fp32": the reference's model.float()
+        # forward in exact-fp32 MFMA GEMMs + fp32 attention (csrc/fp32_path.hip): reference-precision embeddings, no backward
+        self.precision = "bf16"
 
     # ---- flat parameter / gradient / bf16-shadow storage -----------------------------------------------------
     def _ensure_flat(self):
@@ -324,6 +327,75 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
     return dx
 
 
+# ------------------------------------------------------------------------------------------------------------
+# fp32 forward (precision = "fp32"): the same block sequence on uniir_sgemm (exact-fp32 MFMA) + uniir_bias_act_f32 +
+# uniir_attention_f32_fwd + the fp32 LayerNorm kernel.  openai/CLIP model.py semantics as restated in SURVEY.md 3.2.
+# ------------------------------------------------------------------------------------------------------------
+def _linear_f32(x, w, bias=None, *, act=-1, resid=None):
+    """y[M,N] = act(x[M,K] @ w[N,K]^T + bias) (+ resid), all fp32"""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    ops.call("uniir_sgemm", x, K, 1, w, 1, K, y, N, M, N, K, 1.0)
+    if bias is not None or resid is not None or act >= 0:
+        ops.call("uniir_bias_act_f32", y, bias, resid, M, N, act)
+    return y
+
+
+def _tower_fwd_f32(model, prefix, layers, x, M, T, W, heads, causal, p32):
+    R = M * T
+    for i in range(layers):
+        p = f"{prefix}.resblocks.{i}"
+        h = torch.empty(R, W, device=x.device, dtype=torch.float32)
+        ops.layernorm_fwd(x, p32(f"{p}.ln_1.weight"), p32(f"{p}.ln_1.bias"), out_f32=h, rows=R, width=W)
+        qkv = _linear_f32(h, p32(f"{p}.attn.in_proj_weight"), p32(f"{p}.attn.in_proj_bias"))
+        ao = torch.empty(R, W, device=x.device, dtype=torch.float32)
+        ops.call("uniir_attention_f32_fwd", qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, ao, W, None, M, T, T, heads,
+                 int(causal), 0.125)
+        x = _linear_f32(ao, p32(f"{p}.attn.out_proj.weight"), p32(f"{p}.attn.out_proj.bias"), resid=x)
+        ops.layernorm_fwd(x, p32(f"{p}.ln_2.weight"), p32(f"{p}.ln_2.bias"), out_f32=h, rows=R, width=W)
+        g = _linear_f32(h, p32(f"{p}.mlp.c_fc.weight"), p32(f"{p}.mlp.c_fc.bias"), act=ops.ACT_QUICKGELU)
+        x = _linear_f32(g, p32(f"{p}.mlp.c_proj.weight"), p32(f"{p}.mlp.c_proj.bias"), resid=x)
+    return x
+
+
+def _encode_fp32(model, which, inp, p32):
+    cfg = model.cfg
+    dev = inp.device
+    E, M = cfg["embed_dim"], inp.shape[0]
+    if which == "image":
+        W, P, L = cfg["vision_width"], cfg["vision_patch_size"], cfg["vision_layers"]
+        res = cfg["image_resolution"]
+        g = res // P
+        T = g * g + 1
+        # im2col is a pure permutation (no arithmetic): [M,3,g,P,g,P] -> [M*g*g, 3*P*P], the order conv1.weight.view(W,-1) has
+        patches = inp.float().view(M, 3, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(M * g * g, 3 * P * P).contiguous()
+        po = _linear_f32(patches, p32("visual.conv1.weight").view(W, 3 * P * P))
+        x0 = torch.empty(M * T, W, device=dev, dtype=torch.float32)
+        ops.call("uniir_vit_assemble_f32", po, p32("visual.class_embedding"), p32("visual.positional_embedding"), x0, M, T, W)
+        x = torch.empty(M * T, W, device=dev, dtype=torch.float32)
+        ops.layernorm_fwd(x0, p32("visual.ln_pre.weight"), p32("visual.ln_pre.bias"), out_f32=x, rows=M * T, width=W)
+        x = _tower_fwd_f32(model, "visual.transformer", L, x, M, T, W, W // 64, False, p32)
+        rows = torch.empty(M, W, device=dev, dtype=torch.float32)
+        ops.call("uniir_gather_rows", x, None, rows, M, T, W)
+        lnw, lnb, proj = "visual.ln_post.weight", "visual.ln_post.bias", "visual.proj"
+    else:
+        W, L, T = cfg["transformer_width"], cfg["transformer_layers"], cfg["context_length"]
+        x = torch.empty(M * T, W, device=dev, dtype=torch.float32)
+        eot = torch.empty(M, device=dev, dtype=torch.int32)
+        ops.call("uniir_text_embed", inp, p32("token_embedding.weight"), p32("positional_embedding"), x, eot, M, T, W,
+                 cfg["vocab_size"])
+        x = _tower_fwd_f32(model, "transformer", L, x, M, T, W, cfg["transformer_heads"], True, p32)
+        rows = torch.empty(M, W, device=dev, dtype=torch.float32)
+        ops.call("uniir_gather_rows", x, eot, rows, M, T, W)
+        lnw, lnb, proj = "ln_final.weight", "ln_final.bias", "text_projection"
+    pooled = torch.empty(M, W, device=dev, dtype=torch.float32)
+    ops.layernorm_fwd(rows, p32(lnw), p32(lnb), out_f32=pooled, rows=M, width=W)
+    emb = torch.empty(M, E, device=dev, dtype=torch.float32)
+    ops.call("uniir_sgemm", pooled, W, 1, p32(proj), E, 1, emb, E, M, E, W, 1.0)      # pooled @ proj, proj [W, E]
+    return emb
+
+
 class _TowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, which, inp, anchor):
@@ -341,6 +413,13 @@ class _TowerFn(torch.autograd.Function):
             o = fl["off"][name]
             return fl["p32"][o:o + math.prod(fl["shapes"][name])].view(fl["shapes"][name])
 
+        if model.precision == "fp32":
+            if need_grad:
+                raise RuntimeError("precision='fp32' is a forward-only path (embedding extraction / parity); run it under "
+                                   "torch.no_grad() or switch back to precision='bf16' for training")
+            return _encode_fp32(model, which, inp, p32)
+        if model.precision != "bf16":
+            raise RuntimeError(f"unknown precision {model.precision!r}")
         if which == "image":
             W, P, L = cfg["vision_width"], cfg["vision_patch_size"], cfg["vision_layers"]
             res = cfg["image_resolution"]

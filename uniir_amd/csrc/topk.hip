@@ -311,9 +311,10 @@ __global__ __launch_bounds__(128 * WM, 2) void topk_gmax_kernel(const unsigned s
 // REG (the interactive <= 64-query path, one 1024-thread block per query): the query's group maxima are read ONCE, as
 // back-to-back 8-byte loads that all stay in flight, and both passes (thread maxima, collection above the threshold) run
 // on registers -- the two dependent strided passes over global memory were 40 of the kernel's 62 us at 700 k rows.
-template <int BS, bool REG = false>   // threads per query (256: many queries; 1024: <= 64 queries)
-__global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__ gmax, long ngroups, long rows, int nq,
-                                                        int kc, int gcap, int* __restrict__ cand_idx) {
+// `out` (gcap * TK_G row indices, -1 = empty) may be global memory (topk_gsel_kernel) or LDS (the fused tail kernel); every
+// thread of the block returns from this function (no early exit: the fused kernel goes on to the re-score).
+template <int BS, bool REG>
+DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int kc, int gcap, int* out) {
     __shared__ float tmax[BS];
     __shared__ float bval[TK_SELCAP];
     __shared__ int bgrp[TK_SELCAP];
@@ -323,9 +324,7 @@ __global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__
     __shared__ long long si[BS / 64];
     __shared__ float wsel;
     __shared__ long long isel;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const float* g = gmax + (long)q * ngroups;
-    int* out = cand_idx + (long)q * gcap * TK_G;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
     float mx = -INFINITY;
     f32x2_t rv[REG ? TK_SELREG : 1];
@@ -422,8 +421,7 @@ __global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__
                 }
             }
         }
-        return;
-    }
+    } else {
     // fallback: one extraction per round (value desc, group asc), stop after the kc-th value's ties or gcap groups
     float last_s = INFINITY, tk = -INFINITY;
     long long last_g = -1;
@@ -459,6 +457,15 @@ __global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__
             out[j * TK_G + tid] = row < rows ? (int)row : -1;
         }
     }
+    }
+    __syncthreads();
+}
+
+template <int BS, bool REG = false>   // threads per query (256: many queries; 1024: <= 64 queries)
+__global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__ gmax, long ngroups, long rows, int nq,
+                                                        int kc, int gcap, int* __restrict__ cand_idx) {
+    const int q = blockIdx.x;
+    gsel_body<BS, REG>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, cand_idx + (long)q * gcap * TK_G);
 }
 
 static void coarse_plan(int nq, long rows, int* nqt, int* nslices, long* rows_per_slice) {
@@ -638,6 +645,72 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
     }
 }
 
+// The group-max scan of <= 1024 queries over the shard: gmax[q][group] = best approximate score of the 16 rows of the group.
+// Returns 1 when a 1024-thread selection is the matching follow-up (streaming / ping-pong scans), 0 for the 256-thread one,
+// negative on error.
+static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, int64_t rows, int32_t dim,
+                            const void* queries_f16, int32_t nq, float* gmax, hipStream_t st0) {
+    const long ngroups = (rows + TK_G - 1) / TK_G;
+    int nqt, nsl; long rps;
+    coarse_plan(nq, rows, &nqt, &nsl, &rps);
+    static const char* env_st = getenv("UNIIR_TOPK_STREAM");     // "0" disables the streaming scan (experiments)
+    if (nq <= 64 && (dim == 768 || dim == 512) && !(env_st && env_st[0] == '0')) {
+        const long nchunks = (ngroups + TKS_CH - 1) / TKS_CH;
+        const size_t sms = 64 * (dim * 2 + 16) + 8 * 64 * TKS_CH * 4;
+        int grid = 256;
+        if (nchunks < (long)grid * 8) grid = (int)((nchunks + 7) / 8);
+        if (dim == 768) {
+            (void)hipFuncSetAttribute((const void*)topk_stream_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sms);
+            hipLaunchKernelGGL(topk_stream_kernel<24>, dim3(grid), dim3(512), sms, st0, (const unsigned short*)pool_f16,
+                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, nchunks);
+        } else {
+            (void)hipFuncSetAttribute((const void*)topk_stream_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sms);
+            hipLaunchKernelGGL(topk_stream_kernel<16>, dim3(grid), dim3(512), sms, st0, (const unsigned short*)pool_f16,
+                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, nchunks);
+        }
+        HIP_LAUNCH_CHECK();
+        return 1;
+    }
+    static const char* env_pp = getenv("UNIIR_TOPK_PP");         // "0" disables the ping-pong scan (experiments)
+    if (nq > 128 && dim % 64 == 0 && dim >= 192 && !(env_pp && env_pp[0] == '0')) {
+        const int tiles_q = (nq + 255) / 256;
+        const long tiles_c = (rows + 255) / 256;
+        static PerDeviceOnce attr_pp;
+        if (attr_pp.first())
+            (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipLaunchKernelGGL(topk_gmax_pp_kernel, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
+                           (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
+                           (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
+        HIP_LAUNCH_CHECK();
+        return 1;
+    }
+    static const char* env_wm = getenv("UNIIR_TOPK_WM");
+    static const char* env_bl = getenv("UNIIR_TOPK_BLOCKS");
+    const int wmsel = (env_wm && env_wm[0] == '1') ? 1 : 2;
+    const long ct = 128 * wmsel;
+    const long want_blocks = env_bl ? atol(env_bl) : 768;
+    long tiles = (rows + ct - 1) / ct;
+    long want = (want_blocks + nqt - 1) / nqt;
+    if (want > tiles) want = tiles;
+    if (want < 1) want = 1;
+    const long tps = (tiles + want - 1) / want;
+    rps = tps * ct;
+    nsl = (int)((rows + rps - 1) / rps);
+    if (wmsel == 2) {
+        const size_t smg = GldsShape<2, 2, 32>::LDS_BYTES;
+        (void)hipFuncSetAttribute((const void*)topk_gmax_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg);
+        hipLaunchKernelGGL(topk_gmax_kernel<2>, dim3(nsl, nqt), dim3(256), smg, st0, (const unsigned short*)pool_f16,
+                           pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
+    } else {
+        const size_t smg = GldsShape<1, 2, 32>::LDS_BYTES;
+        (void)hipFuncSetAttribute((const void*)topk_gmax_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg);
+        hipLaunchKernelGGL(topk_gmax_kernel<1>, dim3(nsl, nqt), dim3(128), smg, st0, (const unsigned short*)pool_f16,
+                           pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
+    }
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t rows) {
     if (nq <= 0 || kc <= 0 || rows <= 0) return 0;
     if (nq <= TK_GPATH_MAXQ) return (int64_t)nq * ((rows + TK_G - 1) / TK_G) * 4 + 256;
@@ -662,74 +735,17 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
     if (nq <= TK_GPATH_MAXQ) {
         const long ngroups = (rows + TK_G - 1) / TK_G;
         float* gmax = (float*)workspace;
-        static const char* env_st = getenv("UNIIR_TOPK_STREAM");     // "0" disables the streaming scan (experiments)
-        if (nq <= 64 && (dim == 768 || dim == 512) && !(env_st && env_st[0] == '0')) {
-            const long nchunks = (ngroups + TKS_CH - 1) / TKS_CH;
-            const size_t sms = 64 * (dim * 2 + 16) + 8 * 64 * TKS_CH * 4;
-            int grid = 256;
-            if (nchunks < (long)grid * 8) grid = (int)((nchunks + 7) / 8);
-            if (dim == 768) {
-                (void)hipFuncSetAttribute((const void*)topk_stream_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sms);
-                hipLaunchKernelGGL(topk_stream_kernel<24>, dim3(grid), dim3(512), sms, st0, (const unsigned short*)pool_f16,
-                                   pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, nchunks);
-            } else {
-                (void)hipFuncSetAttribute((const void*)topk_stream_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sms);
-                hipLaunchKernelGGL(topk_stream_kernel<16>, dim3(grid), dim3(512), sms, st0, (const unsigned short*)pool_f16,
-                                   pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, nchunks);
-            }
-            if (ngroups % 2 == 0 && ngroups <= 1024L * 2 * TK_SELREG)
-                hipLaunchKernelGGL((topk_gsel_kernel<1024, true>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
-                                   kc, TK_GMULT * kc, cand_idx);
-            else
-                hipLaunchKernelGGL((topk_gsel_kernel<1024, false>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
-                                   kc, TK_GMULT * kc, cand_idx);
-            HIP_LAUNCH_CHECK();
-            return UNIIR_OK;
-        }
-        static const char* env_pp = getenv("UNIIR_TOPK_PP");         // "0" disables the ping-pong scan (experiments)
-        if (nq > 128 && dim % 64 == 0 && dim >= 192 && !(env_pp && env_pp[0] == '0')) {
-            const int tiles_q = (nq + 255) / 256;
-            const long tiles_c = (rows + 255) / 256;
-            static PerDeviceOnce attr_pp;
-            if (attr_pp.first())
-                (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            hipLaunchKernelGGL(topk_gmax_pp_kernel, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
-                               (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
-                               (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
-            if (ngroups % 2 == 0 && ngroups <= 1024L * 2 * TK_SELREG)      // register-resident selection (see above)
-                hipLaunchKernelGGL((topk_gsel_kernel<1024, true>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
-                                   kc, TK_GMULT * kc, cand_idx);
-            else
-                hipLaunchKernelGGL(topk_gsel_kernel<256>, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
-                                   TK_GMULT * kc, cand_idx);
-            HIP_LAUNCH_CHECK();
-            return UNIIR_OK;
-        }
-        static const char* env_wm = getenv("UNIIR_TOPK_WM");
-        static const char* env_bl = getenv("UNIIR_TOPK_BLOCKS");
-        const int wmsel = (env_wm && env_wm[0] == '1') ? 1 : 2;
-        const long ct = 128 * wmsel;
-        const long want_blocks = env_bl ? atol(env_bl) : 768;
-        long tiles = (rows + ct - 1) / ct;
-        long want = (want_blocks + nqt - 1) / nqt;
-        if (want > tiles) want = tiles;
-        if (want < 1) want = 1;
-        const long tps = (tiles + want - 1) / want;
-        rps = tps * ct;
-        nsl = (int)((rows + rps - 1) / rps);
-        if (wmsel == 2) {
-            const size_t smg = GldsShape<2, 2, 32>::LDS_BYTES;
-            (void)hipFuncSetAttribute((const void*)topk_gmax_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg);
-            hipLaunchKernelGGL(topk_gmax_kernel<2>, dim3(nsl, nqt), dim3(256), smg, st0, (const unsigned short*)pool_f16,
-                               pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
-        } else {
-            const size_t smg = GldsShape<1, 2, 32>::LDS_BYTES;
-            (void)hipFuncSetAttribute((const void*)topk_gmax_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg);
-            hipLaunchKernelGGL(topk_gmax_kernel<1>, dim3(nsl, nqt), dim3(128), smg, st0, (const unsigned short*)pool_f16,
-                               pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
-        }
-        hipLaunchKernelGGL(topk_gsel_kernel<256>, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
-                           TK_GMULT * kc, cand_idx);
+        const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, queries_f16, nq, gmax, st0);
+        if (sel < 0) return sel;
+        if (sel == 1 && ngroups % 2 == 0 && ngroups <= 1024L * 2 * TK_SELREG)       // register-resident selection
+            hipLaunchKernelGGL((topk_gsel_kernel<1024, true>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
+                               kc, TK_GMULT * kc, cand_idx);
+        else if (sel == 1 && nq <= 64)
+            hipLaunchKernelGGL((topk_gsel_kernel<1024, false>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
+                               kc, TK_GMULT * kc, cand_idx);
+        else
+            hipLaunchKernelGGL(topk_gsel_kernel<256>, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
+                               TK_GMULT * kc, cand_idx);
         HIP_LAUNCH_CHECK();
         return UNIIR_OK;
     }
@@ -906,6 +922,114 @@ __global__ __launch_bounds__(256) void final_sort_kernel(const float* __restrict
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Fused tail of the group-max path: selection + exact re-score + final sort of ONE query per 1024-thread workgroup, one
+// launch instead of three (topk_gsel / rescore_coalesced / final_sort) and no cand_idx / exact round trips through HBM.
+//   A  gsel_body: the kc best groups (+ ties) -> their member rows in LDS, ranked group-major, live rows first
+//   B  waves 0..7: exact fp32 score of 64 rows each, in the oracle's summation order (one sequential chain per row, the
+//      query pre-multiplied by its inverse norm exactly like FAISS renorm does, candidate rows gathered 128 B at a time
+//      through wave-private LDS staging -- same arithmetic as rescore_coalesced_kernel)
+//   C  rank by counting over the live list in LDS ((score desc, id asc) is a strict total order), ranks < k are written
+#define TKT_WAVES 8
+#define TKT_MAXC 2048          // gcap * TK_G <= 2 * TK_MAXKC * 16
+#define TKT_MAXDIM 1024
+template <bool REG>
+__global__ __launch_bounds__(1024) void topk_tail_kernel(const float* __restrict__ gmax, long ngroups, long rows, int kc,
+                                                         int gcap, const unsigned short* __restrict__ pool,
+                                                         const float* __restrict__ pinv, const long long* __restrict__ ids,
+                                                         const unsigned short* __restrict__ queries,
+                                                         const float* __restrict__ qinv, int dim, int k,
+                                                         float* __restrict__ out_s, long long* __restrict__ out_i) {
+    __shared__ int cand[TKT_MAXC];
+    __shared__ float ex[TKT_MAXC];
+    __shared__ long long exid[TKT_MAXC];
+    __shared__ float qn[TKT_MAXDIM];
+    __shared__ __attribute__((aligned(16))) char stage[TKT_WAVES][64 * RSC_PITCH];
+    __shared__ int nsel16, nvalid;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned short* qr = queries + (long)q * dim;
+    const float iq = qinv[q];
+    for (int c = tid; c < dim; c += 1024) {           // FAISS renorm of the query: x[i] *= inv_nr (untouched when all-zero)
+        const float v = f16_to_f32(qr[c]);
+        qn[c] = iq != 0.f ? __fmul_rn(v, iq) : v;
+    }
+    if (tid == 0) { nsel16 = 0; nvalid = 0; }
+    gsel_body<1024, REG>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, cand);     // ends with a barrier
+    // live entries form a prefix of the ranked list (ranks are exact); its length = last non-empty slot + 1
+    for (int e = tid; e < gcap * TK_G; e += 1024)
+        if (cand[e] >= 0) atomicMax(&nsel16, e + 1);
+    __syncthreads();
+    const int ncl = nsel16;
+    // ---- B: exact scores ----
+    if (w < TKT_WAVES) {
+        char* mine = &stage[w][0];
+        const int piece = lane & 7;
+        for (int base = w * 64; base < ncl; base += TKT_WAVES * 64) {
+            const int slot = base + lane;
+            const int ci = slot < ncl ? cand[slot] : -1;
+            const float ic = ci >= 0 ? pinv[ci] : 0.f;
+            int rows8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rows8[i] = __shfl(ci, 8 * i + (lane >> 3), 64);
+            u32x4_t pre[8];
+            auto fetch = [&](int c0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32x4_t z = {0u, 0u, 0u, 0u};
+                    pre[i] = rows8[i] >= 0 ? *reinterpret_cast<const u32x4_t*>(pool + (long)rows8[i] * dim + c0 + piece * 8) : z;
+                }
+            };
+            float s = 0.f;
+            fetch(0);
+            for (int c0 = 0; c0 < dim; c0 += 64) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<u32x4_t*>(mine + (8 * i + (lane >> 3)) * RSC_PITCH + piece * 16) = pre[i];
+                __builtin_amdgcn_wave_barrier();       // staging is wave-private: the wave's own LDS operations stay in order
+                if (c0 + 64 < dim) fetch(c0 + 64);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(mine + lane * RSC_PITCH + u * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float ca = f16_to_f32((unsigned short)(b[e] & 0xffffu)), cb = f16_to_f32((unsigned short)(b[e] >> 16));
+                        if (ic != 0.f) { ca = __fmul_rn(ca, ic); cb = __fmul_rn(cb, ic); }
+                        s = __fadd_rn(s, __fmul_rn(qn[c0 + 8 * u + 2 * e], ca));
+                        s = __fadd_rn(s, __fmul_rn(qn[c0 + 8 * u + 2 * e + 1], cb));
+                    }
+                }
+            }
+            if (slot < ncl) {
+                ex[slot] = ci >= 0 ? s : -INFINITY;
+                exid[slot] = ci >= 0 ? (ids ? ids[ci] : (long long)ci) : 0x7fffffffffffffffLL;
+                if (ci >= 0) atomicAdd(&nvalid, 1);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- C: rank by counting ----
+    for (int t = tid; t < ncl; t += 1024) {
+        const long long id = exid[t];
+        if (id == 0x7fffffffffffffffLL) continue;
+        const float sc = ex[t];
+        int rank = 0;
+        for (int u = 0; u < ncl; ++u) {
+            const float os = ex[u];
+            const long long oi = exid[u];
+            rank += (oi != 0x7fffffffffffffffLL && (os > sc || (os == sc && oi < id))) ? 1 : 0;
+        }
+        if (rank < k) {
+            out_s[(long)q * k + rank] = sc;
+            out_i[(long)q * k + rank] = id;
+        }
+    }
+    for (int t = nvalid + tid; t < k; t += 1024) {     // FAISS pads missing results with -inf distance / id -1
+        out_s[(long)q * k + t] = -INFINITY;
+        out_i[(long)q * k + t] = -1;
+    }
+}
+
 extern "C" int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids,
                                   int64_t rows, int32_t dim, const void* queries_f16, const float* query_inv_norm,
                                   int32_t nq, const int32_t* cand_idx, int32_t ncand, int32_t k, float* exact_ws,
@@ -933,7 +1057,7 @@ extern "C" int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_no
 
 // k-way merge of per-shard final results (score desc, id asc); ids are unique across shards.
 __global__ __launch_bounds__(256) void merge_shards_kernel(const float* __restrict__ s, const long long* __restrict__ ids,
-                                                           int nshard, int nq, int k, float* __restrict__ os,
+                                                           int nshard, int nq, int kin, int k, float* __restrict__ os,
                                                            long long* __restrict__ oi) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
@@ -941,8 +1065,8 @@ __global__ __launch_bounds__(256) void merge_shards_kernel(const float* __restri
     for (int j = 0; j < k; ++j) {
         float bs = -INFINITY; long long bid = 0x7fffffffffffffffLL; bool found = false;
         for (int sh = 0; sh < nshard; ++sh)
-            for (int c = 0; c < k; ++c) {
-                const long o = ((long)sh * nq + q) * k + c;
+            for (int c = 0; c < kin; ++c) {
+                const long o = ((long)sh * nq + q) * kin + c;
                 const long long id = ids[o];
                 if (id < 0) continue;
                 const float v = s[o];
@@ -958,7 +1082,84 @@ extern "C" int uniir_topk_merge(const float* scores, const int64_t* ids, int32_t
                                 float* out_scores, int64_t* out_ids, void* stream) {
     if (!scores || !ids || !out_scores || !out_ids || nshard <= 0 || nq <= 0 || k <= 0) return UNIIR_EINVAL;
     hipLaunchKernelGGL(merge_shards_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores,
-                       (const long long*)ids, nshard, nq, k, out_scores, (long long*)out_ids);
+                       (const long long*)ids, nshard, nq, k, k, out_scores, (long long*)out_ids);
     HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+// the same with lists of k_in entries per shard merged into the k_out best (k_out may exceed k_in: a large-k search
+// assembled from slices of the pool, uniir_amd/retrieval.py)
+extern "C" int uniir_topk_merge_ex(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k_in,
+                                   int32_t k_out, float* out_scores, int64_t* out_ids, void* stream) {
+    if (!scores || !ids || !out_scores || !out_ids || nshard <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0) return UNIIR_EINVAL;
+    hipLaunchKernelGGL(merge_shards_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores,
+                       (const long long*)ids, nshard, nq, k_in, k_out, out_scores, (long long*)out_ids);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// uniir_topk_ip: the whole search_index of one pool shard in one call (mbeir_retriever.py:188-232 = normalise the queries,
+// exact inner-product top-k): query inverse norms, then per chunk of <= 1024 queries one sweep of the shard (group-max
+// scan) and the fused tail.  k <= 56 (k + 8 <= TK_MAXKC groups per query); larger k is assembled from slices by the caller.
+#define TKI_CHUNK 1024
+static int tki_fused_ok(int32_t dim, int32_t kc, int64_t rows) {
+    static const char* e = getenv("UNIIR_TOPK_FUSED_TAIL");      // "0": the three-kernel tail (A/B experiments)
+    const long ngroups = (rows + TK_G - 1) / TK_G;
+    return !(e && e[0] == '0') && dim % 64 == 0 && dim <= TKT_MAXDIM && TK_GMULT * kc * TK_G <= TKT_MAXC && ngroups >= 1;
+}
+extern "C" int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows) {
+    if (nq <= 0 || k <= 0 || rows <= 0) return 0;
+    const int chunk = nq < TKI_CHUNK ? nq : TKI_CHUNK;
+    const int kc = k + 8 < TK_MAXKC ? k + 8 : TK_MAXKC;
+    const int64_t ncand = uniir_topk_ncand(chunk, kc);
+    return uniir_topk_workspace_bytes(chunk, kc, rows) + (int64_t)nq * 4 + 256 + 2 * ((int64_t)chunk * ncand * 4 + 256);
+}
+extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
+                             int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
+                             int64_t* out_ids, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!pool_f16 || !pool_inv_norm || !queries_f16 || !out_scores || !out_ids || !workspace) return UNIIR_EINVAL;
+    if (rows <= 0 || nq <= 0 || k <= 0) return UNIIR_EINVAL;
+    if (k + 8 > TK_MAXKC || dim % 64 || dim <= 0 || rows > 0x7fffffffL) return UNIIR_ESHAPE;
+    if (((uintptr_t)pool_f16 & 15) || ((uintptr_t)queries_f16 & 15) || ((uintptr_t)pool_inv_norm & 15) ||
+        ((uintptr_t)workspace & 255))
+        return UNIIR_EALIGN;
+    if (workspace_bytes < uniir_topk_ip_workspace_bytes(nq, k, rows)) return UNIIR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int chunk = nq < TKI_CHUNK ? nq : TKI_CHUNK;
+    const int kc = k + 8;
+    const long ngroups = (rows + TK_G - 1) / TK_G;
+    const int ncand = uniir_topk_ncand(chunk, kc);
+    char* ws = (char*)workspace;
+    float* gmax = (float*)ws;
+    const int64_t gbytes = (uniir_topk_workspace_bytes(chunk, kc, rows) + 255) & ~(int64_t)255;
+    float* qinv = (float*)(ws + gbytes);
+    int32_t* cand = (int32_t*)(ws + gbytes + (((int64_t)nq * 4 + 255) & ~(int64_t)255));
+    float* exact = (float*)((char*)cand + (((int64_t)chunk * ncand * 4 + 255) & ~(int64_t)255));
+    int rc = uniir_pool_inv_norms(queries_f16, nq, dim, qinv, stream);
+    if (rc) return rc;
+    const bool fused = tki_fused_ok(dim, kc, rows);
+    for (int lo = 0; lo < nq; lo += chunk) {
+        const int n = nq - lo < chunk ? nq - lo : chunk;
+        const unsigned short* qp = (const unsigned short*)queries_f16 + (long)lo * dim;
+        if (!fused) {
+            rc = uniir_topk_coarse(pool_f16, pool_inv_norm, rows, dim, qp, n, kc, cand, nullptr, gmax, gbytes, stream);
+            if (rc) return rc;
+            rc = uniir_topk_rescore(pool_f16, pool_inv_norm, pool_ids, rows, dim, qp, qinv + lo, n, cand, ncand, k, exact,
+                                    out_scores + (long)lo * k, out_ids + (long)lo * k, stream);
+            if (rc) return rc;
+            continue;
+        }
+        const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, qp, n, gmax, st);
+        if (sel < 0) return sel;
+        if (ngroups % 2 == 0 && ngroups <= 1024L * 2 * TK_SELREG)
+            hipLaunchKernelGGL(topk_tail_kernel<true>, dim3(n), dim3(1024), 0, st, gmax, ngroups, (long)rows, kc, TK_GMULT * kc,
+                               (const unsigned short*)pool_f16, pool_inv_norm, (const long long*)pool_ids, qp, qinv + lo, dim,
+                               k, out_scores + (long)lo * k, (long long*)(out_ids + (long)lo * k));
+        else
+            hipLaunchKernelGGL(topk_tail_kernel<false>, dim3(n), dim3(1024), 0, st, gmax, ngroups, (long)rows, kc, TK_GMULT * kc,
+                               (const unsigned short*)pool_f16, pool_inv_norm, (const long long*)pool_ids, qp, qinv + lo, dim,
+                               k, out_scores + (long)lo * k, (long long*)(out_ids + (long)lo * k));
+        HIP_LAUNCH_CHECK();
+    }
     return UNIIR_OK;
 }

@@ -33,11 +33,23 @@ def query_inv_norms(queries_f16: torch.Tensor) -> torch.Tensor:
     return inv
 
 
-QUERY_CHUNK = 1024   # queries per sweep of the shard (uniir_topk_coarse's group-max path takes <= 1024)
+QUERY_CHUNK = 1024   # queries per sweep of the shard inside uniir_topk_ip (its group-max scan takes <= 1024)
+MAX_K_DIRECT = 64 - COARSE_MARGIN     # 56: the scan keeps k + 8 <= 64 groups per query
+
+
+def _shard_view(shard, lo, hi):
+    """rows [lo, hi) of a resident shard as a shard of its own (views, nothing is copied or recomputed)"""
+    v = object.__new__(PoolShard)
+    v.emb, v.ids, v.inv_norm = shard.emb[lo:hi], shard.ids[lo:hi], shard.inv_norm[lo:hi]
+    v.n, v.dim = hi - lo, shard.dim
+    return v
 
 
 def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None, workspace=None):
-    """Exact top-k of `queries` against one shard -> (scores f32 [q,k] desc, ids int64 [q,k], -1 padded)."""
+    """Exact top-k of `queries` against one shard -> (scores f32 [q,k] desc, ids int64 [q,k], -1 padded).
+    One C call (uniir_topk_ip: query norms, one sweep of the shard per 1024 queries, fused select + exact re-score + sort).
+    k > 56 (FAISS Flat accepts up to 2048; Recall@100, larger hard-negative mining depths): assembled from row slices of the
+    shard, see _search_large_k."""
     from . import _lib
     queries_f16 = queries_f16.contiguous()
     nq = queries_f16.shape[0]
@@ -45,35 +57,49 @@ def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None
     if nq == 0 or shard.n == 0:          # FAISS pads missing results with -inf / -1
         return (torch.full((nq, k), float("-inf"), device=dev, dtype=torch.float32),
                 torch.full((nq, k), -1, device=dev, dtype=torch.int64))
+    if k > MAX_K_DIRECT:
+        return _search_large_k(shard, queries_f16, k)
     out_s = torch.empty(nq, k, device=dev, dtype=torch.float32)       # every slot is written by the final sort (padding included)
     out_i = torch.empty(nq, k, device=dev, dtype=torch.int64)
-    if nq > QUERY_CHUNK:      # many queries (the reference hands over all of them at once): sweep the shard per 1024-query
-        ws = workspace        # chunk on the MFMA group-max path, reusing one workspace
-        for lo in range(0, nq, QUERY_CHUNK):
-            hi = min(nq, lo + QUERY_CHUNK)
-            if ws is None:
-                need = _lib.load().uniir_topk_workspace_bytes(QUERY_CHUNK, min(64, k + COARSE_MARGIN), shard.n)
-                ws = torch.empty(need, device=dev, dtype=torch.uint8)
-            s_, i_ = search_shard(shard, queries_f16[lo:hi], k, None if q_inv is None else q_inv[lo:hi], ws)
-            out_s[lo:hi], out_i[lo:hi] = s_, i_
-        return out_s, out_i
-    if q_inv is None:
-        q_inv = query_inv_norms(queries_f16)
-    kc = min(64, k + COARSE_MARGIN)
-    if k > 64 - COARSE_MARGIN:
-        raise RuntimeError("k too large for the coarse stage (max 56)")
-    need = _lib.load().uniir_topk_workspace_bytes(nq, kc, shard.n)
-    if workspace is None or workspace.numel() < need:
+    need = _lib.load().uniir_topk_ip_workspace_bytes(nq, k, shard.n)
+    if workspace is None or workspace.numel() < need or workspace.data_ptr() % 256:
         workspace = torch.empty(need, device=dev, dtype=torch.uint8)
-    ncand = _lib.load().uniir_topk_ncand(nq, kc)
-    cand = torch.empty(nq, ncand, device=dev, dtype=torch.int32)
-    cand_s = torch.empty(nq, kc, device=dev, dtype=torch.float32)
-    ops.call("uniir_topk_coarse", shard.emb, shard.inv_norm, shard.n, shard.dim, queries_f16, nq, kc, cand, cand_s,
+    ops.call("uniir_topk_ip", shard.emb, shard.inv_norm, shard.ids, shard.n, shard.dim, queries_f16, nq, k, out_s, out_i,
              workspace, workspace.numel())
-    exact = torch.empty(nq, ncand, device=dev, dtype=torch.float32)
-    ops.call("uniir_topk_rescore", shard.emb, shard.inv_norm, shard.ids, shard.n, shard.dim, queries_f16, q_inv, nq,
-             cand, ncand, k, exact, out_s, out_i)
     return out_s, out_i
+
+
+def _search_large_k(shard, queries_f16, k):
+    """top-k for k > 56: the shard is cut into P row slices, each searched for its own top-56 (exact), and the lists are
+    merged.  The merge is the exact global top-k iff no slice can hide a better row, i.e. iff every slice's WORST returned
+    entry ranks after the merged k-th entry (then everything the slice did not return ranks later still).  That is checked
+    on the device; when it fails (more than 56 of the top-k in one slice) P doubles.  Slices of <= 56 rows return all their
+    rows, so the loop ends at the latest when every slice is that small."""
+    nq, dev = queries_f16.shape[0], queries_f16.device
+    kin = MAX_K_DIRECT
+    parts = max(2, -(-2 * k // kin))
+    while True:
+        parts = min(parts, shard.n)
+        per = -(-(-(-shard.n // parts)) // 16) * 16          # slices start on 16-row boundaries (aligned inverse norms)
+        bounds = [(lo, min(lo + per, shard.n)) for lo in range(0, shard.n, per)]
+        res = [search_shard(_shard_view(shard, lo, hi), queries_f16, kin) for lo, hi in bounds]
+        scores = torch.stack([r[0] for r in res]).contiguous()          # [P, nq, kin]
+        ids = torch.stack([r[1] for r in res]).contiguous()
+        out_s = torch.empty(nq, k, device=dev, dtype=torch.float32)
+        out_i = torch.empty(nq, k, device=dev, dtype=torch.int64)
+        ops.call("uniir_topk_merge_ex", scores, ids, len(bounds), nq, kin, k, out_s, out_i)
+        big = torch.tensor([hi - lo > kin for lo, hi in bounds], device=dev)
+        if not bool(big.any()):
+            return out_s, out_i
+        worst_s, worst_i = scores[:, :, kin - 1], ids[:, :, kin - 1]                      # [P, nq]
+        kth_s, kth_i = out_s[:, k - 1].unsqueeze(0), out_i[:, k - 1].unsqueeze(0)
+        # a slice is safe for a query when its worst entry is strictly worse than the merged k-th (score desc, id asc), or the
+        # merged list is not even full (kth id -1: every returned entry of every slice is already in it)
+        after = (worst_s < kth_s) | ((worst_s == kth_s) & (worst_i > kth_i)) | (worst_i < 0)
+        unsafe = big.unsqueeze(1) & ~after & (kth_i >= 0)
+        if not bool(unsafe.any()):
+            return out_s, out_i
+        parts *= 2
 
 
 def merge_shards(scores, ids):
