@@ -318,3 +318,68 @@ def test_blip_ff_train_mode_dropout_matches_masked_oracle():
                  "text_encoder.encoder.layer.1.output.dense.weight", "text_encoder.pooler.dense.weight"):
         r = rel(model.get_parameter(name).grad, sdg[name].grad)
         assert r < 8e-2, (name, r)
+
+
+def test_blip_ff_large_two_pairs_against_the_oracle():
+    """BASELINE configs[4] at its real architecture (blip_ff.py:82-257): ViT-L/16 @224 (197 tokens, 16 heads, width 1024),
+    MED BERT-base with 100 text tokens cross-attending to the 1024-wide image tokens (K / V projections 1024 -> 768), padding
+    masks of different lengths, momentum encoders, queue -- 2 pairs, eval mode (no dropout), against oracle/blip_oracle.py:
+    embeddings, loss, accuracy, d temp, parameter gradients"""
+    from oracle import blip_oracle as bo
+    from uniir_amd.blip_model import BLIPFeatureFusion
+    torch.manual_seed(0)
+    L, pairs, K = 100, 2, 16
+    model = BLIPFeatureFusion(med_config={}, vit="large", queue_size=K, momentum=0.995,
+                              config=types.SimpleNamespace(tokenizer_max_length=L), seed=3).cuda()
+    model.eval()
+    M = 2 * pairs
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(1000, 30000, (M, L), generator=g)
+    ids[:, 0] = 101
+    valid = torch.tensor([L, 37, 5, 64])
+    mask = (torch.arange(L).unsqueeze(0) < valid.unsqueeze(1)).long()
+    ids = ids * mask
+    img = torch.randn(M, 3, 224, 224, generator=g)
+    pdid = torch.tensor([501, 502])
+    # non-trivial queues so that the queue block of the logits matters
+    with torch.no_grad():
+        model.query_queue.copy_(torch.nn.functional.normalize(torch.randn(768, K, generator=g), dim=0).cuda())
+        model.cand_queue.copy_(torch.nn.functional.normalize(torch.randn(768, K, generator=g), dim=0).cuda())
+        model.idx_queue.copy_(torch.arange(900, 900 + K).view(1, K).cuda())
+    sd = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    for n in sd:
+        if sd[n].dtype == torch.float32 and "_m." not in n:
+            sd[n].requires_grad_(True)
+    state = {"query_queue": model.query_queue.detach().cpu().clone(), "cand_queue": model.cand_queue.detach().cpu().clone(),
+             "idx_queue": model.idx_queue.detach().cpu().clone(), "ptr": int(model.new_ptr_queue.item())}
+    im = {"query": [[2 * i] for i in range(pairs)], "pos_cand": [[2 * i + 1] for i in range(pairs)]}
+    out_o = bo.contrastive_loss(sd, state, {"ids": ids, "mask": mask, "img": img, "index_mapping": im, "p_did_list": pdid},
+                                0.4, model.vit_cfg, model.med_cfg, 0.995)
+    out_o["loss"].backward()
+    batch = {"txt_batched": types.SimpleNamespace(input_ids=ids.cuda(), attention_mask=mask.cuda()), "image_batched": img.cuda(),
+             "p_did_list": pdid, "index_mapping": im}
+    model.zero_grad()
+    out_d = model(batch, alpha=0.4)
+    out_d["loss"].backward()
+    print("OBS blip-large loss", out_d["loss"].item(), out_o["loss"].item())
+    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 2e-2 * max(1.0, abs(out_o["loss"].item()))
+    assert out_d["accuracy"].item() == out_o["accuracy"].item()
+    assert np.array_equal(model.idx_queue.cpu().numpy(), state["idx_queue"].numpy())
+    assert rel(model.query_queue, state["query_queue"]) < 2e-2
+    errs = {}
+    for n in ("visual_encoder.blocks.0.attn.qkv.weight", "visual_encoder.blocks.23.mlp.fc2.weight", "visual_encoder.pos_embed",
+              "visual_encoder.patch_embed.proj.weight", "text_encoder.embeddings.word_embeddings.weight",
+              "text_encoder.encoder.layer.0.attention.self.query.weight",
+              "text_encoder.encoder.layer.0.crossattention.self.key.weight",
+              "text_encoder.encoder.layer.11.crossattention.self.value.weight",
+              "text_encoder.encoder.layer.11.output.dense.weight", "text_encoder.pooler.dense.weight"):
+        errs[n] = rel(model.get_parameter(n).grad, sd[n].grad)
+    print("OBS blip-large grad rel", {k.split(".")[-3] + "." + k.split(".")[-2]: round(v, 4) for k, v in errs.items()})
+    assert max(errs.values()) < 8e-2, errs
+    assert rel(model.temp.grad, sd["temp"].grad) < 8e-2
+    # embedding entry point (forward only)
+    with torch.no_grad():
+        emb = model.encode_multimodal_input(batch["txt_batched"], batch["image_batched"])
+        ref = bo.encode_multimodal_input({k: v.detach() for k, v in sd.items()}, ids, mask, img, model.vit_cfg, model.med_cfg)
+    print("OBS blip-large emb rel", rel(emb, ref))
+    assert rel(emb, ref) < 2e-2

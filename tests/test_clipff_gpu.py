@@ -179,3 +179,48 @@ def test_t5_train_mode_dropout_matches_masked_oracle():
         d1 = m.encode_multimodal_input(t, im)
         d2 = m.encode_multimodal_input(t, im)
     assert torch.equal(e0, e1) and torch.equal(d0, d1) and not torch.equal(d0, d2) and rel(d0, e0) > 1e-2
+
+
+def test_clipff_save_resume_then_step(tmp_path):
+    """a CLIP_FF checkpoint maps to the CPU on load (host_utils.load_checkpoint_file); the train.py mirror moves
+    only top-level tensors of the optimizer state back, so the T5 group's moments ("extra": a list of (m, v) tuples) arrive on
+    the CPU -- the first optimizer step after a resume must move them, and the resumed run must continue exactly like the
+    uninterrupted one"""
+    from oracle import clip_oracle as O
+    from uniir_amd.host_utils import load_checkpoint_file
+    from uniir_amd.trainer import NativeAdamW
+    t5_cfg = dict(d_model=128, num_heads=2, d_ff=256, num_layers=2, d_kv=64)
+    cfg = O.tiny_config(embed_dim=128, transformer_width=128, transformer_heads=2)
+    batch = O.synthetic_batch(cfg, 4, seed=23)
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+    def make():
+        m, _ = _model(cfg, t5_cfg, seed=5)
+        m.eval()                                    # no dropout: both runs must see identical arithmetic
+        opt = NativeAdamW(m.clip_model, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2, allreduce=False,
+                          extra=[m.t5_optimizer_group(lr=1e-3)])
+        return m, opt
+
+    def step(m, opt):
+        opt.zero_grad()
+        out = m(dbatch)
+        out["loss"].backward()
+        opt.step()
+        return out["loss"].item()
+
+    m1, o1 = make()
+    step(m1, o1)
+    path = str(tmp_path / "clip_ff_epoch_0.pth")
+    torch.save({"model": m1.state_dict(), "optimizer": o1.state_dict()}, path)
+    l_ref = step(m1, o1)                            # the uninterrupted second step
+    ck = load_checkpoint_file(path)                 # everything on the CPU now
+    assert all(not t.is_cuda for mv in ck["optimizer"]["extra"] for t in mv)
+    m2, o2 = make()
+    m2.load_state_dict(ck["model"])
+    o2.load_state_dict({k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in ck["optimizer"].items()})
+    l_res = step(m2, o2)                            # used to raise "uniir_amd ops need device tensors"
+    assert abs(l_res - l_ref) < 1e-5 * max(1.0, abs(l_ref))
+    q1 = m1.t5_layers.get_parameter("block.0.layer.0.SelfAttention.q.weight")
+    q2 = m2.t5_layers.get_parameter("block.0.layer.0.SelfAttention.q.weight")
+    # same state, same batch -> the same update up to the order of the fp32 atomics in the weight-gradient GEMMs
+    assert (q1 - q2).abs().max().item() < 1e-5 and (m1.clip_model.visual.proj - m2.clip_model.visual.proj).abs().max().item() < 1e-5
