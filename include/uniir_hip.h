@@ -206,6 +206,62 @@ int uniir_sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_
                 float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * [TOWER] a whole CLIP tower per call: what the reference's FFI for this path would bind for
+ * `clip_model.encode_image(image)` / `clip_model.encode_text(text)` (clip_sf.py:44,47; openai/CLIP
+ * VisionTransformer.forward / CLIP.encode_text) and their autograd backward.  The per-layer launch sequence lives in the
+ * library (csrc/tower.hip); the op-level entry points above stay available.
+ *   weights / gradients : raw device pointers in the POD structs below.  "16" fields are the bf16 shadow of the fp32
+ *                         master weights (kept fresh by uniir_adamw_step or uniir_cast_f32_to_bf16); g_* are fp32
+ *                         gradients, ACCUMULATED (+=), may be NULL for a forward-only description.
+ *   activations         : ONE caller-owned workspace of uniir_clip_tower_workspace_bytes() bytes (256-B aligned); with
+ *                         save_for_backward it is the activation stash and must be passed unchanged to the bwd calls.
+ *   forward             : input = images f32 NCHW [batch][3][res][res] (vision) or token ids int32 [batch][tokens] (text)
+ *                         -> emb_out f32 [batch][embed_dim].
+ *   backward            : demb f32 [batch][embed_dim].  uniir_clip_tower_bwd = head + all blocks + stem; the three stages
+ *                         are exported so that a caller can hand finished layers to its gradient all-reduce between
+ *                         uniir_clip_tower_bwd_blocks calls (descending ranges [lo, hi) covering all layers).
+ * Asynchronous on `stream`, no allocation, no host synchronisation; 0 or a negative UNIIR_E* code.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;                 /* [W] */
+    const void *wqkv16, *wo16, *wfc16, *wproj16;                /* bf16 [3W][W], [W][W], [4W][W], [W][4W] */
+    const float *bqkv, *bo, *bfc, *bproj;                       /* [3W], [W], [4W], [W] */
+    float *g_ln1_w, *g_ln1_b, *g_ln2_w, *g_ln2_b;
+    float *g_wqkv, *g_bqkv, *g_wo, *g_bo, *g_wfc, *g_bfc, *g_wproj, *g_bproj;
+} uniir_clip_block;
+
+typedef struct {
+    int32_t is_text;                          /* 0: vision tower, 1: text tower (causal attention, EOT pooling) */
+    int32_t layers, width, heads, tokens;     /* width = 64 * heads; tokens = 1 + (resolution/patch)^2 or context_length */
+    int32_t embed_dim;
+    int32_t resolution, patch, kpad;          /* vision: kpad = 3*patch*patch rounded up to 64 */
+    int32_t vocab;                            /* text */
+    const uniir_clip_block* blocks;           /* HOST array [layers] */
+    const void* conv16;                       /* vision: bf16 [W][kpad] (conv1.weight flattened, zero padded) */
+    const float *class_emb, *pos_emb;         /* vision [W], [tokens][W]; text: pos_emb [tokens][W] */
+    const float *ln_pre_w, *ln_pre_b;         /* vision */
+    const float* token_emb;                   /* text [vocab][W] */
+    const float *ln_post_w, *ln_post_b;       /* visual.ln_post / ln_final */
+    const void* proj16;                       /* bf16 [W][embed_dim]: visual.proj / text_projection */
+    float *g_conv;                            /* fp32 [W][3*patch*patch] (conv1.weight.grad) */
+    float *g_class, *g_pos, *g_ln_pre_w, *g_ln_pre_b, *g_token, *g_ln_post_w, *g_ln_post_b, *g_proj;
+    void* splitk_ws;                          /* optional scratch for the weight-gradient GEMMs' split-K slabs */
+    int64_t splitk_ws_bytes;
+} uniir_clip_tower;
+
+int64_t uniir_clip_tower_workspace_bytes(const uniir_clip_tower* t, int32_t batch, int32_t save_for_backward);
+int uniir_clip_tower_fwd(const uniir_clip_tower* t, const void* input, int32_t batch, float* emb_out, void* workspace,
+                         int64_t workspace_bytes, int32_t save_for_backward, void* stream);
+int uniir_clip_tower_bwd(const uniir_clip_tower* t, const void* input, const float* demb, int32_t batch, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+int uniir_clip_tower_bwd_head(const uniir_clip_tower* t, const float* demb, int32_t batch, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+int uniir_clip_tower_bwd_blocks(const uniir_clip_tower* t, int32_t batch, int32_t layer_lo, int32_t layer_hi, void* workspace,
+                                int64_t workspace_bytes, void* stream);
+int uniir_clip_tower_bwd_stem(const uniir_clip_tower* t, const void* input, int32_t batch, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * [FP32] forward path of the encoders in fp32 ("model.float()" of the reference: clip_sf.py:25-26 keeps fp32 weights,
  * the embedder only autocasts when use_fp16 is set).  Linear layers = uniir_sgemm (exact fp32 MFMA) followed by
  * uniir_bias_act_f32: y = (resid ? resid : 0) + act(y + bias) in place (act < 0: none, else UNIIR_ACT_*);

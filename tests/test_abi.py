@@ -42,3 +42,48 @@ def test_product_path_has_no_cpu_fallback():
     from uniir_amd import ops
     with pytest.raises(RuntimeError):
         ops.call("uniir_cast_f32_to_bf16", torch.zeros(8), torch.zeros(8, dtype=torch.bfloat16), 8)
+
+
+def _tower(image=True, layers=24, width=1024, tokens=257, res=224, patch=14):
+    from uniir_amd import _lib
+    blocks = (_lib.ClipBlock * layers)()
+    for b in blocks:
+        for name, _ in _lib.ClipBlock._fields_:
+            setattr(b, name, 0x1000)            # any non-null address: these calls never touch device memory
+    t = _lib.ClipTower()
+    t.is_text, t.layers, t.width, t.heads, t.tokens, t.embed_dim = int(not image), layers, width, width // 64, tokens, 768
+    t.resolution, t.patch, t.kpad, t.vocab = res, patch, (3 * patch * patch + 63) // 64 * 64, 49408
+    t.blocks = ctypes.cast(blocks, ctypes.POINTER(_lib.ClipBlock))
+    for name in ("conv16", "class_emb", "pos_emb", "ln_pre_w", "ln_pre_b", "token_emb", "ln_post_w", "ln_post_b", "proj16"):
+        setattr(t, name, 0x1000)
+    return t, blocks
+
+
+def test_tower_entry_points_plan_and_validate_on_the_host():
+    """[TOWER] uniir_clip_tower_*: the workspace query is pure host arithmetic (ViT-L/14 at the bench batch: the ~190 GB
+    activation stash DESIGN.md quotes), malformed descriptions and null pointers are errors, never UB"""
+    from uniir_amd import _lib
+    lib = _lib.load()
+    t, keep = _tower()
+    R, W = 1024 * 257, 1024
+    need = lib.uniir_clip_tower_workspace_bytes(ctypes.byref(t), 1024, 1)
+    per_layer = R * W * (4 + 6 + 2 + 4 + 8 + 2 + 2) + 1024 * 16 * 257 * 4        # x qkv ao x2 f h1 h2 + lse
+    assert 24 * per_layer < need < 24 * per_layer * 1.12
+    fwd_only = lib.uniir_clip_tower_workspace_bytes(ctypes.byref(t), 1024, 0)
+    assert 0 < fwd_only < need / 8                                                # one layer's buffers instead of 24
+    assert lib.uniir_clip_tower_workspace_bytes(ctypes.byref(t), 0, 1) > 0
+    t.tokens = 256                                                                # != 1 + (224/14)^2
+    assert lib.uniir_clip_tower_workspace_bytes(ctypes.byref(t), 8, 1) == -1
+    t.tokens, t.width = 257, 1000                                                 # not 64 * heads
+    assert lib.uniir_clip_tower_workspace_bytes(ctypes.byref(t), 8, 1) == -1
+    t.width = 1024
+    assert lib.uniir_clip_tower_fwd(ctypes.byref(t), None, 8, None, None, 0, 1, None) == -1          # UNIIR_EINVAL
+    assert lib.uniir_clip_tower_fwd(ctypes.byref(t), 0x1000, 8, 0x1000, 0x1001, 1 << 40, 1, None) == -3   # unaligned workspace
+    assert lib.uniir_clip_tower_fwd(ctypes.byref(t), 0x1000, 8, 0x1000, 0x1000, 16, 1, None) == -1   # workspace too small
+    assert lib.uniir_clip_tower_bwd_blocks(ctypes.byref(t), 8, 5, 3, 0x1000, 1 << 40, None) == -1    # lo > hi
+    tt, keep2 = _tower(image=False, layers=12, width=768, tokens=77)
+    assert lib.uniir_clip_tower_workspace_bytes(ctypes.byref(tt), 1024, 1) > 12 * 1024 * 77 * 768 * 28
+    tt.token_emb = None
+    assert lib.uniir_clip_tower_workspace_bytes(ctypes.byref(tt), 8, 1) == -1
+    assert lib.uniir_topk_ip_workspace_bytes(100000, 10, 700000) > 1024 * 43750 * 4
+    assert lib.uniir_topk_ip(None, None, None, 10, 64, None, 1, 10, None, None, None, 0, None) == -1

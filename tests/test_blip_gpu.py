@@ -374,7 +374,7 @@ def test_blip_ff_large_two_pairs_against_the_oracle():
               "text_encoder.encoder.layer.11.crossattention.self.value.weight",
               "text_encoder.encoder.layer.11.output.dense.weight", "text_encoder.pooler.dense.weight"):
         errs[n] = rel(model.get_parameter(n).grad, sd[n].grad)
-    print("OBS blip-large grad rel", {k.split(".")[-3] + "." + k.split(".")[-2]: round(v, 4) for k, v in errs.items()})
+    print("OBS blip-large grad rel", {k[-40:]: round(v, 4) for k, v in errs.items()})
     assert max(errs.values()) < 8e-2, errs
     assert rel(model.temp.grad, sd["temp"].grad) < 8e-2
     # embedding entry point (forward only)

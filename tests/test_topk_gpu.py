@@ -121,9 +121,9 @@ def _two_call_search(shard, queries, k):
 
 @pytest.mark.parametrize("n,nq,d,k", [(70001, 64, 768, 10), (30000, 7, 512, 50), (9000, 300, 256, 10), (40, 5, 64, 10),
                                       (70000, 1100, 768, 10)])
-def test_single_call_search_equals_the_three_kernel_tail_bit_for_bit(n, nq, d, k):
-    """uniir_topk_ip (fused select + re-score + sort per query) == coarse + rescore, scores and ids, incl. zero rows,
-    duplicate ties, a ragged last group and -1 padding"""
+def test_single_call_search_equals_the_op_level_sequence_bit_for_bit(n, nq, d, k):
+    """uniir_topk_ip (one call: query norms + per-chunk scan, selection, re-score, sort) == the op-level entry points called
+    one by one, scores and ids, incl. zero rows, duplicate ties, a ragged last group, -1 padding and > 1024 queries"""
     from uniir_amd import retrieval
     torch.manual_seed(11)
     pool = torch.randn(n, d, device=DEV).half()

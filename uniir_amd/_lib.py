@@ -25,6 +25,27 @@ class GemmDesc(C.Structure):
     ]
 
 
+class ClipBlock(C.Structure):
+    """uniir_clip_block (include/uniir_hip.h [TOWER]): one residual block's weights (fp32 / bf16 shadow) and gradients"""
+    _fields_ = [(n, c_void_p) for n in (
+        "ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv16", "wo16", "wfc16", "wproj16", "bqkv", "bo", "bfc", "bproj",
+        "g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b", "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_wfc", "g_bfc", "g_wproj", "g_bproj")]
+
+
+class ClipTower(C.Structure):
+    """uniir_clip_tower"""
+    _fields_ = [
+        ("is_text", c_int), ("layers", c_int), ("width", c_int), ("heads", c_int), ("tokens", c_int), ("embed_dim", c_int),
+        ("resolution", c_int), ("patch", c_int), ("kpad", c_int), ("vocab", c_int),
+        ("blocks", C.POINTER(ClipBlock)),
+        ("conv16", c_void_p), ("class_emb", c_void_p), ("pos_emb", c_void_p), ("ln_pre_w", c_void_p), ("ln_pre_b", c_void_p),
+        ("token_emb", c_void_p), ("ln_post_w", c_void_p), ("ln_post_b", c_void_p), ("proj16", c_void_p),
+        ("g_conv", c_void_p), ("g_class", c_void_p), ("g_pos", c_void_p), ("g_ln_pre_w", c_void_p), ("g_ln_pre_b", c_void_p),
+        ("g_token", c_void_p), ("g_ln_post_w", c_void_p), ("g_ln_post_b", c_void_p), ("g_proj", c_void_p),
+        ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_i64),
+    ]
+
+
 # name -> (restype, argtypes); P = device pointer, S = stream
 P, S = c_void_p, c_void_p
 SIGNATURES = {
@@ -85,6 +106,12 @@ SIGNATURES = {
     "uniir_topk_coarse": (c_int, [P, P, c_i64, c_int, P, c_int, c_int, P, P, P, c_i64, S]),
     "uniir_topk_rescore": (c_int, [P, P, P, c_i64, c_int, P, P, c_int, P, c_int, c_int, P, P, P, S]),
     "uniir_topk_merge": (c_int, [P, P, c_int, c_int, c_int, P, P, S]),
+    "uniir_clip_tower_workspace_bytes": (c_i64, [C.POINTER(ClipTower), c_int, c_int]),
+    "uniir_clip_tower_fwd": (c_int, [C.POINTER(ClipTower), P, c_int, P, P, c_i64, c_int, S]),
+    "uniir_clip_tower_bwd": (c_int, [C.POINTER(ClipTower), P, P, c_int, P, c_i64, S]),
+    "uniir_clip_tower_bwd_head": (c_int, [C.POINTER(ClipTower), P, c_int, P, c_i64, S]),
+    "uniir_clip_tower_bwd_blocks": (c_int, [C.POINTER(ClipTower), c_int, c_int, c_int, P, c_i64, S]),
+    "uniir_clip_tower_bwd_stem": (c_int, [C.POINTER(ClipTower), P, c_int, P, c_i64, S]),
     "uniir_bias_act_f32": (c_int, [P, P, P, c_i64, c_int, c_int, S]),
     "uniir_vit_assemble_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
     "uniir_attention_f32_fwd": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, c_int, c_int, c_int, c_int, c_int, c_float, S]),

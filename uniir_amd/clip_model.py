@@ -8,12 +8,18 @@ fp32 LayerNorm, fused attention, fp32 residual stream.  This file is host plumbi
 (one flat fp32 master buffer + flat grad buffer + bf16 shadow), the per-layer launch sequence of forward and
 backward, and the activation stash.  There is no torch fallback.
 """
+import ctypes as C
 import math
+import os
 
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
+
+# UNIIR_PY_TOWERS=1: run the CLIP towers as the per-op launch sequence below (what CLIP_FF and BLIP use for their variants)
+# instead of the single-call C towers of csrc/tower.hip -- same kernels, same order; kept for A/B comparisons
+_PY_TOWERS = os.environ.get("UNIIR_PY_TOWERS") == "1"
 
 ALIGN = 64  # elements; every parameter starts on a 256-B boundary of the flat buffers
 
@@ -164,6 +170,69 @@ class CLIP(nn.Module):
         fl = self._flat
         o = fl["off"][name]
         return fl["g32"][o:o + math.prod(fl["shapes"][name])].view(fl["shapes"][name])
+
+    def tower_desc(self, which):
+        """the POD description uniir_clip_tower_{fwd,bwd} take (include/uniir_hip.h [TOWER]): raw device pointers into the flat
+        fp32 / bf16-shadow / gradient buffers; cached until the flat storage is rebuilt"""
+        import ctypes as C
+        from ._lib import ClipBlock, ClipTower
+        fl = self._flat
+        key = (which, fl["p32"].data_ptr())
+        cache = fl.setdefault("tower_desc", {})
+        if key in cache:
+            return cache[key][0]
+        cfg = self.cfg
+
+        def p(name):
+            return fl["p32"].data_ptr() + 4 * fl["off"][name]
+
+        def h(name):
+            return fl["w16"].data_ptr() + 2 * fl["off"][name]
+
+        def g(name):
+            return fl["g32"].data_ptr() + 4 * fl["off"][name]
+
+        image = which == "image"
+        prefix = "visual.transformer" if image else "transformer"
+        L = cfg["vision_layers"] if image else cfg["transformer_layers"]
+        W = cfg["vision_width"] if image else cfg["transformer_width"]
+        blocks = (ClipBlock * L)()
+        for i in range(L):
+            b, r = blocks[i], f"{prefix}.resblocks.{i}"
+            b.ln1_w, b.ln1_b, b.ln2_w, b.ln2_b = p(f"{r}.ln_1.weight"), p(f"{r}.ln_1.bias"), p(f"{r}.ln_2.weight"), p(f"{r}.ln_2.bias")
+            b.wqkv16, b.wo16 = h(f"{r}.attn.in_proj_weight"), h(f"{r}.attn.out_proj.weight")
+            b.wfc16, b.wproj16 = h(f"{r}.mlp.c_fc.weight"), h(f"{r}.mlp.c_proj.weight")
+            b.bqkv, b.bo = p(f"{r}.attn.in_proj_bias"), p(f"{r}.attn.out_proj.bias")
+            b.bfc, b.bproj = p(f"{r}.mlp.c_fc.bias"), p(f"{r}.mlp.c_proj.bias")
+            b.g_ln1_w, b.g_ln1_b, b.g_ln2_w, b.g_ln2_b = g(f"{r}.ln_1.weight"), g(f"{r}.ln_1.bias"), g(f"{r}.ln_2.weight"), g(f"{r}.ln_2.bias")
+            b.g_wqkv, b.g_bqkv = g(f"{r}.attn.in_proj_weight"), g(f"{r}.attn.in_proj_bias")
+            b.g_wo, b.g_bo = g(f"{r}.attn.out_proj.weight"), g(f"{r}.attn.out_proj.bias")
+            b.g_wfc, b.g_bfc = g(f"{r}.mlp.c_fc.weight"), g(f"{r}.mlp.c_fc.bias")
+            b.g_wproj, b.g_bproj = g(f"{r}.mlp.c_proj.weight"), g(f"{r}.mlp.c_proj.bias")
+        t = ClipTower()
+        t.is_text, t.layers, t.width, t.embed_dim = int(not image), L, W, cfg["embed_dim"]
+        t.blocks = C.cast(blocks, C.POINTER(ClipBlock))
+        skw = ops._splitk_workspace(fl["dev"], 128 << 20)
+        t.splitk_ws, t.splitk_ws_bytes = skw.data_ptr(), skw.numel()
+        if image:
+            P = cfg["vision_patch_size"]
+            t.heads, t.tokens = W // 64, (cfg["image_resolution"] // P) ** 2 + 1
+            t.resolution, t.patch, t.kpad = cfg["image_resolution"], P, self.kpad
+            t.conv16 = self._conv16.data_ptr()
+            t.class_emb, t.pos_emb = p("visual.class_embedding"), p("visual.positional_embedding")
+            t.ln_pre_w, t.ln_pre_b = p("visual.ln_pre.weight"), p("visual.ln_pre.bias")
+            t.ln_post_w, t.ln_post_b, t.proj16 = p("visual.ln_post.weight"), p("visual.ln_post.bias"), h("visual.proj")
+            t.g_conv, t.g_class, t.g_pos = g("visual.conv1.weight"), g("visual.class_embedding"), g("visual.positional_embedding")
+            t.g_ln_pre_w, t.g_ln_pre_b = g("visual.ln_pre.weight"), g("visual.ln_pre.bias")
+            t.g_ln_post_w, t.g_ln_post_b, t.g_proj = g("visual.ln_post.weight"), g("visual.ln_post.bias"), g("visual.proj")
+        else:
+            t.heads, t.tokens, t.vocab = cfg["transformer_heads"], cfg["context_length"], cfg["vocab_size"]
+            t.pos_emb, t.token_emb = p("positional_embedding"), p("token_embedding.weight")
+            t.ln_post_w, t.ln_post_b, t.proj16 = p("ln_final.weight"), p("ln_final.bias"), h("text_projection")
+            t.g_pos, t.g_token = g("positional_embedding"), g("token_embedding.weight")
+            t.g_ln_post_w, t.g_ln_post_b, t.g_proj = g("ln_final.weight"), g("ln_final.bias"), g("text_projection")
+        cache[key] = (t, blocks, skw)          # keep the host array and the scratch alive with the description
+        return t
 
     def layer_grad_range(self, prefix, i):
         """[lo, hi) of the flat buffers that holds the four weight matrices of residual block i (adjacent: the weight-decay
@@ -420,6 +489,21 @@ class _TowerFn(torch.autograd.Function):
             return _encode_fp32(model, which, inp, p32)
         if model.precision != "bf16":
             raise RuntimeError(f"unknown precision {model.precision!r}")
+        if not _PY_TOWERS:
+            # the whole tower in one C call (csrc/tower.hip); the workspace is the activation stash of the backward
+            lib = _lib.load()
+            desc = model.tower_desc(which)
+            need = lib.uniir_clip_tower_workspace_bytes(C.byref(desc), M, int(need_grad))
+            if need < 0:
+                raise RuntimeError("uniir_clip_tower: unsupported tower geometry")
+            ws = torch.empty(need, device=dev, dtype=torch.uint8)
+            emb = torch.empty(M, E, device=dev, dtype=torch.float32)
+            inp = inp.float().contiguous() if which == "image" else inp
+            _lib.check(lib.uniir_clip_tower_fwd(C.byref(desc), inp.data_ptr(), M, emb.data_ptr(), ws.data_ptr(), need,
+                                                int(need_grad), ops._stream()), "clip_tower_fwd")
+            if need_grad:
+                ctx.stash = dict(ws=ws, inp=inp, ctower=True)
+            return emb
         if which == "image":
             W, P, L = cfg["vision_width"], cfg["vision_patch_size"], cfg["vision_layers"]
             res = cfg["image_resolution"]
@@ -469,6 +553,25 @@ class _TowerFn(torch.autograd.Function):
             return None, None, None, None
         st = ctx.stash
         ctx.stash = None
+        if st.get("ctower"):
+            lib = _lib.load()
+            desc = model.tower_desc(which)
+            ws, inp, stream = st["ws"], st["inp"], ops._stream()
+            demb = demb.contiguous().float()
+            need = ws.numel()
+            reducer = getattr(model, "_grad_reducer", None)
+            _lib.check(lib.uniir_clip_tower_bwd_head(C.byref(desc), demb.data_ptr(), M, ws.data_ptr(), need, stream), "tower_bwd_head")
+            L = desc.layers
+            if reducer is None:
+                _lib.check(lib.uniir_clip_tower_bwd_blocks(C.byref(desc), M, 0, L, ws.data_ptr(), need, stream), "tower_bwd_blocks")
+            else:       # DDP overlap: hand every finished block's weight gradients to the collective stream
+                prefix = "visual.transformer" if which == "image" else "transformer"
+                for i in reversed(range(L)):
+                    _lib.check(lib.uniir_clip_tower_bwd_blocks(C.byref(desc), M, i, i + 1, ws.data_ptr(), need, stream),
+                               "tower_bwd_blocks")
+                    reducer.ready(*model.layer_grad_range(prefix, i))
+            _lib.check(lib.uniir_clip_tower_bwd_stem(C.byref(desc), inp.data_ptr(), M, ws.data_ptr(), need, stream), "tower_bwd_stem")
+            return None, None, None, None
         cfg = model.cfg
         fl = model._flat
         dev = demb.device

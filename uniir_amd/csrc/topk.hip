@@ -822,22 +822,17 @@ __global__ __launch_bounds__(256) void rescore_coalesced_kernel(const unsigned s
     for (int i = 0; i < 8; ++i) rows8[i] = __shfl(ci, 8 * i + (lane >> 3), 64);
     const int piece = lane & 7;
     char* mine = &stage[w][0];
-    u32x4_t pre[8];
-    auto fetch = [&](int c0) {
+    // two 128-B slices of every row are in flight while a third is walked: the gathers are DRAM-latency-bound (random rows),
+    // one slice of look-ahead left ~2 us of exposed latency per slice (12 slices at dim 768)
+    u32x4_t pre[2][8];
+    auto fetch = [&](int c0, u32x4_t (&dst)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const u32x4_t z = {0u, 0u, 0u, 0u};
-            pre[i] = rows8[i] >= 0 ? *reinterpret_cast<const u32x4_t*>(pool + (long)rows8[i] * dim + c0 + piece * 8) : z;
+            dst[i] = rows8[i] >= 0 ? *reinterpret_cast<const u32x4_t*>(pool + (long)rows8[i] * dim + c0 + piece * 8) : z;
         }
     };
-    float s = 0.f;
-    fetch(0);
-    for (int c0 = 0; c0 < dim; c0 += 64) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<u32x4_t*>(mine + (8 * i + (lane >> 3)) * RSC_PITCH + piece * 16) = pre[i];
-        __syncthreads();
-        if (c0 + 64 < dim) fetch(c0 + 64);
+    auto walk = [&](int c0, float s) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const u32x4_t a = *reinterpret_cast<const u32x4_t*>(qr + c0 + 8 * u);
@@ -852,6 +847,27 @@ __global__ __launch_bounds__(256) void rescore_coalesced_kernel(const unsigned s
                 s = __fadd_rn(s, __fmul_rn(qb, cb));
             }
         }
+        return s;
+    };
+    auto park = [&](const u32x4_t (&src)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<u32x4_t*>(mine + (8 * i + (lane >> 3)) * RSC_PITCH + piece * 16) = src[i];
+    };
+    float s = 0.f;
+    fetch(0, pre[0]);
+    if (64 < dim) fetch(64, pre[1]);
+    for (int c0 = 0; c0 < dim; c0 += 128) {       // two slices per trip so that the register buffers keep static indices
+        park(pre[0]);
+        __syncthreads();
+        if (c0 + 128 < dim) fetch(c0 + 128, pre[0]);
+        s = walk(c0, s);
+        __syncthreads();
+        if (c0 + 64 >= dim) break;
+        park(pre[1]);
+        __syncthreads();
+        if (c0 + 192 < dim) fetch(c0 + 192, pre[1]);
+        s = walk(c0 + 64, s);
         __syncthreads();
     }
     if (live) exact[t] = ci >= 0 ? s : -INFINITY;
@@ -919,114 +935,6 @@ __global__ __launch_bounds__(256) void final_sort_kernel(const float* __restrict
         __syncthreads();
         last_s = wsel; last_id = isel;
         __syncthreads();
-    }
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// Fused tail of the group-max path: selection + exact re-score + final sort of ONE query per 1024-thread workgroup, one
-// launch instead of three (topk_gsel / rescore_coalesced / final_sort) and no cand_idx / exact round trips through HBM.
-//   A  gsel_body: the kc best groups (+ ties) -> their member rows in LDS, ranked group-major, live rows first
-//   B  waves 0..7: exact fp32 score of 64 rows each, in the oracle's summation order (one sequential chain per row, the
-//      query pre-multiplied by its inverse norm exactly like FAISS renorm does, candidate rows gathered 128 B at a time
-//      through wave-private LDS staging -- same arithmetic as rescore_coalesced_kernel)
-//   C  rank by counting over the live list in LDS ((score desc, id asc) is a strict total order), ranks < k are written
-#define TKT_WAVES 8
-#define TKT_MAXC 2048          // gcap * TK_G <= 2 * TK_MAXKC * 16
-#define TKT_MAXDIM 1024
-template <bool REG>
-__global__ __launch_bounds__(1024) void topk_tail_kernel(const float* __restrict__ gmax, long ngroups, long rows, int kc,
-                                                         int gcap, const unsigned short* __restrict__ pool,
-                                                         const float* __restrict__ pinv, const long long* __restrict__ ids,
-                                                         const unsigned short* __restrict__ queries,
-                                                         const float* __restrict__ qinv, int dim, int k,
-                                                         float* __restrict__ out_s, long long* __restrict__ out_i) {
-    __shared__ int cand[TKT_MAXC];
-    __shared__ float ex[TKT_MAXC];
-    __shared__ long long exid[TKT_MAXC];
-    __shared__ float qn[TKT_MAXDIM];
-    __shared__ __attribute__((aligned(16))) char stage[TKT_WAVES][64 * RSC_PITCH];
-    __shared__ int nsel16, nvalid;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const unsigned short* qr = queries + (long)q * dim;
-    const float iq = qinv[q];
-    for (int c = tid; c < dim; c += 1024) {           // FAISS renorm of the query: x[i] *= inv_nr (untouched when all-zero)
-        const float v = f16_to_f32(qr[c]);
-        qn[c] = iq != 0.f ? __fmul_rn(v, iq) : v;
-    }
-    if (tid == 0) { nsel16 = 0; nvalid = 0; }
-    gsel_body<1024, REG>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, cand);     // ends with a barrier
-    // live entries form a prefix of the ranked list (ranks are exact); its length = last non-empty slot + 1
-    for (int e = tid; e < gcap * TK_G; e += 1024)
-        if (cand[e] >= 0) atomicMax(&nsel16, e + 1);
-    __syncthreads();
-    const int ncl = nsel16;
-    // ---- B: exact scores ----
-    if (w < TKT_WAVES) {
-        char* mine = &stage[w][0];
-        const int piece = lane & 7;
-        for (int base = w * 64; base < ncl; base += TKT_WAVES * 64) {
-            const int slot = base + lane;
-            const int ci = slot < ncl ? cand[slot] : -1;
-            const float ic = ci >= 0 ? pinv[ci] : 0.f;
-            int rows8[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) rows8[i] = __shfl(ci, 8 * i + (lane >> 3), 64);
-            u32x4_t pre[8];
-            auto fetch = [&](int c0) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const u32x4_t z = {0u, 0u, 0u, 0u};
-                    pre[i] = rows8[i] >= 0 ? *reinterpret_cast<const u32x4_t*>(pool + (long)rows8[i] * dim + c0 + piece * 8) : z;
-                }
-            };
-            float s = 0.f;
-            fetch(0);
-            for (int c0 = 0; c0 < dim; c0 += 64) {
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    *reinterpret_cast<u32x4_t*>(mine + (8 * i + (lane >> 3)) * RSC_PITCH + piece * 16) = pre[i];
-                __builtin_amdgcn_wave_barrier();       // staging is wave-private: the wave's own LDS operations stay in order
-                if (c0 + 64 < dim) fetch(c0 + 64);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(mine + lane * RSC_PITCH + u * 16);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float ca = f16_to_f32((unsigned short)(b[e] & 0xffffu)), cb = f16_to_f32((unsigned short)(b[e] >> 16));
-                        if (ic != 0.f) { ca = __fmul_rn(ca, ic); cb = __fmul_rn(cb, ic); }
-                        s = __fadd_rn(s, __fmul_rn(qn[c0 + 8 * u + 2 * e], ca));
-                        s = __fadd_rn(s, __fmul_rn(qn[c0 + 8 * u + 2 * e + 1], cb));
-                    }
-                }
-            }
-            if (slot < ncl) {
-                ex[slot] = ci >= 0 ? s : -INFINITY;
-                exid[slot] = ci >= 0 ? (ids ? ids[ci] : (long long)ci) : 0x7fffffffffffffffLL;
-                if (ci >= 0) atomicAdd(&nvalid, 1);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- C: rank by counting ----
-    for (int t = tid; t < ncl; t += 1024) {
-        const long long id = exid[t];
-        if (id == 0x7fffffffffffffffLL) continue;
-        const float sc = ex[t];
-        int rank = 0;
-        for (int u = 0; u < ncl; ++u) {
-            const float os = ex[u];
-            const long long oi = exid[u];
-            rank += (oi != 0x7fffffffffffffffLL && (os > sc || (os == sc && oi < id))) ? 1 : 0;
-        }
-        if (rank < k) {
-            out_s[(long)q * k + rank] = sc;
-            out_i[(long)q * k + rank] = id;
-        }
-    }
-    for (int t = nvalid + tid; t < k; t += 1024) {     // FAISS pads missing results with -inf distance / id -1
-        out_s[(long)q * k + t] = -INFINITY;
-        out_i[(long)q * k + t] = -1;
     }
 }
 
@@ -1099,14 +1007,12 @@ extern "C" int uniir_topk_merge_ex(const float* scores, const int64_t* ids, int3
 
 // -------------------------------------------------------------------------------------------------------------
 // uniir_topk_ip: the whole search_index of one pool shard in one call (mbeir_retriever.py:188-232 = normalise the queries,
-// exact inner-product top-k): query inverse norms, then per chunk of <= 1024 queries one sweep of the shard (group-max
-// scan) and the fused tail.  k <= 56 (k + 8 <= TK_MAXKC groups per query); larger k is assembled from slices by the caller.
+// exact inner-product top-k): query inverse norms, then per chunk of <= 1024 queries one sweep of the shard (group-max scan),
+// group selection, exact re-score, sort.  k <= 56 (k + 8 <= TK_MAXKC groups per query); larger k is assembled from slices by
+// the caller.  (A single fused select + re-score + sort launch per query was measured and dropped: with 64 queries the tail is
+// latency-bound and one 1024-thread workgroup per query serialises what the three launches spread over the whole chip:
+// 98 us instead of 80 us behind the 217-us scan; at 1024 queries it made no difference.)
 #define TKI_CHUNK 1024
-static int tki_fused_ok(int32_t dim, int32_t kc, int64_t rows) {
-    static const char* e = getenv("UNIIR_TOPK_FUSED_TAIL");      // "0": the three-kernel tail (A/B experiments)
-    const long ngroups = (rows + TK_G - 1) / TK_G;
-    return !(e && e[0] == '0') && dim % 64 == 0 && dim <= TKT_MAXDIM && TK_GMULT * kc * TK_G <= TKT_MAXC && ngroups >= 1;
-}
 extern "C" int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows) {
     if (nq <= 0 || k <= 0 || rows <= 0) return 0;
     const int chunk = nq < TKI_CHUNK ? nq : TKI_CHUNK;
@@ -1124,10 +1030,8 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
         ((uintptr_t)workspace & 255))
         return UNIIR_EALIGN;
     if (workspace_bytes < uniir_topk_ip_workspace_bytes(nq, k, rows)) return UNIIR_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
     const int chunk = nq < TKI_CHUNK ? nq : TKI_CHUNK;
     const int kc = k + 8;
-    const long ngroups = (rows + TK_G - 1) / TK_G;
     const int ncand = uniir_topk_ncand(chunk, kc);
     char* ws = (char*)workspace;
     float* gmax = (float*)ws;
@@ -1137,29 +1041,14 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
     float* exact = (float*)((char*)cand + (((int64_t)chunk * ncand * 4 + 255) & ~(int64_t)255));
     int rc = uniir_pool_inv_norms(queries_f16, nq, dim, qinv, stream);
     if (rc) return rc;
-    const bool fused = tki_fused_ok(dim, kc, rows);
     for (int lo = 0; lo < nq; lo += chunk) {
         const int n = nq - lo < chunk ? nq - lo : chunk;
         const unsigned short* qp = (const unsigned short*)queries_f16 + (long)lo * dim;
-        if (!fused) {
-            rc = uniir_topk_coarse(pool_f16, pool_inv_norm, rows, dim, qp, n, kc, cand, nullptr, gmax, gbytes, stream);
-            if (rc) return rc;
-            rc = uniir_topk_rescore(pool_f16, pool_inv_norm, pool_ids, rows, dim, qp, qinv + lo, n, cand, ncand, k, exact,
-                                    out_scores + (long)lo * k, out_ids + (long)lo * k, stream);
-            if (rc) return rc;
-            continue;
-        }
-        const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, qp, n, gmax, st);
-        if (sel < 0) return sel;
-        if (ngroups % 2 == 0 && ngroups <= 1024L * 2 * TK_SELREG)
-            hipLaunchKernelGGL(topk_tail_kernel<true>, dim3(n), dim3(1024), 0, st, gmax, ngroups, (long)rows, kc, TK_GMULT * kc,
-                               (const unsigned short*)pool_f16, pool_inv_norm, (const long long*)pool_ids, qp, qinv + lo, dim,
-                               k, out_scores + (long)lo * k, (long long*)(out_ids + (long)lo * k));
-        else
-            hipLaunchKernelGGL(topk_tail_kernel<false>, dim3(n), dim3(1024), 0, st, gmax, ngroups, (long)rows, kc, TK_GMULT * kc,
-                               (const unsigned short*)pool_f16, pool_inv_norm, (const long long*)pool_ids, qp, qinv + lo, dim,
-                               k, out_scores + (long)lo * k, (long long*)(out_ids + (long)lo * k));
-        HIP_LAUNCH_CHECK();
+        rc = uniir_topk_coarse(pool_f16, pool_inv_norm, rows, dim, qp, n, kc, cand, nullptr, gmax, gbytes, stream);
+        if (rc) return rc;
+        rc = uniir_topk_rescore(pool_f16, pool_inv_norm, pool_ids, rows, dim, qp, qinv + lo, n, cand, ncand, k, exact,
+                                out_scores + (long)lo * k, out_ids + (long)lo * k, stream);
+        if (rc) return rc;
     }
     return UNIIR_OK;
 }

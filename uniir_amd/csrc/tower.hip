@@ -1,0 +1,358 @@
+// Tower-level entry points of the C ABI (include/uniir_hip.h [TOWER]): one call runs a whole CLIP tower forward or
+// backward -- the per-layer launch sequence lives HERE, not in the host language, so a binding of libuniir_hip.so gets
+// `encode_image` / `encode_text` (openai/CLIP VisionTransformer.forward / CLIP.encode_text as called from UniIR
+// clip_sf.py:44,47) and their backward without re-writing ~90 launches per direction.  Pure host code: it sequences the
+// op-level entry points of this library on the caller's stream, never allocates, never synchronises.  Weights and
+// gradients are raw device pointers in a POD description; activations live in ONE caller-provided workspace whose layout
+// (plan()) is a pure function of the description and the batch size, so forward and backward agree on it.
+#include "common.h"
+#include "../../include/uniir_hip.h"
+#include <string.h>
+
+namespace {
+
+inline int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct Plan {
+    // sizes
+    int M, T, W, H, L, E, R, G, kpad;
+    bool save;
+    // head / stem
+    int64_t eot, rows, pooled, patches, po, x0;
+    // per layer (stride lay_stride when save, 0 otherwise)
+    int64_t lay0, lay_stride, o_x, o_qkv, o_ao, o_lse, o_x2, o_f, o_h1, o_h2;
+    int64_t x_last;                 // the residual stream after the last block
+    // transients shared by forward and backward (union)
+    int64_t tmp;
+    int64_t g, df, dh, dx, dx2, dxb, dqkv, demb16, dpooled, drows, dx0, dpo, dconv;
+    int64_t total;
+};
+
+Plan plan(const uniir_clip_tower* t, int batch, bool save) {
+    Plan p;
+    memset(&p, 0, sizeof(p));
+    p.M = batch; p.T = t->tokens; p.W = t->width; p.H = t->heads; p.L = t->layers; p.E = t->embed_dim;
+    p.R = batch * t->tokens; p.G = t->tokens - 1; p.kpad = t->kpad; p.save = save;
+    const int64_t R = p.R, W = p.W, M = p.M;
+    int64_t cur = 0;
+    auto take = [&](int64_t bytes) { const int64_t o = cur; cur += al(bytes); return o; };
+    p.eot = take(M * 4);
+    p.rows = take(M * W * 4);
+    p.pooled = take(M * W * 2);
+    if (!t->is_text) {
+        p.patches = take((int64_t)M * p.G * p.kpad * 2);
+        p.po = take((int64_t)M * p.G * W * 2);
+        p.x0 = take(R * W * 4);
+    }
+    // one layer's stash: x, qkv, ao, lse, x2, f, h1, h2
+    int64_t lc = 0;
+    auto ltake = [&](int64_t bytes) { const int64_t o = lc; lc += al(bytes); return o; };
+    p.o_x = ltake(R * W * 4);
+    p.o_qkv = ltake(R * 3 * W * 2);
+    p.o_ao = ltake(R * W * 2);
+    p.o_lse = ltake((int64_t)M * p.H * p.T * 4);
+    p.o_x2 = ltake(R * W * 4);
+    p.o_f = ltake(R * 4 * W * 2);
+    p.o_h1 = ltake(R * W * 2);
+    p.o_h2 = ltake(R * W * 2);
+    p.lay0 = cur;
+    p.lay_stride = save ? lc : 0;
+    cur += save ? lc * p.L : lc;
+    p.x_last = take(R * W * 4);          // with !save the stream ping-pongs between o_x of the single layer set and this
+    // transients: forward needs g only; backward the rest
+    p.tmp = cur;
+    p.g = take(R * 4 * W * 2);
+    p.df = take(R * 4 * W * 2);
+    p.dh = take(R * W * 2);
+    p.dx = take(R * W * 4);
+    p.dx2 = take(R * W * 4);
+    p.dxb = take(R * W * 2);
+    p.dqkv = take(R * 3 * W * 2);
+    p.demb16 = take(M * (int64_t)p.E * 2);
+    p.dpooled = take(M * W * 2);
+    p.drows = take(M * W * 4);
+    if (!t->is_text) {
+        p.dx0 = take(R * W * 4);
+        p.dpo = take((int64_t)M * p.G * W * 2);
+        p.dconv = take((int64_t)W * p.kpad * 4);
+    }
+    p.total = cur;
+    return p;
+}
+
+int check_tower(const uniir_clip_tower* t, int batch) {
+    if (!t || !t->blocks || batch < 0) return UNIIR_EINVAL;
+    if (t->layers <= 0 || t->width <= 0 || t->heads <= 0 || t->tokens < 2 || t->embed_dim <= 0) return UNIIR_EINVAL;
+    if (t->width != t->heads * 64 || t->width % 64 || t->embed_dim % 8 || t->tokens > 512) return UNIIR_ESHAPE;
+    if (!t->pos_emb || !t->ln_post_w || !t->ln_post_b || !t->proj16) return UNIIR_EINVAL;
+    if (t->is_text) {
+        if (!t->token_emb || t->vocab <= 0) return UNIIR_EINVAL;
+    } else {
+        if (!t->conv16 || !t->class_emb || !t->ln_pre_w || !t->ln_pre_b) return UNIIR_EINVAL;
+        if (t->patch <= 0 || t->resolution % t->patch || t->kpad % 64 || t->kpad < 3 * t->patch * t->patch) return UNIIR_ESHAPE;
+        const int g = t->resolution / t->patch;
+        if (g * g + 1 != t->tokens) return UNIIR_ESHAPE;
+    }
+    return UNIIR_OK;
+}
+
+#define TRY(call)                 \
+    do {                          \
+        const int rc__ = (call);  \
+        if (rc__) return rc__;    \
+    } while (0)
+
+void base_desc(uniir_gemm_desc& d) {
+    memset(&d, 0, sizeof(d));
+    d.k_splits = 1;
+    d.alpha = 1.0f;
+    d.dtype = UNIIR_DT_BF16;
+    d.act = UNIIR_ACT_QUICKGELU;
+}
+
+// y[M,N] = x[M,K] @ w[N,K]^T (+ epilogue)
+int linear_fwd(const void* x, const void* w, void* out, int M, int N, int K, int epi, const float* bias, const float* resid,
+               void* C2, void* st) {
+    uniir_gemm_desc d;
+    base_desc(d);
+    d.A = x; d.B = w; d.C = out; d.C2 = C2; d.bias = bias; d.resid = resid;
+    d.M = M; d.N = N; d.K = K; d.lda = K; d.ldb = K; d.ldc = N; d.epilogue = epi;
+    return uniir_gemm(&d, st);
+}
+
+bool uses_tile256(int M, int N, int K) { return K % 64 == 0 && M >= 256 && N >= 128; }   // gemm_shape() in gemm.hip
+
+// dx[M,K] = dy[M,N] @ w[N,K]  (optionally * act'(aux), act(aux) -> act_out, column sums of dx += colsum)
+int linear_dgrad(const void* dy, const void* w, void* out, int M, int N, int K, const void* aux, void* act_out, float* colsum,
+                 void* st) {
+    const bool t256 = uses_tile256(M, K, N);
+    const bool fused_sum = colsum && aux && t256;
+    void* c2 = act_out;
+    if (act_out && !(aux && t256)) {
+        TRY(uniir_act_fwd(aux, act_out, (int64_t)M * K, UNIIR_ACT_QUICKGELU, st));
+        c2 = nullptr;
+    }
+    uniir_gemm_desc d;
+    base_desc(d);
+    d.A = dy; d.B = w; d.C = out; d.C2 = c2; d.aux = aux; d.ldaux = K;
+    d.M = M; d.N = K; d.K = N; d.lda = N; d.ldb = K; d.ldc = K; d.b_tmaj = 1;
+    d.epilogue = aux ? UNIIR_EPI_DACT : UNIIR_EPI_BF16;
+    d.colsum = fused_sum ? colsum : nullptr;
+    TRY(uniir_gemm(&d, st));
+    if (colsum && !fused_sum) TRY(uniir_colsum_bf16(out, K, colsum, M, K, st));
+    return UNIIR_OK;
+}
+
+int wgrad_splits(int rows, int tiles) {     // ops.wgrad_splits: fill the 256 CUs, >= 16 K steps per split
+    const int ncu = 256;
+    int max_s = rows / (64 * 16);
+    if (max_s < 1) max_s = 1;
+    if (max_s > 64) max_s = 64;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= max_s; ++s) {
+        const int blocks = tiles * s;
+        const int rounds = (blocks + ncu - 1) / ncu;
+        const double eff = (double)blocks / ((double)rounds * ncu);
+        if (blocks >= 0.9 * ncu && eff >= 0.9) return s;
+        if (eff > best_eff + 1e-9) { best = s; best_eff = eff; }
+    }
+    return best;
+}
+
+// dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]
+int linear_wgrad(const uniir_clip_tower* t, const void* dy, const void* x, float* dw, int M, int N, int K, void* st) {
+    uniir_gemm_desc d;
+    base_desc(d);
+    d.A = dy; d.B = x; d.C = dw;
+    d.M = N; d.N = K; d.K = M; d.lda = N; d.ldb = K; d.ldc = K; d.a_tmaj = 1; d.b_tmaj = 1;
+    d.epilogue = UNIIR_EPI_ATOMIC_F32;
+    d.k_splits = wgrad_splits(M, ((N + 255) / 256) * ((K + 255) / 256));
+    if (d.k_splits > 1 && t->splitk_ws && t->splitk_ws_bytes >= (int64_t)4 * d.k_splits * N * K) {
+        d.splitk_ws = t->splitk_ws;
+        d.splitk_ws_bytes = t->splitk_ws_bytes;
+    }
+    return uniir_gemm(&d, st);
+}
+
+struct Lay {
+    float *x, *x2, *lse;
+    void *qkv, *ao, *f, *h1, *h2;
+};
+Lay layer_bufs(const Plan& p, char* ws, int i) {
+    char* b = ws + p.lay0 + p.lay_stride * i;
+    Lay l;
+    l.x = (float*)(b + p.o_x); l.qkv = b + p.o_qkv; l.ao = b + p.o_ao; l.lse = (float*)(b + p.o_lse);
+    l.x2 = (float*)(b + p.o_x2); l.f = b + p.o_f; l.h1 = b + p.o_h1; l.h2 = b + p.o_h2;
+    return l;
+}
+// where the residual stream that ENTERS block i lives (block i's stash slot; the tower output after the last block)
+float* stream_in(const Plan& p, char* ws, int i) {
+    if (i == p.L) return (float*)(ws + p.x_last);
+    if (p.save) return (float*)(ws + p.lay0 + p.lay_stride * i + p.o_x);
+    return (i & 1) ? (float*)(ws + p.x_last) : (float*)(ws + p.lay0 + p.o_x);      // ping-pong without a stash
+}
+
+int blocks_fwd(const uniir_clip_tower* t, const Plan& p, char* ws, void* st) {
+    const int R = p.R, W = p.W;
+    for (int i = 0; i < p.L; ++i) {
+        const uniir_clip_block& b = t->blocks[i];
+        Lay l = layer_bufs(p, ws, i);
+        float* x = stream_in(p, ws, i);
+        float* xn = (!p.save && i + 1 == p.L) ? ((i & 1) ? (float*)(ws + p.lay0 + p.o_x) : (float*)(ws + p.x_last))
+                                               : stream_in(p, ws, i + 1);
+        TRY(uniir_layernorm_fwd(x, W, b.ln1_w, b.ln1_b, l.h1, nullptr, R, W, 1e-5f, st));
+        TRY(linear_fwd(l.h1, b.wqkv16, l.qkv, R, 3 * W, W, UNIIR_EPI_BF16, b.bqkv, nullptr, nullptr, st));
+        TRY(uniir_attention_fwd(l.qkv, l.ao, l.lse, p.M, p.T, p.H, t->is_text ? 1 : 0, st));
+        TRY(linear_fwd(l.ao, b.wo16, l.x2, R, W, W, UNIIR_EPI_RESID_F32, b.bo, x, nullptr, st));
+        TRY(uniir_layernorm_fwd(l.x2, W, b.ln2_w, b.ln2_b, l.h2, nullptr, R, W, 1e-5f, st));
+        TRY(linear_fwd(l.h2, b.wfc16, l.f, R, 4 * W, W, UNIIR_EPI_BIAS_ACT, b.bfc, nullptr, ws + p.g, st));
+        TRY(linear_fwd(ws + p.g, b.wproj16, xn, R, W, 4 * W, UNIIR_EPI_RESID_F32, b.bproj, l.x2, nullptr, st));
+    }
+    return UNIIR_OK;
+}
+
+// the tower output stream after blocks_fwd
+float* stream_out(const Plan& p, char* ws) {
+    if (p.save || (p.L & 1) == 0) return p.save ? (float*)(ws + p.x_last) : (float*)(ws + p.lay0 + p.o_x);
+    return (float*)(ws + p.x_last);
+}
+
+}  // namespace
+
+extern "C" int64_t uniir_clip_tower_workspace_bytes(const uniir_clip_tower* t, int32_t batch, int32_t save_for_backward) {
+    if (check_tower(t, batch)) return -1;
+    return plan(t, batch, save_for_backward != 0).total;
+}
+
+extern "C" int uniir_clip_tower_fwd(const uniir_clip_tower* t, const void* input, int32_t batch, float* emb_out,
+                                    void* workspace, int64_t workspace_bytes, int32_t save_for_backward, void* stream) {
+    TRY(check_tower(t, batch));
+    if (!input || !emb_out || !workspace) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if ((uintptr_t)workspace & 255) return UNIIR_EALIGN;
+    const Plan p = plan(t, batch, save_for_backward != 0);
+    if (workspace_bytes < p.total) return UNIIR_EINVAL;
+    char* ws = (char*)workspace;
+    const int M = p.M, T = p.T, W = p.W, R = p.R;
+    float* x_in = stream_in(p, ws, 0);
+    const int32_t* eot = nullptr;
+    if (!t->is_text) {
+        TRY(uniir_patchify((const float*)input, ws + p.patches, M, t->resolution, t->patch, t->kpad, stream));
+        TRY(linear_fwd(ws + p.patches, t->conv16, ws + p.po, M * p.G, W, t->kpad, UNIIR_EPI_BF16, nullptr, nullptr, nullptr, stream));
+        TRY(uniir_vit_assemble(ws + p.po, t->class_emb, t->pos_emb, (float*)(ws + p.x0), M, T, W, stream));
+        TRY(uniir_layernorm_fwd((float*)(ws + p.x0), W, t->ln_pre_w, t->ln_pre_b, nullptr, x_in, R, W, 1e-5f, stream));
+    } else {
+        TRY(uniir_text_embed((const int32_t*)input, t->token_emb, t->pos_emb, x_in, (int32_t*)(ws + p.eot), M, T, W, t->vocab,
+                             stream));
+        eot = (const int32_t*)(ws + p.eot);
+    }
+    TRY(blocks_fwd(t, p, ws, stream));
+    float* x_out = p.save ? (float*)(ws + p.x_last) : stream_out(p, ws);
+    TRY(uniir_gather_rows(x_out, eot, (float*)(ws + p.rows), M, T, W, stream));
+    TRY(uniir_layernorm_fwd((float*)(ws + p.rows), W, t->ln_post_w, t->ln_post_b, ws + p.pooled, nullptr, M, W, 1e-5f, stream));
+    uniir_gemm_desc d;
+    base_desc(d);
+    d.A = ws + p.pooled; d.B = t->proj16; d.C = emb_out;
+    d.M = M; d.N = p.E; d.K = W; d.lda = W; d.ldb = p.E; d.ldc = p.E; d.b_tmaj = 1; d.epilogue = UNIIR_EPI_F32;
+    return uniir_gemm(&d, stream);
+}
+
+// backward, stage 1: projection, ln_post / ln_final, scatter of the pooled row's gradient into the token stream
+extern "C" int uniir_clip_tower_bwd_head(const uniir_clip_tower* t, const float* demb, int32_t batch, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+    TRY(check_tower(t, batch));
+    if (!demb || !workspace || !t->g_proj || !t->g_ln_post_w || !t->g_ln_post_b) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    const Plan p = plan(t, batch, true);
+    if (workspace_bytes < p.total) return UNIIR_EINVAL;
+    char* ws = (char*)workspace;
+    const int M = p.M, T = p.T, W = p.W, R = p.R, E = p.E;
+    TRY(uniir_cast_f32_to_bf16(demb, ws + p.demb16, (int64_t)M * E, stream));
+    uniir_gemm_desc d;
+    base_desc(d);       // dproj[W,E] += pooled^T @ demb
+    d.A = ws + p.pooled; d.B = ws + p.demb16; d.C = t->g_proj;
+    d.M = W; d.N = E; d.K = M; d.lda = W; d.ldb = E; d.ldc = E; d.a_tmaj = 1; d.b_tmaj = 1; d.epilogue = UNIIR_EPI_ATOMIC_F32;
+    TRY(uniir_gemm(&d, stream));
+    base_desc(d);       // dpooled[M,W] = demb @ proj^T
+    d.A = ws + p.demb16; d.B = t->proj16; d.C = ws + p.dpooled;
+    d.M = M; d.N = W; d.K = E; d.lda = E; d.ldb = E; d.ldc = W; d.epilogue = UNIIR_EPI_BF16;
+    TRY(uniir_gemm(&d, stream));
+    TRY(uniir_layernorm_bwd((float*)(ws + p.rows), W, t->ln_post_w, ws + p.dpooled, 0, nullptr, (float*)(ws + p.drows), W, nullptr,
+                            t->g_ln_post_w, t->g_ln_post_b, nullptr, M, W, 1e-5f, stream));
+    if (hipMemsetAsync(ws + p.dx, 0, (size_t)R * W * 4, (hipStream_t)stream) != hipSuccess) return UNIIR_ELAUNCH;
+    TRY(uniir_scatter_rows((float*)(ws + p.drows), t->is_text ? (const int32_t*)(ws + p.eot) : nullptr, (float*)(ws + p.dx), M, T,
+                           W, stream));
+    TRY(uniir_cast_f32_to_bf16((float*)(ws + p.dx), ws + p.dxb, (int64_t)R * W, stream));
+    // bias gradient of the last block's c_proj: column sums of the incoming gradient (the other blocks get theirs from the
+    // LayerNorm backward that produces their incoming gradient)
+    return uniir_colsum_bf16(ws + p.dxb, W, t->blocks[p.L - 1].g_bproj, R, W, stream);
+}
+
+// backward, stage 2: residual blocks layer_hi-1 ... layer_lo (call with descending ranges that cover [0, layers))
+extern "C" int uniir_clip_tower_bwd_blocks(const uniir_clip_tower* t, int32_t batch, int32_t layer_lo, int32_t layer_hi,
+                                           void* workspace, int64_t workspace_bytes, void* stream) {
+    TRY(check_tower(t, batch));
+    if (!workspace || layer_lo < 0 || layer_hi > t->layers || layer_lo > layer_hi) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    const Plan p = plan(t, batch, true);
+    if (workspace_bytes < p.total) return UNIIR_EINVAL;
+    char* ws = (char*)workspace;
+    const int W = p.W, R = p.R;
+    float* dx = (float*)(ws + p.dx);
+    float* dx2 = (float*)(ws + p.dx2);
+    void *dxb = ws + p.dxb, *g = ws + p.g, *df = ws + p.df, *dh = ws + p.dh, *dqkv = ws + p.dqkv;
+    for (int i = layer_hi - 1; i >= layer_lo; --i) {
+        const uniir_clip_block& b = t->blocks[i];
+        if (!b.g_wqkv || !b.g_bqkv || !b.g_wo || !b.g_bo || !b.g_wfc || !b.g_bfc || !b.g_wproj || !b.g_bproj || !b.g_ln1_w ||
+            !b.g_ln1_b || !b.g_ln2_w || !b.g_ln2_b)
+            return UNIIR_EINVAL;
+        Lay l = layer_bufs(p, ws, i);
+        // d(mlp): df = (dx @ Wproj) * act'(f); the same epilogue re-materialises g = act(f) for dWproj and sums df's columns
+        // into the c_fc bias gradient
+        TRY(linear_dgrad(dxb, b.wproj16, df, R, W, 4 * W, l.f, g, b.g_bfc, stream));
+        TRY(linear_wgrad(t, dxb, g, b.g_wproj, R, W, 4 * W, stream));
+        TRY(linear_wgrad(t, df, l.h2, b.g_wfc, R, 4 * W, W, stream));
+        TRY(linear_dgrad(df, b.wfc16, dh, R, 4 * W, W, nullptr, nullptr, nullptr, stream));            // d ln_2 out
+        TRY(uniir_layernorm_bwd(l.x2, W, b.ln2_w, dh, 0, dx, dx2, W, dxb, b.g_ln2_w, b.g_ln2_b, b.g_bo, R, W, 1e-5f, stream));
+        TRY(linear_wgrad(t, dxb, l.ao, b.g_wo, R, W, W, stream));
+        TRY(linear_dgrad(dxb, b.wo16, dh, R, W, W, nullptr, nullptr, nullptr, stream));                // d attention out
+        TRY(uniir_attention_bwd(l.qkv, l.ao, dh, l.lse, dqkv, p.M, p.T, p.H, t->is_text ? 1 : 0, stream));
+        TRY(linear_wgrad(t, dqkv, l.h1, b.g_wqkv, R, 3 * W, W, stream));
+        TRY(uniir_colsum_bf16(dqkv, 3 * W, b.g_bqkv, R, 3 * W, stream));
+        TRY(linear_dgrad(dqkv, b.wqkv16, dh, R, 3 * W, W, nullptr, nullptr, nullptr, stream));         // d ln_1 out
+        TRY(uniir_layernorm_bwd(l.x, W, b.ln1_w, dh, 0, dx2, dx, W, dxb, b.g_ln1_w, b.g_ln1_b,
+                                i > 0 ? t->blocks[i - 1].g_bproj : nullptr, R, W, 1e-5f, stream));
+    }
+    return UNIIR_OK;
+}
+
+// backward, stage 3: what feeds the first block (ln_pre + patch embedding, or the token / positional embeddings)
+extern "C" int uniir_clip_tower_bwd_stem(const uniir_clip_tower* t, const void* input, int32_t batch, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+    TRY(check_tower(t, batch));
+    if (!workspace || !input) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    const Plan p = plan(t, batch, true);
+    if (workspace_bytes < p.total) return UNIIR_EINVAL;
+    char* ws = (char*)workspace;
+    const int M = p.M, T = p.T, W = p.W, R = p.R;
+    if (t->is_text) {
+        if (!t->g_token || !t->g_pos) return UNIIR_EINVAL;
+        return uniir_text_embed_bwd((const int32_t*)input, (float*)(ws + p.dx), t->g_token, t->g_pos, M, T, W, t->vocab, stream);
+    }
+    if (!t->g_conv || !t->g_class || !t->g_pos || !t->g_ln_pre_w || !t->g_ln_pre_b) return UNIIR_EINVAL;
+    TRY(uniir_layernorm_bwd((float*)(ws + p.x0), W, t->ln_pre_w, ws + p.dx, 1, nullptr, (float*)(ws + p.dx0), W, nullptr,
+                            t->g_ln_pre_w, t->g_ln_pre_b, nullptr, R, W, 1e-5f, stream));
+    TRY(uniir_vit_assemble_bwd((float*)(ws + p.dx0), ws + p.dpo, t->g_class, t->g_pos, M, T, W, stream));
+    if (hipMemsetAsync(ws + p.dconv, 0, (size_t)W * p.kpad * 4, (hipStream_t)stream) != hipSuccess) return UNIIR_ELAUNCH;
+    TRY(linear_wgrad(t, ws + p.dpo, ws + p.patches, (float*)(ws + p.dconv), M * p.G, W, p.kpad, stream));
+    return uniir_unpad_add((float*)(ws + p.dconv), t->g_conv, W, 3 * t->patch * t->patch, p.kpad, stream);
+}
+
+extern "C" int uniir_clip_tower_bwd(const uniir_clip_tower* t, const void* input, const float* demb, int32_t batch,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+    TRY(uniir_clip_tower_bwd_head(t, demb, batch, workspace, workspace_bytes, stream));
+    TRY(uniir_clip_tower_bwd_blocks(t, batch, 0, t->layers, workspace, workspace_bytes, stream));
+    return uniir_clip_tower_bwd_stem(t, input, batch, workspace, workspace_bytes, stream);
+}
