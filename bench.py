@@ -61,9 +61,10 @@ def synth_batch(cfg, pairs, seed, device):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baselines (oracle = "port"; bounded samples, rank 0 at N = 1 only, after the timed region)
 # ------------------------------------------------------------------------------------------------------------------
-def _oracle_step_timer(model_name, pairs, threads, warmup, timed, budget_s):
+def _oracle_step_timer(model_name, pairs, threads, warmup, timed, budget_s, warm_pairs=None):
     """oracle/clip_oracle.py train step (fp32 fwd + bwd + AdamW, the reference's two weight-decay groups) on `threads` host
-    threads; returns (median seconds per step, steps timed)"""
+    threads; returns (median seconds per step, steps timed).  warm_pairs: batch size of the warm-up steps (a smaller batch
+    touches the same code paths / allocator for a fraction of the time)"""
     from oracle import clip_oracle as O
     torch.manual_seed(0)
     prev = torch.get_num_threads()
@@ -75,6 +76,7 @@ def _oracle_step_timer(model_name, pairs, threads, warmup, timed, budget_s):
         opt = torch.optim.AdamW([{"params": [p for _, p in nd], "weight_decay": 0.0},
                                  {"params": [p for _, p in d], "weight_decay": 0.2}], lr=1e-5, betas=(0.9, 0.98), eps=1e-6)
         batch = O.synthetic_batch(cfg, pairs, seed=2023)
+        full_batch, warm_batch = batch, (O.synthetic_batch(cfg, warm_pairs, seed=2023) if warm_pairs else batch)
 
         def step():
             t0 = time.perf_counter()
@@ -89,6 +91,7 @@ def _oracle_step_timer(model_name, pairs, threads, warmup, timed, budget_s):
         t_all = time.perf_counter()
         times = []
         for i in range(warmup + timed):
+            batch = warm_batch if i < warmup else full_batch
             dt = step()
             if i >= warmup:
                 times.append(dt)
@@ -107,12 +110,12 @@ def cpu_baseline(model_name):
     (CLIP_SF ViT-B/32, batch 32, fp32, 1 process) on all cores -- median of 3 after 1 warm-up -- and on 1 core."""
     cores = os.cpu_count() or 1
     threads = torch.get_num_threads()
-    t_l, n_l = _oracle_step_timer(model_name, 8, threads, 1, 2, 40.0)
+    t_l, n_l = _oracle_step_timer(model_name, 8, threads, 1, 1, 60.0, warm_pairs=2)
     t_b, n_b = _oracle_step_timer("ViT-B/32", 32, threads, 1, 3, 40.0)
     t_1, n_1 = _oracle_step_timer("ViT-B/32", 4, 1, 0, 1, 30.0)
     return {"value": round(8 / t_l, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/clip_oracle.py CLIP_SF {model_name} fp32 fwd+bwd+AdamW, 8 pairs/step, median of {n_l} step(s) "
-                      f"after 1 warm-up on {threads} host threads ({cores} logical cores)",
+            "sample": f"oracle/clip_oracle.py CLIP_SF {model_name} fp32 fwd+bwd+AdamW, 8 pairs/step, {n_l} timed step "
+                      f"after a 2-pair warm-up step on {threads} host threads ({cores} logical cores)",
             "config1": {"value": round(32 / t_b, 3), "unit": "pairs/s", "cores": threads,
                         "sample": f"BASELINE configs[0] as written: CLIP_SF ViT-B/32, batch 32, fp32, 1 process, median of {n_b} "
                                   f"steps after 1 warm-up"},
@@ -406,7 +409,7 @@ def main():
     if args.dry_run:
         E = 64
         trainer = _DryRunTrainer(args.pairs, E)
-        batch, timing, model, ops = None, [], None, None
+        batch, timing, model, ops = None, (0.0, 0.0, 0), None, None
         flat = trainer.g32
     else:
         from types import SimpleNamespace
@@ -426,16 +429,15 @@ def main():
     for _ in range(args.warmup):
         out = trainer.train_step(batch)
     barrier()
-    if ops is not None:
-        ops.GEMM_TIMING = [] if rank == 0 else None
+    if ops is not None and rank == 0:
+        ops.gemm_timing_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = trainer.train_step(batch)
     barrier()
     dt = time.perf_counter() - t0
-    if ops is not None:
-        timing = ops.GEMM_TIMING or []
-        ops.GEMM_TIMING = None
+    if ops is not None and rank == 0:
+        timing = ops.gemm_timing_stop()          # (flop, seconds, launches) of the sampled GEMM launches
     loss = float(out["loss"].detach())
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -461,8 +463,7 @@ def main():
         if args.dry_run:
             roof = None
         else:
-            gflop = sum(f for f, _, _ in timing)
-            gtime = sum(e0.elapsed_time(e1) for _, e0, e1 in timing) * 1e-3
+            gflop, gtime, nsamp = timing
             traffic, traffic_note = None, "no rocprofv3 --pmc record for this configuration under profiles/"
             if os.path.exists(PMC_FILE):
                 rec = json.load(open(PMC_FILE))
@@ -473,9 +474,9 @@ def main():
                               "forward, dgrad and wgrad of the towers' linear layers)",
                     "achieved": round(gflop / gtime / 1e12, 2) if gtime > 0 else None, "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(gflop / gtime / MFMA_PEAK_BF16, 4) if gtime > 0 else None,
-                    "traffic": traffic, "traffic_note": traffic_note, "launches_timed": len(timing),
-                    "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} GEMM launches of the timed region bracketed by HIP events on the "
-                                "launch stream (2 event records per sampled launch; < 0.1 % of the step)",
+                    "traffic": traffic, "traffic_note": traffic_note, "launches_timed": nsamp,
+                    "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} uniir_gemm calls of the timed region bracketed by HIP events on the "
+                                "launch stream inside the library (uniir_gemm_timing; 2 event records per sampled launch)",
                     "end_to_end_frac": round(value * FLOP_PER_PAIR[args.model] / (world * MFMA_PEAK_BF16), 4)}
         result = {
             "metric": "query+cand pairs/sec in-batch contrastive (CLIP_SF-L)", "value": round(value, 2),

@@ -77,6 +77,11 @@ typedef struct {
 } uniir_gemm_desc;
 
 int uniir_gemm(const uniir_gemm_desc* d, void* stream);
+/* measurement hook (bench.py): stride > 0 brackets every stride-th uniir_gemm call -- from any caller, the tower entry
+ * points included -- with HIP events on its launch stream; 0 switches it off.  uniir_gemm_timing_read (after a stream
+ * synchronise) returns the sums over the sampled launches: 2 M N K, elapsed ms, count.  Single measuring thread. */
+int uniir_gemm_timing(int32_t stride);
+int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launches);
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] building block 2: LayerNorm over the last dim (fp32 statistics, CLIP eps 1e-5).

@@ -58,10 +58,10 @@ def test_forward_backward_matches_oracle(cfgkw):
     emb_d = model.encode_multimodal_input(dbatch["txt_batched"], dbatch["image_batched"], dbatch["txt_mask_batched"],
                                           dbatch["image_mask_batched"])
     print("OBS tiny emb rel", rel(emb_d, emb_o))
-    assert rel(emb_d, emb_o) < 2e-2, rel(emb_d, emb_o)
+    assert rel(emb_d, emb_o) < 1.2e-2, rel(emb_d, emb_o)          # observed 5.0e-3 / 6.1e-3 (gates at ~2x the observed bf16 error)
     out_d = model(dbatch)
     print("OBS tiny loss diff", abs(out_d["loss"].item() - out_o["loss"].item()))
-    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 3e-2 * max(1.0, abs(out_o["loss"].item()))
+    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 5e-3 * max(1.0, abs(out_o["loss"].item()))    # observed 1.7e-3
     out_d["loss"].backward()
     errs = {}
     for n, p in model.clip_model.named_parameters():
@@ -71,14 +71,14 @@ def test_forward_backward_matches_oracle(cfgkw):
         errs[n] = rel(p.grad, go)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
     print("OBS tiny worst grad rel errs:", worst[:3])
-    big = {n: e for n, e in errs.items() if e > 8e-2}
+    big = {n: e for n, e in errs.items() if e > 4e-2}           # observed worst 1.8e-2
     assert not big, big
     # global gradient direction
     gd = torch.cat([p.grad.flatten().cpu() for n, p in model.clip_model.named_parameters() if n in errs])
     go = torch.cat([getattr(oracle, n.replace(".", "__")).grad.flatten() for n, _ in model.clip_model.named_parameters() if n in errs])
     cos = torch.nn.functional.cosine_similarity(gd, go, dim=0).item()
     print("OBS tiny cos", cos)
-    assert cos > 0.999, cos
+    assert cos > 0.9995, cos
 
 
 def test_train_steps_track_oracle():
@@ -108,12 +108,12 @@ def test_train_steps_track_oracle():
         ld.append(tr.train_step(dbatch)["loss"].item())
     print("OBS traj oracle losses", lo, "device losses", ld)
     for a, b in zip(ld, lo):
-        assert abs(a - b) < 5e-2 * max(1.0, abs(b))
+        assert abs(a - b) < 5e-3 * max(1.0, abs(b))             # observed 1.3e-3
     assert ld[-1] < ld[0]
     # weights after 3 steps
     e = rel(model.clip_model.visual.proj, getattr(oracle, "visual__proj"))
     print("OBS traj weight rel", e)
-    assert e < 2e-2, e
+    assert e < 4e-3, e                                          # observed 1.1e-3
 
 
 def test_no_grad_embedding_path():
@@ -130,7 +130,7 @@ def test_no_grad_embedding_path():
                                       batch["txt_mask_batched"], batch["image_mask_batched"])
     assert ids == dbatch["did_list"]
     print("OBS nograd emb rel", rel(emb, emb_o))
-    assert rel(emb, emb_o) < 2e-2
+    assert rel(emb, emb_o) < 1.2e-2                             # observed 5.2e-3
 
 
 def test_hard_negative_batch_through_the_model():
@@ -160,8 +160,8 @@ def test_hard_negative_batch_through_the_model():
     model.clip_model.zero_grad()
     out_d = model(dbatch)
     out_d["loss"].backward()
-    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 3e-2 * max(1.0, abs(out_o["loss"].item()))
+    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 1.5e-2 * max(1.0, abs(out_o["loss"].item()))   # observed 5.9e-3
     g_d = model.clip_model.visual.proj.grad
     g_o = oracle.visual__proj.grad
     print("OBS hardneg loss diff", abs(out_d["loss"].item() - out_o["loss"].item()), "grad rel", rel(g_d, g_o))
-    assert rel(g_d, g_o) < 8e-2, rel(g_d, g_o)
+    assert rel(g_d, g_o) < 4e-2, rel(g_d, g_o)                  # observed 1.6e-2

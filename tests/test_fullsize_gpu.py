@@ -118,8 +118,8 @@ def test_vit_l14_encoder_row_independence_and_gradient_linearity():
 def test_config1_vit_b32_step_against_the_oracle():
     """BASELINE.json configs[0] (the reference's own CPU-runnable case): real CLIP ViT-B/32 dimensions, a few pairs so
     that the fp32 oracle's forward + backward finishes in seconds on the host; embeddings, loss and every parameter
-    gradient against the oracle at the bf16 tolerances of the tiny-model tests (2e-2 / 3e-2 / 8e-2 relative L2,
-    gradient cosine > 0.999)"""
+    gradient against the oracle, gates at ~2x the observed bf16 error (1.2e-2 / 5e-3 / 1e-1 relative L2, gradient
+    cosine > 0.9995); the same configuration at batch 32 in fp32 meets the north-star 1e-3 in tests/test_fp32_parity_gpu.py"""
     import os
     import sys
     from types import SimpleNamespace
@@ -152,10 +152,10 @@ def test_config1_vit_b32_step_against_the_oracle():
         return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
     print("OBS b32 emb rel", rel(emb_d, emb_o))
-    assert rel(emb_d, emb_o) < 2e-2, rel(emb_d, emb_o)
+    assert rel(emb_d, emb_o) < 1.2e-2, rel(emb_d, emb_o)          # observed 5.9e-3
     out_d = model(dbatch)
     print("OBS b32 loss diff", abs(out_d["loss"].item() - out_o["loss"].item()))
-    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 3e-2 * max(1.0, abs(out_o["loss"].item()))
+    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 5e-3 * max(1.0, abs(out_o["loss"].item()))    # observed 1.0e-3
     assert out_d["accuracy"].item() == out_o["accuracy"].item()
     out_d["loss"].backward()
     errs, gd, go = {}, [], []
@@ -167,6 +167,6 @@ def test_config1_vit_b32_step_against_the_oracle():
         gd.append(p.grad.flatten().cpu())
         go.append(g.flatten())
     print("OBS b32 worst grad", max(errs.values()), "cos", torch.nn.functional.cosine_similarity(torch.cat(gd), torch.cat(go), dim=0).item())
-    big = {n: e for n, e in errs.items() if e > 8e-2}
+    big = {n: e for n, e in errs.items() if e > 1e-1}           # observed worst 6.5e-2 (a bias gradient summed over 8 items)
     assert not big, big
-    assert torch.nn.functional.cosine_similarity(torch.cat(gd), torch.cat(go), dim=0).item() > 0.999
+    assert torch.nn.functional.cosine_similarity(torch.cat(gd), torch.cat(go), dim=0).item() > 0.9995

@@ -278,3 +278,108 @@ def test_clip_load_refuses_missing_pretrained_weights(tmp_path, monkeypatch):
     monkeypatch.setenv("UNIIR_ALLOW_RANDOM_INIT", "1")
     with pytest.warns(UserWarning):
         clip_front.load("tiny-missing", device=None, download_root=str(tmp_path))
+
+
+# the key sets of the reference's large CLIP_SF configs (train/inbatch/inbatch.yaml, eval/inbatch/{embed,index,retrieval}.yaml,
+# SURVEY.md section 5.6): key NAMES are the drop-in surface; the values below are this test's own
+_YAML_KEYS = {
+    "inbatch": """experiment.instruct_status experiment.exp_name experiment.description experiment.path_suffix wandb_config.enabled
+        wandb_config.experiment_name logger_config.logger_out_dir logger_config.logger_out_file_name data_config.image_size
+        data_config.hard_neg_num data_config.in_batch_neg_num data_config.shuffle_cand data_config.returns
+        data_config.enable_query_instruct data_config.query_instruct_path data_config.train_query_data_path
+        data_config.train_cand_pool_path data_config.val_query_data_path data_config.val_cand_pool_path
+        dataloader_config.num_workers dataloader_config.train_batch_size dataloader_config.valid_batch_size
+        trainer_config.gradient_accumulation_steps trainer_config.num_train_epochs trainer_config.learning_rate
+        trainer_config.warmup_steps trainer_config.eval_steps trainer_config.print_freq evaluator.enable_eval
+        evaluator.eval_freq evaluator.print_freq model.name model.short_name model.size model.clip_vision_model_name
+        model.pretrained_clip_model_dir model.gather_embeddings model.ckpt_config.ckpt_dir model.ckpt_config.resume_training
+        model.ckpt_config.ckpt_name seed dist_config.dist_url""",
+    "embed": """experiment.instruct_status experiment.exp_name experiment.description experiment.path_suffix
+        embed_config.embed_dir_name embed_config.use_fp16 embed_config.train_datasets_config.enable_embed
+        embed_config.train_datasets_config.datasets_name embed_config.train_datasets_config.correspond_cand_pools_name
+        embed_config.val_datasets_config.enable_embed embed_config.val_datasets_config.datasets_name
+        embed_config.val_datasets_config.correspond_cand_pools_name embed_config.test_datasets_config.enable_embed
+        embed_config.test_datasets_config.datasets_name embed_config.test_datasets_config.correspond_cand_pools_name
+        embed_config.cand_pools_config.enable_embed embed_config.cand_pools_config.embed_union_pool
+        embed_config.cand_pools_config.cand_pools_name_to_embed dataloader_config.num_workers dataloader_config.batch_size
+        model.name model.short_name model.size model.clip_vision_model_name model.pretrained_clip_model_dir
+        model.ckpt_config.ckpt_dir model.ckpt_config.ckpt_name data_config.image_size data_config.shuffle_cand
+        data_config.train_dir_name data_config.val_dir_name data_config.test_dir_name data_config.cand_pool_dir_name
+        data_config.query_instruct_path dist_config.dist_url seed""",
+    "index": """experiment.instruct_status experiment.exp_name experiment.description experiment.path_suffix
+        index_config.faiss_config.idx_type index_config.faiss_config.dim index_config.faiss_config.metric
+        index_config.embed_dir_name index_config.index_dir_name index_config.cand_pools_config.enable_idx
+        index_config.cand_pools_config.cand_pools_name_to_idx model.name model.short_name model.size""",
+    "retrieval": """experiment.instruct_status experiment.exp_name experiment.description experiment.path_suffix
+        retrieval_config.embed_dir_name retrieval_config.index_dir_name retrieval_config.results_dir_name
+        retrieval_config.qrel_dir_name retrieval_config.write_to_tsv retrieval_config.raw_retrieval
+        retrieval_config.retrieve_image_text_pairs retrieval_config.query_dir_name retrieval_config.candidate_dir_name
+        retrieval_config.train_datasets_config.enable_retrieve retrieval_config.train_datasets_config.datasets_name
+        retrieval_config.train_datasets_config.correspond_cand_pools_name retrieval_config.val_datasets_config.enable_retrieve
+        retrieval_config.val_datasets_config.datasets_name retrieval_config.val_datasets_config.correspond_cand_pools_name
+        retrieval_config.val_datasets_config.correspond_qrels_name retrieval_config.test_datasets_config.enable_retrieve
+        retrieval_config.test_datasets_config.datasets_name retrieval_config.test_datasets_config.correspond_cand_pools_name
+        retrieval_config.test_datasets_config.correspond_qrels_name retrieval_config.test_datasets_config.correspond_metrics_name
+        model.name model.short_name model.size""",
+}
+
+
+def _value_for(key):
+    leaf = key.rsplit(".", 1)[-1]
+    special = {"experiment.path_suffix": "${model.short_name}/${model.size}/${experiment.instruct_status}/${experiment.exp_name}/",
+               "wandb_config.experiment_name": "${experiment.description}", "trainer_config.learning_rate": "1e-5",
+               "data_config.image_size": "224, 224", "model.short_name": "CLIP_SF", "model.size": "Large",
+               "experiment.instruct_status": "Instruct", "experiment.exp_name": "InBatch", "experiment.description": "toy run",
+               "model.clip_vision_model_name": "ViT-L/14", "index_config.faiss_config.dim": 768, "seed": 2023,
+               "dist_config.dist_url": "env://", "data_config.returns": None}
+    if key in special:
+        return special[key]
+    if leaf.startswith("enable") or leaf in ("use_fp16", "shuffle_cand", "write_to_tsv", "raw_retrieval", "gather_embeddings",
+                                            "resume_training", "embed_union_pool", "enabled", "retrieve_image_text_pairs"):
+        return True
+    if leaf.endswith("_name") and ("datasets" in leaf or "pools" in leaf or "qrels" in leaf or "metrics" in leaf):
+        return ["visualnews_task0", "mscoco_task3"] if "metrics" not in leaf else ["Recall@1, Recall@5", "Recall@10"]
+    if leaf.startswith("cand_pools_name"):
+        return ["visualnews_task0", "UNION"]
+    if leaf in ("num_workers", "train_batch_size", "valid_batch_size", "batch_size", "gradient_accumulation_steps", "num_train_epochs",
+                "warmup_steps", "eval_steps", "print_freq", "eval_freq", "hard_neg_num", "in_batch_neg_num"):
+        return 5
+    return f"some/{leaf}"
+
+
+def test_config_loader_takes_the_full_key_set_of_the_reference_yamls(tmp_path):
+    """every key of the reference's large inbatch / embed / index / retrieval YAMLs survives common/config.py with its type:
+    ${a.b} interpolation inside and across sections, scientific-notation floats, lists, nulls, booleans, nested sections,
+    assignment of uniir_dir / dist_config.gpu_id the way the entry points do it, and to_yaml round trip"""
+    import sys
+    import yaml
+    sys.path.insert(0, os.path.join(ROOT, "uniir_amd", "src", "common"))
+    from config import OmegaConf
+    for name, keys in _YAML_KEYS.items():
+        tree = {}
+        for key in keys.split():
+            node = tree
+            parts = key.split(".")
+            for part in parts[:-1]:
+                node = node.setdefault(part, {})
+            node[parts[-1]] = _value_for(key)
+        path = tmp_path / f"{name}.yaml"
+        path.write_text(yaml.safe_dump(tree, sort_keys=False))
+        cfg = OmegaConf.load(str(path))
+        for key in keys.split():
+            cur = cfg
+            for part in key.split("."):
+                cur = getattr(cur, part)                     # attribute access all the way down
+        assert cfg.experiment.path_suffix == "CLIP_SF/Large/Instruct/InBatch/"
+        assert cfg.model.size == "Large" and isinstance(cfg.model, dict)
+        if name == "inbatch":
+            assert cfg.trainer_config.learning_rate == 1e-5 and isinstance(cfg.trainer_config.learning_rate, float)
+            assert cfg.wandb_config.experiment_name == "toy run" and cfg.data_config.returns is None
+            assert cfg.model.gather_embeddings is True and cfg.seed == 2023
+            cfg.uniir_dir, cfg.mbeir_data_dir = "/data/UniIR", "/data/M-BEIR"
+            cfg.dist_config.gpu_id, cfg.dist_config.distributed_mode = 3, True
+            assert cfg.dist_config.gpu_id == 3 and cfg.dist_config.dist_url == "env://"
+        if name == "retrieval":
+            assert cfg.retrieval_config.test_datasets_config.correspond_metrics_name == ["Recall@1, Recall@5", "Recall@10"]
+        again = yaml.safe_load(OmegaConf.to_yaml(cfg))
+        assert again["experiment"]["path_suffix"] == "CLIP_SF/Large/Instruct/InBatch/"

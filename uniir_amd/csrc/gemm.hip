@@ -570,7 +570,60 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// Measurement hook (bench.py roofline): every `stride`-th uniir_gemm call is bracketed by a pair of HIP events on the stream
+// it is launched on, whoever the caller is (the C towers of tower.hip or a host-language loop).  Host-side bookkeeping only;
+// not thread-safe (one measuring thread), off by default.
+#define GT_MAX 4096
+static struct {
+    int stride = 0;
+    long counter = 0;
+    int n = 0;
+    bool created = false;
+    hipEvent_t ev[2 * GT_MAX];
+    double flop[GT_MAX];
+} g_gt;
+extern "C" int uniir_gemm_timing(int32_t stride) {
+    if (stride < 0) return UNIIR_EINVAL;
+    if (stride > 0 && !g_gt.created) {
+        for (int i = 0; i < 2 * GT_MAX; ++i)
+            if (hipEventCreate(&g_gt.ev[i]) != hipSuccess) return UNIIR_ELAUNCH;
+        g_gt.created = true;
+    }
+    g_gt.stride = stride;
+    g_gt.counter = 0;
+    g_gt.n = 0;
+    return UNIIR_OK;
+}
+// sums over the sampled launches (call after synchronising the stream): algorithmic 2 M N K, elapsed milliseconds, count
+extern "C" int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launches) {
+    if (!flop || !ms || !launches) return UNIIR_EINVAL;
+    double f = 0.0, t = 0.0;
+    for (int i = 0; i < g_gt.n; ++i) {
+        float e = 0.f;
+        if (hipEventElapsedTime(&e, g_gt.ev[2 * i], g_gt.ev[2 * i + 1]) != hipSuccess) return UNIIR_ELAUNCH;
+        f += g_gt.flop[i];
+        t += e;
+    }
+    *flop = f; *ms = t; *launches = g_gt.n;
+    return UNIIR_OK;
+}
+
+static int gemm_impl(const uniir_gemm_desc* d, void* stream);
 extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
+    const bool sample = g_gt.stride > 0 && d && (++g_gt.counter % g_gt.stride) == 0 && g_gt.n < GT_MAX;
+    if (!sample) return gemm_impl(d, stream);
+    const int i = g_gt.n;
+    (void)hipEventRecord(g_gt.ev[2 * i], (hipStream_t)stream);
+    const int rc = gemm_impl(d, stream);
+    (void)hipEventRecord(g_gt.ev[2 * i + 1], (hipStream_t)stream);
+    if (rc == UNIIR_OK) {
+        g_gt.flop[i] = 2.0 * d->M * d->N * d->K;
+        g_gt.n = i + 1;
+    }
+    return rc;
+}
+
+static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return UNIIR_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->k_splits < 1) return UNIIR_EINVAL;
     if (d->epilogue < 0 || d->epilogue > UNIIR_EPI_ATOMIC_F32) return UNIIR_EINVAL;

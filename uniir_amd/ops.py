@@ -11,9 +11,21 @@ from ._lib import GemmDesc, check
 EPI_BF16, EPI_BIAS_ACT, EPI_RESID_F32, EPI_DACT, EPI_F32, EPI_ATOMIC_F32 = range(6)
 ACT_QUICKGELU, ACT_GELU_ERF, ACT_RELU = range(3)
 DT_BF16, DT_F16 = 0, 1
-GEMM_TIMING = None  # bench.py sets this to a list to collect (flops, start_event, end_event) of sampled GEMM launches
-GEMM_TIMING_STRIDE = 53   # 2 event records per sampled launch; 441 GEMM launches per step and 441 % 53 = 17, so every shape is sampled over a few steps
-_GEMM_COUNTER = [0]
+GEMM_TIMING_STRIDE = 29   # bench.py: every 29th uniir_gemm call is bracketed by HIP events inside the library (uniir_gemm_timing);
+# 441 GEMM launches per step and 441 % 29 = 6, so the sampled positions walk through every shape within a few steps
+
+
+def gemm_timing_start(stride=GEMM_TIMING_STRIDE):
+    check(_lib.load().uniir_gemm_timing(int(stride)), "gemm_timing")
+
+
+def gemm_timing_stop():
+    """-> (sum of 2 M N K, seconds, launches) over the sampled GEMM launches; synchronise the stream first"""
+    f, ms, n = C.c_double(), C.c_double(), C.c_int32()
+    check(_lib.load().uniir_gemm_timing_read(C.byref(f), C.byref(ms), C.byref(n)), "gemm_timing_read")
+    check(_lib.load().uniir_gemm_timing(0), "gemm_timing")
+    return f.value, ms.value * 1e-3, n.value
+
 
 
 def _stream():
@@ -62,14 +74,6 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epi
     if k_splits > 1:
         ws = _splitk_workspace(A.device, 4 * k_splits * M * N)
         d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
-    _GEMM_COUNTER[0] += 1
-    if GEMM_TIMING is not None and _GEMM_COUNTER[0] % GEMM_TIMING_STRIDE == 0:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(_lib.load().uniir_gemm(C.byref(d), _stream()), "gemm")
-        e1.record()
-        GEMM_TIMING.append((2.0 * M * N * K, e0, e1))
-        return C_out
     check(_lib.load().uniir_gemm(C.byref(d), _stream()), "gemm")
     return C_out
 
