@@ -1,0 +1,15 @@
+#!/bin/bash
+# per-kernel rocprofv3 table of one shard search (700k x 768 fp16, k = 10) at several query counts -> gpurun_out/topk_table.txt
+# usage (GPU box): bash tools/topk_table.sh
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/topk_table.txt
+: > $OUT
+for NQ in 16 64 128 1024; do
+  rm -rf /tmp/tkp_$NQ
+  NQ=$NQ rocprofv3 --kernel-trace --stats -d /tmp/tkp_$NQ -o t -- python $R/tools/topk_prof.py > /dev/null 2>&1
+  DB=$(find /tmp/tkp_$NQ -name "*_results.db" | head -1)
+  echo "## nq = $NQ (4 searches; pool 700000 x 768 fp16 = 1.075 GB per sweep)" >> $OUT
+  python $R/tools/rocpd_summary.py $DB | grep -v "randn\|distribution\|copyBuffer\|vectorized\|^# rocprofv3" | head -14 >> $OUT
+done
+cat $OUT
