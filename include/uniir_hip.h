@@ -51,7 +51,9 @@ enum {
     UNIIR_EPI_RESID_F32 = 2,     /* C(f32) = v + bias? + resid(f32, ldc) ; C2(bf16 copy) optional */
     UNIIR_EPI_DACT = 3,          /* C(bf16) = v * act'(aux[m][n]) (aux bf16, ldaux); C2(bf16, ldaux) = act(aux) opt. */
     UNIIR_EPI_F32 = 4,           /* C(f32) = v  (beta = 0)                                        */
-    UNIIR_EPI_ATOMIC_F32 = 5     /* C(f32) += v via atomics; enables split-K (wgrad accumulate)  */
+    UNIIR_EPI_ATOMIC_F32 = 5,    /* C(f32) += v via atomics; enables split-K (wgrad accumulate)  */
+    UNIIR_EPI_ACT_ONLY = 6       /* C(bf16) = act(bf16(v + bias)): BIAS_ACT without the pre-activation output (forward-only
+                                    passes: embedding extraction); same rounding as BIAS_ACT's second output */
 };
 enum { UNIIR_ACT_QUICKGELU = 0, UNIIR_ACT_GELU_ERF = 1, UNIIR_ACT_RELU = 2 };
 enum { UNIIR_DT_BF16 = 0, UNIIR_DT_F16 = 1 };

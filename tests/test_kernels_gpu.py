@@ -74,6 +74,16 @@ def test_gemm_epilogues():
     assert rel_err(f, fref) < 4e-3
     gref = f.float() * torch.sigmoid(1.702 * f.float())
     assert rel_err(g, gref) < 4e-3
+    # ACT_ONLY (forward-only passes): BIAS_ACT's second output alone, bit for bit, on the 256-tile and the general kernel,
+    # QuickGELU and erf-GELU, ragged edges
+    for (m2, n2, k2) in ((M, N, K), (1000, 520, 192), (100, 72, 40)):
+        x2, w2_ = bf(torch.randn(m2, k2, device=DEV)), bf(torch.randn(n2, k2, device=DEV) * 0.1)
+        b2 = torch.randn(n2, device=DEV)
+        for act in (ops.ACT_QUICKGELU, ops.ACT_GELU_ERF):
+            g2 = torch.empty(m2, n2, device=DEV, dtype=torch.bfloat16)
+            ops.linear_fwd(x2, w2_, b2, epilogue=ops.EPI_BIAS_ACT, C2=g2, act=act)
+            only = ops.linear_fwd(x2, w2_, b2, epilogue=ops.EPI_ACT_ONLY, act=act)
+            assert only.dtype == torch.bfloat16 and torch.equal(only, g2)
     # residual fp32
     res = torch.randn(M, N, device=DEV)
     y = ops.linear_fwd(x, w, bias, epilogue=ops.EPI_RESID_F32, resid=res)

@@ -328,8 +328,12 @@ def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5,
             ops.dropout_f32(x2, 0.0, 0, resid=x, out_f32=x2, rowscale=rowscale[i, 0], rows_per_scale=T)
         h2 = torch.empty(R, W, device=dev, dtype=torch.bfloat16) if save else h
         ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), eps, out_bf16=h2, rows=R, width=W)
-        f = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
-        ops.linear_fwd(h2, b.w16("wfc"), b.p32("bfc"), out=f, epilogue=ops.EPI_BIAS_ACT, C2=g, act=act)
+        if save:
+            f = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
+            ops.linear_fwd(h2, b.w16("wfc"), b.p32("bfc"), out=f, epilogue=ops.EPI_BIAS_ACT, C2=g, act=act)
+        else:       # forward only: the pre-activation is not needed, only act(f) is written
+            f = None
+            ops.linear_fwd(h2, b.w16("wfc"), b.p32("bfc"), out=g, epilogue=ops.EPI_ACT_ONLY, act=act)
         if rowscale is None:
             xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32, resid=x2)
         else:

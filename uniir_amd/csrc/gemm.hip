@@ -23,6 +23,7 @@ struct GemmKArgs {
     int asm_loop;   // 1 counted-lgkmcnt double-buffer loop, 2 ping-pong loop
     float* colsum;  // optional [N]: += column sums of the fp32 result (bias gradient), 256-tile staged epilogue only
     int raster_gm, raster_cw;   // 2-D tile rasterisation block (row panels x column panels), 0 = row-major
+    int skip_f;                 // EPI_BIAS_ACT without the pre-activation store (UNIIR_EPI_ACT_ONLY: forward-only passes)
 };
 
 DEVINL float act_fwd(float x, int act) {
@@ -61,7 +62,7 @@ DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[MT][NT], int 
                     *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
                 } else if (EPI == UNIIR_EPI_BIAS_ACT) {
                     u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
+                    if (!p.skip_f) *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
                     const float g0 = act_fwd(__uint_as_float(o[0] << 16), p.act);
                     const float g1 = act_fwd(__uint_as_float(o[0] & 0xffff0000u), p.act);
                     const float g2 = act_fwd(__uint_as_float(o[1] << 16), p.act);
@@ -209,12 +210,12 @@ DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long of
 // bf16 copy-out with the activation copy (EPI_BIAS_ACT): C <- f, C2 <- act(f)
 template <int ACT>
 DEVINL void epi_bf16_copy_act(const char* src, unsigned short* c1, unsigned short* c2, long rstep, bool full, bool colok,
-                              int rows_left) {
+                              int rows_left, bool skip_f) {
 #pragma unroll 2
     for (int it = 0; it < 16; ++it) {
         if (full || (colok && 16 * it < rows_left)) {
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + it * 8192);
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1));
+            if (!skip_f) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1));
             u32x4_t g;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -288,11 +289,11 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
                 c1 += rstep;
             }
         } else if (p.act == UNIIR_ACT_QUICKGELU) {
-            epi_bf16_copy_act<UNIIR_ACT_QUICKGELU>(src, c1, c2, rstep, full, colok, rows_left);
+            epi_bf16_copy_act<UNIIR_ACT_QUICKGELU>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
         } else if (p.act == UNIIR_ACT_GELU_ERF) {
-            epi_bf16_copy_act<UNIIR_ACT_GELU_ERF>(src, c1, c2, rstep, full, colok, rows_left);
+            epi_bf16_copy_act<UNIIR_ACT_GELU_ERF>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
         } else {
-            epi_bf16_copy_act<UNIIR_ACT_RELU>(src, c1, c2, rstep, full, colok, rows_left);
+            epi_bf16_copy_act<UNIIR_ACT_RELU>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
         }
         return;
     }
@@ -626,8 +627,9 @@ extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
 static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return UNIIR_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->k_splits < 1) return UNIIR_EINVAL;
-    if (d->epilogue < 0 || d->epilogue > UNIIR_EPI_ATOMIC_F32) return UNIIR_EINVAL;
+    if (d->epilogue < 0 || d->epilogue > UNIIR_EPI_ACT_ONLY) return UNIIR_EINVAL;
     if (d->k_splits > 1 && d->epilogue != UNIIR_EPI_ATOMIC_F32) return UNIIR_EINVAL;
+    if (d->epilogue == UNIIR_EPI_ACT_ONLY && d->C2) return UNIIR_EINVAL;
     if (d->epilogue == UNIIR_EPI_BIAS_ACT && !d->C2) return UNIIR_EINVAL;
     if (d->epilogue == UNIIR_EPI_DACT && !d->aux) return UNIIR_EINVAL;
     if (d->N % 8) return UNIIR_ESHAPE;
@@ -649,6 +651,12 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldaux = d->ldaux;
     a.epilogue = d->epilogue; a.act = d->act; a.k_splits = d->k_splits;
+    a.skip_f = 0;
+    if (d->epilogue == UNIIR_EPI_ACT_ONLY) {      // the BIAS_ACT epilogue without its first output: C receives act(v + bias)
+        a.epilogue = UNIIR_EPI_BIAS_ACT;
+        a.C2 = d->C;
+        a.skip_f = 1;
+    }
     a.tiles_m = (d->M + GEMM_BM - 1) / GEMM_BM;
     a.tiles_n = (d->N + GEMM_BN - 1) / GEMM_BN;
     a.alpha = d->alpha;

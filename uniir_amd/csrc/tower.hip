@@ -206,7 +206,10 @@ int blocks_fwd(const uniir_clip_tower* t, const Plan& p, char* ws, void* st) {
         TRY(uniir_attention_fwd(l.qkv, l.ao, l.lse, p.M, p.T, p.H, t->is_text ? 1 : 0, st));
         TRY(linear_fwd(l.ao, b.wo16, l.x2, R, W, W, UNIIR_EPI_RESID_F32, b.bo, x, nullptr, st));
         TRY(uniir_layernorm_fwd(l.x2, W, b.ln2_w, b.ln2_b, l.h2, nullptr, R, W, 1e-5f, st));
-        TRY(linear_fwd(l.h2, b.wfc16, l.f, R, 4 * W, W, UNIIR_EPI_BIAS_ACT, b.bfc, nullptr, ws + p.g, st));
+        if (p.save)      // f (pre-activation) is stashed for the backward; a forward-only pass writes act(f) alone
+            TRY(linear_fwd(l.h2, b.wfc16, l.f, R, 4 * W, W, UNIIR_EPI_BIAS_ACT, b.bfc, nullptr, ws + p.g, st));
+        else
+            TRY(linear_fwd(l.h2, b.wfc16, ws + p.g, R, 4 * W, W, UNIIR_EPI_ACT_ONLY, b.bfc, nullptr, nullptr, st));
         TRY(linear_fwd(ws + p.g, b.wproj16, xn, R, W, 4 * W, UNIIR_EPI_RESID_F32, b.bproj, l.x2, nullptr, st));
     }
     return UNIIR_OK;

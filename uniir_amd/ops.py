@@ -8,7 +8,7 @@ import torch
 from . import _lib
 from ._lib import GemmDesc, check
 
-EPI_BF16, EPI_BIAS_ACT, EPI_RESID_F32, EPI_DACT, EPI_F32, EPI_ATOMIC_F32 = range(6)
+EPI_BF16, EPI_BIAS_ACT, EPI_RESID_F32, EPI_DACT, EPI_F32, EPI_ATOMIC_F32, EPI_ACT_ONLY = range(7)
 ACT_QUICKGELU, ACT_GELU_ERF, ACT_RELU = range(3)
 DT_BF16, DT_F16 = 0, 1
 GEMM_TIMING_STRIDE = 29   # bench.py: every 29th uniir_gemm call is bracketed by HIP events inside the library (uniir_gemm_timing);
