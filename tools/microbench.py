@@ -30,7 +30,7 @@ def attn_only(items):
         dqkv = torch.empty_like(qkv)
         t2 = timeit(lambda: ops.attention_bwd(qkv, out, do, lse, b, T, H, causal, dqkv=dqkv), iters=20)
         print(f"attn T={T} H={H} b={b} causal={causal}: fwd {t*1e3:.3f} ms {fl/t/1e12:.1f} TF/s | bwd {t2*1e3:.3f} ms {2.5*fl/t2/1e12:.1f} TF/s "
-              f"(split={os.environ.get('UNIIR_ATTN_SPLIT', '1')})")
+              f"(legacy_stage={os.environ.get('UNIIR_ATTN_LEGACY_STAGE', '0')})")
     # BLIP MED cross-attention: 100 text queries x 197 image keys, 12 heads
     b, tq, tk, H = items, 100, 197, 12
     W = H * 64

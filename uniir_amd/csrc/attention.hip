@@ -12,6 +12,7 @@
 //                    accumulators (k-slots permuted consistently on both operands).
 #include "common.h"
 #include "../../include/uniir_hip.h"
+#include <stdlib.h>
 
 #define ATT_D 64
 #define SCALE_LOG2E 0.18033688011112042f  // (1/sqrt(64)) * log2(e)
@@ -26,8 +27,7 @@ DEVINL int swz_off(int row, int col) {  // byte offset of element (row, col) in 
 #define ATT_THREADS 512
 #define ATT_WAVES (ATT_THREADS / 64)
 
-// stage rows [0, Tp) of a [T][64] bf16 head slice (row stride `ld` elements) into swizzled LDS, zero padded.
-// Loads are issued 4 deep from clamped (always valid) addresses; the zero-select happens at the LDS store.
+// legacy staging (A/B switch UNIIR_ATTN_LEGACY_STAGE=1): one slice, loads 4 deep, one HBM round trip per 2048 chunks
 DEVINL void stage_head(char* lds, const unsigned short* __restrict__ src, long ld, int T, int Tp, int tid) {
     const int total = Tp * 8;
     for (int c0 = 0; c0 < total; c0 += 4 * ATT_THREADS) {
@@ -48,6 +48,50 @@ DEVINL void stage_head(char* lds, const unsigned short* __restrict__ src, long l
             }
         }
     }
+}
+// stage rows [0, Tp) of TWO [T][64] bf16 head slices (row stride `ld` elements each) into swizzled LDS, zero padded.
+// ALL loads of both slices are issued before the first LDS store (one HBM round trip per staging instead of one per 2048
+// chunks and slice -- four at 257 tokens; the PMC anatomy in profiles/r02_attention_pmc.txt shows the waves parked on
+// exactly these waits); loads come from clamped (always valid) addresses, the zero-select happens at the LDS store.
+// NL = 16-B loads per thread and slice: ceil(Tp * 8 / ATT_THREADS) <= 8 for Tp <= 512.
+// `mid` runs between the loads and the LDS stores: independent work (the backward's per-row statistics with their own global
+// loads) that then shares the staging's HBM round trip instead of adding one.
+template <int NL, class F>
+DEVINL void stage_two_n(char* ldsA, const unsigned short* __restrict__ srcA, long ldA, char* ldsB,
+                        const unsigned short* __restrict__ srcB, long ldB, int T, int Tp, int tid, F&& mid) {
+    const int total = Tp * 8;
+    u32x4_t va[NL], vb[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int c = u * ATT_THREADS + tid;
+        const int row = min(c >> 3, T - 1), kc = c & 7;
+        va[u] = *reinterpret_cast<const u32x4_t*>(srcA + (long)row * ldA + kc * 8);
+        vb[u] = *reinterpret_cast<const u32x4_t*>(srcB + (long)row * ldB + kc * 8);
+    }
+    mid();
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int c = u * ATT_THREADS + tid;
+        const int row = c >> 3, kc = c & 7;
+        if (c < total) {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            const int off = row * 128 + ((kc ^ (row & 7)) << 4);
+            *reinterpret_cast<u32x4_t*>(ldsA + off) = (row < T) ? va[u] : z;
+            *reinterpret_cast<u32x4_t*>(ldsB + off) = (row < T) ? vb[u] : z;
+        }
+    }
+}
+template <class F>
+DEVINL void stage_two(char* ldsA, const unsigned short* __restrict__ srcA, long ldA, char* ldsB,
+                      const unsigned short* __restrict__ srcB, long ldB, int T, int Tp, int tid, F&& mid) {
+    const int nl = (Tp * 8 + ATT_THREADS - 1) / ATT_THREADS;       // wave-uniform
+    if (nl <= 2) stage_two_n<2>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
+    else if (nl <= 5) stage_two_n<5>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
+    else stage_two_n<8>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
+}
+DEVINL void stage_two(char* ldsA, const unsigned short* __restrict__ srcA, long ldA, char* ldsB,
+                      const unsigned short* __restrict__ srcB, long ldB, int T, int Tp, int tid) {
+    stage_two(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, [] {});
 }
 // b128 fragment: 8 consecutive d (k-step s) of row r0 + (lane&15)
 DEVINL bf16x8_t frag_rows(const char* lds, int r0, int s, int lane) {
@@ -107,6 +151,7 @@ struct AttnArgs {
     // mask(seed, ((m H + h) Tq + q) Tk + key) (common.h drop_hash); the softmax statistics stay those of the full P
     float drop_p;
     unsigned drop_seed;
+    int legacy_stage;             // 1 = one slice at a time, statistics before it (see launch_attn_bwd for when)
 };
 
 template <bool REL, bool DROP>
@@ -128,16 +173,29 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     float* dbias = reinterpret_cast<float*>(lds + 2 * Tkp * 128);    // bias of every diagonal key - query (x log2 e)
     if (REL)
         for (int d = tid; d < Tq + Tk - 1; d += ATT_THREADS) dbias[d] = a.rel_emb[a.rel_bucket[d] * H + h] * LOG2EF;
-    stage_head(ldsK, kbase, a.kv_ld, Tk, Tkp, tid);
-    stage_head(ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
-    __syncthreads();
     const int nqt = (Tq + 15) >> 4;
     const int qi = lane & 15, g = lane >> 4;
+    // the query fragments of a tile come straight from global memory: the first tile's ride the staging round trip, every
+    // further tile's are fetched while the previous tile computes
+    bf16x8_t qnext[2];
+    qnext[0] = frag_rows_global(qbase, a.q_ld, w * 16, 0, lane, Tq);
+    qnext[1] = frag_rows_global(qbase, a.q_ld, w * 16, 1, lane, Tq);
+    if (a.legacy_stage) {
+        stage_head(ldsK, kbase, a.kv_ld, Tk, Tkp, tid);
+        stage_head(ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
+    } else {
+        stage_two(ldsK, kbase, a.kv_ld, ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
+    }
+    __syncthreads();
     for (int qt = w; qt < nqt; qt += ATT_WAVES) {
         const int q0 = qt * 16, q = q0 + qi;
         bf16x8_t qf[2];
-        qf[0] = frag_rows_global(qbase, a.q_ld, q0, 0, lane, Tq);
-        qf[1] = frag_rows_global(qbase, a.q_ld, q0, 1, lane, Tq);
+        qf[0] = qnext[0];
+        qf[1] = qnext[1];
+        if (qt + ATT_WAVES < nqt) {
+            qnext[0] = frag_rows_global(qbase, a.q_ld, q0 + 16 * ATT_WAVES, 0, lane, Tq);
+            qnext[1] = frag_rows_global(qbase, a.q_ld, q0 + 16 * ATT_WAVES, 1, lane, Tq);
+        }
         f32x4_t o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -271,31 +329,38 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     unsigned short* dvbase = a.dv + (long)m * Tk * a.dkv_ld + h * ATT_D;
     const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
 
-    for (int r = tid; r < Tqp; r += ATT_THREADS) {
-        float d = 0.f, l = 0.f;
-        if (r < Tq) {
+    auto row_stats = [&] {          // D[q] = dO[q] . O[q], lse2[q] = lse[q] * log2 e; the bias / gradient rows of a T5 head
+        for (int r = tid; r < Tqp; r += ATT_THREADS) {
+            float d = 0.f, l = 0.f;
+            if (r < Tq) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const u32x4_t x = *reinterpret_cast<const u32x4_t*>(obase + (long)r * a.out_ld + c * 8);
-                const u32x4_t y = *reinterpret_cast<const u32x4_t*>(dobase + (long)r * a.out_ld + c * 8);
+                for (int c = 0; c < 8; ++c) {
+                    const u32x4_t x = *reinterpret_cast<const u32x4_t*>(obase + (long)r * a.out_ld + c * 8);
+                    const u32x4_t y = *reinterpret_cast<const u32x4_t*>(dobase + (long)r * a.out_ld + c * 8);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    d += __uint_as_float(x[e] << 16) * __uint_as_float(y[e] << 16);
-                    d += __uint_as_float(x[e] & 0xffff0000u) * __uint_as_float(y[e] & 0xffff0000u);
+                    for (int e = 0; e < 4; ++e) {
+                        d += __uint_as_float(x[e] << 16) * __uint_as_float(y[e] << 16);
+                        d += __uint_as_float(x[e] & 0xffff0000u) * __uint_as_float(y[e] & 0xffff0000u);
+                    }
                 }
+                l = a.lse[((long)m * H + h) * Tq + r] * LOG2EF;
             }
-            l = a.lse[((long)m * H + h) * Tq + r] * LOG2EF;
+            Dq[r] = d;
+            lse2[r] = l;
         }
-        Dq[r] = d;
-        lse2[r] = l;
+        if (REL)
+            for (int d = tid; d < Tq + Tk - 1; d += ATT_THREADS) {
+                dbias[d] = a.rel_emb[a.rel_bucket[d] * H + h] * LOG2EF;
+                ddiag[d] = 0.f;
+            }
+    };
+    if (a.legacy_stage) {
+        row_stats();
+        stage_head(bufA, qbase, a.q_ld, Tq, Tqp, tid);
+        stage_head(bufB, dobase, a.out_ld, Tq, Tqp, tid);
+    } else {
+        stage_two(bufA, qbase, a.q_ld, bufB, dobase, a.out_ld, Tq, Tqp, tid, row_stats);
     }
-    if (REL)
-        for (int d = tid; d < Tq + Tk - 1; d += ATT_THREADS) {
-            dbias[d] = a.rel_emb[a.rel_bucket[d] * H + h] * LOG2EF;
-            ddiag[d] = 0.f;
-        }
-    stage_head(bufA, qbase, a.q_ld, Tq, Tqp, tid);
-    stage_head(bufB, dobase, a.out_ld, Tq, Tqp, tid);
     __syncthreads();
 
     const int li = lane & 15, g = lane >> 4;
@@ -403,8 +468,12 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
         }
     }
     __syncthreads();
-    stage_head(bufA, kbase, a.kv_ld, Tk, Tkp, tid);
-    stage_head(bufB, vbase, a.kv_ld, Tk, Tkp, tid);
+    if (a.legacy_stage) {
+        stage_head(bufA, kbase, a.kv_ld, Tk, Tkp, tid);
+        stage_head(bufB, vbase, a.kv_ld, Tk, Tkp, tid);
+    } else {
+        stage_two(bufA, kbase, a.kv_ld, bufB, vbase, a.kv_ld, Tk, Tkp, tid);
+    }
     __syncthreads();
     // ---------------- phase 2: dQ ----------------
     for (int qt = w; qt < nqtile; qt += ATT_WAVES) {
@@ -480,7 +549,18 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     }
 }
 
-static int launch_attn_fwd(const AttnArgs& a, int batch, hipStream_t st) {
+// Staging policy (A/B on one MI355X, 1024 items, tools/microbench.py MB_ONLY=attn; legacy -> batched):
+//   forward : 257 tokens 0.783 -> 0.760 ms, 197: 0.488 -> 0.487, 77 causal: 0.146 -> 0.132, 50: 0.116 -> 0.095   => always batched
+//   backward: 257 tokens 2.026 -> 2.021 ms, 197: 1.399 -> 1.446 (worse), 77: 0.388 -> 0.359, 50: 0.336 -> 0.294   => batched up to 128 tokens
+// UNIIR_ATTN_LEGACY_STAGE=1 / =0 forces one or the other (experiments).
+static int attn_legacy_stage(bool backward, int tmax) {
+    static const char* e = getenv("UNIIR_ATTN_LEGACY_STAGE");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return backward && tmax > 128;
+}
+static int launch_attn_fwd(const AttnArgs& a0, int batch, hipStream_t st) {
+    AttnArgs a = a0;
+    a.legacy_stage = attn_legacy_stage(false, a.Tk);
     const int Tkp = (a.Tk + 31) & ~31;
     const int sm = 2 * Tkp * 128 + (a.rel_emb ? (a.Tq + a.Tk) * 4 : 0);
     static PerDeviceOnce attr;
@@ -500,7 +580,9 @@ static int launch_attn_fwd(const AttnArgs& a, int batch, hipStream_t st) {
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
-static int launch_attn_bwd(const AttnArgs& a, int batch, hipStream_t st) {
+static int launch_attn_bwd(const AttnArgs& a0, int batch, hipStream_t st) {
+    AttnArgs a = a0;
+    a.legacy_stage = attn_legacy_stage(true, a.Tq > a.Tk ? a.Tq : a.Tk);
     const int Tqp = (a.Tq + 31) & ~31, Tkp = (a.Tk + 31) & ~31;
     const int Tmax = Tqp > Tkp ? Tqp : Tkp;
     const int sm = 2 * Tmax * 128 + 2 * Tqp * 4 + (a.rel_emb ? 2 * (a.Tq + a.Tk) * 4 : 0);
