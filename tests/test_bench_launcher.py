@@ -50,3 +50,27 @@ def test_world_size_mismatch_is_an_error():
     p, _ = _run(["--gpus", "4", "--dry-run"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                                              "MASTER_PORT": "29999"})
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_line_schema_on_the_device():
+    """the real (non dry-run) bench path at a small configuration: one JSON line with the contract's keys, a live GEMM sample
+    from the library-side timing hook, the measured-traffic record only for the configuration it was measured on"""
+    p, lines = _run(["--steps", "2", "--warmup", "1", "--pairs", "16", "--model", "ViT-B/32", "--no-cpu-baseline", "--no-secondary",
+                     "--no-retrieval"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["dtype"] == "bf16" and r["data"] == "synthetic" and r["vs_baseline"] is None
+    assert "workload" in r["config"] and r["config"]["global_batch"] == 16
+    rf = r["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert rf["launches_timed"] > 0 and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is None            # profiles/pmc_gemm_traffic.json is the ViT-L/14, 512-pair measurement
+    assert abs(r["value"] - 16 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-2 * r["value"]

@@ -116,9 +116,12 @@ def test_train_steps_track_oracle():
     assert e < 4e-3, e                                          # observed 1.1e-3
 
 
-def test_no_grad_embedding_path():
+@pytest.mark.parametrize("cfgkw", [dict(), dict(vision_layers=3, transformer_layers=1), dict(vision_layers=1, transformer_layers=4)])
+def test_no_grad_embedding_path(cfgkw):
+    """forward-only towers (one layer's buffers for every layer, the residual stream ping-ponging between two buffers, act-only
+    MLP epilogue): even and odd layer counts"""
     from oracle import clip_oracle as O
-    cfg = O.tiny_config()
+    cfg = O.tiny_config(**cfgkw)
     model, oracle, O = _build(cfg, seed=4)
     batch = O.synthetic_batch(cfg, 5, seed=6)
     dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
