@@ -587,62 +587,76 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
     }
     __syncthreads();
     const char* qb = qs + li * QS + lg * 16;     // + j * 16 * QS + s * 64
+    // Every wave owns ONE contiguous range of tiles, sizes differing by at most one tile (43 750 tiles over 2 048 waves: 21 or 22
+    // each).  Strided chunks of 8 tiles left 2.67 chunks per wave, i.e. a third round that only 2/3 of the waves took part in
+    // (89 % balance), and drained the two-tile load pipeline at every chunk start; here the pipeline runs through the whole range
+    // and only the 32-byte gmax runs are flushed every TKS_CH tiles.
     const long gw = (long)blockIdx.x * 8 + w, nw = (long)gridDim.x * 8;
-    for (long chunk = gw; chunk < nchunks; chunk += nw) {
-        const long tile0 = chunk * TKS_CH;
-        u32x4_t a[2][NK];
-        auto load_tile = [&](long tile, u32x4_t (&dst)[NK]) {
-            long row = tile * 16 + li;
-            if (row > rows - 1) row = rows - 1;
-            const u32x4_t* src = reinterpret_cast<const u32x4_t*>(pool + row * DIM) + lg;
+    const long lo = gw * ngroups / nw, hi = (gw + 1) * ngroups / nw;
+    u32x4_t a[2][NK];
+    auto load_tile = [&](long tile, u32x4_t (&dst)[NK]) {
+        long row = tile * 16 + li;
+        if (row > rows - 1) row = rows - 1;
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(pool + row * DIM) + lg;
 #pragma unroll
-            for (int s = 0; s < NK; ++s) dst[s] = TKS_LOAD(src + 4 * s);
-        };
-        auto do_tile = [&](long tile, int t, const u32x4_t (&af)[NK]) {
-            f32x4_t acc[4];
+        for (int s = 0; s < NK; ++s) dst[s] = TKS_LOAD(src + 4 * s);
+    };
+    auto do_tile = [&](long tile, int t, const u32x4_t (&af)[NK]) {
+        f32x4_t acc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < NK; ++s) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(qb + j * 16 * QS + s * 64);
-                    acc[j] = ElemF16::mfma(af[s], b, acc[j]);
-                }
-            }
-            // D: lane -> query j*16 + li, candidates 4 lg + r of the tile
-            const long r0 = tile * 16 + 4 * lg;
-            f32x4_t iv = {0.f, 0.f, 0.f, 0.f};
-            if (r0 + 3 < rows) iv = *reinterpret_cast<const f32x4_t*>(pinv + r0);
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (r0 + r < rows) iv[r] = pinv[r0 + r];
-            }
+        for (int s = 0; s < NK; ++s) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float m = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m = fmaxf(m, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
-                m = group_max(m);
-                if (lg == 0) stage[(j * 16 + li) * TKS_CH + t] = m;
+                const u32x4_t b = *reinterpret_cast<const u32x4_t*>(qb + j * 16 * QS + s * 64);
+                acc[j] = ElemF16::mfma(af[s], b, acc[j]);
             }
-        };
-        load_tile(tile0, a[0]);
-#pragma unroll
-        for (int t = 0; t < TKS_CH; t += 2) {
-            load_tile(tile0 + t + 1, a[1]);
-            do_tile(tile0 + t, t, a[0]);
-            if (t + 2 < TKS_CH) load_tile(tile0 + t + 2, a[0]);
-            do_tile(tile0 + t + 1, t + 1, a[1]);
         }
-        // lane q writes its TKS_CH consecutive groups (wave-private staging: program order suffices)
-        if (lane < nq) {
-            float* dst = gmax + (long)lane * ngroups + tile0;
+        // D: lane -> query j*16 + li, candidates 4 lg + r of the tile
+        const long r0 = tile * 16 + 4 * lg;
+        f32x4_t iv = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + 3 < rows) iv = *reinterpret_cast<const f32x4_t*>(pinv + r0);
+        else {
 #pragma unroll
-            for (int g = 0; g < TKS_CH; ++g)
-                if (tile0 + g < ngroups) dst[g] = stage[lane * TKS_CH + g];
+            for (int r = 0; r < 4; ++r) if (r0 + r < rows) iv[r] = pinv[r0 + r];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
+            m = group_max(m);
+            if (lg == 0) stage[(j * 16 + li) * TKS_CH + t] = m;
+        }
+    };
+    auto flush = [&](long g0, int n) {       // lane q writes its n <= TKS_CH consecutive groups starting at g0
+        if (lane < nq) {                      // (wave-private staging: program order suffices)
+            float* dst = gmax + (long)lane * ngroups + g0;
+            for (int g = 0; g < n; ++g) dst[g] = stage[lane * TKS_CH + g];
+        }
+    };
+    if (lo >= hi) return;
+    load_tile(lo, a[0]);
+    long g0 = lo;
+    int slot = 0;
+    for (long ta = lo; ta + 1 < hi; ta += 2) {              // two tiles per trip: the register buffers keep static indices
+        load_tile(ta + 1, a[1]);
+        do_tile(ta, slot, a[0]);
+        load_tile(ta + 2 < hi ? ta + 2 : hi - 1, a[0]);      // always issued (the last one re-reads a tile): no branch in the loop
+        do_tile(ta + 1, slot + 1, a[1]);
+        slot += 2;
+        if (slot == TKS_CH) {
+            flush(g0, TKS_CH);
+            g0 += TKS_CH;
+            slot = 0;
         }
     }
+    if ((hi - lo) & 1) {                                      // odd range: its last tile is the one a[0] holds
+        do_tile(hi - 1, slot, a[0]);
+        ++slot;
+    }
+    if (slot) flush(g0, slot);
 }
 
 // The group-max scan of <= 1024 queries over the shard: gmax[q][group] = best approximate score of the 16 rows of the group.
