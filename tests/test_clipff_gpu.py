@@ -224,3 +224,48 @@ def test_clipff_save_resume_then_step(tmp_path):
     q2 = m2.t5_layers.get_parameter("block.0.layer.0.SelfAttention.q.weight")
     # same state, same batch -> the same update up to the order of the fp32 atomics in the weight-gradient GEMMs
     assert (q1 - q2).abs().max().item() < 1e-5 and (m1.clip_model.visual.proj - m2.clip_model.visual.proj).abs().max().item() < 1e-5
+
+
+def test_clipff_vit_l14_two_pairs_against_the_oracle():
+    """CLIP_FF at its large architecture (clip_ff.py:161-192): ViT-L/14 towers without pooling (257 image + 77 text tokens, all
+    projected to 768), 2-layer T5 fusion with 12 heads and relative position bias over the 334 tokens, mean pooling, InfoNCE --
+    2 pairs, eval mode (no dropout), against oracle/clipff_oracle.py: embeddings, loss, accuracy, gradients of both stacks"""
+    from oracle import clip_oracle as O
+    from oracle import clipff_oracle as FF
+    from models.uniir_clip.clip_featurefusion.clip_ff import CLIPFeatureFusion
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    cfg = CLIP_CONFIGS["ViT-L/14"]
+    t5_cfg = dict(d_model=768, num_heads=12, d_ff=2048, num_layers=2, d_kv=64)
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=False), data_config=SimpleNamespace(in_batch_neg_num=0))
+    m = CLIPFeatureFusion("ViT-L/14", device="cuda", config=config)
+    sd = O.init_state_dict(cfg, seed=11)
+    sd.pop("text_projection")
+    m.clip_model.load_state_dict(sd, strict=True)
+    m.eval()
+    pairs = 2
+    batch = O.synthetic_batch(cfg, pairs, seed=31)
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    t5o = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in m.t5_layers.named_parameters()}
+    emb_o = FF.encode_multimodal_input(sdo, t5o, cfg, t5_cfg, batch["txt_batched"], batch["image_batched"])
+    out_o = O.inbatch_contrastive_loss(emb_o, batch["index_mapping"], sdo["logit_scale"].exp())
+    out_o["loss"].backward()
+    m.clip_model._ensure_flat()
+    m._ensure_t5()
+    m.zero_grad()
+    with torch.no_grad():
+        emb_d = m.encode_multimodal_input(dbatch["txt_batched"], dbatch["image_batched"])
+    print("OBS clipff-L emb rel", rel(emb_d, emb_o))
+    assert rel(emb_d, emb_o) < 2e-2, rel(emb_d, emb_o)
+    out_d = m(dbatch)
+    out_d["loss"].backward()
+    print("OBS clipff-L loss", out_d["loss"].item(), out_o["loss"].item())
+    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 2e-2 * max(1.0, abs(out_o["loss"].item()))
+    assert out_d["accuracy"].item() == out_o["accuracy"].item()
+    for name in ("block.0.layer.0.SelfAttention.q.weight", "block.1.layer.1.DenseReluDense.wo.weight",
+                 "block.0.layer.0.SelfAttention.relative_attention_bias.weight", "final_layer_norm.weight"):
+        deep_ok(m.t5_layers.get_parameter(name).grad, t5o[name].grad, name)
+    for name in ("visual.proj", "visual.conv1.weight", "token_embedding.weight", "ln_final.weight",
+                 "visual.transformer.resblocks.0.attn.in_proj_weight", "visual.transformer.resblocks.23.mlp.c_proj.weight",
+                 "transformer.resblocks.11.attn.out_proj.weight"):
+        deep_ok(m.clip_model.get_parameter(name).grad, sdo[name].grad, name)
