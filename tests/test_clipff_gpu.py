@@ -256,11 +256,11 @@ def test_clipff_vit_l14_two_pairs_against_the_oracle():
     with torch.no_grad():
         emb_d = m.encode_multimodal_input(dbatch["txt_batched"], dbatch["image_batched"])
     print("OBS clipff-L emb rel", rel(emb_d, emb_o))
-    assert rel(emb_d, emb_o) < 2e-2, rel(emb_d, emb_o)
+    assert rel(emb_d, emb_o) < 1.5e-2, rel(emb_d, emb_o)         # observed 7.7e-3
     out_d = m(dbatch)
     out_d["loss"].backward()
     print("OBS clipff-L loss", out_d["loss"].item(), out_o["loss"].item())
-    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 2e-2 * max(1.0, abs(out_o["loss"].item()))
+    assert abs(out_d["loss"].item() - out_o["loss"].item()) < 4e-3 * max(1.0, abs(out_o["loss"].item()))     # observed 7.5e-4
     assert out_d["accuracy"].item() == out_o["accuracy"].item()
     for name in ("block.0.layer.0.SelfAttention.q.weight", "block.1.layer.1.DenseReluDense.wo.weight",
                  "block.0.layer.0.SelfAttention.relative_attention_bias.weight", "final_layer_norm.weight"):
