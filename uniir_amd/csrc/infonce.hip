@@ -5,6 +5,7 @@
 // fmaf chain, so the logits are reproducible bit-for-bit by oracle/infonce_oracle.c.
 #include "common.h"
 #include "../../include/uniir_hip.h"
+#include <stdlib.h>
 
 #define SG_BM 64
 #define SG_BN 64
@@ -74,9 +75,127 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
             }
 }
 
+// The same GEMM for the big shapes (BLIP's [256 x 768] x [768 x 57 344] queue logits and their backward; the InfoNCE logits at
+// global batch 4096): 128 x 128 tile, 4 waves of 64 x 64 (4 x 4 MFMA tiles), K step 16, 16-byte global loads along whichever
+// operand dimension is contiguous, the next K step's operands fetched into registers while the current one computes.  Every
+// output element is still ONE accumulator fed by v_mfma_f32_16x16x4_f32 in ascending k: bit-identical to sgemm_kernel and to
+// the CPU oracle's fmaf chain.  The 64 x 64 kernel above measured 15.7 TFLOP/s on the queue logits (10 % of the fp32 MFMA peak:
+// scalar loads, one tile per wave).
+#define SGL_BM 128
+#define SGL_BN 128
+#define SGL_PITCH 132     // floats per k-row in LDS (128 + 4 pad)
+// loads one operand tile [128 mn][16 k] as 2 float4 per thread; CONTIG_K: k is the contiguous dimension, else mn is
+template <bool CONTIG_K>
+DEVINL void sgl_fetch(const float* __restrict__ P, long s_mn, long s_k, int mn0, int mn_total, int k0, int tid, f32x4_t (&v)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i;                      // 512 float4 per tile
+        if (CONTIG_K) {
+            const int mn = e >> 2, k4 = (e & 3) * 4;
+            const int g = min(mn0 + mn, mn_total - 1);    // clamped rows: their products are never stored
+            v[i] = *reinterpret_cast<const f32x4_t*>(P + (long)g * s_mn + (long)(k0 + k4));
+        } else {
+            const int k = e >> 5, mn4 = (e & 31) * 4;
+            const int g = min(mn0 + mn4, mn_total - 4);   // mn_total % 4 == 0 on this path
+            v[i] = *reinterpret_cast<const f32x4_t*>(P + (long)(k0 + k) * s_k + (long)g);
+        }
+    }
+}
+template <bool CONTIG_K>
+DEVINL void sgl_park(float* lds, int tid, const f32x4_t (&v)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i;
+        if (CONTIG_K) {
+            const int mn = e >> 2, k4 = (e & 3) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[(k4 + r) * SGL_PITCH + mn] = v[i][r];
+        } else {
+            const int k = e >> 5, mn4 = (e & 31) * 4;
+            *reinterpret_cast<f32x4_t*>(lds + k * SGL_PITCH + mn4) = v[i];
+        }
+    }
+}
+template <bool A_CK, bool B_CK>
+__global__ __launch_bounds__(256) void sgemm128_kernel(const float* __restrict__ A, long sam, long sak,
+                                                       const float* __restrict__ B, long sbk, long sbn,
+                                                       float* __restrict__ C, long ldc, int M, int N, int K, float alpha_host,
+                                                       const float* __restrict__ alpha_dev, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float As[SG_BK * SGL_PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[SG_BK * SGL_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.y * SGL_BM, n0 = blockIdx.x * SGL_BN;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t va[2], vb[2];
+    sgl_fetch<A_CK>(A, sam, sak, m0, M, 0, tid, va);
+    sgl_fetch<B_CK>(B, sbn, sbk, n0, N, 0, tid, vb);
+    for (int k0 = 0; k0 < K; k0 += SG_BK) {
+        sgl_park<A_CK>(As, tid, va);
+        sgl_park<B_CK>(Bs, tid, vb);
+        __syncthreads();
+        if (k0 + SG_BK < K) {
+            sgl_fetch<A_CK>(A, sam, sak, m0, M, k0 + SG_BK, tid, va);
+            sgl_fetch<B_CK>(B, sbn, sbk, n0, N, k0 + SG_BK, tid, vb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < SG_BK / 4; ++ks) {
+            const int kr = ks * 4 + (lane >> 4);
+            float af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = As[kr * SGL_PITCH + wm + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = Bs[kr * SGL_PITCH + wn + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float alpha = alpha_host * (alpha_dev ? *alpha_dev : 1.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + 4 * (lane >> 4) + r;
+                const int n = n0 + wn + j * 16 + (lane & 15);
+                if (m < M && n < N) {
+                    float* c = C + (long)m * ldc + n;
+                    *c = accumulate ? *c + acc[i][j][r] * alpha : acc[i][j][r] * alpha;
+                }
+            }
+}
+
 static int launch_sgemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
                         long ldc, int M, int N, int K, float alpha, const float* alpha_dev, hipStream_t st,
                         int accumulate = 0) {
+    // the 128-tile kernel: both operands with one unit stride, 16-byte aligned vectors, whole K steps, enough tiles to matter
+    static const char* env = getenv("UNIIR_SGEMM_SMALL");      // "1": always the 64-tile kernel (A/B experiments)
+    const bool a_ck = sak == 1, a_cm = sam == 1, b_ck = sbk == 1, b_cn = sbn == 1;
+    auto vec_ok = [](const float* p, long ld, bool contig_k, int ext) {
+        return (((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && (contig_k || ext % 4 == 0);
+    };
+    const bool big = !(env && env[0] == '1') && K % SG_BK == 0 && M >= 64 && N >= 64 && (long)M * N >= 128L * 128 * 8 &&
+                     (a_ck || a_cm) && (b_ck || b_cn) && vec_ok(A, a_ck ? sam : sak, a_ck, M) && vec_ok(B, b_ck ? sbn : sbk, b_ck, N);
+    if (big) {
+        dim3 grid((N + SGL_BN - 1) / SGL_BN, (M + SGL_BM - 1) / SGL_BM);
+#define SGL(AK, BK_) hipLaunchKernelGGL((sgemm128_kernel<AK, BK_>), grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, alpha_dev, accumulate)
+        if (a_ck && b_ck) SGL(true, true);
+        else if (a_ck) SGL(true, false);
+        else if (b_ck) SGL(false, true);
+        else SGL(false, false);
+#undef SGL
+        HIP_LAUNCH_CHECK();
+        return UNIIR_OK;
+    }
     dim3 grid((N + SG_BN - 1) / SG_BN, (M + SG_BM - 1) / SG_BM);
     hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha,
                        alpha_dev, accumulate);
