@@ -76,6 +76,8 @@ typedef struct {
     int64_t splitk_ws_bytes;  /* plain fp32 slabs that one reduce kernel adds into C (no atomics)               */
     float* colsum;            /* optional [N] fp32: += column sums of the result before rounding (bias gradient);
                                  honoured by the 256x256 kernel with EPI_RESID_F32 / EPI_DACT / EPI_F32 only     */
+    const float* row_scale;   /* optional [M] fp32, EPI_RESID_F32 only: C = (v + bias) * row_scale[m] + resid -- DropPath /
+                                 stochastic depth of a residual branch (BLIP ViT, backbone/vit.py:79-80) without a separate pass */
 } uniir_gemm_desc;
 
 int uniir_gemm(const uniir_gemm_desc* d, void* stream);
@@ -99,6 +101,12 @@ int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float* gamma, co
                         int32_t dy_is_f32, const float* dres, float* dx_f32, int64_t dx_stride,
                         void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int32_t rows,
                         int32_t width, float eps, void* stream);
+/* the same with a per-row factor (fp32 [rows]) for what leaves towards the next residual branch: dx_bf16 = bf16(branch_scale[r] *
+ * dx) and dx_colsum += branch_scale[r] * dx; dx_f32 stays the unscaled residual-stream gradient (DropPath in backward) */
+int uniir_layernorm_bwd_ex(const float* x, int64_t x_stride, const float* gamma, const void* dy,
+                           int32_t dy_is_f32, const float* dres, float* dx_f32, int64_t dx_stride,
+                           void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, const float* branch_scale,
+                           int32_t rows, int32_t width, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] building block 3: fused multi-head attention, head_dim 64, seq <= 512.

@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
         ("a_tmaj", c_int), ("b_tmaj", c_int),
         ("epilogue", c_int), ("act", c_int), ("dtype", c_int),
         ("k_splits", c_int), ("alpha", c_float),
-        ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_i64), ("colsum", c_void_p),
+        ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_i64), ("colsum", c_void_p), ("row_scale", c_void_p),
     ]
 
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "uniir_gemm_timing_read": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
     "uniir_layernorm_fwd": (c_int, [P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
     "uniir_layernorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
+    "uniir_layernorm_bwd_ex": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, P, P, c_int, c_int, c_float, S]),
     "uniir_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_attention_fwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, P, c_int, c_int, c_int, c_int, c_int, c_float,

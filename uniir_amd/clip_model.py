@@ -313,6 +313,8 @@ def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5,
     h = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
     g = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
     saved = []
+    # DropPath factors per ROW (item factor repeated over its T tokens): applied inside the residual GEMM's epilogue
+    rs_rows = None if rowscale is None else rowscale.repeat_interleave(T, dim=2).contiguous()
     for i in range(layers):
         b = blk(i)
         # with save, the two LayerNorm outputs are kept for the weight gradients (26 GB at ViT-L/14 x 1024 items:
@@ -324,8 +326,7 @@ def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5,
         if rowscale is None:
             x2 = ops.linear_fwd(ao, b.w16("wo"), b.p32("bo"), epilogue=ops.EPI_RESID_F32, resid=x)
         else:
-            x2 = ops.linear_fwd(ao, b.w16("wo"), b.p32("bo"), epilogue=ops.EPI_RESID_F32)
-            ops.dropout_f32(x2, 0.0, 0, resid=x, out_f32=x2, rowscale=rowscale[i, 0], rows_per_scale=T)
+            x2 = ops.linear_fwd(ao, b.w16("wo"), b.p32("bo"), epilogue=ops.EPI_RESID_F32, resid=x, row_scale=rs_rows[i, 0])
         h2 = torch.empty(R, W, device=dev, dtype=torch.bfloat16) if save else h
         ops.layernorm_fwd(x2, b.p32("ln2w"), b.p32("ln2b"), eps, out_bf16=h2, rows=R, width=W)
         if save:
@@ -337,8 +338,7 @@ def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5,
         if rowscale is None:
             xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32, resid=x2)
         else:
-            xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32)
-            ops.dropout_f32(xn, 0.0, 0, resid=x2, out_f32=xn, rowscale=rowscale[i, 1], rows_per_scale=T)
+            xn = ops.linear_fwd(g, b.w16("wproj"), b.p32("bproj"), epilogue=ops.EPI_RESID_F32, resid=x2, row_scale=rs_rows[i, 1])
         if save:
             saved.append((x, qkv, ao, lse, x2, f, h1, h2))
         x = xn
@@ -348,8 +348,9 @@ def _tower_fwd(model, prefix, layers, x, M, T, W, heads, causal, save, eps=1e-5,
 def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, eps=1e-5, act=ops.ACT_QUICKGELU,
                blk=None, rowscale=None):
     """dx fp32 [R,W] and its bf16 copy dxb: gradient w.r.t. the tower output.  Returns d(tower input) (fp32).
-    With DropPath factors (rowscale, see _tower_fwd) the branch gradient is rowscale * dx: the bf16 copy is scaled in
-    place and the two bias gradients are its column sums (instead of the sums fused into the LayerNorm backward)."""
+    With DropPath factors (rowscale, see _tower_fwd) the gradient entering a branch is rowscale * dx: the LayerNorm backward
+    that produces dx writes its bf16 copy and the branch's bias gradient already scaled (uniir_layernorm_bwd_ex); only the
+    tower's incoming gradient is scaled by a separate pass."""
     # DDP overlap: with a reducer armed (trainer.NativeAdamW.arm_overlap) a finished block's weight gradients go to the
     # collective stream while the remaining blocks still run (only the stock CLIP block naming has a range lookup)
     reducer = getattr(model, "_grad_reducer", None) if blk is None else None
@@ -361,15 +362,14 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
     dh = torch.empty(R, W, device=dev, dtype=torch.bfloat16)
     # bias gradient of the last block's c_proj: column sums of the incoming gradient (the other blocks get theirs from
     # the LayerNorm backward that produces their incoming gradient)
-    if rowscale is None:
-        ops.call("uniir_colsum_bf16", dxb, W, blk(layers - 1).g("bproj"), R, W)
+    rs_rows = None if rowscale is None else rowscale.repeat_interleave(T, dim=2).contiguous()     # factor per row
+    if rowscale is not None:
+        ops.dropout_bf16_(dxb, 0.0, 0, rowscale=rowscale[layers - 1, 1], rows_per_scale=T)
+    ops.call("uniir_colsum_bf16", dxb, W, blk(layers - 1).g("bproj"), R, W)
     for i in reversed(range(layers)):
         b = blk(i)
         x, qkv, ao, lse, x2, f, h1, h2 = saved[i]
         saved[i] = None
-        if rowscale is not None:
-            ops.dropout_bf16_(dxb, 0.0, 0, rowscale=rowscale[i, 1], rows_per_scale=T)
-            ops.call("uniir_colsum_bf16", dxb, W, b.g("bproj"), R, W)
         # d(mlp): df = (dx @ Wproj) * act'(f); the same epilogue re-materialises g = act(f) for dWproj and sums
         # df's columns into the c_fc bias gradient
         ops.linear_dgrad(dxb, b.w16("wproj"), out=df, aux=f, act_out=g, colsum=b.g("bfc"), act=act)
@@ -378,12 +378,9 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
         ops.linear_dgrad(df, b.w16("wfc"), out=dh)                               # dh := d ln_2 out
         dx2 = torch.empty(R, W, device=dev, dtype=torch.float32)
         ops.layernorm_bwd(x2, b.p32("ln2w"), dh, b.g("ln2w"), b.g("ln2b"), eps, dres=dx, dx=dx2, dx_bf16=dxb,
-                          rows=R, width=W, dx_colsum=(b.g("bo") if rowscale is None else None))   # d x2 also is
-        # d(out_proj out): its bias grad
+                          rows=R, width=W, dx_colsum=b.g("bo"),             # d x2 also is d(out_proj out): its bias grad
+                          branch_scale=None if rs_rows is None else rs_rows[i, 0])
         del x2, f, h2
-        if rowscale is not None:
-            ops.dropout_bf16_(dxb, 0.0, 0, rowscale=rowscale[i, 0], rows_per_scale=T)
-            ops.call("uniir_colsum_bf16", dxb, W, b.g("bo"), R, W)
         ops.linear_wgrad(dxb, ao, b.g("wo"))
         ops.linear_dgrad(dxb, b.w16("wo"), out=dh)                               # dh := d attn out
         dqkv = ops.attention_bwd(qkv, ao, dh, lse, M, T, heads, causal)
@@ -393,7 +390,8 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
         ops.linear_dgrad(dqkv, b.w16("wqkv"), out=dh)                            # dh := d ln_1 out
         del dqkv, h1
         ops.layernorm_bwd(x, b.p32("ln1w"), dh, b.g("ln1w"), b.g("ln1b"), eps, dres=dx2, dx=dx, dx_bf16=dxb,
-                          rows=R, width=W, dx_colsum=(blk(i - 1).g("bproj") if i > 0 and rowscale is None else None))
+                          rows=R, width=W, dx_colsum=(blk(i - 1).g("bproj") if i > 0 else None),
+                          branch_scale=None if (rs_rows is None or i == 0) else rs_rows[i - 1, 1])
         del x, dx2
         if reducer is not None:
             reducer.ready(*model.layer_grad_range(prefix, i))

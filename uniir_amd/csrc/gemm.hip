@@ -24,6 +24,7 @@ struct GemmKArgs {
     float* colsum;  // optional [N]: += column sums of the fp32 result (bias gradient), 256-tile staged epilogue only
     int raster_gm, raster_cw;   // 2-D tile rasterisation block (row panels x column panels), 0 = row-major
     int skip_f;                 // EPI_BIAS_ACT without the pre-activation store (UNIIR_EPI_ACT_ONLY: forward-only passes)
+    const float* row_scale;     // EPI_RESID_F32: (v + bias) * row_scale[m] + resid (DropPath factor of the row's item), or nullptr
 };
 
 DEVINL float act_fwd(float x, int act) {
@@ -70,6 +71,7 @@ DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[MT][NT], int 
                     u32x2_t o2 = {pack_bf16x2(g0, g1), pack_bf16x2(g2, g3)};
                     *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o2;
                 } else if (EPI == UNIIR_EPI_RESID_F32) {
+                    if (p.row_scale) v *= p.row_scale[m];
                     if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
                     *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
                     if (p.C2) {
@@ -172,13 +174,14 @@ DEVINL int epi_col(int j, int w, int wn) {
 // loop body carries no per-element branching
 template <int EPI, int ACT>
 DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long offa, long rstep, long rstep_aux, bool full,
-                         bool colok, int rows_left, f32x4_t& csum) {
+                         bool colok, int rows_left, f32x4_t& csum, int mrow) {
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
         if (full || (colok && 8 * it < rows_left)) {
             f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + it * 8192);
             const long off = off0 + it * rstep;
             if (EPI == UNIIR_EPI_RESID_F32) {
+                if (p.row_scale) v *= p.row_scale[mrow + 8 * it];
                 if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
                 *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
                 if (p.C2) {
@@ -329,15 +332,15 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
         const long offa = (long)mrow * p.ldaux + n0 + ch * 4;
         const int rows_left = p.M - mrow;
         if (epi == UNIIR_EPI_RESID_F32)
-            epi_f32_copy<UNIIR_EPI_RESID_F32, 0>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
+            epi_f32_copy<UNIIR_EPI_RESID_F32, 0>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
         else if (epi == UNIIR_EPI_F32)
-            epi_f32_copy<UNIIR_EPI_F32, 0>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
+            epi_f32_copy<UNIIR_EPI_F32, 0>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
         else if (p.act == UNIIR_ACT_QUICKGELU)
-            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_QUICKGELU>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
+            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_QUICKGELU>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
         else if (p.act == UNIIR_ACT_GELU_ERF)
-            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_GELU_ERF>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
+            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_GELU_ERF>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
         else
-            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_RELU>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum);
+            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_RELU>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
     }
     if (p.colsum) {
         // this thread's 4 columns (ch = tid & 63) summed over its rows of both passes; 8 threads share a column group
@@ -630,6 +633,7 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     if (d->epilogue < 0 || d->epilogue > UNIIR_EPI_ACT_ONLY) return UNIIR_EINVAL;
     if (d->k_splits > 1 && d->epilogue != UNIIR_EPI_ATOMIC_F32) return UNIIR_EINVAL;
     if (d->epilogue == UNIIR_EPI_ACT_ONLY && d->C2) return UNIIR_EINVAL;
+    if (d->row_scale && d->epilogue != UNIIR_EPI_RESID_F32) return UNIIR_EINVAL;
     if (d->epilogue == UNIIR_EPI_BIAS_ACT && !d->C2) return UNIIR_EINVAL;
     if (d->epilogue == UNIIR_EPI_DACT && !d->aux) return UNIIR_EINVAL;
     if (d->N % 8) return UNIIR_ESHAPE;
@@ -652,6 +656,7 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldaux = d->ldaux;
     a.epilogue = d->epilogue; a.act = d->act; a.k_splits = d->k_splits;
     a.skip_f = 0;
+    a.row_scale = d->epilogue == UNIIR_EPI_RESID_F32 ? d->row_scale : nullptr;
     if (d->epilogue == UNIIR_EPI_ACT_ONLY) {      // the BIAS_ACT epilogue without its first output: C receives act(v + bias)
         a.epilogue = UNIIR_EPI_BIAS_ACT;
         a.C2 = d->C;

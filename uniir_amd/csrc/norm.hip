@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, (EXACT && NC <= 4) ? 3 : 1) void ln_bwd_kernel
                                                      float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta,
                                                      float* __restrict__ dx_colsum, int rows, int width,
-                                                     float eps, int rms) {
+                                                     float eps, int rms, const float* __restrict__ bscale) {
     __shared__ float red[4][64 * 4 * NC];  // per wave staging for the column reduction
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nchunk = width >> 2;
@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256, (EXACT && NC <= 4) ? 3 : 1) void ln_bwd_kernel
             }
         }
         const float c1 = rms ? 0.f : wave_sum(s1) * inv_w, c2 = wave_sum(s2) * inv_w;
+        // bscale: the row's DropPath factor of the residual BRANCH this gradient enters next (its last linear layer's bias
+        // gradient and 16-bit operand see bscale * dx; the fp32 residual gradient itself stays unscaled)
+        const float bs = bscale ? bscale[row] : 1.0f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256, (EXACT && NC <= 4) ? 3 : 1) void ln_bwd_kernel
                 f32x4_t o = (d[i] - c1 - v[i] * c2) * rstd;
                 if (dres) o += rs[i];
                 *reinterpret_cast<f32x4_t*>(dx + row * dx_stride + 4 * c) = o;
+                if (bscale) o = o * bs;
                 if (dx_colsum) ac[i] += o;
                 if (dx_bf16) {
                     u32x2_t pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
@@ -187,7 +191,7 @@ static void launch_ln_fwd(const float* x, long x_stride, const float* gamma, con
 template <int NC, bool F32>
 static void launch_ln_bwd(const float* x, long x_stride, const float* gamma, const void* dy, const float* dres,
                           float* dx, long dx_stride, unsigned short* dxb, float* dgamma, float* dbeta, float* dxsum,
-                          int rows, int width, float eps, hipStream_t st, int rms = 0) {
+                          int rows, int width, float eps, hipStream_t st, int rms = 0, const float* bscale = nullptr) {
     // persistent rows: one resident wave of workgroups (occupancy x 256 CUs), no tail wave
     static int resident[2] = {0, 0};
     const bool exact = width == 256 * NC;
@@ -201,10 +205,10 @@ static void launch_ln_bwd(const float* x, long x_stride, const float* gamma, con
     if (g > resident[exact]) g = resident[exact];
     if (exact)
         hipLaunchKernelGGL((ln_bwd_kernel<NC, F32, true>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
-                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms);
+                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms, bscale);
     else
         hipLaunchKernelGGL((ln_bwd_kernel<NC, F32, false>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
-                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms);
+                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms, bscale);
 }
 static inline int ln_nc(int width) {
     const int c = (width / 4 + 63) / 64;
@@ -229,10 +233,9 @@ extern "C" int uniir_layernorm_fwd(const float* x, int64_t x_stride, const float
     return UNIIR_OK;
 }
 
-extern "C" int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float* gamma, const void* dy,
-                                   int32_t dy_is_f32, const float* dres, float* dx_f32, int64_t dx_stride,
-                                   void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int32_t rows,
-                                   int32_t width, float eps, void* stream) {
+static int layernorm_bwd_impl(const float* x, int64_t x_stride, const float* gamma, const void* dy, int32_t dy_is_f32,
+                              const float* dres, float* dx_f32, int64_t dx_stride, void* dx_bf16, float* dgamma, float* dbeta,
+                              float* dx_colsum, const float* branch_scale, int32_t rows, int32_t width, float eps, void* stream) {
     if (!x || !gamma || !dy || !dx_f32 || !dgamma || !dbeta || rows < 0) return UNIIR_EINVAL;
     if (rows == 0) return UNIIR_OK;
     if (width % 4 || width > 64 * 4 * LN_MAXC || width <= 0 || x_stride % 4 || dx_stride % 4) return UNIIR_ESHAPE;
@@ -240,8 +243,8 @@ extern "C" int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float
     unsigned short* dxb = (unsigned short*)dx_bf16;
 #define LNB(NC)                                                                                                   \
     do {                                                                                                          \
-        if (dy_is_f32) launch_ln_bwd<NC, true>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, dx_colsum, rows, width, eps, st); \
-        else launch_ln_bwd<NC, false>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, dx_colsum, rows, width, eps, st);          \
+        if (dy_is_f32) launch_ln_bwd<NC, true>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, dx_colsum, rows, width, eps, st, 0, branch_scale); \
+        else launch_ln_bwd<NC, false>(x, x_stride, gamma, dy, dres, dx_f32, dx_stride, dxb, dgamma, dbeta, dx_colsum, rows, width, eps, st, 0, branch_scale);          \
     } while (0)
     switch (ln_nc(width)) {
         case 2: LNB(2); break;
@@ -252,6 +255,22 @@ extern "C" int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float
 #undef LNB
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
+}
+extern "C" int uniir_layernorm_bwd(const float* x, int64_t x_stride, const float* gamma, const void* dy,
+                                   int32_t dy_is_f32, const float* dres, float* dx_f32, int64_t dx_stride,
+                                   void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int32_t rows,
+                                   int32_t width, float eps, void* stream) {
+    return layernorm_bwd_impl(x, x_stride, gamma, dy, dy_is_f32, dres, dx_f32, dx_stride, dx_bf16, dgamma, dbeta, dx_colsum,
+                              nullptr, rows, width, eps, stream);
+}
+// the same with a per-row factor for what leaves towards the next residual BRANCH: dx_bf16 = bf16(branch_scale[row] * dx) and
+// dx_colsum += branch_scale[row] * dx, while dx_f32 (the residual-stream gradient) stays unscaled -- DropPath in backward
+extern "C" int uniir_layernorm_bwd_ex(const float* x, int64_t x_stride, const float* gamma, const void* dy,
+                                      int32_t dy_is_f32, const float* dres, float* dx_f32, int64_t dx_stride,
+                                      void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum,
+                                      const float* branch_scale, int32_t rows, int32_t width, float eps, void* stream) {
+    return layernorm_bwd_impl(x, x_stride, gamma, dy, dy_is_f32, dres, dx_f32, dx_stride, dx_bf16, dgamma, dbeta, dx_colsum,
+                              branch_scale, rows, width, eps, stream);
 }
 
 // RMS norm (transformers T5LayerNorm, used by the CLIP_FF fusion stack): same kernels, rms = 1

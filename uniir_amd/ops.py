@@ -60,7 +60,7 @@ def uses_tile256(M, N, K):
 
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epilogue=EPI_BF16, bias=None,
          resid=None, aux=None, ldaux=0, C2=None, act=ACT_QUICKGELU, k_splits=1, alpha=1.0, dtype=DT_BF16,
-         colsum=None):
+         colsum=None, row_scale=None):
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = A.data_ptr(), B.data_ptr(), C_out.data_ptr(), (C2.data_ptr() if C2 is not None else None)
     d.bias = bias.data_ptr() if bias is not None else None
@@ -71,6 +71,7 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epi
     d.a_tmaj, d.b_tmaj = int(a_tmaj), int(b_tmaj)
     d.epilogue, d.act, d.dtype, d.k_splits, d.alpha = epilogue, act, dtype, k_splits, alpha
     d.colsum = colsum.data_ptr() if colsum is not None else None
+    d.row_scale = row_scale.data_ptr() if row_scale is not None else None
     if k_splits > 1:
         ws = _splitk_workspace(A.device, 4 * k_splits * M * N)
         d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
@@ -78,14 +79,15 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epi
     return C_out
 
 
-def linear_fwd(x, w, bias=None, *, out=None, epilogue=EPI_BF16, resid=None, C2=None, act=ACT_QUICKGELU):
-    """y[M,N] = x[M,K] @ w[N,K]^T (+bias ...).  x, w bf16 contiguous."""
+def linear_fwd(x, w, bias=None, *, out=None, epilogue=EPI_BF16, resid=None, C2=None, act=ACT_QUICKGELU, row_scale=None):
+    """y[M,N] = x[M,K] @ w[N,K]^T (+bias ...).  x, w bf16 contiguous.  row_scale (fp32 [M], EPI_RESID_F32): the branch output is
+    multiplied by it before the residual is added (DropPath)."""
     M, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, device=x.device,
                           dtype=torch.float32 if epilogue in (EPI_RESID_F32, EPI_F32) else torch.bfloat16)
-    return gemm(x, w, out, M, N, K, K, K, N, epilogue=epilogue, bias=bias, resid=resid, C2=C2, act=act)
+    return gemm(x, w, out, M, N, K, K, K, N, epilogue=epilogue, bias=bias, resid=resid, C2=C2, act=act, row_scale=row_scale)
 
 
 def linear_dgrad(dy, w, *, out=None, aux=None, act=ACT_QUICKGELU, act_out=None, colsum=None):
@@ -150,14 +152,20 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, *, out_bf16=None, out_f32=None, rows
 
 
 def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5, *, dres=None, dx=None, dx_bf16=None, rows=None,
-                  width=None, x_stride=None, dx_stride=None, dx_colsum=None):
-    """dx_colsum (fp32 [width]): += column sums of dx (bias gradient of the linear layer that produced x)"""
+                  width=None, x_stride=None, dx_stride=None, dx_colsum=None, branch_scale=None):
+    """dx_colsum (fp32 [width]): += column sums of dx (bias gradient of the linear layer that produced x).
+    branch_scale (fp32 [rows]): dx_bf16 and dx_colsum carry branch_scale[row] * dx (DropPath of the branch dx enters next)"""
     width = width or x.shape[-1]
     rows = rows if rows is not None else x.numel() // width
     x_stride = x_stride or width
     dx_stride = dx_stride or width
     if dx is None:
         dx = torch.empty(rows, width, device=x.device, dtype=torch.float32)
+    if branch_scale is not None:
+        check(_lib.load().uniir_layernorm_bwd_ex(_p(x), x_stride, _p(gamma), _p(dy), int(dy.dtype == torch.float32),
+                                                 _p(dres), _p(dx), dx_stride, _p(dx_bf16), _p(dgamma), _p(dbeta),
+                                                 _p(dx_colsum), _p(branch_scale), rows, width, eps, _stream()), "layernorm_bwd_ex")
+        return dx
     check(_lib.load().uniir_layernorm_bwd(_p(x), x_stride, _p(gamma), _p(dy), int(dy.dtype == torch.float32),
                                           _p(dres), _p(dx), dx_stride, _p(dx_bf16), _p(dgamma), _p(dbeta),
                                           _p(dx_colsum), rows, width, eps, _stream()), "layernorm_bwd")
