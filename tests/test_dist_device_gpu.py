@@ -75,6 +75,62 @@ def test_two_rank_device_step_equals_single_process_on_the_global_batch():
         assert abs(res[r][2] - model.clip_model.logit_scale.item()) < 1e-4
 
 
+def _accum_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O, cfg, model, _ = _build(gather=True)
+    from uniir_amd.trainer import NativeTrainer
+    tr = NativeTrainer(model, lr=1e-3, t_total=10, accumulation_steps=2)
+    armed = []
+    ready_orig = tr.opt.__class__.arm_overlap
+
+    def spy(self, last=True):
+        armed.append(bool(last))
+        return ready_orig(self, last)
+
+    tr.opt.__class__.arm_overlap = spy
+    try:
+        for micro in range(2):                      # one accumulation window = one optimizer step
+            full = O.synthetic_batch(cfg, 8, seed=41 + micro)
+            lo, hi = rank * 8, (rank + 1) * 8
+            b = {k: (v[lo:hi].cuda() if isinstance(v, torch.Tensor) else v) for k, v in full.items()}
+            b["index_mapping"] = {"query": [[2 * i] for i in range(4)], "pos_cand": [[2 * i + 1] for i in range(4)]}
+            tr.train_step(b)
+    finally:
+        tr.opt.__class__.arm_overlap = ready_orig
+    torch.cuda.synchronize()
+    q.put((rank, armed, tr.opt.opt_step, tr.opt.last_collectives, model.clip_model.visual.proj.detach().cpu().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_accumulation_reduces_only_on_the_last_micro_batch():
+    """DDP no_sync semantics of the overlapped all-reduce: with gradient_accumulation_steps = 2 (engine.py:30-46) blocks are
+    handed to the reducer only during the window's last backward; the update equals the single-process one that accumulates the
+    same two global micro-batches"""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, 2, 29543, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (a, n, c, w) for r, a, n, c, w in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(2):
+        assert res[r][0] == [False, True] and res[r][1] == 1 and res[r][2] >= 2      # armed once, one step, several collectives
+    assert np.array_equal(res[0][3], res[1][3])
+    O, cfg, model, _ = _build(gather=False)
+    from uniir_amd.trainer import NativeTrainer
+    tr = NativeTrainer(model, lr=1e-3, t_total=10, accumulation_steps=2)
+    for micro in range(2):
+        full = O.synthetic_batch(cfg, 8, seed=41 + micro)
+        tr.train_step({k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in full.items()})
+    w_ref = model.clip_model.visual.proj.detach().cpu().numpy()
+    step = np.abs(w_ref - O.init_state_dict(cfg, seed=9)["visual.proj"].numpy()).max()
+    assert np.abs(res[0][3] - w_ref).max() < 0.05 * step + 1e-7, (np.abs(res[0][3] - w_ref).max(), step)
+
+
 def _resident_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
