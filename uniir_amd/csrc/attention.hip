@@ -28,19 +28,20 @@ DEVINL int swz_off(int row, int col) {  // byte offset of element (row, col) in 
 #define ATT_WAVES (ATT_THREADS / 64)
 
 // legacy staging (A/B switch UNIIR_ATTN_LEGACY_STAGE=1): one slice, loads 4 deep, one HBM round trip per 2048 chunks
+template <int NT>
 DEVINL void stage_head(char* lds, const unsigned short* __restrict__ src, long ld, int T, int Tp, int tid) {
     const int total = Tp * 8;
-    for (int c0 = 0; c0 < total; c0 += 4 * ATT_THREADS) {
+    for (int c0 = 0; c0 < total; c0 += 4 * NT) {
         u32x4_t v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * ATT_THREADS + tid;
+            const int c = c0 + u * NT + tid;
             const int row = min(c >> 3, T - 1), kc = c & 7;
             v[u] = *reinterpret_cast<const u32x4_t*>(src + (long)row * ld + kc * 8);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * ATT_THREADS + tid;
+            const int c = c0 + u * NT + tid;
             const int row = c >> 3, kc = c & 7;
             if (c < total) {
                 const u32x4_t z = {0u, 0u, 0u, 0u};
@@ -53,17 +54,18 @@ DEVINL void stage_head(char* lds, const unsigned short* __restrict__ src, long l
 // ALL loads of both slices are issued before the first LDS store (one HBM round trip per staging instead of one per 2048
 // chunks and slice -- four at 257 tokens; the PMC anatomy in profiles/r02_attention_pmc.txt shows the waves parked on
 // exactly these waits); loads come from clamped (always valid) addresses, the zero-select happens at the LDS store.
-// NL = 16-B loads per thread and slice: ceil(Tp * 8 / ATT_THREADS) <= 8 for Tp <= 512.
+// NL = 16-B loads per thread and slice: ceil(Tp * 8 / NT) (<= 8 for Tp <= 512 at 512 threads; the 384-thread backward only
+// runs up to 128 tokens).
 // `mid` runs between the loads and the LDS stores: independent work (the backward's per-row statistics with their own global
 // loads) that then shares the staging's HBM round trip instead of adding one.
-template <int NL, class F>
+template <int NT, int NL, class F>
 DEVINL void stage_two_n(char* ldsA, const unsigned short* __restrict__ srcA, long ldA, char* ldsB,
                         const unsigned short* __restrict__ srcB, long ldB, int T, int Tp, int tid, F&& mid) {
     const int total = Tp * 8;
     u32x4_t va[NL], vb[NL];
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-        const int c = u * ATT_THREADS + tid;
+        const int c = u * NT + tid;
         const int row = min(c >> 3, T - 1), kc = c & 7;
         va[u] = *reinterpret_cast<const u32x4_t*>(srcA + (long)row * ldA + kc * 8);
         vb[u] = *reinterpret_cast<const u32x4_t*>(srcB + (long)row * ldB + kc * 8);
@@ -71,7 +73,7 @@ DEVINL void stage_two_n(char* ldsA, const unsigned short* __restrict__ srcA, lon
     mid();
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-        const int c = u * ATT_THREADS + tid;
+        const int c = u * NT + tid;
         const int row = c >> 3, kc = c & 7;
         if (c < total) {
             const u32x4_t z = {0u, 0u, 0u, 0u};
@@ -81,17 +83,18 @@ DEVINL void stage_two_n(char* ldsA, const unsigned short* __restrict__ srcA, lon
         }
     }
 }
-template <class F>
+template <int NT, class F>
 DEVINL void stage_two(char* ldsA, const unsigned short* __restrict__ srcA, long ldA, char* ldsB,
                       const unsigned short* __restrict__ srcB, long ldB, int T, int Tp, int tid, F&& mid) {
-    const int nl = (Tp * 8 + ATT_THREADS - 1) / ATT_THREADS;       // wave-uniform
-    if (nl <= 2) stage_two_n<2>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
-    else if (nl <= 5) stage_two_n<5>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
-    else stage_two_n<8>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
+    const int nl = (Tp * 8 + NT - 1) / NT;       // wave-uniform
+    if (nl <= 2) stage_two_n<NT, 2>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
+    else if (nl <= 5) stage_two_n<NT, 5>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
+    else stage_two_n<NT, 8>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
 }
+template <int NT>
 DEVINL void stage_two(char* ldsA, const unsigned short* __restrict__ srcA, long ldA, char* ldsB,
                       const unsigned short* __restrict__ srcB, long ldB, int T, int Tp, int tid) {
-    stage_two(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, [] {});
+    stage_two<NT>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, [] {});
 }
 // b128 fragment: 8 consecutive d (k-step s) of row r0 + (lane&15)
 DEVINL bf16x8_t frag_rows(const char* lds, int r0, int s, int lane) {
@@ -181,10 +184,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     qnext[0] = frag_rows_global(qbase, a.q_ld, w * 16, 0, lane, Tq);
     qnext[1] = frag_rows_global(qbase, a.q_ld, w * 16, 1, lane, Tq);
     if (a.legacy_stage) {
-        stage_head(ldsK, kbase, a.kv_ld, Tk, Tkp, tid);
-        stage_head(ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
+        stage_head<ATT_THREADS>(ldsK, kbase, a.kv_ld, Tk, Tkp, tid);
+        stage_head<ATT_THREADS>(ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
     } else {
-        stage_two(ldsK, kbase, a.kv_ld, ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
+        stage_two<ATT_THREADS>(ldsK, kbase, a.kv_ld, ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
     }
     __syncthreads();
     for (int qt = w; qt < nqt; qt += ATT_WAVES) {
@@ -299,8 +302,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 // Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
 // Phase 2 (per 16-query tile): dQ^T += K^T dS^T with S^T = K Q^T oriented [key][q].
 // CAUSAL (CLIP text tower, 77 tokens): compile-time; its short loops are mostly boundary tiles, so masks are always on
-template <bool REL, bool DROP, bool CAUSAL>
-__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
+// NT threads: 512 (8 waves, 128 registers) or 384 (6 waves, 168 registers: no spills, and 5 key tiles of a 77-token head keep 5 of
+// 6 waves busy instead of 5 of 8) -- the launcher picks 384 up to 128 tokens (measured: 50 tokens 0.335 -> 0.261 ms, 77 causal
+// 0.518 -> 0.386 ms at 1024 items; 197 / 257 tokens lose 15-20 % with fewer waves).
+template <bool REL, bool DROP, bool CAUSAL, int NT>
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArgs a) {
+    constexpr int NWAVES = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tq = a.Tq, Tk = a.Tk, H = a.H;
     constexpr bool causal = CAUSAL;
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
 
     auto row_stats = [&] {          // D[q] = dO[q] . O[q], lse2[q] = lse[q] * log2 e; the bias / gradient rows of a T5 head
-        for (int r = tid; r < Tqp; r += ATT_THREADS) {
+        for (int r = tid; r < Tqp; r += NT) {
             float d = 0.f, l = 0.f;
             if (r < Tq) {
 #pragma unroll
@@ -349,17 +356,17 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
             lse2[r] = l;
         }
         if (REL)
-            for (int d = tid; d < Tq + Tk - 1; d += ATT_THREADS) {
+            for (int d = tid; d < Tq + Tk - 1; d += NT) {
                 dbias[d] = a.rel_emb[a.rel_bucket[d] * H + h] * LOG2EF;
                 ddiag[d] = 0.f;
             }
     };
     if (a.legacy_stage) {
         row_stats();
-        stage_head(bufA, qbase, a.q_ld, Tq, Tqp, tid);
-        stage_head(bufB, dobase, a.out_ld, Tq, Tqp, tid);
+        stage_head<NT>(bufA, qbase, a.q_ld, Tq, Tqp, tid);
+        stage_head<NT>(bufB, dobase, a.out_ld, Tq, Tqp, tid);
     } else {
-        stage_two(bufA, qbase, a.q_ld, bufB, dobase, a.out_ld, Tq, Tqp, tid, row_stats);
+        stage_two<NT>(bufA, qbase, a.q_ld, bufB, dobase, a.out_ld, Tq, Tqp, tid, row_stats);
     }
     __syncthreads();
 
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     };
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
     // ---------------- phase 1: dK, dV ----------------
-    for (int kt = w; kt < nktile; kt += ATT_WAVES) {
+    for (int kt = w; kt < nktile; kt += NWAVES) {
         const int k0 = kt * 16, key = k0 + li;
         bf16x8_t kf[2], vf[2];
 #pragma unroll
@@ -469,14 +476,14 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     }
     __syncthreads();
     if (a.legacy_stage) {
-        stage_head(bufA, kbase, a.kv_ld, Tk, Tkp, tid);
-        stage_head(bufB, vbase, a.kv_ld, Tk, Tkp, tid);
+        stage_head<NT>(bufA, kbase, a.kv_ld, Tk, Tkp, tid);
+        stage_head<NT>(bufB, vbase, a.kv_ld, Tk, Tkp, tid);
     } else {
-        stage_two(bufA, kbase, a.kv_ld, bufB, vbase, a.kv_ld, Tk, Tkp, tid);
+        stage_two<NT>(bufA, kbase, a.kv_ld, bufB, vbase, a.kv_ld, Tk, Tkp, tid);
     }
     __syncthreads();
     // ---------------- phase 2: dQ ----------------
-    for (int qt = w; qt < nqtile; qt += ATT_WAVES) {
+    for (int qt = w; qt < nqtile; qt += NWAVES) {
         const int q0 = qt * 16, q = q0 + li;
         bf16x8_t qf[2], dof[2];
 #pragma unroll
@@ -540,11 +547,11 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(AttnArgs a) {
     if (REL && a.drel) {      // diagonals -> buckets -> global (one atomic per touched bucket and workgroup)
         __syncthreads();
         float* bsum = lse2;     // phase 2 is over: reuse
-        for (int b = tid; b < a.nbuckets; b += ATT_THREADS) bsum[b] = 0.f;
+        for (int b = tid; b < a.nbuckets; b += NT) bsum[b] = 0.f;
         __syncthreads();
-        for (int d = tid; d < Tq + Tk - 1; d += ATT_THREADS) atomicAdd(&bsum[a.rel_bucket[d]], ddiag[d]);
+        for (int d = tid; d < Tq + Tk - 1; d += NT) atomicAdd(&bsum[a.rel_bucket[d]], ddiag[d]);
         __syncthreads();
-        for (int b = tid; b < a.nbuckets; b += ATT_THREADS)
+        for (int b = tid; b < a.nbuckets; b += NT)
             if (bsum[b] != 0.f) atomicAdd(a.drel + b * H + h, bsum[b]);
     }
 }
@@ -580,33 +587,40 @@ static int launch_attn_fwd(const AttnArgs& a0, int batch, hipStream_t st) {
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
-static int launch_attn_bwd(const AttnArgs& a0, int batch, hipStream_t st) {
-    AttnArgs a = a0;
-    a.legacy_stage = attn_legacy_stage(true, a.Tq > a.Tk ? a.Tq : a.Tk);
-    const int Tqp = (a.Tq + 31) & ~31, Tkp = (a.Tk + 31) & ~31;
-    const int Tmax = Tqp > Tkp ? Tqp : Tkp;
-    const int sm = 2 * Tmax * 128 + 2 * Tqp * 4 + (a.rel_emb ? 2 * (a.Tq + a.Tk) * 4 : 0);
+template <int NT>
+static int launch_attn_bwd_nt(const AttnArgs& a, int batch, int sm, hipStream_t st) {
     static PerDeviceOnce attr;
     if (attr.first()) {
         const int big = 2 * 512 * 128 + 2 * 512 * 4 + 2 * 1024 * 4;
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false, false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true, false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, false, false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true, true, false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false, true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true, true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     }
-    const dim3 g(batch * a.H), b(ATT_THREADS);
+    const dim3 g(batch * a.H), b(NT);
     const bool drop = a.drop_p > 0.f;
     if (a.causal && a.rel_emb) return UNIIR_ESHAPE;
-    if (a.causal && drop) hipLaunchKernelGGL((attn_bwd_kernel<false, true, true>), g, b, sm, st, a);
-    else if (a.causal) hipLaunchKernelGGL((attn_bwd_kernel<false, false, true>), g, b, sm, st, a);
-    else if (a.rel_emb && drop) hipLaunchKernelGGL((attn_bwd_kernel<true, true, false>), g, b, sm, st, a);
-    else if (a.rel_emb) hipLaunchKernelGGL((attn_bwd_kernel<true, false, false>), g, b, sm, st, a);
-    else if (drop) hipLaunchKernelGGL((attn_bwd_kernel<false, true, false>), g, b, sm, st, a);
-    else hipLaunchKernelGGL((attn_bwd_kernel<false, false, false>), g, b, sm, st, a);
+    if (a.causal && drop) hipLaunchKernelGGL((attn_bwd_kernel<false, true, true, NT>), g, b, sm, st, a);
+    else if (a.causal) hipLaunchKernelGGL((attn_bwd_kernel<false, false, true, NT>), g, b, sm, st, a);
+    else if (a.rel_emb && drop) hipLaunchKernelGGL((attn_bwd_kernel<true, true, false, NT>), g, b, sm, st, a);
+    else if (a.rel_emb) hipLaunchKernelGGL((attn_bwd_kernel<true, false, false, NT>), g, b, sm, st, a);
+    else if (drop) hipLaunchKernelGGL((attn_bwd_kernel<false, true, false, NT>), g, b, sm, st, a);
+    else hipLaunchKernelGGL((attn_bwd_kernel<false, false, false, NT>), g, b, sm, st, a);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
+}
+static int launch_attn_bwd(const AttnArgs& a0, int batch, hipStream_t st) {
+    AttnArgs a = a0;
+    const int tmax = a.Tq > a.Tk ? a.Tq : a.Tk;
+    a.legacy_stage = attn_legacy_stage(true, tmax);
+    const int Tqp = (a.Tq + 31) & ~31, Tkp = (a.Tk + 31) & ~31;
+    const int Tmax = Tqp > Tkp ? Tqp : Tkp;
+    const int sm = 2 * Tmax * 128 + 2 * Tqp * 4 + (a.rel_emb ? 2 * (a.Tq + a.Tk) * 4 : 0);
+    static const char* e = getenv("UNIIR_ATTN_BWD_THREADS");          // 384 / 512 forces one (experiments)
+    const bool six = e ? (e[0] == '3') : tmax <= 128;
+    return six ? launch_attn_bwd_nt<384>(a, batch, sm, st) : launch_attn_bwd_nt<512>(a, batch, sm, st);
 }
 
 extern "C" int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32_t batch, int32_t seq,
