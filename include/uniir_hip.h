@@ -78,6 +78,9 @@ typedef struct {
                                  honoured by the 256x256 kernel with EPI_RESID_F32 / EPI_DACT / EPI_F32 only     */
     const float* row_scale;   /* optional [M] fp32, EPI_RESID_F32 only: C = (v + bias) * row_scale[m] + resid -- DropPath /
                                  stochastic depth of a residual branch (BLIP ViT, backbone/vit.py:79-80) without a separate pass */
+    float* a_rowsum;          /* optional [M] fp32, a_tmaj only: += sum over K of op(A)'s rows -- the bias gradient of a
+                                 weight-gradient GEMM dW = dy^T x, taken from the dy fragments inside the 256x256 transposed
+                                 kernel (bf16, b_tmaj) and by a separate pass over A otherwise                              */
 } uniir_gemm_desc;
 
 int uniir_gemm(const uniir_gemm_desc* d, void* stream);

@@ -61,6 +61,23 @@ def test_gemm_wgrad_tn_splitk(M, N, K):
     assert rel_err(dw, ref) < 1e-3, rel_err(dw, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 1024), (16384, 3072, 1024), (20000, 520, 256), (5000, 1024, 768), (263, 384, 64),
+                                   (1000, 136, 200)])
+def test_gemm_wgrad_with_bias_gradient(M, N, K):
+    """uniir_gemm_desc.a_rowsum: the bias gradient (column sums of dy) out of the weight-gradient GEMM's own pass over dy -- inside
+    the 256x256 transposed kernel (first four shapes: several K splits, an N that is not a tile multiple, row sums only from the
+    first column panel) and by the separate pass for problems that run another kernel (last two); accumulates into dbias"""
+    ops = _ops()
+    torch.manual_seed(12)
+    dy, x = bf(torch.randn(M, N, device=DEV) + 0.25), bf(torch.randn(M, K, device=DEV))
+    dw = torch.zeros(N, K, device=DEV)
+    db = torch.full((N,), 3.0, device=DEV)
+    ops.linear_wgrad(dy, x, dw, dbias=db)
+    assert rel_err(dw, dy.float().t() @ x.float()) < 1e-3
+    ref = dy.float().sum(0) + 3.0
+    assert rel_err(db, ref) < 1e-5, rel_err(db, ref)
+
+
 def test_gemm_epilogues():
     ops = _ops()
     torch.manual_seed(3)

@@ -22,6 +22,7 @@ class GemmDesc(C.Structure):
         ("epilogue", c_int), ("act", c_int), ("dtype", c_int),
         ("k_splits", c_int), ("alpha", c_float),
         ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_i64), ("colsum", c_void_p), ("row_scale", c_void_p),
+        ("a_rowsum", c_void_p),
     ]
 
 

@@ -385,8 +385,7 @@ def _tower_bwd(model, prefix, layers, dx, dxb, saved, M, T, W, heads, causal, ep
         ops.linear_dgrad(dxb, b.w16("wo"), out=dh)                               # dh := d attn out
         dqkv = ops.attention_bwd(qkv, ao, dh, lse, M, T, heads, causal)
         del qkv, ao, lse
-        ops.linear_wgrad(dqkv, h1, b.g("wqkv"))
-        ops.call("uniir_colsum_bf16", dqkv, 3 * W, b.g("bqkv"), R, 3 * W)
+        ops.linear_wgrad(dqkv, h1, b.g("wqkv"), dbias=b.g("bqkv"))             # + the in_proj bias gradient, same pass over dqkv
         ops.linear_dgrad(dqkv, b.w16("wqkv"), out=dh)                            # dh := d ln_1 out
         del dqkv, h1
         ops.layernorm_bwd(x, b.p32("ln1w"), dh, b.g("ln1w"), b.g("ln1b"), eps, dres=dx2, dx=dx, dx_bf16=dxb,

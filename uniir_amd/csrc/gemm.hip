@@ -25,6 +25,7 @@ struct GemmKArgs {
     int raster_gm, raster_cw;   // 2-D tile rasterisation block (row panels x column panels), 0 = row-major
     int skip_f;                 // EPI_BIAS_ACT without the pre-activation store (UNIIR_EPI_ACT_ONLY: forward-only passes)
     const float* row_scale;     // EPI_RESID_F32: (v + bias) * row_scale[m] + resid (DropPath factor of the row's item), or nullptr
+    float* a_rowsum;            // optional [M]: += sum_k A^T[m][k] (transposed-A ping-pong kernel only, see gemm_core_pp.h)
 };
 
 DEVINL float act_fwd(float x, int act) {
@@ -395,7 +396,8 @@ extern "C" int uniir_debug_read_ts(void* out, int n) {
 #else
 #define PP_STAMP(i)
 #endif
-// LOOP: 0 = compiler-scheduled loop, 1 = counted-lgkmcnt asm loop, 2 = ping-pong 8-phase loop (gemm_core_pp.h)
+// LOOP: 0 = compiler-scheduled loop, 1 = counted-lgkmcnt asm loop, 2 = ping-pong 8-phase loop (gemm_core_pp.h), 3 = the same
+// with the row sums of A^T (a_rowsum)
 template <typename Elem, bool A_TMAJ, bool B_TMAJ, int WM, int WN, int BK, int LOOP>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p) {
     using S = GldsShape<WM, WN, BK>;
@@ -439,9 +441,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     PP_STAMP(0);
-    constexpr bool PP = (WM == 2 && WN == 4 && BK == 64 && LOOP == 2);
+    constexpr bool PP = (WM == 2 && WN == 4 && BK == 64 && (LOOP == 2 || LOOP == 3));
     if (PP)
-        glds_mainloop_pp<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
+        glds_mainloop_pp<Elem, A_TMAJ, B_TMAJ, LOOP == 3>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc,
+                                                          p.a_rowsum, nt, p.tiles_n);
     else if (WM == 2 && WN == 4 && BK == 64 && LOOP == 1)
         glds_mainloop_asm<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
     else
@@ -523,17 +526,44 @@ static int gemm_shape(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
     return 1;
 }
 
+// does this problem run the ping-pong loop?
+static bool pp_eligible(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
+    if (gemm_shape(a, a_tmaj, b_tmaj) != 1 || a.asm_loop != 2) return false;
+    // the ping-pong loop needs >= 3 K steps in every split
+    const int ksteps = a.K / 64, per = (ksteps + a.k_splits - 1) / a.k_splits;
+    const int last = ksteps - per * (a.k_splits - 1);
+    // ... and addresses the K advance of a T-major operand as a 32-bit byte offset
+    const bool k32 = (!a_tmaj || (uint64_t)a.K * a.lda * 2 < (1ull << 32)) &&
+                     (!b_tmaj || (uint64_t)a.K * a.ldb * 2 < (1ull << 32));
+    return last >= 3 && k32;
+}
+// the transposed-A / transposed-B ping-pong kernel with the row sums of A^T (bf16 only: v_dot2c_f32_bf16)
+static int launch_glds_rowsum(GemmKArgs a, hipStream_t st) {
+    using S = GldsShape<2, 4, 64>;
+    a.tiles_m = (a.M + S::BM - 1) / S::BM;
+    a.tiles_n = (a.N + S::BN - 1) / S::BN;
+    a.raster_gm = 0;
+    a.raster_cw = 4;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first())
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<ElemBF16, true, true, 2, 4, 64, 3>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+    hipLaunchKernelGGL((gemm_glds_kernel<ElemBF16, true, true, 2, 4, 64, 3>), dim3(a.tiles_m * a.tiles_n * a.k_splits), dim3(S::T),
+                       S::LDS_BYTES, st, a);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
 template <typename Elem>
 static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t st) {
     const int shape = gemm_shape(a, a_tmaj, b_tmaj);
     if (shape == 1) {
-        // the ping-pong loop needs >= 3 K steps in every split
-        const int ksteps = a.K / 64, per = (ksteps + a.k_splits - 1) / a.k_splits;
-        const int last = ksteps - per * (a.k_splits - 1);
-        // ... and addresses the K advance of a T-major operand as a 32-bit byte offset
-        const bool k32 = (!a_tmaj || (uint64_t)a.K * a.lda * 2 < (1ull << 32)) &&
-                         (!b_tmaj || (uint64_t)a.K * a.ldb * 2 < (1ull << 32));
-        if (a.asm_loop == 2 && last >= 3 && k32) return launch_glds<Elem, 2, 4, 64, 2>(a, a_tmaj, b_tmaj, st);
+        if (pp_eligible(a, a_tmaj, b_tmaj)) {
+#ifndef UNIIR_EXP_BUILD
+            if (a.a_rowsum && std::is_same<Elem, ElemBF16>::value) return launch_glds_rowsum(a, st);
+#endif
+            return launch_glds<Elem, 2, 4, 64, 2>(a, a_tmaj, b_tmaj, st);
+        }
         return launch_glds<Elem, 2, 4, 64, 1>(a, a_tmaj, b_tmaj, st);
     }
     const int grid = a.tiles_m * a.tiles_n * a.k_splits;
@@ -667,6 +697,7 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     a.alpha = d->alpha;
     a.slab = nullptr;
     a.colsum = d->colsum;
+    a.a_rowsum = nullptr;
     {
         static const char* e = getenv("UNIIR_GEMM_LOOP");   // "1": counted-lgkmcnt double-buffer loop instead of ping-pong
         a.asm_loop = (e && e[0] == '1') ? 1 : 2;
@@ -684,6 +715,15 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
             d->splitk_ws_bytes >= (int64_t)splits * d->M * d->N * 4)
             a.slab = (float*)d->splitk_ws;
     }
+    // row sums of A^T (the bias gradient of a weight-gradient GEMM): inside the transposed ping-pong kernel when the problem
+    // runs it, otherwise as a separate pass over A
+    bool rowsum_fused = false;
+    if (d->a_rowsum) {
+        static const char* e = getenv("UNIIR_GEMM_ROWSUM");     // "0": always the separate pass (A/B)
+        if (!d->a_tmaj) return UNIIR_EUNSUPPORTED;
+        rowsum_fused = !(e && e[0] == '0') && d->dtype == UNIIR_DT_BF16 && d->b_tmaj && pp_eligible(a, d->a_tmaj, d->b_tmaj);
+        if (rowsum_fused) a.a_rowsum = d->a_rowsum;
+    }
     int rc;
     if (d->dtype == UNIIR_DT_BF16) rc = launch_gemm<ElemBF16>(a, d->a_tmaj, d->b_tmaj, st);
 #ifndef UNIIR_EXP_BUILD
@@ -691,6 +731,10 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
 #endif
     else return UNIIR_EINVAL;
     if (rc) return rc;
+    if (d->a_rowsum && !rowsum_fused) {
+        rc = uniir_colsum_bf16(d->A, d->lda, d->a_rowsum, d->K, d->M, stream);
+        if (rc) return rc;
+    }
     if (a.slab) {
         const long mn = (long)d->M * d->N;
         long g = (mn / 4 + 255) / 256;

@@ -121,6 +121,37 @@ DEVINL void pp_mfma16(const u32x4_t (&af)[4][2], const u32x4_t (&bf)[2][2], f32x
             for (int j = 0; j < 2; ++j) acc[H * 4 + i][HP * 2 + j] = Elem::mfma(bf[j][s], af[i][s], acc[H * 4 + i][HP * 2 + j]);
     __builtin_amdgcn_s_setprio(0);
 }
+// Row sums of A^T next to the GEMM (ROWSUM kernels): rs += the 8 k-values this lane holds of A row 16 I + (lane & 15), for both
+// k-substeps of the fragments in `af` -- for a weight-gradient GEMM dW = dy^T x that is the bias gradient, taken from the dy
+// fragments the matrix pipe is fed with anyway (v_dot2c_f32_bf16 against ones) instead of a second pass over dy.
+//  * The work is spread evenly: a K step is summed by the workgroup of ONE column panel (t % tiles_n), and there wave (wr, wc)
+//    takes fragment I = wc -- 4 dot products per 64 MFMAs on average, the same for every wave (summing in the first column
+//    panel's waves wc = 0, 1 only made those workgroups 17 % slower, and the GEMM with them).
+//  * It runs in the wave's LOAD segment of the following phase (the A fragments stay in registers for two phases), not between
+//    the MFMAs: a second variant of the MFMA sequence makes the compiler move all 128 accumulators between two register sets
+//    (+13 % on the GEMM).
+//  * An ext-vector element must be copied to a scalar before __builtin_bit_cast: bit_cast(T, v[c]) reads element 0 with this hipcc.
+template <int I>
+DEVINL void pp_rowsum_frag(const u32x4_t (&af)[4][2], float& rs) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    const bf2_t ones = __builtin_bit_cast(bf2_t, 0x3F803F80u);
+    float r1 = 0.f;                              // two chains: the dot products are back-to-back dependent otherwise
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned e0 = af[I][0][c], e1 = af[I][1][c];
+        rs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, e0), ones, rs, false);
+        r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, e1), ones, r1, false);
+    }
+    rs += r1;
+}
+DEVINL void pp_rowsum_wc(int wc, const u32x4_t (&af)[4][2], float& rs) {
+    switch (wc) {
+        case 0: pp_rowsum_frag<0>(af, rs); break;
+        case 1: pp_rowsum_frag<1>(af, rs); break;
+        case 2: pp_rowsum_frag<2>(af, rs); break;
+        default: pp_rowsum_frag<3>(af, rs); break;
+    }
+}
 
 template <typename Elem, bool A_TMAJ, bool B_TMAJ>
 struct PPState {
@@ -132,11 +163,18 @@ struct PPState {
     unsigned lbase;
     char* lds;
     int w;
+    int rs_nt, rs_tiles;              // ROWSUM kernels: this workgroup sums the K steps t with t % rs_tiles == rs_nt (-1: none)
 };
 
 // one K step (4 phases).  MODE 0: steady state; 1: second to last K step (stages q=0,1 only); 2: last (stages nothing)
-template <typename Elem, bool A_TMAJ, bool B_TMAJ, int MODE>
-DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&acc)[8][4]) {
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, int MODE, bool ROWSUM = false>
+DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&acc)[8][4], float (&rs)[2], int& rs_cd) {
+    // this workgroup's turn every rs_tiles-th K step (a countdown: t % rs_tiles with a run-time divisor costs ~100 cycles per K step)
+    bool rs_turn = false;
+    if (ROWSUM && st.rs_nt >= 0) {
+        rs_turn = rs_cd == 0;
+        rs_cd = rs_turn ? st.rs_tiles - 1 : rs_cd - 1;
+    }
     const unsigned sb = st.lbase + (t & 1) * 65536;            // this K step's four slots
     char* const cur = st.lds + (t & 1) * 65536;
     char* const oth = st.lds + ((t + 1) & 1) * 65536;
@@ -165,6 +203,8 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     __builtin_amdgcn_sched_barrier(0);
     if (MODE <= 1) pp_stage(st.rA, st.gA[1], kA1, oth + 3 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
+    if (ROWSUM && rs_turn) pp_rowsum_wc(st.w & 3, af, rs[0]);            // A0 rows (still in registers)
+    __builtin_amdgcn_sched_barrier(0);
     asm_wait_vm<MODE <= 1 ? 8 : 0>();
     pp_barrier();
     asm_wait_lgkm<0>();
@@ -185,6 +225,8 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     pp_barrier();
     // ---- phase 3: quadrant (A1,B0), B0 still in registers; stages (t+2, B0)
     if (MODE == 0) pp_stage(st.rB, st.gB[0], kB2, cur + 1 * 16384, st.w);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ROWSUM && rs_turn) pp_rowsum_wc(st.w & 3, af, rs[1]);            // A1 rows (still in registers)
     __builtin_amdgcn_sched_barrier(0);
     if (MODE == 0) asm_wait_vm<8>();
     if (MODE == 1) asm_wait_vm<4>();
@@ -233,23 +275,42 @@ DEVINL void pp_prologue(const PPState<Elem, A_TMAJ, B_TMAJ>& st) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename Elem, bool A_TMAJ, bool B_TMAJ>
-DEVINL void pp_main(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int nk, f32x4_t (&acc)[8][4]) {
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false>
+DEVINL void pp_main(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int nk, f32x4_t (&acc)[8][4], float (&rs)[2]) {
     const int wr = st.w >> 2;
     asm_wait_vm<8>();
     pp_barrier();
     if (wr == 1) pp_barrier();          // group 1 runs one barrier behind from here on
-    for (int t = 0; t < nk - 2; ++t) pp_kstep<Elem, A_TMAJ, B_TMAJ, 0>(st, t, acc);
-    pp_kstep<Elem, A_TMAJ, B_TMAJ, 1>(st, nk - 2, acc);
-    pp_kstep<Elem, A_TMAJ, B_TMAJ, 2>(st, nk - 1, acc);
+    int rs_cd = st.rs_nt;                // first turn at t = rs_nt
+    for (int t = 0; t < nk - 2; ++t) pp_kstep<Elem, A_TMAJ, B_TMAJ, 0, ROWSUM>(st, t, acc, rs, rs_cd);
+    pp_kstep<Elem, A_TMAJ, B_TMAJ, 1, ROWSUM>(st, nk - 2, acc, rs, rs_cd);
+    pp_kstep<Elem, A_TMAJ, B_TMAJ, 2, ROWSUM>(st, nk - 1, acc, rs, rs_cd);
     if (wr == 0) pp_barrier();          // re-align the groups
 }
 
-template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+// a_rowsum (ROWSUM kernels, transposed A only): += sum over this block's K range of A^T's rows m0 .. m0 + 255; nt / tiles_n: the
+// block's column panel and their number.
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false>
 DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int M, const unsigned short* __restrict__ B,
-                             long ldb, int N, int m0, int n0, int kbeg, int kend, char* lds, f32x4_t (&acc)[8][4]) {
+                             long ldb, int N, int m0, int n0, int kbeg, int kend, char* lds, f32x4_t (&acc)[8][4],
+                             float* a_rowsum = nullptr, int nt = 0, int tiles_n = 1) {
     PPState<Elem, A_TMAJ, B_TMAJ> st;
     pp_setup(st, A, lda, M, B, ldb, N, m0, n0, kbeg, lds);
+    st.rs_nt = (ROWSUM && a_rowsum) ? nt : -1;
+    st.rs_tiles = tiles_n;
+    float rs[2] = {0.f, 0.f};
     pp_prologue(st);
-    pp_main(st, (kend - kbeg) / 64, acc);
+    pp_main<Elem, A_TMAJ, B_TMAJ, ROWSUM>(st, (kend - kbeg) / 64, acc, rs);
+    if (ROWSUM && st.rs_nt >= 0) {
+        // rs[h]: lane (row 128 h + 64 wr + 16 wc + (lane & 15), k group lane >> 4) -> add the four k groups, one atomic per row
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v = rs[h];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int m = m0 + h * 128 + (st.w >> 2) * 64 + 16 * (st.w & 3) + (lane & 15);
+            if (lane < 16 && m < M) unsafeAtomicAdd(a_rowsum + m, v);
+        }
+    }
 }

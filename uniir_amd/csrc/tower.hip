@@ -161,10 +161,12 @@ int wgrad_splits(int rows, int tiles) {     // ops.wgrad_splits: fill the 256 CU
 }
 
 // dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]
-int linear_wgrad(const uniir_clip_tower* t, const void* dy, const void* x, float* dw, int M, int N, int K, void* st) {
+// dbias (optional): += column sums of dy, from the same pass over dy
+int linear_wgrad(const uniir_clip_tower* t, const void* dy, const void* x, float* dw, int M, int N, int K, void* st,
+                 float* dbias = nullptr) {
     uniir_gemm_desc d;
     base_desc(d);
-    d.A = dy; d.B = x; d.C = dw;
+    d.A = dy; d.B = x; d.C = dw; d.a_rowsum = dbias;
     d.M = N; d.N = K; d.K = M; d.lda = N; d.ldb = K; d.ldc = K; d.a_tmaj = 1; d.b_tmaj = 1;
     d.epilogue = UNIIR_EPI_ATOMIC_F32;
     d.k_splits = wgrad_splits(M, ((N + 255) / 256) * ((K + 255) / 256));
@@ -321,8 +323,7 @@ extern "C" int uniir_clip_tower_bwd_blocks(const uniir_clip_tower* t, int32_t ba
         TRY(linear_wgrad(t, dxb, l.ao, b.g_wo, R, W, W, stream));
         TRY(linear_dgrad(dxb, b.wo16, dh, R, W, W, nullptr, nullptr, nullptr, stream));                // d attention out
         TRY(uniir_attention_bwd(l.qkv, l.ao, dh, l.lse, dqkv, p.M, p.T, p.H, t->is_text ? 1 : 0, stream));
-        TRY(linear_wgrad(t, dqkv, l.h1, b.g_wqkv, R, 3 * W, W, stream));
-        TRY(uniir_colsum_bf16(dqkv, 3 * W, b.g_bqkv, R, 3 * W, stream));
+        TRY(linear_wgrad(t, dqkv, l.h1, b.g_wqkv, R, 3 * W, W, stream, b.g_bqkv));       // + the in_proj bias gradient
         TRY(linear_dgrad(dqkv, b.wqkv16, dh, R, 3 * W, W, nullptr, nullptr, nullptr, stream));         // d ln_1 out
         TRY(uniir_layernorm_bwd(l.x, W, b.ln1_w, dh, 0, dx2, dx, W, dxb, b.g_ln1_w, b.g_ln1_b,
                                 i > 0 ? t->blocks[i - 1].g_bproj : nullptr, R, W, 1e-5f, stream));

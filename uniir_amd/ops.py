@@ -60,7 +60,7 @@ def uses_tile256(M, N, K):
 
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epilogue=EPI_BF16, bias=None,
          resid=None, aux=None, ldaux=0, C2=None, act=ACT_QUICKGELU, k_splits=1, alpha=1.0, dtype=DT_BF16,
-         colsum=None, row_scale=None):
+         colsum=None, row_scale=None, a_rowsum=None):
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = A.data_ptr(), B.data_ptr(), C_out.data_ptr(), (C2.data_ptr() if C2 is not None else None)
     d.bias = bias.data_ptr() if bias is not None else None
@@ -72,6 +72,7 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, a_tmaj=False, b_tmaj=False, epi
     d.epilogue, d.act, d.dtype, d.k_splits, d.alpha = epilogue, act, dtype, k_splits, alpha
     d.colsum = colsum.data_ptr() if colsum is not None else None
     d.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    d.a_rowsum = a_rowsum.data_ptr() if a_rowsum is not None else None
     if k_splits > 1:
         ws = _splitk_workspace(A.device, 4 * k_splits * M * N)
         d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
@@ -131,13 +132,14 @@ def wgrad_splits(rows, tiles):
     return best
 
 
-def linear_wgrad(dy, x, dw):
-    """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]."""
+def linear_wgrad(dy, x, dw, *, dbias=None):
+    """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K];  dbias[N] (fp32) += column sums of dy (from the same pass over dy when the
+    256x256 transposed kernel runs)."""
     M, N = dy.shape
     K = x.shape[1]
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     return gemm(dy, x, dw, N, K, M, N, K, K, a_tmaj=True, b_tmaj=True, epilogue=EPI_ATOMIC_F32,
-                k_splits=wgrad_splits(M, tiles))
+                k_splits=wgrad_splits(M, tiles), a_rowsum=dbias)
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, *, out_bf16=None, out_f32=None, rows=None, width=None, x_stride=None):
