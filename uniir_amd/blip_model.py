@@ -336,8 +336,7 @@ def _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum):
         df = torch.empty(R, I, **b16)
         ops.linear_dgrad(d16, st.w16(b + "output.dense.weight"), out=df, aux=sv["f"], act_out=g,
                          colsum=G(b + "intermediate.dense.bias"), act=ops.ACT_GELU_ERF)
-        ops.linear_wgrad(d16, g, G(b + "output.dense.weight"))
-        colsum(d16, W, b + "output.dense.bias")
+        ops.linear_wgrad(d16, g, G(b + "output.dense.weight"), dbias=G(b + "output.dense.bias"))
         ops.linear_wgrad(df, sv["c16"], G(b + "intermediate.dense.weight"))
         dc = torch.empty(R, W, **f32)       # d c32 = df @ Wi + dt3 (the residual branch)
         ops.gemm(df, st.w16(b + "intermediate.dense.weight"), dc, R, W, I, I, W, W, b_tmaj=True,
@@ -351,8 +350,8 @@ def _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum):
                                     G(b + "crossattention.output.LayerNorm.bias"), eps, dx_bf16=d16, rows=R, width=W)
             if ph:
                 ops.dropout_bf16_(d16, ph, so2)
-            ops.linear_wgrad(d16, sv["co"], G(b + "crossattention.output.dense.weight"))
-            colsum(d16, W, b + "crossattention.output.dense.bias")
+            ops.linear_wgrad(d16, sv["co"], G(b + "crossattention.output.dense.weight"),
+                             dbias=G(b + "crossattention.output.dense.bias"))
             dco = ops.linear_dgrad(d16, st.w16(b + "crossattention.output.dense.weight"))
             dcq = torch.empty(R, W, **b16)
             dckv = torch.empty(M * Ti, 2 * W, **b16)
@@ -360,12 +359,10 @@ def _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum):
             ops.attention_bwd_ex(sv["cq"], W, ckv, ckv[:, W:], 2 * W, sv["co"], dco, sv["lse2"], dcq, W, dckv, dckv[:, W:],
                                  2 * W, M, L, Ti, heads, drop_p=pa, drop_seed=sa2)
             Ew = img16.shape[1]
-            ops.linear_wgrad(dckv, img16, G(c + "key.weight", (2 * W, Ew)))
-            colsum(dckv, 2 * W, c + "key.bias", (2 * W,))
+            ops.linear_wgrad(dckv, img16, G(c + "key.weight", (2 * W, Ew)), dbias=G(c + "key.bias", (2 * W,)))
             ops.gemm(dckv, st.w16(c + "key.weight", (2 * W, Ew)), dimg, M * Ti, Ew, 2 * W, 2 * W, Ew, Ew, b_tmaj=True,
                      epilogue=ops.EPI_RESID_F32, resid=dimg)          # dimg += dckv @ Wkv (in place: same element r/w)
-            ops.linear_wgrad(dcq, sv["a16"], G(c + "query.weight"))
-            colsum(dcq, W, c + "query.bias")
+            ops.linear_wgrad(dcq, sv["a16"], G(c + "query.weight"), dbias=G(c + "query.bias"))
             da = torch.empty(R, W, **f32)       # d a32 = dcq @ Wcq + dt2
             ops.gemm(dcq, st.w16(c + "query.weight"), da, R, W, W, W, W, W, b_tmaj=True, epilogue=ops.EPI_RESID_F32,
                      resid=dt2)
@@ -375,15 +372,13 @@ def _bert_layers_backward(st, prefix, cfg, do, dimg, g, stash, cross, colsum):
                                 eps, dx_bf16=d16, rows=R, width=W)
         if ph:
             ops.dropout_bf16_(d16, ph, so1)
-        ops.linear_wgrad(d16, sv["ao"], G(b + "attention.output.dense.weight"))
-        colsum(d16, W, b + "attention.output.dense.bias")
+        ops.linear_wgrad(d16, sv["ao"], G(b + "attention.output.dense.weight"), dbias=G(b + "attention.output.dense.bias"))
         dao = ops.linear_dgrad(d16, st.w16(b + "attention.output.dense.weight"))
         qkv = sv["qkv"]
         dqkv = torch.empty(R, 3 * W, **b16)
         ops.attention_bwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, sv["ao"], dao, sv["lse1"], dqkv, 3 * W,
                              dqkv[:, W:], dqkv[:, 2 * W:], 3 * W, M, L, L, heads, key_len=key_len, drop_p=pa, drop_seed=sa1)
-        ops.linear_wgrad(dqkv, sv["h16"], G(s + "query.weight", (3 * W, W)))
-        colsum(dqkv, 3 * W, s + "query.bias", (3 * W,))
+        ops.linear_wgrad(dqkv, sv["h16"], G(s + "query.weight", (3 * W, W)), dbias=G(s + "query.bias", (3 * W,)))
         do = torch.empty(R, W, **f32)       # d h32 = dqkv @ Wqkv + dt1
         ops.gemm(dqkv, st.w16(s + "query.weight", (3 * W, W)), do, R, W, 3 * W, 3 * W, W, W, b_tmaj=True,
                  epilogue=ops.EPI_RESID_F32, resid=dt1)
@@ -800,8 +795,7 @@ class _EncodeSFFn(torch.autograd.Function):
         def proj_bwd(dy, x16, name):
             dy16 = torch.empty(M, E, device=dev, dtype=torch.bfloat16)
             ops.call("uniir_cast_f32_to_bf16", dy, dy16, dy.numel())
-            ops.linear_wgrad(dy16, x16, G(name + ".weight"))
-            ops.call("uniir_colsum_bf16", dy16, E, G(name + ".bias"), M, E)
+            ops.linear_wgrad(dy16, x16, G(name + ".weight"), dbias=G(name + ".bias"))
             K = x16.shape[1]
             dx = torch.empty(M, K, device=dev, dtype=torch.float32)
             ops.gemm(dy16, st.w16(name + ".weight"), dx, M, K, E, E, K, K, b_tmaj=True, epilogue=ops.EPI_F32)
