@@ -78,6 +78,14 @@ def test_gemm_wgrad_with_bias_gradient(M, N, K):
     assert rel_err(db, ref) < 1e-5, rel_err(db, ref)
 
 
+def test_gemm_row_sums_need_a_transposed_bf16_operand():
+    ops = _ops()
+    x, w = bf(torch.randn(256, 128, device=DEV)), bf(torch.randn(256, 128, device=DEV))
+    out = torch.empty(256, 256, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, w, out, 256, 256, 128, 128, 128, 256, a_rowsum=torch.zeros(256, device=DEV))        # A not transposed
+
+
 def test_gemm_epilogues():
     ops = _ops()
     torch.manual_seed(3)

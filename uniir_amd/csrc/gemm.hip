@@ -720,7 +720,7 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     bool rowsum_fused = false;
     if (d->a_rowsum) {
         static const char* e = getenv("UNIIR_GEMM_ROWSUM");     // "0": always the separate pass (A/B)
-        if (!d->a_tmaj) return UNIIR_EUNSUPPORTED;
+        if (!d->a_tmaj || d->dtype != UNIIR_DT_BF16) return UNIIR_EUNSUPPORTED;     // (the separate pass reads bf16 too)
         rowsum_fused = !(e && e[0] == '0') && d->dtype == UNIIR_DT_BF16 && d->b_tmaj && pp_eligible(a, d->a_tmaj, d->b_tmaj);
         if (rowsum_fused) a.a_rowsum = d->a_rowsum;
     }
