@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference/src"
 sys.path.insert(0, ROOT)
@@ -301,8 +302,121 @@ def g9():
         out["recall"].append({"rel": rel, "ret": ret, "k": k, "v": mr.compute_recall_at_k(rel, ret, k)})
     for s in ["  hello world ", '"quoted text"', "", None, "Ends with period.", "question?", "a\r\nb"]:
         out["format"].append({"in": s, "out": format_string(s)})
+    out["collator"] = _g9_collators()
+    out["runfile"] = _g9_runfile()
+    out["dataset"] = _g9_dataset()
     json.dump(out, open(os.path.join(HERE, "g9_host.json"), "w"), indent=1)
     print("g9 ok")
+
+
+# ---- batch ABI: the reference's own collators / datasets on hand-made instances -------------------
+from g9_helpers import (g9_tokenizer, g9_image, g9_materialise, g9_flatten, g9_write_tree, g9_img_fn,  # noqa: E402
+                        g9_dataset_rows)
+
+
+G9_CASES = {
+    # train mode with hard negatives: text-only / image-only / both, empty string and None both count as "no text"
+    "train_neg": {"collator": "main", "mode": "train", "batch": [
+        {"query": {"txt": "q zero", "img": None}, "pos_cand": {"txt": "", "img": 0.5},
+         "neg_cand_list": [{"txt": "n0", "img": None}, {"txt": None, "img": 0.25}], "p_did": 700001},
+        {"query": {"txt": "what is this?", "img": 1.0}, "pos_cand": {"txt": "p one", "img": None},
+         "neg_cand_list": [{"txt": "n2", "img": 2.0}, {"txt": "n3", "img": None}], "p_did": 900002},
+        {"query": {"txt": None, "img": 3.0}, "pos_cand": {"txt": "p two", "img": 4.0},
+         "neg_cand_list": [{"txt": "n4", "img": None}, {"txt": "n5", "img": None}], "p_did": 5}]},
+    # train mode without neg_cand_list
+    "train_plain": {"collator": "main", "mode": "train", "batch": [
+        {"query": {"txt": "alpha", "img": None}, "pos_cand": {"txt": "beta", "img": 0.125}, "p_did": 11},
+        {"query": {"txt": "", "img": 6.0}, "pos_cand": {"txt": "gamma", "img": None}, "p_did": 12}]},
+    # eval mode: qid / task_id popped into lists, no pos_cand in the mapping even when the instance carries one
+    "eval": {"collator": "main", "mode": "eval", "batch": [
+        {"query": {"txt": "e0", "img": None}, "qid": 9000001, "task_id": 3},
+        {"query": {"txt": "e1", "img": 7.0}, "pos_cand": {"txt": "ignored", "img": None}, "qid": 9000002, "task_id": 0},
+        {"query": {"txt": None, "img": 8.0}, "qid": 9000003, "task_id": 8}]},
+    "inference_only": {"collator": "inference", "batch": [
+        {"query": {"txt": "i0", "img": None}, "qid": 1, "task_id": 2},
+        {"query": {"txt": "", "img": 9.0}, "qid": 2},
+        {"query": {"txt": "i2", "img": 10.0}, "task_id": 4}]},
+    "cand_pool": {"collator": "pool", "batch": [
+        {"txt": "c0", "img": None, "did": 123}, {"txt": "", "img": 0.75, "did": 124}, {"txt": "c2", "img": 1.5, "did": 125},
+        {"txt": None, "img": 2.5, "modality": "image", "did": 126}]},
+    "cand_pool_no_did": {"collator": "pool", "batch": [{"txt": "x", "img": None}, {"txt": "y", "img": 1.0}]},
+}
+
+
+def _g9_collators():
+    import importlib
+    sys.modules.pop("data.mbeir_dataset", None)
+    md = importlib.import_module("data.mbeir_dataset")       # the reference's own module (typeguard stubbed to identity)
+    assert md.__file__.startswith(REF), md.__file__
+    res = {}
+    for name, case in G9_CASES.items():
+        kind = case["collator"]
+        if kind == "main":
+            col = md.MBEIRMainCollator(g9_tokenizer, (4, 4), mode=md.Mode.TRAIN if case["mode"] == "train" else md.Mode.EVAL)
+        elif kind == "inference":
+            col = md.MBEIRInferenceOnlyCollator(g9_tokenizer, (4, 4))
+        else:
+            col = md.MBEIRCandidatePoolCollator(g9_tokenizer, 4)
+        out = col([g9_materialise(b) for b in case["batch"]])
+        res[name] = {"case": case, "out": g9_flatten(out)}
+    return res
+
+
+def _g9_runfile():
+    """the run-file line of mbeir_retriever.py:438-443: the reference's own f-string, lifted from its AST and evaluated on two
+    hits (the surrounding run_retrieval needs FAISS + a whole M-BEIR tree)"""
+    import ast
+    from data.preprocessing.utils import unhash_qid, unhash_did, hash_qid, hash_did
+    src = open(os.path.join(REF, "common", "mbeir_retriever.py")).read()
+    node = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "run_file_line")
+    fmt = compile(ast.Expression(node.value), "<mbeir_retriever.run_file_line>", "eval")
+    rows = []
+    run_id = "mbeir_mscoco_task0_union_pool_test_k10"
+    dists = np.array([[0.8731712, 0.5], [1.0, -0.0317]], dtype=np.float32)
+    idx = np.array([[hash_did("9:42"), hash_did("9:7")], [hash_did("1:499999"), hash_did("0:1")]], dtype=np.int64)
+    for qi, hq in enumerate([hash_qid("9:3"), hash_qid("2:100")]):
+        qid = unhash_qid(hq)
+        for rank, (hashed_doc_id, score) in enumerate(zip(idx[qi], dists[qi]), start=1):
+            doc_id = unhash_did(hashed_doc_id)
+            task_id = 3 if qi == 0 else 0
+            line = eval(fmt, {}, dict(qid=qid, doc_id=doc_id, rank=rank, score=score, run_id=run_id, task_id=task_id))
+            rows.append({"hq": int(hq), "hd": int(hashed_doc_id), "score_f32_bits": int(np.float32(score).view(np.int32)),
+                         "rank": rank, "run_id": run_id, "task_id": task_id, "line": line})
+    return rows
+
+
+G9_TREE = {
+    "instructions": "query_modality\tcand_modality\tdataset_name\tdataset_id\tprompt_1\tprompt_2\n"
+                    "text\timage\tmscoco\t9\tFind an image for the caption.\t\n"
+                    "image\ttext\tmscoco\t9\tDescribe the picture\t\n"
+                    "image,text\timage\tcirr\t7\tFind a similar image, modified as told.\t\n",
+    "cand_pool": [
+        {"did": "9:1", "txt": None, "img_path": "img/a.png", "modality": "image", "src_content": None},
+        {"did": "9:2", "txt": "  a dog on grass ", "img_path": None, "modality": "text", "src_content": None},
+        {"did": "9:3", "txt": '"a cat"', "img_path": None, "modality": "text", "src_content": None},
+        {"did": "7:1", "txt": None, "img_path": "img/b.png", "modality": "image", "src_content": None},
+        {"did": "7:2", "txt": None, "img_path": "img/a.png", "modality": "image", "src_content": None},
+    ],
+    "queries": [
+        {"qid": "9:1", "query_txt": "a photo of a dog", "query_img_path": None, "query_modality": "text",
+         "query_src_content": None, "pos_cand_list": ["9:1"], "neg_cand_list": ["7:2"], "task_id": 0},
+        {"qid": "9:2", "query_txt": None, "query_img_path": "img/a.png", "query_modality": "image",
+         "query_src_content": None, "pos_cand_list": ["9:2", "9:3"], "neg_cand_list": ["9:3"], "task_id": 3},
+        {"qid": "7:1", "query_txt": "make it red", "query_img_path": "img/b.png", "query_modality": "image,text",
+         "query_src_content": None, "pos_cand_list": ["7:1"], "neg_cand_list": ["7:2", "7:1"], "task_id": 7},
+    ],
+    "images": {"img/a.png": [10, 200, 30], "img/b.png": [250, 0, 120]},
+}
+
+
+def _g9_dataset():
+    import importlib
+    import tempfile
+    md = importlib.import_module("data.mbeir_dataset")
+    assert md.__file__.startswith(REF), md.__file__
+    with tempfile.TemporaryDirectory() as root:
+        g9_write_tree(root, G9_TREE)
+        return {"tree": G9_TREE, "rows": g9_dataset_rows(md, root)}
 
 
 def g10():

@@ -91,6 +91,62 @@ def test_main_collator_batch_abi():
     assert pool["did_list"] == [5, 6] and pool["txt_mask_batched"].tolist() == [1, 0]
 
 
+def _g9():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import g9_helpers
+    return g9_helpers
+
+
+def test_collators_match_the_reference_fixture_key_for_key():
+    """every collator of the mirror on the instances of g9_host.json["collator"], whose expected outputs were
+    produced by the REFERENCE's MBEIRMainCollator / MBEIRInferenceOnlyCollator / MBEIRCandidatePoolCollator
+    (mbeir_dataset.py:440-526,529-570,572-610; tests/golden/make_golden.py g9): index_mapping counter, masks, padding rows,
+    qid / task_id / p_did / did lists, key sets and dtypes."""
+    from data.mbeir_dataset import MBEIRCandidatePoolCollator, MBEIRInferenceOnlyCollator, MBEIRMainCollator, Mode
+    H = _g9()
+    assert set(G9["collator"]) >= {"train_neg", "train_plain", "eval", "inference_only", "cand_pool", "cand_pool_no_did"}
+    for name, rec in G9["collator"].items():
+        case, want = rec["case"], rec["out"]
+        if case["collator"] == "main":
+            col = MBEIRMainCollator(H.g9_tokenizer, (4, 4), mode=Mode.TRAIN if case["mode"] == "train" else Mode.EVAL)
+        elif case["collator"] == "inference":
+            col = MBEIRInferenceOnlyCollator(H.g9_tokenizer, (4, 4))
+        else:
+            col = MBEIRCandidatePoolCollator(H.g9_tokenizer, 4)
+        got = H.g9_flatten(col([H.g9_materialise(b) for b in case["batch"]]))
+        assert set(got) == set(want), (name, sorted(got), sorted(want))
+        for k in want:
+            assert got[k] == want[k], (name, k, got[k], want[k])
+
+
+def test_run_file_line_matches_the_reference_format():
+    """the run-file line (mbeir_retriever.py:438-443): the mirror's writer on the fixture's hits == the reference's own f-string
+    evaluated on them (float32 scores print with numpy's repr digits)"""
+    import numpy as np
+    from data.preprocessing.utils import unhash_did, unhash_qid
+    import mbeir_retriever as mr
+    for r in G9["runfile"]:
+        score = np.array([r["score_f32_bits"]], dtype=np.int32).view(np.float32)[0]
+        line = mr.run_file_line(unhash_qid(r["hq"]), unhash_did(r["hd"]), r["rank"], score, r["run_id"], r["task_id"])
+        assert line == r["line"], (line, r["line"])
+
+
+def test_datasets_match_the_reference_fixture(tmp_path):
+    """MBEIRMainDataset (train with 2 hard negatives / train without instructions / eval) and MBEIRCandidatePoolDataset
+    __getitem__ on a 3-query M-BEIR tree == the reference's (mbeir_dataset.py:179-277,376-411): prompt + query text through
+    format_string, first positive, wrapped hard negatives, hashed ids, task ids, image hand-over to img_preprocess_fn."""
+    import data.mbeir_dataset as md
+    H = _g9()
+    H.g9_write_tree(str(tmp_path), G9["dataset"]["tree"])
+    got = H.g9_dataset_rows(md, str(tmp_path))
+    want = G9["dataset"]["rows"]
+    assert set(got) == set(want)
+    for tag in want:
+        assert len(got[tag]) == len(want[tag]), tag
+        for i, (g, w) in enumerate(zip(got[tag], want[tag])):
+            assert g == w, (tag, i, g, w)
+
+
 def test_wgrad_split_heuristic_fills_the_chip():
     from uniir_amd.ops import wgrad_splits
     for tiles in (12, 16, 48, 64):
@@ -264,6 +320,28 @@ def test_checkpoint_loader_does_not_resolve_arbitrary_globals(tmp_path):
     sd = load_checkpoint_file(path)
     assert torch.equal(sd["model"]["w"], torch.arange(4.0))
     assert not (tmp_path / "pwned").exists()
+
+    # gadgets that live UNDER the allowed roots must not resolve either (an exact (module, name) list, not roots)
+    class TorchGadget:
+        def __reduce__(self):
+            import torch.utils.collect_env as ce
+            return (ce.run, ("touch " + str(tmp_path / "pwned_torch"),))
+
+    class NumpyGadget:
+        def __reduce__(self):
+            from numpy.testing._private.utils import runstring
+            return (runstring, ("open(%r, 'w').close()" % str(tmp_path / "pwned_numpy"), {}))
+
+    class BuiltinGadget:
+        def __reduce__(self):
+            return (eval, ("__import__('os').system('touch %s')" % str(tmp_path / "pwned_eval"),))
+
+    for i, g in enumerate((TorchGadget(), NumpyGadget(), BuiltinGadget())):
+        path = str(tmp_path / f"evil{i}.pth")
+        torch.save({"model": {"w": torch.arange(4.0), "h": torch.ones(2, dtype=torch.bfloat16)}, "config": g, "odd": Evil()}, path)
+        sd = load_checkpoint_file(path)
+        assert torch.equal(sd["model"]["w"], torch.arange(4.0)) and sd["model"]["h"].dtype == torch.bfloat16
+    assert not any((tmp_path / n).exists() for n in ("pwned", "pwned_torch", "pwned_numpy", "pwned_eval"))
 
 
 def test_clip_load_refuses_missing_pretrained_weights(tmp_path, monkeypatch):

@@ -121,6 +121,12 @@ _DATASET_ORDER = ["visualnews_task0", "mscoco_task0", "fashion200k_task0", "webq
 _RECALLS = ["Recall@1", "Recall@5", "Recall@10", "Recall@20", "Recall@50"]
 
 
+def run_file_line(qid, doc_id, rank, score, run_id, task_id):
+    """one TREC-style hit: query-id Q0 document-id rank score run-id task-id (reference mbeir_retriever.py:438-443; pinned by
+    tests/golden/g9_host.json["runfile"]).  `score` is the numpy float32 the search returned: it prints with float32 repr digits."""
+    return f"{qid} Q0 {doc_id} {rank} {score} {run_id} {task_id}\n"
+
+
 def run_retrieval(config, query_embedder_config=None):
     rc = config.retrieval_config
     expt = config.experiment.path_suffix
@@ -160,7 +166,7 @@ def run_retrieval(config, query_embedder_config=None):
                     task = qid_to_task[qid]
                     docs = [unhash_did(int(h)) for h in ix]
                     for rank, (doc, score) in enumerate(zip(docs, ds), start=1):
-                        rf.write(f"{qid} Q0 {doc} {rank} {score} {run_id} {task}\n")
+                        rf.write(run_file_line(qid, doc, rank, score, run_id, task))
                     for m in recalls:
                         by_task[task][m].append(compute_recall_at_k(qrel[qid], docs, int(m.split("@")[1])))
             for task, vals in by_task.items():

@@ -55,12 +55,15 @@ class MBEIRDatasetBase(Dataset):
         return self.img_preprocess_fn(Image.open(path).convert("RGB"))
 
     def _get_random_query_prompt(self, dataset_id, query_modality, cand_modality):
-        key = f"{dataset_id}, {query_modality}, {cand_modality}"
-        prompts = self.query_instructions.get(key, [])
-        assert prompts, f"Cannot find prompts for {key}"
-        prompt = format_string(random.choice(prompts))
-        assert prompt, f"Prompt is empty for {key}"
-        return prompt
+        """one instruction of the (dataset, query modality, candidate modality) row of the TSV, cleaned up like every text"""
+        lookup = ", ".join((str(dataset_id), str(query_modality), str(cand_modality)))
+        choices = self.query_instructions.get(lookup) or []
+        if not choices:
+            raise AssertionError(f"no instruction row for ({lookup}) in the query-instruction TSV")
+        picked = format_string(random.choice(choices))
+        if not picked:
+            raise AssertionError(f"instruction row ({lookup}) holds an empty prompt")
+        return picked
 
     def _item(self, txt, img_path):
         return {"txt": txt, "img": self._load_and_preprocess_image(img_path)}
