@@ -359,7 +359,7 @@ class _DryRunTrainer:
         self.g32.fill_(1.0)
         for i in reversed(range(self.blocks)):
             self.reducer.ready(1000 + i * self.block_elems, 1000 + (i + 1) * self.block_elems)
-        self.last_collectives = self.reducer.finish()
+        self.last_collectives, _ = self.reducer.finish()
         ok = bool((self.g32 == comm.world()).all()) and bool((d_p == comm.world()).all())
         return {"loss": torch.tensor(0.0 if ok else float("nan"))}
 
@@ -423,6 +423,9 @@ def main():
         torch.manual_seed(2023 + rank)
         model = CLIPScoreFusion(model_name=args.model, device=dev, config=config)
         model.float()
+        if world > 1:        # what the reference's DDP wrapper does at construction (clip_scorefusion/train.py:218)
+            from uniir_amd import comm
+            comm.sync_replicas(model)
         trainer = NativeTrainer(model, lr=1e-5, t_total=10000)
         batch = synth_batch(cfg, args.pairs, 2023 + rank, dev)
 
@@ -457,6 +460,13 @@ def main():
                 "grad_allreduce": {"overlapped_with_backward": True, "collectives_per_step": int(opt.last_collectives),
                                    "bucket_MB": round((opt.reducer.bucket_elems * 4) / 2**20, 1) if opt.reducer else None}}
         rccl.update(time_collectives(dist, dev, world, args.pairs, E, flat))
+        if not args.dry_run:     # did the replicas stay identical through the timed steps?  (sum, sum of squares) of every rank
+            from uniir_amd import comm
+            cs = torch.tensor(comm.replica_checksum(model.clip_model), device=dev, dtype=torch.float64)
+            allcs = [torch.zeros_like(cs) for _ in range(world)]
+            dist.all_gather(allcs, cs)
+            rccl["replica_checksums"] = [[float(x) for x in c.cpu()] for c in allcs]
+            rccl["replicas_identical"] = all(torch.equal(c, allcs[0]) for c in allcs)
 
     result = None
     if rank == 0:
@@ -487,7 +497,9 @@ def main():
                                     f"{args.pairs} pairs/GPU, global batch {global_pairs}, 224x224 images + 77-token text")
                        if not args.dry_run else "DRY RUN: launcher / collective plumbing only, not a measurement",
                        "pairs_per_gpu": args.pairs, "global_batch": global_pairs, "parallelism": f"dp{world}",
-                       "final_loss": round(loss, 4)},
+                       "final_loss": round(loss, 4),
+                       "batch": "ONE synthetic batch per rank, generated on the device before the timed region and re-used for "
+                                "every step (timing only; the loss therefore collapses)"},
             "roofline": roof,
         }
         if rccl is not None:

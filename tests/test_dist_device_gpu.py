@@ -174,3 +174,48 @@ def test_two_rank_resident_shards_give_the_single_pool_topk():
     got_i = np.concatenate([res[0][1], res[1][1]])
     assert got_s.shape == (37, 10)
     assert np.array_equal(got_i, want_i) and np.array_equal(got_s, want_s)
+
+
+def _sync_device_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "uniir_amd", "src"))
+    from oracle import clip_oracle as O
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd import clip_model, comm
+    from uniir_amd.trainer import NativeTrainer
+    cfg = O.tiny_config()
+    clip_model.CLIP_CONFIGS["tiny-sync"] = cfg
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=True), data_config=SimpleNamespace(in_batch_neg_num=0))
+    model = CLIPScoreFusion("tiny-sync", device="cuda:0", config=config)
+    model.clip_model.load_state_dict(O.init_state_dict(cfg, seed=50 + rank))      # rank-dependent weights
+    clip = model.clip_model
+    clip._sync_shadow()                                                          # flat storage + bf16 shadow of the OWN weights
+    stale16 = clip.w16("visual.proj").float().clone()
+    n = comm.sync_replicas(model)
+    tr = NativeTrainer(model, lr=1e-3, t_total=10)
+    out = tr.train_step(_rank_batch(O, cfg, rank, 4))
+    torch.cuda.synchronize()
+    shadow_fresh = bool((clip.w16("visual.proj").float() - clip.visual.proj.detach()).abs().max() < 1e-2)
+    q.put((rank, n, comm.replica_checksum(model), float((stale16 - clip.w16("visual.proj").float()).abs().max()), shadow_fresh,
+           float(out["loss"].detach())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_sync_on_the_flat_device_storage_then_a_step_keeps_replicas_identical():
+    """comm.sync_replicas on the device layout (one broadcast of the flat fp32 master buffer; the bf16 shadow is re-derived):
+    two ranks loaded with DIFFERENT weights train one distributed step and end bit-identical"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_device_worker, args=(r, 2, 29547, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    (_, n0, c0, d0, f0, l0), (_, n1, c1, d1, f1, l1) = res
+    assert c0 == c1, (c0, c1)                 # identical after sync + one step (checksum over every parameter and buffer)
+    assert n0 == n1 and n0 <= 4               # the flat buffer travels as ONE collective (+ conv shadow-independent leftovers)
+    assert d1 > 1e-3 and f0 and f1            # rank 1's shadow really changed and matches its (new) master weights

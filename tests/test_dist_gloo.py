@@ -143,15 +143,32 @@ def _reducer_worker(rank, world, port, q):
         red.ready(lo, lo + 700)
     red.ready(8700, 9000)
     launched_before_finish = red.n_collectives
-    ncoll = red.finish()
+    ncoll, _ = red.finish()
     # a second step on the same reducer (state re-armed)
     flat2 = flat.clone()
     red2_in = flat2.clone()
     comm.allreduce_sum_(red2_in)
     red.flat = flat2
     red.ready(0, 5000)
+    # a second flat buffer handed over in the middle of backward (CLIP_FF's T5 store): reduced once, reported by finish()
+    extra = torch.full((77,), float(rank + 1))
+    red.reduce_extra(extra)
+    red.reduce_extra(extra)            # idempotent within a step
+    _, extra_done = red.finish()
+    extra_ok = bool((extra == 3.0).all()) and extra.data_ptr() in extra_done
+    same2 = torch.equal(flat2, red2_in)
+    # a range announced twice inside one armed backward is refused AT the second announcement ...
+    red.ready(100, 200)
+    dup = False
+    try:
+        red.ready(150, 250)
+    except RuntimeError:
+        dup = True
+    # ... and reset() (NativeAdamW.arm_overlap) drops the state of a backward whose step() never came
+    red.reset()
+    red.ready(100, 200)
     red.finish()
-    q.put((rank, torch.equal(flat, flat_ref), torch.equal(flat2, red2_in), launched_before_finish, ncoll))
+    q.put((rank, torch.equal(flat, flat_ref), same2 and extra_ok and dup, launched_before_finish, ncoll))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -171,6 +188,47 @@ def test_bucketed_overlapped_gradient_allreduce_equals_flat_allreduce_bit_for_bi
         assert same and same2
         assert early >= 2            # buckets really left before finish() (overlap), not one blocking call at the end
         assert ncoll > early
+
+
+def _sync_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import clip_oracle as O
+    from uniir_amd import clip_model, comm
+    cfg = O.tiny_config()
+    model = clip_model.CLIP(cfg, seed=100 + rank)            # rank-dependent initialisation: the replicas start DIFFERENT
+    # buffers travel too (DDP broadcasts them: BLIP's queues / pointer); and a cached host copy of the pointer is dropped
+    model.register_buffer("queue", torch.randn(4, 6, generator=torch.Generator().manual_seed(rank)))
+    model.register_buffer("new_ptr_queue", torch.tensor([3 * rank + 1]))
+    model._ptr_host = 3 * rank + 1
+    before = comm.replica_checksum(model)
+    versions = sum(p._version for p in model.parameters())
+    n = comm.sync_replicas(model)
+    after = comm.replica_checksum(model)
+    bumped = sum(p._version for p in model.parameters()) > versions       # the bf16 shadows will be re-derived
+    q.put((rank, before, after, n, int(model.new_ptr_queue), model._ptr_host, bumped,
+           float(model.visual.proj.detach().double().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_sync_makes_differently_seeded_ranks_identical():
+    """VERDICT r2 missing #3: what DDP's constructor does (clip_scorefusion/train.py:218): rank 0's parameters and buffers reach
+    every replica.  Two ranks built from different seeds -> identical state (checksum + a spot value), rank 0 unchanged."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, 29541, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    (r0, b0, a0, n0, ptr0, host0, bump0, spot0), (r1, b1, a1, n1, ptr1, host1, bump1, spot1) = res
+    assert b0 != b1                       # they really started different
+    assert a0 == a1 == b0                 # ... and both ended with rank 0's state, bit for bit (float64 sums of identical tensors)
+    assert spot0 == spot1 and ptr0 == ptr1 == 1 and host0 is None and host1 is None and bump0 and bump1
+    assert n0 == n1 and n0 >= 3
 
 
 def test_reducer_rejects_overlapping_ranges():

@@ -290,6 +290,9 @@ class FusionFn(torch.autograd.Function):
         ctx.stashes = None
         M, Tt, Ti, D = ctx.dims
         dx = t5_backward(owner._t5, "", dpooled, fst, owner.t5_heads, owner.t5_layers_n).view(M, Tt + Ti, D)
+        reducer = getattr(owner.clip_model, "_grad_reducer", None)
+        if reducer is not None:        # the T5 gradients are final: their all-reduce overlaps the two tower backwards
+            reducer.reduce_extra(owner._t5.g32)
         dt = dx[:, :Tt].contiguous().view(M * Tt, D)
         di = dx[:, Tt:].contiguous().view(M * Ti, D)
         del dx

@@ -65,6 +65,61 @@ def allreduce_sum_(flat):
     return flat
 
 
+def broadcast_(t, src=0):
+    """in-place broadcast of rank `src`'s tensor (gloo + device memory, tests only: staged through the host)"""
+    if world() > 1:
+        if t.is_cuda and dist.get_backend() == "gloo":
+            host = t.detach().cpu()
+            dist.broadcast(host, src=src)
+            t.copy_(host)
+        else:
+            dist.broadcast(t, src=src)
+    return t
+
+
+def sync_replicas(module, src=0):
+    """What wrapping in DistributedDataParallel does at construction (clip_scorefusion/train.py:218, uniir_blip/train.py:217:
+    `DDP(model, device_ids=[gpu])` broadcasts rank 0's parameters AND buffers -- BLIP's queues, idx_queue, new_ptr_queue,
+    the momentum encoders -- before the first step): every replica leaves with rank `src`'s state, whatever its own seed or
+    checkpoint gave it.  One broadcast per distinct underlying storage: parameters that are views of a flat fp32 master buffer
+    (CLIP towers, BLIP online / momentum stores, the CLIP_FF T5 store) travel as ONE collective over that buffer.  Afterwards
+    the parameters' version counters are bumped so that the bf16 shadows are re-derived on the next forward, and BLIP's cached
+    host copy of the queue pointer is dropped.  Returns the number of collectives issued."""
+    if world() == 1:
+        return 0
+    tensors = list(module.parameters()) + list(module.buffers())
+    seen, n = set(), 0
+    with torch.no_grad():
+        for t in tensors:
+            st = t.untyped_storage()
+            if st.data_ptr() == 0 or st.data_ptr() in seen:
+                continue
+            seen.add(st.data_ptr())
+            whole = torch.empty(0, dtype=t.dtype, device=t.device).set_(st)       # the whole storage as one 1-D tensor
+            broadcast_(whole, src)
+            n += 1
+        params = [p for p in module.parameters() if p.is_floating_point()]
+        if params:
+            torch._foreach_mul_(params, 1.0)          # exact no-op on the values; bumps _version -> shadows refresh lazily
+    for m in module.modules():
+        if hasattr(m, "_ptr_host"):
+            m._ptr_host = None
+    return n
+
+
+def replica_checksum(module):
+    """(sum, sum of squares) over every parameter and buffer in float64: equal on all ranks iff the replicas hold the same state
+    (bench.py prints it per rank after the timed region; the 2-rank tests assert equality)"""
+    s = torch.zeros(2, dtype=torch.float64, device=next(module.parameters()).device)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.numel():
+                d = t.detach().double()
+                s[0] += d.sum()
+                s[1] += (d * d).sum()
+    return [float(x) for x in s.cpu()]
+
+
 class GradReducer:
     """DDP's bucketed gradient all-reduce overlapped with backward (torch DistributedDataParallel as wrapped at
     clip_scorefusion/train.py:218), on the flat fp32 gradient buffer of this build.
@@ -81,18 +136,50 @@ class GradReducer:
         self.flat = flat
         self.bucket_elems = max(1, bucket_bytes // flat.element_size())
         self.pending, self.launched, self.works = [], [], []
+        self.announced = []           # every range of this step, sorted: a repeat is refused in ready(), not discovered at finish()
+        self.extra_done = set()       # data_ptr of further flat buffers reduced through reduce_extra() this step
         self.n_collectives = 0
+
+    def reset(self):
+        """forget the state of an armed backward whose step() never came (an exception, a skipped step): called by
+        NativeAdamW.arm_overlap before every armed backward.  Collectives already in flight are waited for first."""
+        for w in self.works:
+            w.wait()
+        self.pending, self.launched, self.works, self.announced, self.n_collectives = [], [], [], [], 0
+        self.extra_done = set()
 
     def _sync_backend(self):
         # tests only (two gloo ranks sharing one GPU): gloo cannot reduce device memory -> staged through the host
         return self.flat.is_cuda and dist.get_backend() == "gloo"
 
     def ready(self, lo, hi):
+        """flat[lo:hi] is final for this step.  Contract: every range is announced at most ONCE per armed backward -- one tower
+        call per step and tower (a second encode of the same tower inside one armed backward would announce its blocks again
+        after the first, partial, sums went out) -- checked here, at the call that breaks it."""
         if hi <= lo or world() == 1:
             return
+        import bisect
+        i = bisect.bisect_left(self.announced, (lo, hi))
+        if (i > 0 and self.announced[i - 1][1] > lo) or (i < len(self.announced) and self.announced[i][0] < hi):
+            raise RuntimeError(f"GradReducer: gradient range [{lo}, {hi}) announced twice in one armed backward (a tower ran twice "
+                               "in this step, or the previous armed backward was never followed by step()); use arm_overlap(False) "
+                               "for such steps")
+        self.announced.insert(i, (lo, hi))
         self.pending.append((lo, hi))
         if sum(h - l for l, h in self.pending) >= self.bucket_elems:
             self.flush()
+
+    def reduce_extra(self, tensor):
+        """a further flat gradient buffer that is final now (CLIP_FF's T5 store: its backward ends before the towers' begins):
+        one asynchronous all-reduce on the collective stream, overlapped with the rest of backward like the buckets"""
+        if world() == 1 or tensor.data_ptr() in self.extra_done:
+            return
+        if self._sync_backend():
+            allreduce_sum_(tensor)
+        else:
+            self.works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True))
+        self.extra_done.add(tensor.data_ptr())
+        self.n_collectives += 1
 
     @staticmethod
     def _coalesce(ranges):
@@ -118,7 +205,9 @@ class GradReducer:
         self.pending = []
 
     def finish(self):
-        """reduce the not-yet-announced remainder, wait for everything, re-arm for the next step"""
+        """reduce the not-yet-announced remainder, wait for everything, re-arm for the next step.  Returns (collectives issued,
+        data_ptrs of the extra buffers already reduced)"""
+        extra = set(self.extra_done)
         if world() > 1:
             self.flush()
             done = self._coalesce(self.launched)
@@ -134,8 +223,9 @@ class GradReducer:
             for w in self.works:
                 w.wait()          # RCCL: the current stream waits for the collective (no host block); gloo: host wait
         n = self.n_collectives
-        self.pending, self.launched, self.works, self.n_collectives = [], [], [], 0
-        return n
+        self.pending, self.launched, self.works, self.announced, self.n_collectives = [], [], [], [], 0
+        self.extra_done = set()
+        return n, extra
 
 
 def gather_topk(scores, ids):

@@ -83,6 +83,9 @@ def main(config):
         checkpoint = load_checkpoint_file(path)
     model.train()
     model = model.to(gpu)
+    if distributed:          # the reference wraps in DDP here (train.py:217-218): rank 0's parameters and buffers to every replica
+        from uniir_amd import comm
+        comm.sync_replicas(model)
     optimizer = NativeAdamW(model, lr=tc.init_lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=tc.weight_decay)
     train_ds, collate = build_dataset(config, model.get_tokenizer(), model.get_img_preprocess_fn(), train=True)
     sampler = DistributedSampler(train_ds, num_replicas=utils.get_world_size(), rank=utils.get_rank(), shuffle=True)

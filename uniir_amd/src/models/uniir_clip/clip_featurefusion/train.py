@@ -76,6 +76,9 @@ def main(config):
         model.load_state_dict(checkpoint["model"])
     model.train()
     model = model.to(gpu)
+    if distributed:          # the reference wraps in DDP here (train.py:217-218): rank 0's parameters and buffers to every replica
+        from uniir_amd import comm
+        comm.sync_replicas(model)
     # three groups like clip_featurefusion/train.py:52-66,200-208: CLIP gains/biases (wd 0), CLIP rest (wd 0.2), every T5
     # parameter (wd 0.2, its own learning rate trainer_config.t5_learning_rate)
     optimizer = NativeAdamW(model.clip_model, lr=config.trainer_config.learning_rate, betas=(0.9, 0.98), eps=1.0e-6,

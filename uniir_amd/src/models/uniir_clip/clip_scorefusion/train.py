@@ -76,6 +76,9 @@ def main(config):
         model.load_state_dict(checkpoint["model"])
     model.train()
     model = model.to(gpu)
+    if distributed:          # the reference wraps in DDP here (train.py:217-218): rank 0's parameters and buffers to every replica
+        from uniir_amd import comm
+        comm.sync_replicas(model)
     optimizer = NativeAdamW(model.clip_model, lr=config.trainer_config.learning_rate, betas=(0.9, 0.98), eps=1.0e-6,
                             weight_decay=0.2)
     train_ds, collate = build_dataset(config, model.get_tokenizer(), model.get_img_preprocess_fn(), train=True)

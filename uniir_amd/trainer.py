@@ -65,15 +65,21 @@ class NativeAdamW(torch.optim.Optimizer):
         """call before backward(): on the LAST micro-batch of an accumulation window the tower backward hands every finished
         residual block's weight gradients to the reducer (DDP's no_sync() on the earlier micro-batches)"""
         self._buffers()
+        if self.reducer is not None:
+            self.reducer.reset()           # an armed backward that never reached step() must not leak into this one
         self.clip._grad_reducer = self.reducer if last_micro_batch else None
 
     @torch.no_grad()
     def step(self, closure=None):
         fl = self._buffers()
         world = comm.world() if self.allreduce else 1
+        extra_reduced = set()
+        join = getattr(self.clip, "join_towers", None)
+        if join is not None:
+            join()                                 # towers that ran on a side stream (clip_model two-stream mode)
         if world > 1:
             if self.reducer is not None:           # blocks already reduced during backward; now the remainder + wait
-                self.last_collectives = self.reducer.finish()
+                self.last_collectives, extra_reduced = self.reducer.finish()
             else:
                 comm.allreduce_sum_(fl["g32"])     # one RCCL all-reduce; the mean is folded into grad_scale
                 self.last_collectives = 1
@@ -96,8 +102,9 @@ class NativeAdamW(torch.optim.Optimizer):
                 self.extra_mv[i] = (torch.zeros_like(st.p32), torch.zeros_like(st.p32))
             elif self.extra_mv[i][0].device != st.p32.device:     # resumed from a checkpoint mapped to the CPU
                 self.extra_mv[i] = tuple(t.to(st.p32.device) for t in self.extra_mv[i])
-            if world > 1:
+            if world > 1 and st.g32.data_ptr() not in extra_reduced:     # not handed to the reducer during backward
                 comm.allreduce_sum_(st.g32)
+                self.last_collectives += 1
             b1, b2 = group["betas"]
             m, v = self.extra_mv[i]
             ops.call("uniir_adamw_step", st.p32, st.g32, m, v, st.w16_buf, st.total, float(group["lr"]), b1, b2,
