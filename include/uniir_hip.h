@@ -390,13 +390,16 @@ int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_norm, const i
                        float* out_scores, int64_t* out_ids, void* stream);
 /* The whole search of one pool shard in ONE call -- what the reference's FFI for this path would bind
  * (mbeir_retriever.py:188-232 search_index: faiss.normalize_L2(queries); index.search(queries, k)):
- * query inverse norms, then per chunk of <= 1024 queries one sweep of the shard (MFMA group-max scan) and one fused
- * selection + exact re-score + sort launch.  k <= 56.  Same results as coarse + rescore, bit for bit.
+ * per chunk of <= 1024 queries one sweep of the shard (MFMA group-max scan), then group selection + exact re-score and the
+ * final sort.  k <= 56.  Same results as coarse + rescore, bit for bit.
  * workspace: uniir_topk_ip_workspace_bytes(nq, k, rows) bytes, 256-B aligned. */
 int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows);
 int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
                   int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
                   int64_t* out_ids, void* workspace, int64_t workspace_bytes, void* stream);
+/* queries per sweep inside uniir_topk_ip (default / maximum 1024; 0 restores the default).  Results never depend on it: the hook
+ * exists so that tests can drive the sweep loop with small inputs.  Process-wide host setting. */
+int uniir_topk_set_chunk(int32_t queries_per_sweep);
 /* k-way merge of per-shard results (score desc, id asc): in [nshard][nq][k] -> out [nq][k] */
 int uniir_topk_merge(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k,
                      float* out_scores, int64_t* out_ids, void* stream);

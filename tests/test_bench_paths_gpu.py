@@ -1,0 +1,139 @@
+"""Checkers for paths that so far only ran inside bench.py ("what's weak"):
+  (i)   the BLIP_FF [b, b+K] queue logits and their backward at the REAL queue size K = 57 344, b = 256 -- the strided two-block
+        uniir_sgemm / uniir_sgemm_acc calls of blip_model._SoftTargetLossFn (reference blip_ff.py:219-229) take the 128-tile
+        sgemm128_kernel there (<A k-contiguous, B n-contiguous> forward, <k-contiguous, k-contiguous> backward); every other
+        BLIP test uses K = 16 (64-tile kernel).  Bit-exact against oracle.c's fmaf chains.
+  (ii)  retrieval.search_shard's multi-sweep query loop (uniir_topk_ip chunks of TKI_CHUNK queries): forced to 64-query sweeps,
+        1 000 queries x 20 000 rows == the C oracle (reference mbeir_retriever.py:188-232).
+  (iii) the modality masks of encode_multimodal_input (clip_sf.py:53-63: image-only / text-only / pair = BASELINE config 3's three
+        cases) on the HEADLINE architecture, ViT-L/14, forward-only (the embedding-extraction path: no stash, UNIIR_EPI_ACT_ONLY)."""
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "uniir_amd", "src"))
+
+
+def _oracle_chains(q, p):
+    """oracle.c fmaf chains score[i][j] = sum_k q[i][k] p[j][k] (k ascending), rows split over host threads (ctypes drops the GIL)"""
+    from oracle import c_oracle
+    q, p = np.ascontiguousarray(q, np.float32), np.ascontiguousarray(p, np.float32)
+    nthr = min(32, os.cpu_count() or 1, q.shape[0])
+    parts = np.array_split(np.arange(q.shape[0]), nthr)
+    with ThreadPoolExecutor(nthr) as ex:
+        outs = list(ex.map(lambda idx: c_oracle.infonce_scores(q[idx], p, 1.0), parts))
+    return np.concatenate(outs, axis=0)
+
+
+@pytest.mark.parametrize("hn", [0, 512])
+def test_blip_queue_logits_and_backward_at_the_real_queue_size(hn):
+    """sims(a, blocks) / dfeat(dsim, blocks) of blip_model._SoftTargetLossFn restated call for call at K = 57 344, b = 256,
+    E = 768; hn > 0 is the hard-negative variant whose queue block starts at column hn (t[:, hn:], blip_ff.py:219-229 with the
+    hard negatives' columns taken out of the queue)."""
+    from uniir_amd import ops
+    b, E, K = 256, 768, 57_344
+    g = torch.Generator(device=DEV).manual_seed(5 + hn)
+    a = torch.nn.functional.normalize(torch.randn(b, E, device=DEV, generator=g), dim=1)
+    rows = torch.nn.functional.normalize(torch.randn(b, E, device=DEV, generator=g), dim=1)
+    queue = torch.nn.functional.normalize(torch.randn(E, K, device=DEV, generator=g), dim=0)        # the reference's [E, K] buffer
+    negs = torch.randn(hn, E, device=DEV, generator=g) if hn else None
+    n = b + K                                       # [rows | (negatives) | queue[:, hn:]] is always b + K columns wide
+    blocks = [("rows", rows, b)] + ([("rows", negs, hn)] if hn else []) + [("queue", queue, hn)]
+    out = torch.full((b, n), float("nan"), device=DEV)
+    col = 0
+    for kind, t, arg in blocks:
+        if kind == "rows":
+            ops.call("uniir_sgemm", a, E, 1, t, 1, E, out[:, col:], n, b, arg, E, 1.0)
+            col += arg
+        else:
+            ops.call("uniir_sgemm", a, E, 1, t[:, arg:], K, 1, out[:, col:], n, b, K - arg, E, 1.0)
+            col += K - arg
+    assert col == n
+    cols = [rows] + ([negs] if hn else []) + [queue[:, hn:].t().contiguous()]
+    want = _oracle_chains(a.cpu().numpy(), torch.cat(cols, 0).cpu().numpy())
+    got = out.cpu().numpy()
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+    # backward: d a = sum over blocks of dsim[:, cols] @ block, first block overwrites, the others accumulate
+    dsim = torch.randn(b, n, device=DEV, generator=g) * 1e-2
+    da = torch.full((b, E), float("nan"), device=DEV)
+    col, first = 0, True
+    for kind, t, arg in blocks:
+        fn = "uniir_sgemm" if first else "uniir_sgemm_acc"
+        if kind == "rows":
+            ops.call(fn, dsim[:, col:], n, 1, t, E, 1, da, E, b, E, arg, 1.0)
+            col += arg
+        else:
+            ops.call(fn, dsim[:, col:], n, 1, t[:, arg:], 1, K, da, E, b, E, K - arg, 1.0)
+            col += K - arg
+        first = False
+    dn = dsim.cpu().numpy()
+    want_da, col = None, 0
+    for mat in cols:                                # chain over the block's columns, blocks added in fp32 in call order
+        w = mat.shape[0]
+        part = _oracle_chains(dn[:, col:col + w], mat.t().contiguous().cpu().numpy())
+        want_da = part if want_da is None else (want_da + part).astype(np.float32)
+        col += w
+    got_da = da.cpu().numpy()
+    assert np.array_equal(got_da, want_da), float(np.abs(got_da - want_da).max())
+
+
+def test_search_shard_multi_sweep_loop_equals_the_oracle(monkeypatch):
+    """1 000 queries in sweeps of 64 (15 full sweeps + one of 40) over a 20 000-row shard: scores bit-exact, ids identical"""
+    from oracle import c_oracle
+    from uniir_amd import _lib, retrieval
+    lib = _lib.load()
+    assert lib.uniir_topk_set_chunk(64) == 0
+    try:
+        n, d, nq, k = 20_000, 768, 1_000, 10
+        g = torch.Generator(device=DEV).manual_seed(123)
+        pool = torch.randn(n, d, device=DEV, generator=g).half()
+        pool[17] = 0                                                    # a zero row (inverse norm 0)
+        pool[4000:4003] = pool[77]                                      # exact duplicates: ties broken by id
+        queries = torch.randn(nq, d, device=DEV, generator=g).half()
+        queries[5] = pool[77]
+        ids = torch.randperm(n, device=DEV, generator=g).to(torch.int64) + 9_000_000
+        s, i = retrieval.search_shard(retrieval.PoolShard(pool, ids), queries, k)
+        ws, wi = c_oracle.topk(pool.cpu().numpy(), ids.cpu().numpy(), queries.cpu().numpy(), k)
+        assert np.array_equal(i.cpu().numpy(), wi)
+        assert np.array_equal(s.cpu().numpy(), ws)
+    finally:
+        assert lib.uniir_topk_set_chunk(0) == 0
+
+
+def test_vit_l14_forward_only_modality_masks_against_the_oracle():
+    """6 items through the no-grad towers of the headline model: 2 image-only, 2 text-only, 2 pairs (clip_sf.py:61-62: the
+    masked tower's output is multiplied by 0, so a masked-out modality must contribute exactly nothing)"""
+    from oracle import clip_oracle as O
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    cfg = CLIP_CONFIGS["ViT-L/14"]
+    sd = O.init_state_dict(cfg, seed=4)
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=False), data_config=SimpleNamespace(in_batch_neg_num=0))
+    os.environ["UNIIR_ALLOW_RANDOM_INIT"] = "1"
+    model = CLIPScoreFusion("ViT-L/14", device=DEV, config=config)
+    model.clip_model.load_state_dict(sd, strict=True)
+    model.eval()
+    batch = O.synthetic_batch(cfg, 3, seed=91)                        # 6 items
+    tmask = torch.tensor([0, 0, 1, 1, 1, 1])
+    imask = torch.tensor([1, 1, 0, 0, 1, 1])
+    with torch.no_grad():
+        emb_o = O.encode_multimodal_input(sd, cfg, batch["txt_batched"], batch["image_batched"], tmask, imask)
+        emb_d = model.encode_multimodal_input(batch["txt_batched"].to(DEV), batch["image_batched"].to(DEV), tmask.to(DEV),
+                                              imask.to(DEV)).cpu()
+        # the same items with garbage in the masked-out modality: bitwise the same embeddings
+        txt2, img2 = batch["txt_batched"].clone(), batch["image_batched"].clone()
+        txt2[:2] = txt2[4:6]
+        img2[2:4] = img2[4:6] * 3.0
+        emb_g = model.encode_multimodal_input(txt2.to(DEV), img2.to(DEV), tmask.to(DEV), imask.to(DEV)).cpu()
+    for r in range(6):
+        rel = ((emb_d[r] - emb_o[r]).norm() / emb_o[r].norm()).item()
+        assert rel < 1.2e-2, (r, rel)                                  # bf16 towers vs the fp32 oracle (observed ~6e-3 on pairs)
+    assert torch.equal(emb_g, emb_d)

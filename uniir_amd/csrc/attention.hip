@@ -619,7 +619,8 @@ static int launch_attn_bwd(const AttnArgs& a0, int batch, hipStream_t st) {
     const int Tmax = Tqp > Tkp ? Tqp : Tkp;
     const int sm = 2 * Tmax * 128 + 2 * Tqp * 4 + (a.rel_emb ? 2 * (a.Tq + a.Tk) * 4 : 0);
     static const char* e = getenv("UNIIR_ATTN_BWD_THREADS");          // 384 / 512 forces one (experiments)
-    const bool six = e ? (e[0] == '3') : tmax <= 128;
+    bool six = e ? (e[0] == '3') : tmax <= 128;
+    if (six && (Tmax * 8 + 383) / 384 > 8) six = false;      // stage_two holds <= 8 loads per thread and slice: 384 threads stop at 384 tokens
     return six ? launch_attn_bwd_nt<384>(a, batch, sm, st) : launch_attn_bwd_nt<512>(a, batch, sm, st);
 }
 

@@ -666,6 +666,9 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     if (d->row_scale && d->epilogue != UNIIR_EPI_RESID_F32) return UNIIR_EINVAL;
     if (d->epilogue == UNIIR_EPI_BIAS_ACT && !d->C2) return UNIIR_EINVAL;
     if (d->epilogue == UNIIR_EPI_DACT && !d->aux) return UNIIR_EINVAL;
+    // column sums of the result ride the fp32 copy-out passes only (DACT / RESID_F32 / F32 epilogues)
+    if (d->colsum && d->epilogue != UNIIR_EPI_DACT && d->epilogue != UNIIR_EPI_RESID_F32 && d->epilogue != UNIIR_EPI_F32)
+        return UNIIR_EUNSUPPORTED;
     if (d->N % 8) return UNIIR_ESHAPE;
     if (!d->a_tmaj && (d->K % 8)) return UNIIR_ESHAPE;
     if (!d->b_tmaj && (d->K % 8)) return UNIIR_ESHAPE;
@@ -725,12 +728,34 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
         if (rowsum_fused) a.a_rowsum = d->a_rowsum;
     }
     int rc;
+    // colsum and the DACT epilogue's second output act(aux) exist in the LDS-staged epilogue of the 256-tile kernel only; when the
+    // problem runs the general 128-tile kernel they are produced HERE by separate passes (bf16 column sums of the stored result,
+    // act(aux) elementwise), so that callers need not mirror gemm_shape()
+    const bool staged = gemm_shape(a, d->a_tmaj, d->b_tmaj) == 1;
+    bool colsum_after = false;
+    if (!staged) {
+        if (d->colsum) {
+            if (d->epilogue != UNIIR_EPI_DACT) return UNIIR_EUNSUPPORTED;      // fp32 outputs: no separate column-sum pass exists
+            a.colsum = nullptr;
+            colsum_after = true;
+        }
+        if (d->epilogue == UNIIR_EPI_DACT && d->C2) {
+            if (d->ldaux != d->N) return UNIIR_EUNSUPPORTED;
+            rc = uniir_act_fwd(d->aux, d->C2, (int64_t)d->M * d->N, d->act, stream);
+            if (rc) return rc;
+            a.C2 = nullptr;
+        }
+    }
     if (d->dtype == UNIIR_DT_BF16) rc = launch_gemm<ElemBF16>(a, d->a_tmaj, d->b_tmaj, st);
 #ifndef UNIIR_EXP_BUILD
     else if (d->dtype == UNIIR_DT_F16) rc = launch_gemm<ElemF16>(a, d->a_tmaj, d->b_tmaj, st);
 #endif
     else return UNIIR_EINVAL;
     if (rc) return rc;
+    if (colsum_after) {
+        rc = uniir_colsum_bf16(d->C, d->ldc, d->colsum, d->M, d->N, stream);
+        if (rc) return rc;
+    }
     if (d->a_rowsum && !rowsum_fused) {
         rc = uniir_colsum_bf16(d->A, d->lda, d->a_rowsum, d->K, d->M, stream);
         if (rc) return rc;

@@ -1065,7 +1065,16 @@ extern "C" int uniir_topk_merge_ex(const float* scores, const int64_t* ids, int3
 // the caller.  (A single fused select + re-score + sort launch per query was measured and dropped: with 64 queries the tail is
 // latency-bound and one 1024-thread workgroup per query serialises what the three launches spread over the whole chip:
 // 98 us instead of 80 us behind the 217-us scan; at 1024 queries it made no difference.)
-#define TKI_CHUNK 1024
+#define TKI_CHUNK_MAX 1024
+static int g_tki_chunk = TKI_CHUNK_MAX;
+#define TKI_CHUNK g_tki_chunk
+// queries per sweep of uniir_topk_ip: 0 restores the default (1024, the most the group-max scan takes).  A smaller value only
+// forces more sweeps (tests of the sweep loop; tuning); results do not depend on it.  Host-side setting, not thread-safe.
+extern "C" int uniir_topk_set_chunk(int32_t queries_per_sweep) {
+    if (queries_per_sweep < 0 || queries_per_sweep > TKI_CHUNK_MAX) return UNIIR_EINVAL;
+    g_tki_chunk = queries_per_sweep == 0 ? TKI_CHUNK_MAX : queries_per_sweep;
+    return UNIIR_OK;
+}
 extern "C" int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows) {
     if (nq <= 0 || k <= 0 || rows <= 0) return 0;
     const int chunk = nq < TKI_CHUNK ? nq : TKI_CHUNK;

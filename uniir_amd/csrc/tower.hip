@@ -52,7 +52,7 @@ Plan plan(const uniir_clip_tower* t, int batch, bool save) {
     p.o_ao = ltake(R * W * 2);
     p.o_lse = ltake((int64_t)M * p.H * p.T * 4);
     p.o_x2 = ltake(R * W * 4);
-    p.o_f = ltake(R * 4 * W * 2);
+    p.o_f = save ? ltake(R * 4 * W * 2) : 0;      // the pre-activation is stashed for the backward only
     p.o_h1 = ltake(R * W * 2);
     p.o_h2 = ltake(R * W * 2);
     p.lay0 = cur;
@@ -62,6 +62,10 @@ Plan plan(const uniir_clip_tower* t, int batch, bool save) {
     // transients: forward needs g only; backward the rest
     p.tmp = cur;
     p.g = take(R * 4 * W * 2);
+    if (!save) {            // a forward-only pass (embedding extraction) needs none of the backward transients below
+        p.total = cur;
+        return p;
+    }
     p.df = take(R * 4 * W * 2);
     p.dh = take(R * W * 2);
     p.dx = take(R * W * 4);
@@ -120,26 +124,18 @@ int linear_fwd(const void* x, const void* w, void* out, int M, int N, int K, int
     return uniir_gemm(&d, st);
 }
 
-bool uses_tile256(int M, int N, int K) { return K % 64 == 0 && M >= 256 && N >= 128; }   // gemm_shape() in gemm.hip
-
-// dx[M,K] = dy[M,N] @ w[N,K]  (optionally * act'(aux), act(aux) -> act_out, column sums of dx += colsum)
+// dx[M,K] = dy[M,N] @ w[N,K]  (optionally * act'(aux), act(aux) -> act_out, column sums of dx += colsum).  uniir_gemm produces
+// act_out / colsum itself whichever kernel shape the problem runs (fused in the 256-tile epilogue, separate passes otherwise).
 int linear_dgrad(const void* dy, const void* w, void* out, int M, int N, int K, const void* aux, void* act_out, float* colsum,
                  void* st) {
-    const bool t256 = uses_tile256(M, K, N);
-    const bool fused_sum = colsum && aux && t256;
-    void* c2 = act_out;
-    if (act_out && !(aux && t256)) {
-        TRY(uniir_act_fwd(aux, act_out, (int64_t)M * K, UNIIR_ACT_QUICKGELU, st));
-        c2 = nullptr;
-    }
     uniir_gemm_desc d;
     base_desc(d);
-    d.A = dy; d.B = w; d.C = out; d.C2 = c2; d.aux = aux; d.ldaux = K;
+    d.A = dy; d.B = w; d.C = out; d.C2 = aux ? act_out : nullptr; d.aux = aux; d.ldaux = K;
     d.M = M; d.N = K; d.K = N; d.lda = N; d.ldb = K; d.ldc = K; d.b_tmaj = 1;
     d.epilogue = aux ? UNIIR_EPI_DACT : UNIIR_EPI_BF16;
-    d.colsum = fused_sum ? colsum : nullptr;
+    d.colsum = aux ? colsum : nullptr;
     TRY(uniir_gemm(&d, st));
-    if (colsum && !fused_sum) TRY(uniir_colsum_bf16(out, K, colsum, M, K, st));
+    if (colsum && !aux) TRY(uniir_colsum_bf16(out, K, colsum, M, K, st));
     return UNIIR_OK;
 }
 

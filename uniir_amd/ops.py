@@ -43,12 +43,14 @@ def _p(t):
 _SPLITK_WS = {}
 
 
-def _splitk_workspace(device, nbytes):
-    """one reusable scratch buffer per device for the split-K slabs (stream-ordered reuse)"""
-    ws = _SPLITK_WS.get(device)
+def _splitk_workspace(device, nbytes, tag=None):
+    """one reusable scratch buffer per (device, tag) for the split-K slabs (stream-ordered reuse: users that may run on
+    different streams at the same time -- the two CLIP towers -- pass different tags)"""
+    key = (device, tag)
+    ws = _SPLITK_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 128 << 20), device=device, dtype=torch.uint8)
-        _SPLITK_WS[device] = ws
+        _SPLITK_WS[key] = ws
     return ws
 
 
