@@ -165,3 +165,40 @@ def test_large_k_beyond_the_pool_pads_like_faiss():
     s, i = retrieval.search_shard(retrieval.PoolShard(pool, torch.arange(70)), torch.randn(3, 64, device=DEV).half(), 90)
     assert (i[:, :70] >= 0).all() and (i[:, 70:] == -1).all() and torch.isinf(s[:, 70:]).all()
     assert all(sorted(r.tolist()) == list(range(70)) for r in i[:, :70])
+
+
+def _oracle_topk_mt(pool, ids, queries, k):
+    """oracle.c top-k with the queries split over host threads (ctypes releases the GIL)"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle
+    p, i, q = pool.cpu().numpy(), ids.cpu().numpy(), queries.cpu().numpy()
+    nthr = max(1, min(32, os.cpu_count() or 1, q.shape[0]))
+    parts = np.array_split(np.arange(q.shape[0]), nthr)
+    with ThreadPoolExecutor(nthr) as ex:
+        outs = list(ex.map(lambda idx: c_oracle.topk(p, i, q[idx], k), parts))
+    return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
+
+
+@pytest.mark.parametrize("n,nq,k", [(40030, 1, 10), (40030, 37, 10), (65536, 64, 10), (40003, 64, 10), (40030, 64, 50),
+                                    (40030, 100, 10), (40030, 128, 10), (40030, 200, 10), (40030, 300, 50), (40030, 700, 10)])
+def test_round3_scan_and_fused_tail_equal_the_c_oracle(n, nq, k):
+    """round 3 kernels against oracle.c (reference mbeir_retriever.py:188-232), scores bit-exact and ids identical:
+    <= 64 queries: topk_stream2_kernel (queries in registers, pool by LDS-DMA; needs >= 2048 groups) incl. a ragged last tile
+    (40030 = 2501 x 16 + 14) and an odd group count (40003 -> 2501 groups: the round-2 tail behind the new scan);
+    65..128 queries: the ping-pong scan without its padded query half; > 128: the full tile; behind all of them the fused tail
+    (selection + query norm + exact re-score in one launch with 4 / 2 / 1 workgroups per query, rank-count sort in the second),
+    also at k = 50 (116 groups = 1 856 re-score slots per query, several 512-slot rounds per workgroup)."""
+    from uniir_amd import retrieval
+    g = torch.Generator(device=DEV).manual_seed(1000 + n + nq)
+    pool = torch.randn(n, 768, device=DEV, generator=g).half()
+    pool[17] = 0                                  # zero row: inverse norm 0, score 0
+    pool[n - 1] = pool[5]                         # duplicates incl. the very last row (ragged tile): ties broken by id
+    pool[2000:2003] = pool[5]
+    queries = torch.randn(nq, 768, device=DEV, generator=g).half()
+    queries[0] = pool[5]
+    ids = torch.randperm(n, device=DEV, generator=g).to(torch.int64) * 5 + 123
+    s, i = retrieval.search_shard(retrieval.PoolShard(pool, ids), queries, k)
+    ws, wi = _oracle_topk_mt(pool, ids, queries, k)
+    assert np.array_equal(i.cpu().numpy(), wi), np.argwhere(i.cpu().numpy() != wi)[:5]
+    assert np.array_equal(s.cpu().numpy(), ws)

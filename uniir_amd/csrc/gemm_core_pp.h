@@ -167,7 +167,9 @@ struct PPState {
 };
 
 // one K step (4 phases).  MODE 0: steady state; 1: second to last K step (stages q=0,1 only); 2: last (stages nothing)
-template <typename Elem, bool A_TMAJ, bool B_TMAJ, int MODE, bool ROWSUM = false>
+// HALFN (the top-k scan with <= 128 queries): the column half B1 holds no real columns -- its fragment reads and the two MFMA
+// phases that use it are dropped (half the matrix work); the staging schedule, and with it every hazard argument above, is unchanged
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, int MODE, bool ROWSUM = false, bool HALFN = false>
 DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&acc)[8][4], float (&rs)[2], int& rs_cd) {
     // this workgroup's turn every rs_tiles-th K step (a countdown: t % rs_tiles with a run-time divisor costs ~100 cycles per K step)
     bool rs_turn = false;
@@ -198,8 +200,10 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     pp_mfma16<Elem, 0, 0>(af, b0, acc);
     pp_barrier();
     // ---- phase 1: quadrant (A0,B1); reads B1; stages (t+1, A1)
-    b1[0][0] = st.fb.template read<0, 0>(sb + 2 * 16384); b1[1][0] = st.fb.template read<1, 0>(sb + 2 * 16384);
-    b1[0][1] = st.fb.template read<0, 1>(sb + 2 * 16384); b1[1][1] = st.fb.template read<1, 1>(sb + 2 * 16384);
+    if (!HALFN) {
+        b1[0][0] = st.fb.template read<0, 0>(sb + 2 * 16384); b1[1][0] = st.fb.template read<1, 0>(sb + 2 * 16384);
+        b1[0][1] = st.fb.template read<0, 1>(sb + 2 * 16384); b1[1][1] = st.fb.template read<1, 1>(sb + 2 * 16384);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (MODE <= 1) pp_stage(st.rA, st.gA[1], kA1, oth + 3 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
@@ -208,7 +212,7 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     asm_wait_vm<MODE <= 1 ? 8 : 0>();
     pp_barrier();
     asm_wait_lgkm<0>();
-    pp_mfma16<Elem, 0, 1>(af, b1, acc);
+    if (!HALFN) pp_mfma16<Elem, 0, 1>(af, b1, acc);
     pp_barrier();
     // ---- phase 2: quadrant (A1,B1); reads A1; stages (t+2, A0)
     af[0][0] = st.fa.template read<0, 0>(sb + 3 * 16384); af[1][0] = st.fa.template read<1, 0>(sb + 3 * 16384);
@@ -221,7 +225,7 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     if (MODE == 0) asm_wait_vm<8>();
     pp_barrier();
     asm_wait_lgkm<0>();
-    pp_mfma16<Elem, 1, 1>(af, b1, acc);
+    if (!HALFN) pp_mfma16<Elem, 1, 1>(af, b1, acc);
     pp_barrier();
     // ---- phase 3: quadrant (A1,B0), B0 still in registers; stages (t+2, B0)
     if (MODE == 0) pp_stage(st.rB, st.gB[0], kB2, cur + 1 * 16384, st.w);
@@ -275,22 +279,22 @@ DEVINL void pp_prologue(const PPState<Elem, A_TMAJ, B_TMAJ>& st) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false>
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false, bool HALFN = false>
 DEVINL void pp_main(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int nk, f32x4_t (&acc)[8][4], float (&rs)[2]) {
     const int wr = st.w >> 2;
     asm_wait_vm<8>();
     pp_barrier();
     if (wr == 1) pp_barrier();          // group 1 runs one barrier behind from here on
     int rs_cd = st.rs_nt;                // first turn at t = rs_nt
-    for (int t = 0; t < nk - 2; ++t) pp_kstep<Elem, A_TMAJ, B_TMAJ, 0, ROWSUM>(st, t, acc, rs, rs_cd);
-    pp_kstep<Elem, A_TMAJ, B_TMAJ, 1, ROWSUM>(st, nk - 2, acc, rs, rs_cd);
-    pp_kstep<Elem, A_TMAJ, B_TMAJ, 2, ROWSUM>(st, nk - 1, acc, rs, rs_cd);
+    for (int t = 0; t < nk - 2; ++t) pp_kstep<Elem, A_TMAJ, B_TMAJ, 0, ROWSUM, HALFN>(st, t, acc, rs, rs_cd);
+    pp_kstep<Elem, A_TMAJ, B_TMAJ, 1, ROWSUM, HALFN>(st, nk - 2, acc, rs, rs_cd);
+    pp_kstep<Elem, A_TMAJ, B_TMAJ, 2, ROWSUM, HALFN>(st, nk - 1, acc, rs, rs_cd);
     if (wr == 0) pp_barrier();          // re-align the groups
 }
 
 // a_rowsum (ROWSUM kernels, transposed A only): += sum over this block's K range of A^T's rows m0 .. m0 + 255; nt / tiles_n: the
 // block's column panel and their number.
-template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false>
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false, bool HALFN = false>
 DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int M, const unsigned short* __restrict__ B,
                              long ldb, int N, int m0, int n0, int kbeg, int kend, char* lds, f32x4_t (&acc)[8][4],
                              float* a_rowsum = nullptr, int nt = 0, int tiles_n = 1) {
@@ -300,7 +304,7 @@ DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int
     st.rs_tiles = tiles_n;
     float rs[2] = {0.f, 0.f};
     pp_prologue(st);
-    pp_main<Elem, A_TMAJ, B_TMAJ, ROWSUM>(st, (kend - kbeg) / 64, acc, rs);
+    pp_main<Elem, A_TMAJ, B_TMAJ, ROWSUM, HALFN>(st, (kend - kbeg) / 64, acc, rs);
     if (ROWSUM && st.rs_nt >= 0) {
         // rs[h]: lane (row 128 h + 64 wr + 16 wc + (lane & 15), k group lane >> 4) -> add the four k groups, one atomic per row
         const int lane = threadIdx.x & 63;

@@ -314,8 +314,8 @@ __global__ __launch_bounds__(128 * WM, 2) void topk_gmax_kernel(const unsigned s
 // on registers -- the two dependent strided passes over global memory were 40 of the kernel's 62 us at 700 k rows.
 // `out` (gcap * TK_G row indices, -1 = empty) may be global memory (topk_gsel_kernel) or LDS (the fused tail kernel); every
 // thread of the block returns from this function (no early exit: the fused kernel goes on to the re-score).
-template <int BS, bool REG>
-DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int kc, int gcap, int* out) {
+template <int BS, bool REG, class F>
+DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int kc, int gcap, int* out, F&& mid) {
     __shared__ float tmax[BS];
     __shared__ float bval[TK_SELCAP];
     __shared__ int bgrp[TK_SELCAP];
@@ -335,9 +335,11 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
             const long e = 2L * (it * BS + tid);
             rv[it] = e < ngroups ? *reinterpret_cast<const f32x2_t*>(g + e) : f32x2_t{-INFINITY, -INFINITY};   // ngroups is even
         }
+        mid();      // independent work of the caller that rides the round trip of the loads above (the fused tail: the query norm)
 #pragma unroll
         for (int it = 0; it < TK_SELREG; ++it) mx = fmaxf(mx, fmaxf(rv[it][0], rv[it][1]));
     } else {
+        mid();
         for (long e = tid; e < ngroups; e += BS) mx = fmaxf(mx, g[e]);
     }
     if (tid == 0) { bcnt = 0; tau0 = -INFINITY; tau = -INFINITY; }
@@ -466,7 +468,7 @@ template <int BS, bool REG = false>   // threads per query (256: many queries; 1
 __global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__ gmax, long ngroups, long rows, int nq,
                                                         int kc, int gcap, int* __restrict__ cand_idx) {
     const int q = blockIdx.x;
-    gsel_body<BS, REG>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, cand_idx + (long)q * gcap * TK_G);
+    gsel_body<BS, REG>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, cand_idx + (long)q * gcap * TK_G, [] {});
 }
 
 static void coarse_plan(int nq, long rows, int* nqt, int* nslices, long* rows_per_slice) {
@@ -497,6 +499,7 @@ struct ElemF16Direct {   // operands in the order the main loop hands them over 
 // workgroup on the ping-pong LDS-DMA loop of the training GEMMs (gemm_core_pp.h, fp16 operands, K = dim), group maxima
 // straight from the accumulators.  Accumulator map: acc[4h+i][2h'+j][r] = candidate 128h + 64wr + 16i + (lane & 15),
 // query 128h' + 32wc + 16j + 4 (lane >> 4) + r.
+template <bool HALFN>       // HALFN: <= 128 queries, the second half of the query tile is padding -> half the MFMA work (gemm_core_pp.h)
 __global__ __launch_bounds__(512, 2) void topk_gmax_pp_kernel(const unsigned short* __restrict__ pool,
                                                               const float* __restrict__ pinv, long rows, int dim,
                                                               const unsigned short* __restrict__ queries, int nq,
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void topk_gmax_pp_kernel(const unsigned sho
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // un-swapped MFMA operands here: D[row = 4 (lane >> 4) + r -> candidate][col = lane & 15 -> query], so the maximum over
     // the 16 candidates of a group is 3 in-lane max + 2 cross-row exchanges per 16x16 tile (instead of 16 DPP steps)
-    glds_mainloop_pp<ElemF16Direct, false, false>(pool, dim, (int)rows, queries, dim, nq, m0, q0, 0, dim, lds, acc);
+    glds_mainloop_pp<ElemF16Direct, false, false, false, HALFN>(pool, dim, (int)rows, queries, dim, nq, m0, q0, 0, dim, lds, acc);
     // group maxima -> LDS image [256 queries][16 groups] (the ring is idle now), then 32-B runs per query to gmax
     float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void topk_gmax_pp_kernel(const unsigned sho
         }
         const bool full = n0r + 3 < rows;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < (HALFN ? 2 : 4); ++j) {
             const int ql = (j >> 1) * 128 + (w & 3) * 32 + (j & 1) * 16 + li;
             const f32x4_t v = acc[i][j] * iv;
             float x;
@@ -660,6 +663,161 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
     if (slot) flush(g0, slot);
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Streaming group-max scan, second generation (nq <= 64, dim = 768): THE QUERIES LIVE IN REGISTERS, THE POOL STREAMS THROUGH LDS.
+//   * One wave per SIMD (256-thread workgroups, one per CU).  Every wave holds the MFMA B fragments of all 64 queries for the whole
+//     kernel: 4 query tiles x 24 k-steps x 4 registers = 384 of its 512 VGPRs -- no LDS reads for the queries at all (the first
+//     generation re-read 96 KiB of query fragments from LDS per 24.5-KiB pool tile).
+//   * The pool goes HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): 8 consecutive lanes fetch one whole 128-byte line, i.e.
+//     every request is a full line (the register-direct A-fragment loads of the first generation were 64-byte pieces at a
+//     1536-byte stride, two requests per line).  Each wave owns a private ring of three half-tiles (16 rows x 384 dims = 12 KiB
+//     = 12 DMA instructions); two half-tiles (24 KiB per wave, 96 KiB per CU) are in flight while the third is multiplied.  The
+//     ring is wave-private, so the only ordering needed is the issuing wave's own counted vmcnt: no barrier anywhere.
+//   * A fragments come back from LDS with ds_read_b128; the swizzle g(row) = (row >> 1) & 7 is applied on the SOURCE side (which
+//     16-byte chunk of its line a lane fetches) and undone in the read address: conflict-free for the 4 x 16-lane service groups of
+//     ds_read_b128 (checked exhaustively in tools/r3/check_stream2_layout.py).
+//   * The 16 inverse norms of a tile ride the same DMA queue (one dword LDS-DMA per tile), so vmcnt counting stays exact.
+// LDS image of a half-tile: instruction j (0..11) writes 1 KiB = [8 rows][8 chunks]: rows 8 (j & 1) + (lane >> 3), column block
+// j >> 1 (128 bytes), position lane & 7 holds chunk (lane & 7) ^ g(row).
+#define TKR_HALF_BYTES 12288
+#define TKR_PINV_OFF (3 * TKR_HALF_BYTES)
+#define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512)
+template <int N>
+DEVINL void tkr_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+struct TkrState {
+    __amdgpu_buffer_rsrc_t rp, ri;     // pool rows (bounds = rows * 1536 bytes: rows past the end read as zeros), inverse norms
+    unsigned vb0, vb1, vpi;            // per-lane source byte offsets inside a tile (even / odd DMA instruction), inverse norms
+    unsigned la0, la1;                 // per-lane LDS byte offsets of the A fragment reads (even / odd k-step)
+    unsigned lbase;
+    char* my;
+};
+template <int HALF>
+DEVINL void tkr_issue(const TkrState& st, long tile, int slot) {
+    // the position inside the row goes into the SCALAR offset: it is excluded from the bounds check (so the check is exactly "is
+    // this row inside the shard": voffset = first line of the row) and, unlike the instruction's immediate offset, is not added
+    // to the LDS address as well
+    const unsigned tb = (unsigned)(tile * (16 * 1536));
+    const unsigned v0 = st.vb0 + tb, v1 = st.vb1 + tb;
+    char* dst = st.my + slot * TKR_HALF_BYTES;
+#define TKR_DMA(J)                                                                                                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rp, (void __attribute__((address_space(3)))*)(dst + (J) * 1024), 16, \
+                                             ((J) & 1) ? v1 : v0, ((J) >> 1) * 128 + HALF * 768, 0, 0);
+    TKR_DMA(0) TKR_DMA(1) TKR_DMA(2) TKR_DMA(3) TKR_DMA(4) TKR_DMA(5) TKR_DMA(6) TKR_DMA(7) TKR_DMA(8) TKR_DMA(9) TKR_DMA(10) TKR_DMA(11)
+#undef TKR_DMA
+    if (HALF == 0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(st.ri, (void __attribute__((address_space(3)))*)(st.my + TKR_PINV_OFF + (int)(tile & 1) * 256),
+                                                 4, st.vpi + (unsigned)(tile * 64), 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int HALF>
+DEVINL void tkr_process(const TkrState& st, int slot, const u32x4_t (&qf)[4][24], f32x4_t (&acc)[4]) {
+    const unsigned sb = st.lbase + slot * TKR_HALF_BYTES;
+    const unsigned a0 = sb + st.la0, a1 = sb + st.la1;
+    u32x4_t a[12];
+    a[0] = asm_ds_read_b128<0 * 2048>(a0);  a[1] = asm_ds_read_b128<0 * 2048>(a1);
+    a[2] = asm_ds_read_b128<1 * 2048>(a0);  a[3] = asm_ds_read_b128<1 * 2048>(a1);
+    a[4] = asm_ds_read_b128<2 * 2048>(a0);  a[5] = asm_ds_read_b128<2 * 2048>(a1);
+    a[6] = asm_ds_read_b128<3 * 2048>(a0);  a[7] = asm_ds_read_b128<3 * 2048>(a1);
+    a[8] = asm_ds_read_b128<4 * 2048>(a0);  a[9] = asm_ds_read_b128<4 * 2048>(a1);
+    a[10] = asm_ds_read_b128<5 * 2048>(a0); a[11] = asm_ds_read_b128<5 * 2048>(a1);
+    __builtin_amdgcn_sched_barrier(0);
+#define TKR_STEP(SH)                                                                              \
+    asm_wait_lgkm<11 - (SH)>();                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] = ElemF16::mfma(a[SH], qf[j][12 * HALF + (SH)], acc[j]);
+    TKR_STEP(0) TKR_STEP(1) TKR_STEP(2) TKR_STEP(3) TKR_STEP(4) TKR_STEP(5)
+    TKR_STEP(6) TKR_STEP(7) TKR_STEP(8) TKR_STEP(9) TKR_STEP(10) TKR_STEP(11)
+#undef TKR_STEP
+    __builtin_amdgcn_sched_barrier(0);
+}
+__global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned short* __restrict__ pool,
+                                                             const float* __restrict__ pinv, long rows,
+                                                             const unsigned short* __restrict__ queries, int nq,
+                                                             float* __restrict__ gmax, long ngroups) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    // one contiguous range of tiles (groups of 16 rows) per wave, sizes differing by at most one
+    const long gw = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
+    const long lo = gw * ngroups / nw, hi = (gw + 1) * ngroups / nw;
+    if (lo >= hi) return;                 // wave-uniform; the kernel has no workgroup barrier
+    TkrState st;
+    st.my = lds + w * TKR_WAVE_LDS;
+    st.lbase = lds_addr32(st.my);
+    st.rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * 1536), 0x00020000);
+    st.ri = __builtin_amdgcn_make_buffer_rsrc((void*)pinv, 0, (int)(rows * 4), 0x00020000);
+    {
+        const int r8 = lane >> 3, c8 = lane & 7;
+        const int row0 = r8, row1 = 8 + r8;                                   // even / odd DMA instruction
+        st.vb0 = (unsigned)(row0 * 1536 + ((c8 ^ ((row0 >> 1) & 7)) << 4));
+        st.vb1 = (unsigned)(row1 * 1536 + ((c8 ^ ((row1 >> 1) & 7)) << 4));
+        st.vpi = (unsigned)((lane & 15) * 4);
+        const int g = (li >> 1) & 7;
+        st.la0 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + (((0 + lg) ^ g) << 4));
+        st.la1 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + (((4 + lg) ^ g) << 4));
+    }
+    // the first two half-tiles are on their way before the query fragments are fetched
+    tkr_issue<0>(st, lo, 0);
+    tkr_issue<1>(st, lo, 1);
+    u32x4_t qf[4][24];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = j * 16 + li;
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(queries + (long)(q < nq ? q : 0) * 768) + lg;
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            const u32x4_t v = src[4 * s];
+            qf[j][s] = q < nq ? v : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
+    f32x4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto finish_tile = [&](long tile) {
+        // D: lane -> query j * 16 + li, candidates 4 lg + r of the tile
+        const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + TKR_PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
+        asm_wait_lgkm<0>();
+        const f32x4_t iv = __builtin_bit_cast(f32x4_t, ivb);
+        const long r0 = tile * 16 + 4 * lg;
+        float m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x = fmaxf(x, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
+            m[j] = group_max(x);
+            acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        const float mine = lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lg * 16 + li = lane
+        if (lane < nq) gmax[(long)lane * ngroups + tile] = mine;
+    };
+    // half-tile h = 2 (tile - lo) + half lives in ring slot h % 3; two half-tiles stay in flight (12 + 13 DMA instructions: the
+    // inverse norms travel with the first half), so every wait is vmcnt(25).  The group-max stores also count in vmcnt: they can
+    // only make a wait stricter, never looser.
+    int slot = 0;
+    long t = lo;
+    for (; t + 1 < hi; ++t) {
+        tkr_issue<0>(st, t + 1, slot == 0 ? 2 : slot - 1);       // h + 2 -> slot (h + 2) % 3
+        tkr_wait_vm<25>();
+        tkr_process<0>(st, slot, qf, acc);
+        slot = slot == 2 ? 0 : slot + 1;
+        tkr_issue<1>(st, t + 1, slot == 0 ? 2 : slot - 1);
+        tkr_wait_vm<25>();
+        tkr_process<1>(st, slot, qf, acc);
+        slot = slot == 2 ? 0 : slot + 1;
+        finish_tile(t);
+    }
+    tkr_wait_vm<12>();
+    tkr_process<0>(st, slot, qf, acc);
+    slot = slot == 2 ? 0 : slot + 1;
+    tkr_wait_vm<0>();
+    tkr_process<1>(st, slot, qf, acc);
+    finish_tile(t);
+}
+
 // The group-max scan of <= 1024 queries over the shard: gmax[q][group] = best approximate score of the 16 rows of the group.
 // Returns 1 when a 1024-thread selection is the matching follow-up (streaming / ping-pong scans), 0 for the 256-thread one,
 // negative on error.
@@ -669,6 +827,26 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
     int nqt, nsl; long rps;
     coarse_plan(nq, rows, &nqt, &nsl, &rps);
     static const char* env_st = getenv("UNIIR_TOPK_STREAM");     // "0" disables the streaming scan (experiments)
+    // second-generation streaming scan (queries in registers, pool by LDS-DMA): dim 768, the shard's bytes addressable by the
+    // 31-bit buffer bound, enough tiles that every one of the 4 waves of every workgroup has work
+    static const char* env_s2 = getenv("UNIIR_TOPK_STREAM2");    // "0": the first-generation streaming scan (A/B)
+    if (nq <= 64 && dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048 && !(env_st && env_st[0] == '0') &&
+        !(env_s2 && env_s2[0] == '0')) {
+        static int ncu = 0;
+        if (!ncu) {
+            int d = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&prop, d) != hipSuccess) return UNIIR_ELAUNCH;
+            ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        static PerDeviceOnce attr_s2;
+        if (attr_s2.first())
+            (void)hipFuncSetAttribute((const void*)topk_stream2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
+        hipLaunchKernelGGL(topk_stream2_kernel, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
+                           pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups);
+        HIP_LAUNCH_CHECK();
+        return 1;
+    }
     if (nq <= 64 && (dim == 768 || dim == 512) && !(env_st && env_st[0] == '0')) {
         const long nchunks = (ngroups + TKS_CH - 1) / TKS_CH;
         const size_t sms = 64 * (dim * 2 + 16) + 8 * 64 * TKS_CH * 4;
@@ -687,15 +865,23 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
         return 1;
     }
     static const char* env_pp = getenv("UNIIR_TOPK_PP");         // "0" disables the ping-pong scan (experiments)
-    if (nq > 128 && dim % 64 == 0 && dim >= 192 && !(env_pp && env_pp[0] == '0')) {
+    if (nq > 64 && dim % 64 == 0 && dim >= 192 && !(env_pp && env_pp[0] == '0')) {
         const int tiles_q = (nq + 255) / 256;
         const long tiles_c = (rows + 255) / 256;
         static PerDeviceOnce attr_pp;
-        if (attr_pp.first())
-            (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipLaunchKernelGGL(topk_gmax_pp_kernel, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
-                           (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
-                           (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
+        if (attr_pp.first()) {
+            (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        }
+        static const char* env_hn = getenv("UNIIR_TOPK_HALFN");       // "0": always the full 256-query tile (A/B)
+        if (nq <= 128 && !(env_hn && env_hn[0] == '0'))
+            hipLaunchKernelGGL(topk_gmax_pp_kernel<true>, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
+                               (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
+                               (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
+        else
+            hipLaunchKernelGGL(topk_gmax_pp_kernel<false>, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
+                               (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
+                               (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
         HIP_LAUNCH_CHECK();
         return 1;
     }
@@ -726,6 +912,23 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
     return 0;
 }
 
+// the stand-alone group selection behind a scan (`sel` = launch_gmax_scan's return value)
+static int topk_select_after_scan(int sel, const float* gmax, int64_t rows, int32_t nq, int32_t kc, int32_t* cand_idx,
+                                  hipStream_t st0) {
+    const long ngroups = (rows + TK_G - 1) / TK_G;
+    if (sel == 1 && ngroups % 2 == 0 && ngroups <= 1024L * 2 * TK_SELREG)       // register-resident selection
+        hipLaunchKernelGGL((topk_gsel_kernel<1024, true>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
+                           kc, TK_GMULT * kc, cand_idx);
+    else if (sel == 1 && nq <= 64)
+        hipLaunchKernelGGL((topk_gsel_kernel<1024, false>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
+                           kc, TK_GMULT * kc, cand_idx);
+    else
+        hipLaunchKernelGGL(topk_gsel_kernel<256>, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
+                           TK_GMULT * kc, cand_idx);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
 extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t rows) {
     if (nq <= 0 || kc <= 0 || rows <= 0) return 0;
     if (nq <= TK_GPATH_MAXQ) return (int64_t)nq * ((rows + TK_G - 1) / TK_G) * 4 + 256;
@@ -752,17 +955,7 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
         float* gmax = (float*)workspace;
         const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, queries_f16, nq, gmax, st0);
         if (sel < 0) return sel;
-        if (sel == 1 && ngroups % 2 == 0 && ngroups <= 1024L * 2 * TK_SELREG)       // register-resident selection
-            hipLaunchKernelGGL((topk_gsel_kernel<1024, true>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
-                               kc, TK_GMULT * kc, cand_idx);
-        else if (sel == 1 && nq <= 64)
-            hipLaunchKernelGGL((topk_gsel_kernel<1024, false>), dim3(nq), dim3(1024), 0, st0, gmax, ngroups, (long)rows, nq,
-                               kc, TK_GMULT * kc, cand_idx);
-        else
-            hipLaunchKernelGGL(topk_gsel_kernel<256>, dim3(nq), dim3(256), 0, st0, gmax, ngroups, (long)rows, nq, kc,
-                               TK_GMULT * kc, cand_idx);
-        HIP_LAUNCH_CHECK();
-        return UNIIR_OK;
+        return topk_select_after_scan(sel, gmax, rows, nq, kc, cand_idx, st0);
     }
     TkEntry* bufs = (TkEntry*)workspace;
     TkEntry* partial = bufs + (long)nqt * nsl * TK_QT * TK_CAP;
@@ -1059,6 +1252,206 @@ extern "C" int uniir_topk_merge_ex(const float* scores, const int64_t* ids, int3
 }
 
 // -------------------------------------------------------------------------------------------------------------
+// Fused tail of a group-max search (round 3): after the scan, TWO launches instead of four (query norms, group selection, exact
+// re-score, sort) and no separate pass over the queries.
+//   topk_tail_select_rescore_kernel, grid (nq, PARTS), 1024 threads: every workgroup of a query runs the register-resident group
+//     selection on the query's row of group maxima (the PARTS copies are redundant on purpose: 175 KB from L2 per copy buys a
+//     four times wider re-score), while wave 0 computes the query's inverse norm -- the oracle's sequential fp32 chain -- inside the
+//     round trip of the selection's loads; then the workgroup re-scores the groups of rank == part (mod PARTS) exactly
+//     (rescore_wave: the arithmetic of rescore_coalesced_kernel, the oracle's summation order) and writes exact[q][slot] /
+//     cand[q][slot].  With PARTS = 4 the 64 queries of the interactive regime occupy all 256 CUs, ~1.3 re-score waves per CU.
+//   topk_tail_sort_kernel, grid nq, 256 threads: rank by counting over the <= 1024 slots held in LDS, ids fetched for the k winners only.
+#define TKT_THREADS 1024
+DEVINL float rescore_wave(const unsigned short* __restrict__ pool, const unsigned short* __restrict__ qr, float iq, float ic,
+                          int ci, int dim, char* mine, int lane) {
+    // lane -> (row 8 i + lane / 8 of the wave's 64 rows, 16-B piece lane % 8) for the cooperative 128-byte gathers
+    int rows8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rows8[i] = __shfl(ci, 8 * i + (lane >> 3), 64);
+    const int piece = lane & 7;
+    u32x4_t pre[8];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            pre[i] = rows8[i] >= 0 ? *reinterpret_cast<const u32x4_t*>(pool + (long)rows8[i] * dim + c0 + piece * 8) : z;
+        }
+    };
+    float s = 0.f;
+    fetch(0);
+    for (int c0 = 0; c0 < dim; c0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<u32x4_t*>(mine + (8 * i + (lane >> 3)) * RSC_PITCH + piece * 16) = pre[i];
+        __builtin_amdgcn_wave_barrier();
+        if (c0 + 64 < dim) fetch(c0 + 64);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u32x4_t a = *reinterpret_cast<const u32x4_t*>(qr + c0 + 8 * u);
+            const u32x4_t b = *reinterpret_cast<const u32x4_t*>(mine + lane * RSC_PITCH + u * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float qa = f16_to_f32((unsigned short)(a[e] & 0xffffu)), ca = f16_to_f32((unsigned short)(b[e] & 0xffffu));
+                float qb = f16_to_f32((unsigned short)(a[e] >> 16)), cb = f16_to_f32((unsigned short)(b[e] >> 16));
+                if (iq != 0.f) { qa = __fmul_rn(qa, iq); qb = __fmul_rn(qb, iq); }
+                if (ic != 0.f) { ca = __fmul_rn(ca, ic); cb = __fmul_rn(cb, ic); }
+                s = __fadd_rn(s, __fmul_rn(qa, ca));
+                s = __fadd_rn(s, __fmul_rn(qb, cb));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return s;
+}
+
+template <int PARTS>
+__global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
+    const unsigned short* __restrict__ pool, const float* __restrict__ pinv, long rows, int dim,
+    const unsigned short* __restrict__ queries, const float* __restrict__ gmax, long ngroups, int kc, int gcap,
+    int* __restrict__ cand, float* __restrict__ exact) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];       // re-score staging: one 64 x RSC_PITCH image per active wave
+    __shared__ int sel[2 * TK_MAXKC * TK_G];                         // the selection's output: gcap * 16 row indices, -1 = empty
+    __shared__ __attribute__((aligned(16))) unsigned short qrow[4096];
+    __shared__ float s_iq;
+    const int q = blockIdx.x, part = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned short* qr = queries + (long)q * dim;
+    // the query's inverse norm (FAISS fvec_renorm_L2 as restated by the oracle: sequential fp32 sum of squares, no fma; see
+    // inv_norm_kernel) by lane 0 of wave 0, from a wave-private LDS copy of the query, while the selection's loads are in flight
+    auto qnorm = [&] {
+        if (w != 0) return;
+        for (int c = lane; c < dim / 8; c += 64)
+            *reinterpret_cast<u32x4_t*>(qrow + c * 8) = *reinterpret_cast<const u32x4_t*>(qr + c * 8);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            float s = 0.f;
+            for (int c = 0; c < dim; c += 8) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(qrow + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = f16_to_f32((unsigned short)(v[e] & 0xffffu));
+                    const float hi = f16_to_f32((unsigned short)(v[e] >> 16));
+                    s = __fadd_rn(s, __fmul_rn(lo, lo));
+                    s = __fadd_rn(s, __fmul_rn(hi, hi));
+                }
+            }
+            s_iq = s > 0.f ? (float)(1.0 / (double)(float)sqrt((double)s)) : 0.f;
+        }
+    };
+    gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm);     // ends with a barrier
+    // this workgroup's share: groups of rank part, part + PARTS, ...; thread t -> member t % 16 of its (t / 16)-th group.  Eight
+    // waves (512 slots) re-score at a time: the staging images of more would not fit next to the selection's LDS.
+    const int ngrp = (gcap - part + PARTS - 1) / PARTS;
+    const int nth = ngrp * TK_G;
+    if (w >= 8) return;                                               // no barrier follows
+    const float iq = s_iq;
+    for (int base = 0; base + w * 64 < nth; base += 512) {
+        const int t = base + tid;
+        const int slot = t < nth ? ((t >> 4) * PARTS + part) * TK_G + (t & 15) : -1;
+        const int ci = slot >= 0 ? sel[slot] : -1;
+        const float ic = ci >= 0 ? pinv[ci] : 0.f;
+        const float sc = rescore_wave(pool, qr, iq, ic, ci, dim, dyn + w * (64 * RSC_PITCH), lane);
+        if (slot >= 0) {
+            const long o = (long)q * gcap * TK_G + slot;
+            cand[o] = ci;
+            exact[o] = ci >= 0 ? sc : -INFINITY;
+        }
+    }
+}
+
+// one workgroup per query: rank by counting over the shortlist slots (score desc, id asc), results for rank < k
+#define TKT_SORTCAP (2 * TK_MAXKC * TK_G)     // 2048 slots at most (gcap <= 128 groups)
+__global__ __launch_bounds__(256) void topk_tail_sort_kernel(const float* __restrict__ exact, const int* __restrict__ cand,
+                                                            const long long* __restrict__ ids, int ncand, int k,
+                                                            float* __restrict__ out_s, long long* __restrict__ out_i) {
+    __shared__ __attribute__((aligned(16))) float ls[TKT_SORTCAP + 16];
+    __shared__ int lrow[TKT_SORTCAP];
+    __shared__ int nlive;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* es = exact + (long)q * ncand;
+    const int* ci = cand + (long)q * ncand;
+    if (tid == 0) nlive = 0;
+    const int n16 = (ncand + 15) & ~15;
+    int mylive = 0;
+    for (int c = tid; c < n16; c += 256) {
+        const int row = c < ncand ? ci[c] : -1;
+        ls[c] = row >= 0 ? es[c] : -INFINITY;          // dead slots: never better than, and (live scores are finite) never equal to, a live one
+        if (c < ncand) lrow[c] = row;
+        mylive += row >= 0 ? 1 : 0;
+    }
+    __syncthreads();
+    if (mylive) atomicAdd(&nlive, mylive);
+    for (int e = tid; e < ncand; e += 256) {
+        const int row = lrow[e];
+        if (row < 0) continue;
+        const float sc = ls[e];
+        int rank = 0, ties = 0;
+        for (int u = 0; u < n16; u += 16) {
+            f32x4_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4_t*>(ls + u + 4 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rank += v[j][r] > sc ? 1 : 0;
+                    ties += v[j][r] == sc ? 1 : 0;
+                }
+        }
+        if (rank >= k) continue;
+        const long long id = ids ? ids[row] : (long long)row;
+        if (ties > 1) {                                   // exact score ties (duplicate rows): the id decides
+            for (int u = 0; u < ncand; ++u) {
+                const int ru = lrow[u];
+                if (ru >= 0 && u != e && ls[u] == sc) rank += (ids ? ids[ru] : (long long)ru) < id ? 1 : 0;
+            }
+        }
+        if (rank < k) {
+            out_s[(long)q * k + rank] = sc;
+            out_i[(long)q * k + rank] = id;
+        }
+    }
+    __syncthreads();
+    for (int t = nlive + tid; t < k; t += 256) {          // FAISS pads missing results with -inf distance / id -1
+        out_s[(long)q * k + t] = -INFINITY;
+        out_i[(long)q * k + t] = -1;
+    }
+}
+
+// selection + exact re-score + sort behind a finished group-max scan; false when the shape does not fit the fused kernels
+static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int64_t* pool_ids, int64_t rows, int32_t dim,
+                              const void* queries_f16, int32_t nq, int32_t kc, int32_t k, const float* gmax, int32_t* cand,
+                              float* exact, float* out_scores, int64_t* out_ids, hipStream_t st) {
+    static const char* env = getenv("UNIIR_TOPK_FUSED_TAIL");          // "0": the round-2 tail (four launches), for A/B
+    const long ngroups = (rows + TK_G - 1) / TK_G;
+    const int gcap = TK_GMULT * kc;
+    if ((env && env[0] == '0') || dim % 64 || dim > 4096 || ngroups % 2 || ngroups > 1024L * 2 * TK_SELREG ||
+        gcap * TK_G > TKT_SORTCAP || gcap > 2 * TK_MAXKC)
+        return false;
+    const int parts = nq <= 64 ? 4 : nq <= 128 ? 2 : 1;
+    int waves = ((gcap + parts - 1) / parts * TK_G + 63) / 64;
+    if (waves > 8) waves = 8;
+    const size_t sm = (size_t)waves * 64 * RSC_PITCH;
+    const dim3 g(nq, parts), b(TKT_THREADS);
+#define TKT_LAUNCH(P)                                                                                                  \
+    do {                                                                                                               \
+        static PerDeviceOnce attr;                                                                                     \
+        if (attr.first())                                                                                              \
+            (void)hipFuncSetAttribute((const void*)topk_tail_select_rescore_kernel<P>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * RSC_PITCH);                 \
+        hipLaunchKernelGGL(topk_tail_select_rescore_kernel<P>, g, b, sm, st, (const unsigned short*)pool_f16, pinv,    \
+                           (long)rows, dim, (const unsigned short*)queries_f16, gmax, ngroups, kc, gcap, cand, exact); \
+    } while (0)
+    if (parts == 4) TKT_LAUNCH(4);
+    else if (parts == 2) TKT_LAUNCH(2);
+    else TKT_LAUNCH(1);
+#undef TKT_LAUNCH
+    hipLaunchKernelGGL(topk_tail_sort_kernel, dim3(nq), dim3(256), 0, st, exact, cand, (const long long*)pool_ids,
+                       gcap * TK_G, k, out_scores, (long long*)out_ids);
+    return true;
+}
+
+// -------------------------------------------------------------------------------------------------------------
 // uniir_topk_ip: the whole search_index of one pool shard in one call (mbeir_retriever.py:188-232 = normalise the queries,
 // exact inner-product top-k): query inverse norms, then per chunk of <= 1024 queries one sweep of the shard (group-max scan),
 // group selection, exact re-score, sort.  k <= 56 (k + 8 <= TK_MAXKC groups per query); larger k is assembled from slices by
@@ -1101,13 +1494,30 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
     float* qinv = (float*)(ws + gbytes);
     int32_t* cand = (int32_t*)(ws + gbytes + (((int64_t)nq * 4 + 255) & ~(int64_t)255));
     float* exact = (float*)((char*)cand + (((int64_t)chunk * ncand * 4 + 255) & ~(int64_t)255));
-    int rc = uniir_pool_inv_norms(queries_f16, nq, dim, qinv, stream);
-    if (rc) return rc;
+    int rc = UNIIR_OK;
+    bool have_qinv = false;
     for (int lo = 0; lo < nq; lo += chunk) {
         const int n = nq - lo < chunk ? nq - lo : chunk;
         const unsigned short* qp = (const unsigned short*)queries_f16 + (long)lo * dim;
-        rc = uniir_topk_coarse(pool_f16, pool_inv_norm, rows, dim, qp, n, kc, cand, nullptr, gmax, gbytes, stream);
-        if (rc) return rc;
+        if (n <= TK_GPATH_MAXQ) {       // group-max scan, then the fused tail (selection + query norm + exact re-score | sort)
+            const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, qp, n, gmax, (hipStream_t)stream);
+            if (sel < 0) return sel;
+            if (sel == 1 && launch_fused_tail(pool_f16, pool_inv_norm, pool_ids, rows, dim, qp, n, kc, k, gmax, cand, exact,
+                                              out_scores + (long)lo * k, out_ids + (long)lo * k, (hipStream_t)stream)) {
+                HIP_LAUNCH_CHECK();
+                continue;
+            }
+            rc = topk_select_after_scan(sel, gmax, rows, n, kc, cand, (hipStream_t)stream);
+            if (rc) return rc;
+        } else {
+            rc = uniir_topk_coarse(pool_f16, pool_inv_norm, rows, dim, qp, n, kc, cand, nullptr, gmax, gbytes, stream);
+            if (rc) return rc;
+        }
+        if (!have_qinv) {               // the unfused tail reads the query norms from a separate pass
+            rc = uniir_pool_inv_norms(queries_f16, nq, dim, qinv, stream);
+            if (rc) return rc;
+            have_qinv = true;
+        }
         rc = uniir_topk_rescore(pool_f16, pool_inv_norm, pool_ids, rows, dim, qp, qinv + lo, n, cand, ncand, k, exact,
                                 out_scores + (long)lo * k, out_ids + (long)lo * k, stream);
         if (rc) return rc;
