@@ -21,11 +21,14 @@ from . import _lib, ops
 # instead of the single-call C towers of csrc/tower.hip -- same kernels, same order; kept for A/B comparisons
 _PY_TOWERS = os.environ.get("UNIIR_PY_TOWERS") == "1"
 
-# UNIIR_TOWER_STREAMS=0: run the text tower on the caller's stream like the image tower (A/B).  Default: inside
-# `with model.concurrent_towers():` (encode_multimodal_input of the clip_sf mirror) the text tower's forward -- and, through
-# autograd's stream bookkeeping, its backward -- is enqueued on a second HIP stream, so that its small GEMMs (924 tiles = 3.6 rounds
-# of the 256 CUs) fill the tail rounds of the image tower's kernels instead of each leaving part of the chip idle.
-_TOWER_STREAMS = os.environ.get("UNIIR_TOWER_STREAMS", "1") != "0"
+# UNIIR_TOWER_STREAMS=1: inside `with model.concurrent_towers():` (encode_multimodal_input of the clip_sf mirror) the text
+# tower's forward -- and, through autograd's stream bookkeeping, its backward -- is enqueued on a second HIP stream beside the image
+# tower, so that its small GEMMs (924 tiles = 3.6 rounds of the 256 CUs) could fill the tail rounds of the image tower's kernels.
+# Measured on the headline step (round 3, same box, A/B/A/B): 625.4 / 627.4 ms on one stream, 623.0 / 623.4 ms on two (-0.5 %):
+# the hardware queues barely overlap two kernels that each want the whole chip (1 workgroup of 128 KiB LDS per CU), and the
+# per-kernel durations the roofline is priced on become meaningless when kernels share CUs.  Off by default; the results are
+# identical either way (tests/test_clip_model_gpu.py::test_two_stream_towers_equal_the_single_stream_step).
+_TOWER_STREAMS = os.environ.get("UNIIR_TOWER_STREAMS", "0") == "1"
 
 ALIGN = 64  # elements; every parameter starts on a 256-B boundary of the flat buffers
 

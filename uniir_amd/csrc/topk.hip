@@ -694,7 +694,7 @@ struct TkrState {
     unsigned lbase;
     char* my;
 };
-template <int HALF>
+template <int HALF, int AUX>      // AUX: cache policy of the pool stream (0 default, 2 = nt: read-once data)
 DEVINL void tkr_issue(const TkrState& st, long tile, int slot) {
     // the position inside the row goes into the SCALAR offset: it is excluded from the bounds check (so the check is exactly "is
     // this row inside the shard": voffset = first line of the row) and, unlike the instruction's immediate offset, is not added
@@ -704,7 +704,7 @@ DEVINL void tkr_issue(const TkrState& st, long tile, int slot) {
     char* dst = st.my + slot * TKR_HALF_BYTES;
 #define TKR_DMA(J)                                                                                                  \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rp, (void __attribute__((address_space(3)))*)(dst + (J) * 1024), 16, \
-                                             ((J) & 1) ? v1 : v0, ((J) >> 1) * 128 + HALF * 768, 0, 0);
+                                             ((J) & 1) ? v1 : v0, ((J) >> 1) * 128 + HALF * 768, 0, AUX);
     TKR_DMA(0) TKR_DMA(1) TKR_DMA(2) TKR_DMA(3) TKR_DMA(4) TKR_DMA(5) TKR_DMA(6) TKR_DMA(7) TKR_DMA(8) TKR_DMA(9) TKR_DMA(10) TKR_DMA(11)
 #undef TKR_DMA
     if (HALF == 0)
@@ -732,6 +732,7 @@ DEVINL void tkr_process(const TkrState& st, int slot, const u32x4_t (&qf)[4][24]
 #undef TKR_STEP
     __builtin_amdgcn_sched_barrier(0);
 }
+template <int AUX>
 __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned short* __restrict__ pool,
                                                              const float* __restrict__ pinv, long rows,
                                                              const unsigned short* __restrict__ queries, int nq,
@@ -742,8 +743,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     const int li = lane & 15, lg = lane >> 4;
     // one contiguous range of tiles (groups of 16 rows) per wave, sizes differing by at most one
     const long gw = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
-    const long lo = gw * ngroups / nw, hi = (gw + 1) * ngroups / nw;
-    if (lo >= hi) return;                 // wave-uniform; the kernel has no workgroup barrier
+    const long lo = gw * ngroups / nw, hi = (gw + 1) * ngroups / nw;      // never empty: the launcher asks for >= 2048 groups
     TkrState st;
     st.my = lds + w * TKR_WAVE_LDS;
     st.lbase = lds_addr32(st.my);
@@ -759,20 +759,38 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
         st.la0 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + (((0 + lg) ^ g) << 4));
         st.la1 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + (((4 + lg) ^ g) << 4));
     }
-    // the first two half-tiles are on their way before the query fragments are fetched
-    tkr_issue<0>(st, lo, 0);
-    tkr_issue<1>(st, lo, 1);
+    // The query fragments: 96 x 16 bytes per lane.  As plain global loads hipcc serialises them (load, wait, move to an AGPR, 96
+    // times: ~45 us per wave, measured as 244 vs 202 us between 64 and 16 queries' worth of ... the same loads).  So the 64 x 1536
+    // bytes of queries are first copied into LDS by LDS-DMA (the rings are not in use yet; 16-byte chunk index ^= (query & 15) on
+    // the source side, so that the 16 queries x 4 chunks of a fragment read are conflict-free), then every wave reads all of them.
     u32x4_t qf[4][24];
+    {
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)queries, 0, nq * 1536, 0x00020000);
+        // 98 304 bytes = 96 DMA instructions of 1 KiB over 4 waves: instruction i covers LDS bytes [1024 i, +1024): query i * 2 / 3 ...
+        // lane -> LDS byte b = 1024 i + 16 lane -> query b / 1536, position p = (b % 1536) / 16, source chunk p ^ (query & 15)
+        // (the XOR stays inside the row: 96 chunks = 6 blocks of 16)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = j * 16 + li;
-        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(queries + (long)(q < nq ? q : 0) * 768) + lg;
-#pragma unroll
-        for (int s = 0; s < 24; ++s) {
-            const u32x4_t v = src[4 * s];
-            qf[j][s] = q < nq ? v : u32x4_t{0u, 0u, 0u, 0u};
+        for (int ii = 0; ii < 24; ++ii) {
+            const int i = ii * 4 + w;
+            const unsigned b = 1024u * i + 16u * lane;
+            const unsigned qq = b / 1536u, p = (b % 1536u) >> 4;
+            const unsigned src = qq * 1536u + (((p & ~15u) | ((p ^ qq) & 15u)) << 4);        // queries >= nq: out of bounds -> zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (void __attribute__((address_space(3)))*)(lds + 1024 * i), 16, src, 0, 0, 0);
         }
+        __syncthreads();                 // hipcc drains the LDS-DMA in front of the barrier
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = j * 16 + li;
+#pragma unroll
+            for (int s = 0; s < 24; ++s) {
+                const int c = 4 * s + lg;
+                qf[j][s] = *reinterpret_cast<const u32x4_t*>(lds + q * 1536 + (((c & ~15) | ((c ^ q) & 15)) << 4));
+            }
+        }
+        __syncthreads();                 // every wave has its fragments: the rings may be filled
     }
+    tkr_issue<0, AUX>(st, lo, 0);
+    tkr_issue<1, AUX>(st, lo, 1);
     f32x4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -800,11 +818,11 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     int slot = 0;
     long t = lo;
     for (; t + 1 < hi; ++t) {
-        tkr_issue<0>(st, t + 1, slot == 0 ? 2 : slot - 1);       // h + 2 -> slot (h + 2) % 3
+        tkr_issue<0, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);       // h + 2 -> slot (h + 2) % 3
         tkr_wait_vm<25>();
         tkr_process<0>(st, slot, qf, acc);
         slot = slot == 2 ? 0 : slot + 1;
-        tkr_issue<1>(st, t + 1, slot == 0 ? 2 : slot - 1);
+        tkr_issue<1, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);
         tkr_wait_vm<25>();
         tkr_process<1>(st, slot, qf, acc);
         slot = slot == 2 ? 0 : slot + 1;
@@ -840,10 +858,17 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
             ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         static PerDeviceOnce attr_s2;
-        if (attr_s2.first())
-            (void)hipFuncSetAttribute((const void*)topk_stream2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
-        hipLaunchKernelGGL(topk_stream2_kernel, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                           pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups);
+        if (attr_s2.first()) {
+            (void)hipFuncSetAttribute((const void*)topk_stream2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
+            (void)hipFuncSetAttribute((const void*)topk_stream2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
+        }
+        static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "1": nt cache policy on the pool stream (A/B)
+        if (env_nt && env_nt[0] == '1')
+            hipLaunchKernelGGL(topk_stream2_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
+                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups);
+        else
+            hipLaunchKernelGGL(topk_stream2_kernel<0>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
+                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups);
         HIP_LAUNCH_CHECK();
         return 1;
     }
@@ -1304,14 +1329,89 @@ DEVINL float rescore_wave(const unsigned short* __restrict__ pool, const unsigne
     return s;
 }
 
-template <int PARTS>
+// The same exact re-score with the candidate rows gathered by LDS-DMA (buffer_load_dwordx4 ... lds) into a wave-private ring of
+// DEPTH slices (64 rows x 128 bytes = 8 KiB each): DEPTH - 1 slices are in flight while one is walked, at no register cost -- the
+// register-staged gather above exposes one HBM round trip per 128-byte slice (12 per row: ~2 us each, 25 us per re-score).  Layout:
+// DMA instruction i covers rows 8 i + (lane >> 3); position p of a row holds its 16-byte piece p ^ ((row >> 1) & 7) (source-side
+// swizzle, conflict-free for the row-per-lane ds_read_b128).  qn = the query already scaled by its inverse norm, fp32, in LDS
+// (computed once per workgroup: the oracle's qn[j]); the candidate's scaling by ic is applied unconditionally (ic == 0 only for
+// an all-zero row, where x * 0 == x bit for bit).  Same summation order as the oracle: one sequential fp32 chain per pair.
+template <int DEPTH>
+DEVINL float rescore_wave_dma(__amdgpu_buffer_rsrc_t rp, unsigned qn32, float ic, int ci, int dim, char* ring, int lane) {
+    const unsigned ring32 = lds_addr32(ring);
+    unsigned vo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rloc = 8 * i + (lane >> 3);
+        const int r = __shfl(ci, rloc, 64);
+        const unsigned piece = (unsigned)((lane & 7) ^ ((rloc >> 1) & 7));
+        vo[i] = r >= 0 ? (unsigned)r * (unsigned)(dim * 2) + piece * 16u : 0xffffff00u;       // out of bounds -> zeros
+    }
+    const unsigned rd = ring32 + lane * 128;                       // this lane's row inside a slice
+    const unsigned sw = (unsigned)((lane >> 1) & 7);
+    // slice t >= nsl: the same 8 instructions with out-of-bounds offsets (zeros, no memory traffic) -- the DMA count per trip stays
+    // constant, so one counted vmcnt serves the whole loop and no separate tail code exists
+    auto issue = [&](int t, int slot, bool real) {
+        char* dst = ring + slot * 8192;
+        const unsigned so = real ? (unsigned)t * 128u : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (void __attribute__((address_space(3)))*)(dst + i * 1024), 16,
+                                                     real ? vo[i] : 0xffffff00u, so, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    float s = 0.f;
+    auto consume = [&](int t, int slot) {
+        const unsigned base = rd + slot * 8192;
+        u32x4_t b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = asm_ds_read_b128<0>(base + (((unsigned)u ^ sw) << 4));
+        const unsigned qa = qn32 + (unsigned)t * 256u;             // 64 floats of qn per slice
+        u32x4_t q0 = asm_ds_read_b128<0>(qa), q1 = asm_ds_read_b128<16>(qa);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            asm_wait_lgkm<0>();
+            const f32x4_t a0 = __builtin_bit_cast(f32x4_t, q0), a1 = __builtin_bit_cast(f32x4_t, q1);
+            const u32x4_t bb = b[u];
+            if (u < 7) {
+                q0 = asm_ds_read_b128<0>(qa + (u + 1) * 32);
+                q1 = asm_ds_read_b128<16>(qa + (u + 1) * 32);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ca = __fmul_rn(f16_to_f32((unsigned short)(bb[e] & 0xffffu)), ic);
+                const float cb = __fmul_rn(f16_to_f32((unsigned short)(bb[e] >> 16)), ic);
+                const float x0 = e < 2 ? a0[2 * e] : a1[2 * e - 4], x1 = e < 2 ? a0[2 * e + 1] : a1[2 * e - 3];
+                s = __fadd_rn(s, __fmul_rn(x0, ca));
+                s = __fadd_rn(s, __fmul_rn(x1, cb));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int nsl = dim / 64;
+#pragma unroll
+    for (int t = 0; t < DEPTH - 1; ++t) issue(t, t, t < nsl);
+    int slot = 0;
+    for (int t = 0; t < nsl; ++t) {
+        issue(t + DEPTH - 1, slot == 0 ? DEPTH - 1 : slot - 1, t + DEPTH - 1 < nsl);       // slot (t + DEPTH - 1) % DEPTH
+        tkr_wait_vm<(DEPTH - 1) * 8>();
+        consume(t, slot);
+        slot = slot == DEPTH - 1 ? 0 : slot + 1;
+    }
+    tkr_wait_vm<0>();            // the trailing dummies: nothing may be in flight towards the ring when the caller reuses it
+    return s;
+}
+
+// PARTS workgroups per query; RW waves of a workgroup re-score at a time, each with a DEPTH-slice gather ring (RW x DEPTH x 8 KiB)
+template <int PARTS, int RW, int DEPTH>
 __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     const unsigned short* __restrict__ pool, const float* __restrict__ pinv, long rows, int dim,
     const unsigned short* __restrict__ queries, const float* __restrict__ gmax, long ngroups, int kc, int gcap,
     int* __restrict__ cand, float* __restrict__ exact) {
-    extern __shared__ __attribute__((aligned(16))) char dyn[];       // re-score staging: one 64 x RSC_PITCH image per active wave
+    extern __shared__ __attribute__((aligned(16))) char dyn[];       // the gather rings
     __shared__ int sel[2 * TK_MAXKC * TK_G];                         // the selection's output: gcap * 16 row indices, -1 = empty
     __shared__ __attribute__((aligned(16))) unsigned short qrow[4096];
+    __shared__ __attribute__((aligned(16))) float qn[4096];
     __shared__ float s_iq;
     const int q = blockIdx.x, part = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1339,18 +1439,26 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
         }
     };
     gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm);     // ends with a barrier
-    // this workgroup's share: groups of rank part, part + PARTS, ...; thread t -> member t % 16 of its (t / 16)-th group.  Eight
-    // waves (512 slots) re-score at a time: the staging images of more would not fit next to the selection's LDS.
+    {
+        const float iq = s_iq;                 // the normalised query, once per workgroup (the oracle's qn[j])
+        for (int j = tid; j < dim; j += TKT_THREADS) {
+            const float v = f16_to_f32(qrow[j]);
+            qn[j] = iq != 0.f ? __fmul_rn(v, iq) : v;
+        }
+    }
+    __syncthreads();
+    // this workgroup's share: groups of rank part, part + PARTS, ...; thread t -> member t % 16 of its (t / 16)-th group
     const int ngrp = (gcap - part + PARTS - 1) / PARTS;
     const int nth = ngrp * TK_G;
-    if (w >= 8) return;                                               // no barrier follows
-    const float iq = s_iq;
-    for (int base = 0; base + w * 64 < nth; base += 512) {
+    if (w >= RW) return;                                              // no barrier follows
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * dim * 2), 0x00020000);
+    const unsigned qn32 = lds_addr32(reinterpret_cast<const char*>(qn));
+    for (int base = 0; base + w * 64 < nth; base += RW * 64) {
         const int t = base + tid;
         const int slot = t < nth ? ((t >> 4) * PARTS + part) * TK_G + (t & 15) : -1;
         const int ci = slot >= 0 ? sel[slot] : -1;
         const float ic = ci >= 0 ? pinv[ci] : 0.f;
-        const float sc = rescore_wave(pool, qr, iq, ic, ci, dim, dyn + w * (64 * RSC_PITCH), lane);
+        const float sc = rescore_wave_dma<DEPTH>(rp, qn32, ic, ci, dim, dyn + w * (DEPTH * 8192), lane);
         if (slot >= 0) {
             const long o = (long)q * gcap * TK_G + slot;
             cand[o] = ci;
@@ -1359,31 +1467,41 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     }
 }
 
-// one workgroup per query: rank by counting over the shortlist slots (score desc, id asc), results for rank < k
+// one workgroup per query: the live slots are compacted into LDS (about half of the gcap * 16 slots are: the groups beyond the
+// kc-th best and its ties stay empty), then every live entry counts the entries that beat it (score desc, id asc); rank < k is the
+// answer.  1024 threads: one entry per thread, ~n / 16 trips of 16 compares each (the 256-thread, uncompacted form of this kernel
+// took 22 us: 576^2 compares on four waves).
 #define TKT_SORTCAP (2 * TK_MAXKC * TK_G)     // 2048 slots at most (gcap <= 128 groups)
-__global__ __launch_bounds__(256) void topk_tail_sort_kernel(const float* __restrict__ exact, const int* __restrict__ cand,
-                                                            const long long* __restrict__ ids, int ncand, int k,
-                                                            float* __restrict__ out_s, long long* __restrict__ out_i) {
+__global__ __launch_bounds__(1024) void topk_tail_sort_kernel(const float* __restrict__ exact, const int* __restrict__ cand,
+                                                             const long long* __restrict__ ids, int ncand, int k,
+                                                             float* __restrict__ out_s, long long* __restrict__ out_i) {
     __shared__ __attribute__((aligned(16))) float ls[TKT_SORTCAP + 16];
     __shared__ int lrow[TKT_SORTCAP];
     __shared__ int nlive;
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const float* es = exact + (long)q * ncand;
     const int* ci = cand + (long)q * ncand;
     if (tid == 0) nlive = 0;
-    const int n16 = (ncand + 15) & ~15;
-    int mylive = 0;
-    for (int c = tid; c < n16; c += 256) {
+    __syncthreads();
+    for (int c0 = 0; c0 < ncand; c0 += 1024) {           // <= 2 trips; wave-uniform trip count
+        const int c = c0 + tid;
         const int row = c < ncand ? ci[c] : -1;
-        ls[c] = row >= 0 ? es[c] : -INFINITY;          // dead slots: never better than, and (live scores are finite) never equal to, a live one
-        if (c < ncand) lrow[c] = row;
-        mylive += row >= 0 ? 1 : 0;
+        const float sc = row >= 0 ? es[c] : 0.f;
+        const unsigned long long m = __ballot(row >= 0);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&nlive, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (row >= 0) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            ls[pos] = sc;
+            lrow[pos] = row;
+        }
     }
     __syncthreads();
-    if (mylive) atomicAdd(&nlive, mylive);
-    for (int e = tid; e < ncand; e += 256) {
-        const int row = lrow[e];
-        if (row < 0) continue;
+    const int n = nlive, n16 = (n + 15) & ~15;
+    if (tid < 16) ls[n + tid] = -INFINITY;                // pad to the 16-wide compare loop (never better than, never equal to a live score)
+    __syncthreads();
+    for (int e = tid; e < n; e += 1024) {
         const float sc = ls[e];
         int rank = 0, ties = 0;
         for (int u = 0; u < n16; u += 16) {
@@ -1399,20 +1517,18 @@ __global__ __launch_bounds__(256) void topk_tail_sort_kernel(const float* __rest
                 }
         }
         if (rank >= k) continue;
+        const int row = lrow[e];
         const long long id = ids ? ids[row] : (long long)row;
         if (ties > 1) {                                   // exact score ties (duplicate rows): the id decides
-            for (int u = 0; u < ncand; ++u) {
-                const int ru = lrow[u];
-                if (ru >= 0 && u != e && ls[u] == sc) rank += (ids ? ids[ru] : (long long)ru) < id ? 1 : 0;
-            }
+            for (int u = 0; u < n; ++u)
+                if (u != e && ls[u] == sc) rank += (ids ? ids[lrow[u]] : (long long)lrow[u]) < id ? 1 : 0;
         }
         if (rank < k) {
             out_s[(long)q * k + rank] = sc;
             out_i[(long)q * k + rank] = id;
         }
     }
-    __syncthreads();
-    for (int t = nlive + tid; t < k; t += 256) {          // FAISS pads missing results with -inf distance / id -1
+    for (int t = n + tid; t < k; t += 1024) {             // FAISS pads missing results with -inf distance / id -1
         out_s[(long)q * k + t] = -INFINITY;
         out_i[(long)q * k + t] = -1;
     }
@@ -1428,25 +1544,25 @@ static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int
     if ((env && env[0] == '0') || dim % 64 || dim > 4096 || ngroups % 2 || ngroups > 1024L * 2 * TK_SELREG ||
         gcap * TK_G > TKT_SORTCAP || gcap > 2 * TK_MAXKC)
         return false;
+    if (rows * dim * 2 >= (1L << 31)) return false;                  // the gather's 31-bit buffer bound
     const int parts = nq <= 64 ? 4 : nq <= 128 ? 2 : 1;
-    int waves = ((gcap + parts - 1) / parts * TK_G + 63) / 64;
-    if (waves > 8) waves = 8;
-    const size_t sm = (size_t)waves * 64 * RSC_PITCH;
     const dim3 g(nq, parts), b(TKT_THREADS);
-#define TKT_LAUNCH(P)                                                                                                  \
+#define TKT_LAUNCH(P, RW, DEPTH)                                                                                       \
     do {                                                                                                               \
         static PerDeviceOnce attr;                                                                                     \
         if (attr.first())                                                                                              \
-            (void)hipFuncSetAttribute((const void*)topk_tail_select_rescore_kernel<P>,                                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * RSC_PITCH);                 \
-        hipLaunchKernelGGL(topk_tail_select_rescore_kernel<P>, g, b, sm, st, (const unsigned short*)pool_f16, pinv,    \
-                           (long)rows, dim, (const unsigned short*)queries_f16, gmax, ngroups, kc, gcap, cand, exact); \
+            (void)hipFuncSetAttribute((const void*)topk_tail_select_rescore_kernel<P, RW, DEPTH>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, RW * DEPTH * 8192);                  \
+        hipLaunchKernelGGL((topk_tail_select_rescore_kernel<P, RW, DEPTH>), g, b, RW * DEPTH * 8192, st,               \
+                           (const unsigned short*)pool_f16, pinv, (long)rows, dim, (const unsigned short*)queries_f16, \
+                           gmax, ngroups, kc, gcap, cand, exact);                                                      \
     } while (0)
-    if (parts == 4) TKT_LAUNCH(4);
-    else if (parts == 2) TKT_LAUNCH(2);
-    else TKT_LAUNCH(1);
+    // rings: 3 waves x 4 slices (the interactive regime: 144 slots per workgroup at k = 10) or 5 waves x 2 slices = 96 / 80 KiB
+    if (parts == 4) TKT_LAUNCH(4, 3, 4);
+    else if (parts == 2) TKT_LAUNCH(2, 5, 2);
+    else TKT_LAUNCH(1, 5, 2);
 #undef TKT_LAUNCH
-    hipLaunchKernelGGL(topk_tail_sort_kernel, dim3(nq), dim3(256), 0, st, exact, cand, (const long long*)pool_ids,
+    hipLaunchKernelGGL(topk_tail_sort_kernel, dim3(nq), dim3(1024), 0, st, exact, cand, (const long long*)pool_ids,
                        gcap * TK_G, k, out_scores, (long long*)out_ids);
     return true;
 }
