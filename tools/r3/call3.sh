@@ -7,7 +7,7 @@ cd $R
 timeout 600 python -m pytest tests/test_topk_gpu.py tests/test_bench_paths_gpu.py::test_search_shard_multi_sweep_loop_equals_the_oracle "tests/test_fullsize_gpu.py::test_topk_full_shard_properties" tests/test_parity_exact_gpu.py tests/test_pipeline_gpu.py -x -q > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log
 tail -4 $O/pytest.log
-for cfg in "new::" "nt:UNIIR_TOPK_NT=1:" "old_scan:UNIIR_TOPK_STREAM2=0:"; do
+for cfg in "new::" "nont:UNIIR_TOPK_NT=0:"; do
   name=${cfg%%:*}; rest=${cfg#*:}; e1=${rest%%:*}; e2=${rest#*:}
   env $e1 $e2 NQS=16,64,128,256,1024 timeout 300 python tools/r3/topk_bench.py > $O/tb_$name.txt 2>&1
   echo "== $name"; grep topk $O/tb_$name.txt

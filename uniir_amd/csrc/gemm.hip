@@ -518,8 +518,10 @@ static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
 }
 
 // shape choice: 0 = general 128x128 register-staged kernel, 1 = 256x256x64 LDS-DMA kernel (1 workgroup / CU)
+static thread_local int g_force_general = 0;     // set around the remainder-rows launch of gemm_impl
 static int gemm_shape(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
     static const char* force = getenv("UNIIR_GEMM_SHAPE");      // "0": force the general kernel (tests / experiments)
+    if (g_force_general) return 0;
     if (a.K % 64) return 0;
     if (a.M < 256 || a.N < 128) return 0;    // small problems: the 128-tile kernel fills the chip better
     if (force && force[0] == '0') return 0;
@@ -677,6 +679,48 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15) || ((uintptr_t)d->C & 15)) return UNIIR_EALIGN;
     if (d->aux && ((d->ldaux % 4) || ((uintptr_t)d->aux & 7))) return UNIIR_EALIGN;
     if (d->bias && ((uintptr_t)d->bias & 15)) return UNIIR_EALIGN;
+    // Tile quantisation (round 3).  One 256x256 workgroup per CU: tiles_m x tiles_n tiles take ceil(tiles / CUs) rounds, and a
+    // last round with a few tiles costs a whole tile time on an almost idle chip -- the ViT-L/14 step has 263 168 = 1028 x 256 rows,
+    // i.e. 16 tiles (N = 1024: out / proj forward, the qkv / fc / out dgrads), 48 (N = 3072) or 64 (N = 4096) left over after
+    // 16 / 48 / 64 full rounds.  When the leftover is at most a quarter round, the row panels that make up whole rounds run the
+    // 256-tile kernel and the remaining rows (1024 here) a second launch of the general 128x128 kernel: 4x the workgroups at a
+    // quarter of the work each, one short round instead of one long one.  Every epilogue is row-wise, so the split is exact.
+    if (!g_force_general && !d->a_tmaj && d->k_splits == 1 && d->M % 256 == 0 && d->K % 64 == 0 && d->N >= 128 &&
+        d->epilogue != UNIIR_EPI_ATOMIC_F32) {
+        static const char* env = getenv("UNIIR_GEMM_REMAINDER");      // "0": one launch, whatever the last round looks like (A/B)
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+        }
+        const long tm = d->M / 256, tn = (d->N + 255) / 256, tiles = tm * tn, rem = tiles % ncu;
+        if (!(env && env[0] == '0') && tiles / ncu >= 4 && rem > 0 && rem * 4 <= ncu) {
+            long g = tn, h = ncu;
+            while (h) { const long r = g % h; g = h; h = r; }          // gcd(tn, ncu)
+            const long step = ncu / g, tm_main = tm / step * step;
+            if (tm_main > 0 && tm_main < tm && (tm - tm_main) * 256 <= 4096) {
+                const long m0 = tm_main * 256;
+                const bool c32 = d->epilogue == UNIIR_EPI_RESID_F32 || d->epilogue == UNIIR_EPI_F32;
+                uniir_gemm_desc d1 = *d, d2 = *d;
+                d1.M = (int)m0;
+                d2.M = d->M - (int)m0;
+                d2.A = (const char*)d->A + m0 * d->lda * 2;
+                d2.C = (char*)d->C + m0 * d->ldc * (c32 ? 4 : 2);
+                if (d->C2) d2.C2 = (char*)d->C2 + m0 * (d->epilogue == UNIIR_EPI_DACT ? d->ldaux : d->ldc) * 2;
+                if (d->resid) d2.resid = d->resid + m0 * d->ldc;
+                if (d->aux) d2.aux = (const char*)d->aux + m0 * d->ldaux * 2;
+                if (d->row_scale) d2.row_scale = d->row_scale + m0;
+                int rc = gemm_impl(&d1, stream);
+                if (rc) return rc;
+                g_force_general = 1;
+                rc = gemm_impl(&d2, stream);
+                g_force_general = 0;
+                return rc;
+            }
+        }
+    }
     GemmKArgs a;
     a.A = (const unsigned short*)d->A;
     a.B = (const unsigned short*)d->B;

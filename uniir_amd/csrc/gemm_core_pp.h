@@ -100,12 +100,13 @@ DEVINL void pp_src(long ld, int mn_base, int mn0, int mn_total, int tid, unsigne
     }
 }
 
+template <int AUX = 0>      // cache policy of this operand's stream: 0 default, 2 = nt (read once: the top-k scan's pool rows)
 DEVINL void pp_stage(__amdgpu_buffer_rsrc_t rs, const unsigned (&vo)[2], unsigned koff_bytes, char* slot, int w) {
     if (PP_EXP & 1) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         char* dst = slot + (i * 512 + w * 64) * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)dst, 16, vo[i], koff_bytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)dst, 16, vo[i], koff_bytes, 0, AUX);
     }
 }
 
@@ -169,7 +170,7 @@ struct PPState {
 // one K step (4 phases).  MODE 0: steady state; 1: second to last K step (stages q=0,1 only); 2: last (stages nothing)
 // HALFN (the top-k scan with <= 128 queries): the column half B1 holds no real columns -- its fragment reads and the two MFMA
 // phases that use it are dropped (half the matrix work); the staging schedule, and with it every hazard argument above, is unchanged
-template <typename Elem, bool A_TMAJ, bool B_TMAJ, int MODE, bool ROWSUM = false, bool HALFN = false>
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, int MODE, bool ROWSUM = false, bool HALFN = false, int AUXA = 0>
 DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&acc)[8][4], float (&rs)[2], int& rs_cd) {
     // this workgroup's turn every rs_tiles-th K step (a countdown: t % rs_tiles with a run-time divisor costs ~100 cycles per K step)
     bool rs_turn = false;
@@ -205,7 +206,7 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
         b1[0][1] = st.fb.template read<0, 1>(sb + 2 * 16384); b1[1][1] = st.fb.template read<1, 1>(sb + 2 * 16384);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE <= 1) pp_stage(st.rA, st.gA[1], kA1, oth + 3 * 16384, st.w);
+    if (MODE <= 1) pp_stage<AUXA>(st.rA, st.gA[1], kA1, oth + 3 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
     if (ROWSUM && rs_turn) pp_rowsum_wc(st.w & 3, af, rs[0]);            // A0 rows (still in registers)
     __builtin_amdgcn_sched_barrier(0);
@@ -220,7 +221,7 @@ DEVINL void pp_kstep(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int t, f32x4_t (&a
     af[0][1] = st.fa.template read<0, 1>(sb + 3 * 16384); af[1][1] = st.fa.template read<1, 1>(sb + 3 * 16384);
     af[2][1] = st.fa.template read<2, 1>(sb + 3 * 16384); af[3][1] = st.fa.template read<3, 1>(sb + 3 * 16384);
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE == 0) pp_stage(st.rA, st.gA[0], kA2, cur + 0 * 16384, st.w);
+    if (MODE == 0) pp_stage<AUXA>(st.rA, st.gA[0], kA2, cur + 0 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
     if (MODE == 0) asm_wait_vm<8>();
     pp_barrier();
@@ -266,35 +267,35 @@ DEVINL void pp_setup(PPState<Elem, A_TMAJ, B_TMAJ>& st, const unsigned short* __
     st.w = w;
 }
 
-template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, int AUXA = 0>
 DEVINL void pp_prologue(const PPState<Elem, A_TMAJ, B_TMAJ>& st) {
     // half-tiles 0..5 = (0,A0) (0,B0) (0,B1) (0,A1) (1,A0) (1,B0)
     char* lds = st.lds;
-    pp_stage(st.rA, st.gA[0], 0, lds + 0 * 16384, st.w);
+    pp_stage<AUXA>(st.rA, st.gA[0], 0, lds + 0 * 16384, st.w);
     pp_stage(st.rB, st.gB[0], 0, lds + 1 * 16384, st.w);
     pp_stage(st.rB, st.gB[1], 0, lds + 2 * 16384, st.w);
-    pp_stage(st.rA, st.gA[1], 0, lds + 3 * 16384, st.w);
-    pp_stage(st.rA, st.gA[0], st.kstepA, lds + 65536 + 0 * 16384, st.w);
+    pp_stage<AUXA>(st.rA, st.gA[1], 0, lds + 3 * 16384, st.w);
+    pp_stage<AUXA>(st.rA, st.gA[0], st.kstepA, lds + 65536 + 0 * 16384, st.w);
     pp_stage(st.rB, st.gB[0], st.kstepB, lds + 65536 + 1 * 16384, st.w);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false, bool HALFN = false>
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false, bool HALFN = false, int AUXA = 0>
 DEVINL void pp_main(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int nk, f32x4_t (&acc)[8][4], float (&rs)[2]) {
     const int wr = st.w >> 2;
     asm_wait_vm<8>();
     pp_barrier();
     if (wr == 1) pp_barrier();          // group 1 runs one barrier behind from here on
     int rs_cd = st.rs_nt;                // first turn at t = rs_nt
-    for (int t = 0; t < nk - 2; ++t) pp_kstep<Elem, A_TMAJ, B_TMAJ, 0, ROWSUM, HALFN>(st, t, acc, rs, rs_cd);
-    pp_kstep<Elem, A_TMAJ, B_TMAJ, 1, ROWSUM, HALFN>(st, nk - 2, acc, rs, rs_cd);
-    pp_kstep<Elem, A_TMAJ, B_TMAJ, 2, ROWSUM, HALFN>(st, nk - 1, acc, rs, rs_cd);
+    for (int t = 0; t < nk - 2; ++t) pp_kstep<Elem, A_TMAJ, B_TMAJ, 0, ROWSUM, HALFN, AUXA>(st, t, acc, rs, rs_cd);
+    pp_kstep<Elem, A_TMAJ, B_TMAJ, 1, ROWSUM, HALFN, AUXA>(st, nk - 2, acc, rs, rs_cd);
+    pp_kstep<Elem, A_TMAJ, B_TMAJ, 2, ROWSUM, HALFN, AUXA>(st, nk - 1, acc, rs, rs_cd);
     if (wr == 0) pp_barrier();          // re-align the groups
 }
 
 // a_rowsum (ROWSUM kernels, transposed A only): += sum over this block's K range of A^T's rows m0 .. m0 + 255; nt / tiles_n: the
 // block's column panel and their number.
-template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false, bool HALFN = false>
+template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false, bool HALFN = false, int AUXA = 0>
 DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int M, const unsigned short* __restrict__ B,
                              long ldb, int N, int m0, int n0, int kbeg, int kend, char* lds, f32x4_t (&acc)[8][4],
                              float* a_rowsum = nullptr, int nt = 0, int tiles_n = 1) {
@@ -303,8 +304,8 @@ DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int
     st.rs_nt = (ROWSUM && a_rowsum) ? nt : -1;
     st.rs_tiles = tiles_n;
     float rs[2] = {0.f, 0.f};
-    pp_prologue(st);
-    pp_main<Elem, A_TMAJ, B_TMAJ, ROWSUM, HALFN>(st, (kend - kbeg) / 64, acc, rs);
+    pp_prologue<Elem, A_TMAJ, B_TMAJ, AUXA>(st);
+    pp_main<Elem, A_TMAJ, B_TMAJ, ROWSUM, HALFN, AUXA>(st, (kend - kbeg) / 64, acc, rs);
     if (ROWSUM && st.rs_nt >= 0) {
         // rs[h]: lane (row 128 h + 64 wr + 16 wc + (lane & 15), k group lane >> 4) -> add the four k groups, one atomic per row
         const int lane = threadIdx.x & 63;

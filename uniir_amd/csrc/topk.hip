@@ -499,7 +499,9 @@ struct ElemF16Direct {   // operands in the order the main loop hands them over 
 // workgroup on the ping-pong LDS-DMA loop of the training GEMMs (gemm_core_pp.h, fp16 operands, K = dim), group maxima
 // straight from the accumulators.  Accumulator map: acc[4h+i][2h'+j][r] = candidate 128h + 64wr + 16i + (lane & 15),
 // query 128h' + 32wc + 16j + 4 (lane >> 4) + r.
-template <bool HALFN>       // HALFN: <= 128 queries, the second half of the query tile is padding -> half the MFMA work (gemm_core_pp.h)
+// HALFN: <= 128 queries, the second half of the query tile is padding -> half the MFMA work (gemm_core_pp.h); AUXA: cache policy
+// of the pool stream (2 = nt: every pool row is read once per sweep)
+template <bool HALFN, int AUXA>
 __global__ __launch_bounds__(512, 2) void topk_gmax_pp_kernel(const unsigned short* __restrict__ pool,
                                                               const float* __restrict__ pinv, long rows, int dim,
                                                               const unsigned short* __restrict__ queries, int nq,
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void topk_gmax_pp_kernel(const unsigned sho
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // un-swapped MFMA operands here: D[row = 4 (lane >> 4) + r -> candidate][col = lane & 15 -> query], so the maximum over
     // the 16 candidates of a group is 3 in-lane max + 2 cross-row exchanges per 16x16 tile (instead of 16 DPP steps)
-    glds_mainloop_pp<ElemF16Direct, false, false, false, HALFN>(pool, dim, (int)rows, queries, dim, nq, m0, q0, 0, dim, lds, acc);
+    glds_mainloop_pp<ElemF16Direct, false, false, false, HALFN, AUXA>(pool, dim, (int)rows, queries, dim, nq, m0, q0, 0, dim, lds, acc);
     // group maxima -> LDS image [256 queries][16 groups] (the ring is idle now), then 32-B runs per query to gmax
     float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -681,7 +683,8 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
 // j >> 1 (128 bytes), position lane & 7 holds chunk (lane & 7) ^ g(row).
 #define TKR_HALF_BYTES 12288
 #define TKR_PINV_OFF (3 * TKR_HALF_BYTES)
-#define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512)
+#define TKR_STAGE_OFF (TKR_PINV_OFF + 512)
+#define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 1024)
 template <int N>
 DEVINL void tkr_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N));
@@ -794,6 +797,8 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     f32x4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned stg = st.lbase + TKR_STAGE_OFF + lane * 16;
+    const unsigned qoff = (unsigned)(((long)lane * ngroups) & 3);
     auto finish_tile = [&](long tile) {
         // D: lane -> query j * 16 + li, candidates 4 lg + r of the tile
         const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + TKR_PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
@@ -810,7 +815,28 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
             acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         const float mine = lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lg * 16 + li = lane
-        if (lane < nq) gmax[(long)lane * ngroups + tile] = mine;
+        // Four consecutive group maxima of a query leave as ONE 16-byte store (one 4-byte store per lane and tile -- 64 scattered
+        // requests per tile, 2.8 M per sweep -- cost the 64-query scan ~25 us against the 16-query one).  The lane's 16 bytes of LDS
+        // serve as an indexed register file (asm accesses: the compiler must not order them against the LDS-DMA stream); the quad
+        // phase is per lane, so that the store is 16-byte aligned whatever (query * ngroups) % 4 is.
+        const unsigned k = ((unsigned)tile + qoff) & 3u;
+        asm volatile("ds_write_b32 %0, %1" ::"v"(stg + k * 4u), "v"(mine) : "memory");
+        if (k == 3u || tile == hi - 1) {
+            const u32x4_t sv = asm_ds_read_b128<0>(stg);
+            asm_wait_lgkm<0>();
+            const f32x4_t v4 = __builtin_bit_cast(f32x4_t, sv);
+            const long g0 = tile - k;                        // first group of this lane's quad
+            if (lane < nq) {
+                float* dst = gmax + (long)lane * ngroups + g0;
+                if (k == 3u && g0 >= lo) {
+                    *reinterpret_cast<f32x4_t*>(dst) = v4;
+                } else {                                     // head of the wave's range / end of the range: the groups this wave computed
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i <= (int)k && g0 + i >= lo) dst[i] = v4[i];
+                }
+            }
+        }
     };
     // half-tile h = 2 (tile - lo) + half lives in ring slot h % 3; two half-tiles stay in flight (12 + 13 DMA instructions: the
     // inverse norms travel with the first half), so every wait is vmcnt(25).  The group-max stores also count in vmcnt: they can
@@ -862,8 +888,9 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
             (void)hipFuncSetAttribute((const void*)topk_stream2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
             (void)hipFuncSetAttribute((const void*)topk_stream2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
         }
-        static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "1": nt cache policy on the pool stream (A/B)
-        if (env_nt && env_nt[0] == '1')
+        // nt on the pool stream (read exactly once): measured 0.2729 -> 0.2466 ms per 64-query search, 0.2382 -> 0.2124 at 16
+        static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "0": default cache policy (A/B)
+        if (!(env_nt && env_nt[0] == '0'))
             hipLaunchKernelGGL(topk_stream2_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
                                pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups);
         else
@@ -893,20 +920,24 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
     if (nq > 64 && dim % 64 == 0 && dim >= 192 && !(env_pp && env_pp[0] == '0')) {
         const int tiles_q = (nq + 255) / 256;
         const long tiles_c = (rows + 255) / 256;
-        static PerDeviceOnce attr_pp;
-        if (attr_pp.first()) {
-            (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        }
         static const char* env_hn = getenv("UNIIR_TOPK_HALFN");       // "0": always the full 256-query tile (A/B)
-        if (nq <= 128 && !(env_hn && env_hn[0] == '0'))
-            hipLaunchKernelGGL(topk_gmax_pp_kernel<true>, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
-                               (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
-                               (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
-        else
-            hipLaunchKernelGGL(topk_gmax_pp_kernel<false>, dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,
-                               (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim,
-                               (const unsigned short*)queries_f16, nq, gmax, ngroups, tiles_q);
+        static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "0": default cache policy on the pool stream (A/B)
+        const bool halfn = nq <= 128 && !(env_hn && env_hn[0] == '0');
+        const bool nt = nq <= 256 && !(env_nt && env_nt[0] == '0');   // one query tile: every pool row is read exactly once
+#define TKPP_LAUNCH(H, A)                                                                                                      \
+    do {                                                                                                                       \
+        static PerDeviceOnce attr;                                                                                             \
+        if (attr.first())                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)topk_gmax_pp_kernel<H, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+        hipLaunchKernelGGL((topk_gmax_pp_kernel<H, A>), dim3((unsigned)(tiles_c * tiles_q)), dim3(512), 131072, st0,          \
+                           (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, \
+                           nq, gmax, ngroups, tiles_q);                                                                        \
+    } while (0)
+        if (halfn && nt) TKPP_LAUNCH(true, 2);
+        else if (halfn) TKPP_LAUNCH(true, 0);
+        else if (nt) TKPP_LAUNCH(false, 2);
+        else TKPP_LAUNCH(false, 0);
+#undef TKPP_LAUNCH
         HIP_LAUNCH_CHECK();
         return 1;
     }
