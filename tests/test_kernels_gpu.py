@@ -514,3 +514,48 @@ def test_device_image_transform_is_bit_exact():
     sq = clip_front.preprocess_on_device([z["c4_img"]], 48, DEV, center_crop=False)[0].cpu().numpy()
     r = c_oracle.resize_bicubic(z["c4_img"], 48, 48).astype(np.float32) / np.float32(255.0)
     assert np.array_equal(sq, ((r.transpose(2, 0, 1) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]))
+
+
+def test_gemm_remainder_rows_split_matches_a_reference_on_both_parts():
+    """round 3: 260 row panels x 4 column panels = 1040 tiles = 4 rounds of the 256 CUs + 16 tiles -> the last 1024 rows run the
+    general 128-tile kernel in a second launch (csrc/gemm.hip gemm_impl).  Every epilogue of the step, checked separately on the rows
+    of the first launch and on the remainder rows, incl. the outputs the general kernel produces by extra passes (act(aux), column
+    sums) and the per-row operands (resid, row_scale, aux)."""
+    ops = _ops()
+    torch.manual_seed(9)
+    M, N, K = 260 * 256, 1024, 512
+    lo = 256 * 256                                            # first remainder row
+    x = bf(torch.randn(M, K, device=DEV))
+    w = bf(torch.randn(N, K, device=DEV) * 0.05)
+    bias = torch.randn(N, device=DEV)
+    ref = x.float() @ w.float().t() + bias
+
+    def both(got, want, tol):
+        for sl in (slice(0, lo), slice(lo, M)):
+            assert rel_err(got[sl], want[sl]) < tol, (sl, rel_err(got[sl], want[sl]))
+
+    y = ops.linear_fwd(x, w, bias)                             # bf16 out
+    both(y, ref, 4e-3)
+    g = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    f = ops.linear_fwd(x, w, bias, epilogue=ops.EPI_BIAS_ACT, C2=g)
+    both(f, ref, 4e-3)
+    both(g, f.float() * torch.sigmoid(1.702 * f.float()), 4e-3)
+    only = ops.linear_fwd(x, w, bias, epilogue=ops.EPI_ACT_ONLY)
+    assert torch.equal(only, g)
+    res = torch.randn(M, N, device=DEV)
+    scale = torch.rand(M, device=DEV) + 0.5
+    z = ops.linear_fwd(x, w, bias, epilogue=ops.EPI_RESID_F32, resid=res, row_scale=scale)
+    both(z, ref * scale[:, None] + res, 4e-3)
+    # dgrad with act'(aux), the recomputed activation and the column sums (fc bias gradient)
+    dy = bf(torch.randn(M, N, device=DEV))
+    w2 = bf(torch.randn(N, K, device=DEV) * 0.05)
+    aux = bf(torch.randn(M, K, device=DEV))
+    act_out = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+    colsum = torch.zeros(K, device=DEV)
+    dx = ops.linear_dgrad(dy, w2, aux=aux, act_out=act_out, colsum=colsum)
+    a = aux.float()
+    sg = torch.sigmoid(1.702 * a)
+    dref = (dy.float() @ w2.float()) * (sg * (1 + 1.702 * a * (1 - sg)))
+    both(dx, dref, 5e-3)
+    both(act_out, a * sg, 4e-3)
+    assert rel_err(colsum, dref.sum(0)) < 5e-3

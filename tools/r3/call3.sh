@@ -12,6 +12,14 @@ for cfg in "new::" "nont:UNIIR_TOPK_NT=0:"; do
   env $e1 $e2 NQS=16,64,128,256,1024 timeout 300 python tools/r3/topk_bench.py > $O/tb_$name.txt 2>&1
   echo "== $name"; grep topk $O/tb_$name.txt
 done
+cd $R
+timeout 400 python -m pytest tests/test_kernels_gpu.py -x -q > $O/pytest_kernels.log 2>&1; echo "kernels rc=$?"; tail -2 $O/pytest_kernels.log
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-retrieval"
+for i in a b; do
+  UNIIR_GEMM_REMAINDER=0 python bench.py $ARGS > $O/bench_rem0$i.json 2> $O/bench_rem0$i.err
+  python bench.py $ARGS > $O/bench_rem1$i.json 2> $O/bench_rem1$i.err
+done
+for f in $O/bench_rem*.json; do echo $f; python -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['end_to_end_frac'])"; done
 cd /tmp && export TMPDIR=/tmp
 : > $O/topk_table.txt
 for NQ in 16 64 128 256 1024; do
