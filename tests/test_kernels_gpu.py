@@ -517,7 +517,8 @@ def test_device_image_transform_is_bit_exact():
 
 
 def test_gemm_remainder_rows_split_matches_a_reference_on_both_parts():
-    """round 3: 260 row panels x 4 column panels = 1040 tiles = 4 rounds of the 256 CUs + 16 tiles -> the last 1024 rows run the
+    """round 3 (experiment, on with UNIIR_GEMM_REMAINDER=1; without it this is one more large-shape test of every epilogue):
+    260 row panels x 4 column panels = 1040 tiles = 4 rounds of the 256 CUs + 16 tiles -> the last 1024 rows run the
     general 128-tile kernel in a second launch (csrc/gemm.hip gemm_impl).  Every epilogue of the step, checked separately on the rows
     of the first launch and on the remainder rows, incl. the outputs the general kernel produces by extra passes (act(aux), column
     sums) and the per-row operands (resid, row_scale, aux)."""

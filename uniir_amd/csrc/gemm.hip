@@ -685,9 +685,13 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     // 16 / 48 / 64 full rounds.  When the leftover is at most a quarter round, the row panels that make up whole rounds run the
     // 256-tile kernel and the remaining rows (1024 here) a second launch of the general 128x128 kernel: 4x the workgroups at a
     // quarter of the work each, one short round instead of one long one.  Every epilogue is row-wise, so the split is exact.
+    // An experiment that did not pay (see below): kept behind UNIIR_GEMM_REMAINDER=1.
     if (!g_force_general && !d->a_tmaj && d->k_splits == 1 && d->M % 256 == 0 && d->K % 64 == 0 && d->N >= 128 &&
         d->epilogue != UNIIR_EPI_ATOMIC_F32) {
-        static const char* env = getenv("UNIIR_GEMM_REMAINDER");      // "0": one launch, whatever the last round looks like (A/B)
+        // MEASURED (round 3, headline step, same box, A/B/A/B): 625.5 / 626.8 ms without the split, 628.5 / 630.5 ms with it -- the
+        // 128-tile kernel's short round plus the extra launch cost more than the idle tail of the 256-tile round they replace.  Off
+        // unless asked for.
+        static const char* env = getenv("UNIIR_GEMM_REMAINDER");      // "1": split the remainder rows off (experiments)
         static int ncu = 0;
         if (!ncu) {
             int dev = 0;
@@ -696,7 +700,7 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
                       ? prop.multiProcessorCount : 256;
         }
         const long tm = d->M / 256, tn = (d->N + 255) / 256, tiles = tm * tn, rem = tiles % ncu;
-        if (!(env && env[0] == '0') && tiles / ncu >= 4 && rem > 0 && rem * 4 <= ncu) {
+        if (env && env[0] == '1' && tiles / ncu >= 4 && rem > 0 && rem * 4 <= ncu) {
             long g = tn, h = ncu;
             while (h) { const long r = g % h; g = h; h = r; }          // gcd(tn, ncu)
             const long step = ncu / g, tm_main = tm / step * step;

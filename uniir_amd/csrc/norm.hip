@@ -5,6 +5,15 @@
 #include "../../include/uniir_hip.h"
 
 #define LN_MAXC 8  // float4 chunks per lane -> width <= 64*4*8 = 2048 (kernels are instantiated for NC = 2,3,4,8)
+// the row operands are read exactly once per launch: nt policy (-DUNIIR_LN_NT=0 for the A/B build)
+#ifndef UNIIR_LN_NT
+#define UNIIR_LN_NT 0
+#endif
+#if UNIIR_LN_NT
+#define LN_LD(p) __builtin_nontemporal_load(p)
+#else
+#define LN_LD(p) (*(p))
+#endif
 
 template <int NC, bool EXACT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long x_stride,
@@ -25,7 +34,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (EXACT || c < nchunk) {
-                v[i] = *reinterpret_cast<const f32x4_t*>(xr + 4 * c);
+                v[i] = LN_LD(reinterpret_cast<const f32x4_t*>(xr + 4 * c));
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
         }
@@ -91,14 +100,14 @@ __global__ __launch_bounds__(256, (EXACT && NC <= 4) ? 3 : 1) void ln_bwd_kernel
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (EXACT || c < nchunk) {
-                v[i] = *reinterpret_cast<const f32x4_t*>(xr + 4 * c);
-                if (dres) rs[i] = *reinterpret_cast<const f32x4_t*>(dres + row * dx_stride + 4 * c);
+                v[i] = LN_LD(reinterpret_cast<const f32x4_t*>(xr + 4 * c));
+                if (dres) rs[i] = LN_LD(reinterpret_cast<const f32x4_t*>(dres + row * dx_stride + 4 * c));
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
                 if (DY_F32) {
-                    d[i] = *reinterpret_cast<const f32x4_t*>((const float*)dy_ + row * width + 4 * c);
+                    d[i] = LN_LD(reinterpret_cast<const f32x4_t*>((const float*)dy_ + row * width + 4 * c));
                 } else {
                     const u32x2_t pk =
-                        *reinterpret_cast<const u32x2_t*>((const unsigned short*)dy_ + row * width + 4 * c);
+                        LN_LD(reinterpret_cast<const u32x2_t*>((const unsigned short*)dy_ + row * width + 4 * c));
                     d[i] = f32x4_t{__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
                                    __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
                 }

@@ -684,7 +684,7 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
 #define TKR_HALF_BYTES 12288
 #define TKR_PINV_OFF (3 * TKR_HALF_BYTES)
 #define TKR_STAGE_OFF (TKR_PINV_OFF + 512)
-#define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 1024)
+#define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 2048)
 template <int N>
 DEVINL void tkr_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N));
@@ -797,8 +797,8 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     f32x4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const unsigned stg = st.lbase + TKR_STAGE_OFF + lane * 16;
-    const unsigned qoff = (unsigned)(((long)lane * ngroups) & 3);
+    const unsigned stg = st.lbase + TKR_STAGE_OFF + lane * 32;
+    const unsigned qoff = (unsigned)(((long)lane * ngroups) & 3);     // 16-byte alignment of the stores (octets start on it)
     auto finish_tile = [&](long tile) {
         // D: lane -> query j * 16 + li, candidates 4 lg + r of the tile
         const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + TKR_PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
@@ -815,25 +815,26 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
             acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         const float mine = lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lg * 16 + li = lane
-        // Four consecutive group maxima of a query leave as ONE 16-byte store (one 4-byte store per lane and tile -- 64 scattered
-        // requests per tile, 2.8 M per sweep -- cost the 64-query scan ~25 us against the 16-query one).  The lane's 16 bytes of LDS
-        // serve as an indexed register file (asm accesses: the compiler must not order them against the LDS-DMA stream); the quad
-        // phase is per lane, so that the store is 16-byte aligned whatever (query * ngroups) % 4 is.
-        const unsigned k = ((unsigned)tile + qoff) & 3u;
+        // Eight consecutive group maxima of a query leave as two 16-byte stores to one 32-byte run (one 4-byte store per lane and
+        // tile is 64 scattered requests per tile, 2.8 M per sweep).  The lane's 32 bytes of LDS serve as an indexed register file
+        // (asm accesses: the compiler must not order them against the LDS-DMA stream); the octet phase is per lane, so that the
+        // stores are 16-byte aligned whatever (query * ngroups) % 4 is.
+        const unsigned k = ((unsigned)tile + qoff) & 7u;
         asm volatile("ds_write_b32 %0, %1" ::"v"(stg + k * 4u), "v"(mine) : "memory");
-        if (k == 3u || tile == hi - 1) {
-            const u32x4_t sv = asm_ds_read_b128<0>(stg);
+        if (k == 7u || tile == hi - 1) {
+            const u32x4_t s0 = asm_ds_read_b128<0>(stg), s1 = asm_ds_read_b128<16>(stg);
             asm_wait_lgkm<0>();
-            const f32x4_t v4 = __builtin_bit_cast(f32x4_t, sv);
-            const long g0 = tile - k;                        // first group of this lane's quad
+            const f32x4_t v0 = __builtin_bit_cast(f32x4_t, s0), v1 = __builtin_bit_cast(f32x4_t, s1);
+            const long g0 = tile - k;                        // first group of this lane's octet
             if (lane < nq) {
                 float* dst = gmax + (long)lane * ngroups + g0;
-                if (k == 3u && g0 >= lo) {
-                    *reinterpret_cast<f32x4_t*>(dst) = v4;
+                if (k == 7u && g0 >= lo) {
+                    *reinterpret_cast<f32x4_t*>(dst) = v0;
+                    *reinterpret_cast<f32x4_t*>(dst + 4) = v1;
                 } else {                                     // head of the wave's range / end of the range: the groups this wave computed
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i <= (int)k && g0 + i >= lo) dst[i] = v4[i];
+                    for (int i = 0; i < 8; ++i)
+                        if (i <= (int)k && g0 + i >= lo) dst[i] = i < 4 ? v0[i] : v1[i - 4];
                 }
             }
         }
@@ -1438,7 +1439,8 @@ template <int PARTS, int RW, int DEPTH>
 __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     const unsigned short* __restrict__ pool, const float* __restrict__ pinv, long rows, int dim,
     const unsigned short* __restrict__ queries, const float* __restrict__ gmax, long ngroups, int kc, int gcap,
-    int* __restrict__ cand, float* __restrict__ exact) {
+    int* __restrict__ cand, float* __restrict__ exact, int stop_after) {
+    // stop_after (timing experiments only, UNIIR_TOPK_TAIL_STOP): 1 = return after the selection, 2 = after the query scaling
     extern __shared__ __attribute__((aligned(16))) char dyn[];       // the gather rings
     __shared__ int sel[2 * TK_MAXKC * TK_G];                         // the selection's output: gcap * 16 row indices, -1 = empty
     __shared__ __attribute__((aligned(16))) unsigned short qrow[4096];
@@ -1470,6 +1472,7 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
         }
     };
     gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm);     // ends with a barrier
+    if (stop_after == 1) return;
     {
         const float iq = s_iq;                 // the normalised query, once per workgroup (the oracle's qn[j])
         for (int j = tid; j < dim; j += TKT_THREADS) {
@@ -1478,6 +1481,7 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
         }
     }
     __syncthreads();
+    if (stop_after == 2) return;
     // this workgroup's share: groups of rank part, part + PARTS, ...; thread t -> member t % 16 of its (t / 16)-th group
     const int ngrp = (gcap - part + PARTS - 1) / PARTS;
     const int nth = ngrp * TK_G;
@@ -1577,6 +1581,8 @@ static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int
         return false;
     if (rows * dim * 2 >= (1L << 31)) return false;                  // the gather's 31-bit buffer bound
     const int parts = nq <= 64 ? 4 : nq <= 128 ? 2 : 1;
+    static const char* env_stop = getenv("UNIIR_TOPK_TAIL_STOP");     // timing experiments: results are garbage when set
+    const int stop_after = env_stop ? atoi(env_stop) : 0;
     const dim3 g(nq, parts), b(TKT_THREADS);
 #define TKT_LAUNCH(P, RW, DEPTH)                                                                                       \
     do {                                                                                                               \
@@ -1586,7 +1592,7 @@ static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, RW * DEPTH * 8192);                  \
         hipLaunchKernelGGL((topk_tail_select_rescore_kernel<P, RW, DEPTH>), g, b, RW * DEPTH * 8192, st,               \
                            (const unsigned short*)pool_f16, pinv, (long)rows, dim, (const unsigned short*)queries_f16, \
-                           gmax, ngroups, kc, gcap, cand, exact);                                                      \
+                           gmax, ngroups, kc, gcap, cand, exact, stop_after);                                          \
     } while (0)
     // rings: 3 waves x 4 slices (the interactive regime: 144 slots per workgroup at k = 10) or 5 waves x 2 slices = 96 / 80 KiB
     if (parts == 4) TKT_LAUNCH(4, 3, 4);
