@@ -14,6 +14,15 @@
 #include "../../include/uniir_hip.h"
 #include <stdlib.h>
 
+// K / V / Q / dO of a head are read by exactly one workgroup: -DUNIIR_ATT_NT=1 stages them with the nt policy (A/B build)
+#ifndef UNIIR_ATT_NT
+#define UNIIR_ATT_NT 0
+#endif
+#if UNIIR_ATT_NT
+#define ATT_LD(p) __builtin_nontemporal_load(p)
+#else
+#define ATT_LD(p) (*(p))
+#endif
 #define ATT_D 64
 #define SCALE_LOG2E 0.18033688011112042f  // (1/sqrt(64)) * log2(e)
 #define ATT_SCALE 0.125f
@@ -37,7 +46,7 @@ DEVINL void stage_head(char* lds, const unsigned short* __restrict__ src, long l
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u * NT + tid;
             const int row = min(c >> 3, T - 1), kc = c & 7;
-            v[u] = *reinterpret_cast<const u32x4_t*>(src + (long)row * ld + kc * 8);
+            v[u] = ATT_LD(reinterpret_cast<const u32x4_t*>(src + (long)row * ld + kc * 8));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -67,8 +76,8 @@ DEVINL void stage_two_n(char* ldsA, const unsigned short* __restrict__ srcA, lon
     for (int u = 0; u < NL; ++u) {
         const int c = u * NT + tid;
         const int row = min(c >> 3, T - 1), kc = c & 7;
-        va[u] = *reinterpret_cast<const u32x4_t*>(srcA + (long)row * ldA + kc * 8);
-        vb[u] = *reinterpret_cast<const u32x4_t*>(srcB + (long)row * ldB + kc * 8);
+        va[u] = ATT_LD(reinterpret_cast<const u32x4_t*>(srcA + (long)row * ldA + kc * 8));
+        vb[u] = ATT_LD(reinterpret_cast<const u32x4_t*>(srcB + (long)row * ldB + kc * 8));
     }
     mid();
 #pragma unroll

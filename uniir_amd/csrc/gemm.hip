@@ -7,6 +7,17 @@
 #include "../../include/uniir_hip.h"
 #include <stdlib.h>
 
+// per-row epilogue operands (residual stream, stashed pre-activation) are read exactly once: -DUNIIR_EPI_NT=1 loads them with the
+// nt policy (A/B build)
+#ifndef UNIIR_EPI_NT
+#define UNIIR_EPI_NT 0
+#endif
+#if UNIIR_EPI_NT
+#define EPI_LD(p) __builtin_nontemporal_load(p)
+#else
+#define EPI_LD(p) (*(p))
+#endif
+
 struct GemmKArgs {
     const unsigned short* A;
     const unsigned short* B;
@@ -183,7 +194,7 @@ DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long of
             const long off = off0 + it * rstep;
             if (EPI == UNIIR_EPI_RESID_F32) {
                 if (p.row_scale) v *= p.row_scale[mrow + 8 * it];
-                if (p.resid) v += *reinterpret_cast<const f32x4_t*>(p.resid + off);
+                if (p.resid) v += EPI_LD(reinterpret_cast<const f32x4_t*>(p.resid + off));
                 *reinterpret_cast<f32x4_t*>((float*)p.C + off) = v;
                 if (p.C2) {
                     const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -191,7 +202,7 @@ DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long of
                 }
             } else if (EPI == UNIIR_EPI_DACT) {
                 const long oa = offa + it * rstep_aux;
-                const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p.aux + oa);
+                const u32x2_t a = EPI_LD(reinterpret_cast<const u32x2_t*>(p.aux + oa));
                 const float f0 = __uint_as_float(a[0] << 16), f1 = __uint_as_float(a[0] & 0xffff0000u);
                 const float f2 = __uint_as_float(a[1] << 16), f3 = __uint_as_float(a[1] & 0xffff0000u);
                 v[0] *= act_bwd(f0, ACT); v[1] *= act_bwd(f1, ACT);

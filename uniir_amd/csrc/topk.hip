@@ -464,6 +464,100 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
     __syncthreads();
 }
 
+// Hierarchical selection behind the stream2 scan (<= 64 queries): the scan also leaves the maximum of every WAVE's range of groups
+// (wmax[q][nw], nw <= 1024 waves of ~43 consecutive groups).  One value per thread instead of 48: the threshold comes from the
+// wave maxima (the kc-th largest quarter-wave maximum: at least kc waves, hence at least kc groups, reach it), the ~20 waves that
+// reach it hand in their groups (~900 values), the ~20 of those above the threshold are ranked exactly.  Same output as gsel_body
+// (both collect every group >= a valid lower bound of the kc-th best value and rank the collection by (value desc, group asc)).
+// Returns false (workgroup-uniform, nothing written but the -1 fill) when a cap overflows: the caller then runs gsel_body.
+#define TK_HWAVES 128        // candidate waves kept
+template <int BS, class F>
+DEVINL bool gsel_hier(const float* __restrict__ g, const float* __restrict__ wm, int nw, long ngroups, long rows, int kc, int gcap,
+                      int* out, F&& mid) {
+    __shared__ float qmax[64];
+    __shared__ int cwave[TK_HWAVES];
+    __shared__ float hval[TK_SELCAP];
+    __shared__ int hgrp[TK_SELCAP];
+    __shared__ int ccnt, hcnt;
+    __shared__ float htau0, htau;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
+    const float v = tid < nw ? wm[tid] : -INFINITY;
+    mid();
+    if (tid == 0) { ccnt = 0; hcnt = 0; htau0 = -INFINITY; htau = -INFINITY; }
+    const float qm = row16_max(v);
+    if ((tid & 15) == 0) qmax[tid >> 4] = qm;
+    __syncthreads();
+    if (tid < 64) {
+        const float x = qmax[tid];
+        int rank = 0;
+        for (int t = 0; t < 64; ++t) {
+            const float o = qmax[t];
+            rank += (o > x || (o == x && t < tid)) ? 1 : 0;
+        }
+        if (rank == min(kc, 64) - 1) htau0 = x;
+    }
+    __syncthreads();
+    const float t0 = htau0;
+    if (v >= t0 && v > -INFINITY) {
+        const int pos = atomicAdd(&ccnt, 1);
+        if (pos < TK_HWAVES) cwave[pos] = tid;
+    }
+    __syncthreads();
+    const int nc = ccnt;
+    if (nc > TK_HWAVES) return false;
+    // 16 candidate waves per trip: thread -> (candidate tid / 64, group lo + tid % 64) -- a wave's range holds <= 64 groups
+    for (int c0 = 0; c0 < nc; c0 += BS / 64) {
+        const int c = c0 + (tid >> 6);
+        if (c < nc) {
+            const long wv = cwave[c];
+            const long lo = wv * ngroups / nw, hi = (wv + 1) * ngroups / nw;
+            const long e = lo + (tid & 63);
+            if (e < hi) {
+                const float x = g[e];
+                if (x >= t0 && x > -INFINITY) {
+                    const int pos = atomicAdd(&hcnt, 1);
+                    if (pos < TK_SELCAP) { hval[pos] = x; hgrp[pos] = (int)e; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = hcnt;
+    if (n > TK_SELCAP) return false;
+    for (int e = tid; e < n; e += BS) {
+        const float x = hval[e];
+        const int gi = hgrp[e];
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            const float o = hval[t];
+            const int og = hgrp[t];
+            rank += (o > x || (o == x && og < gi)) ? 1 : 0;
+        }
+        if (rank == min(kc, n) - 1) htau = x;
+    }
+    __syncthreads();
+    const float tt = htau;
+    for (int e = tid; e < n; e += BS) {
+        const float x = hval[e];
+        const int gi = hgrp[e];
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            const float o = hval[t];
+            const int og = hgrp[t];
+            rank += (o > x || (o == x && og < gi)) ? 1 : 0;
+        }
+        if (rank < gcap && x >= tt) {
+            for (int m = 0; m < TK_G; ++m) {
+                const long row = (long)gi * TK_G + m;
+                out[rank * TK_G + m] = row < rows ? (int)row : -1;
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
 template <int BS, bool REG = false>   // threads per query (256: many queries; 1024: <= 64 queries)
 __global__ __launch_bounds__(BS) void topk_gsel_kernel(const float* __restrict__ gmax, long ngroups, long rows, int nq,
                                                         int kc, int gcap, int* __restrict__ cand_idx) {
@@ -739,7 +833,8 @@ template <int AUX>
 __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned short* __restrict__ pool,
                                                              const float* __restrict__ pinv, long rows,
                                                              const unsigned short* __restrict__ queries, int nq,
-                                                             float* __restrict__ gmax, long ngroups) {
+                                                             float* __restrict__ gmax, long ngroups,
+                                                             float* __restrict__ wmax) {      // optional [nq][waves]: per-wave maxima
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -797,6 +892,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     f32x4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float wave_best = -INFINITY;       // maximum over this wave's whole range, per query (gsel_hier starts from these)
     const unsigned stg = st.lbase + TKR_STAGE_OFF + lane * 32;
     const unsigned qoff = (unsigned)(((long)lane * ngroups) & 3);     // 16-byte alignment of the stores (octets start on it)
     auto finish_tile = [&](long tile) {
@@ -815,6 +911,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
             acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         const float mine = lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lg * 16 + li = lane
+        wave_best = fmaxf(wave_best, mine);
         // Eight consecutive group maxima of a query leave as two 16-byte stores to one 32-byte run (one 4-byte store per lane and
         // tile is 64 scattered requests per tile, 2.8 M per sweep).  The lane's 32 bytes of LDS serve as an indexed register file
         // (asm accesses: the compiler must not order them against the LDS-DMA stream); the octet phase is per lane, so that the
@@ -861,13 +958,17 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     tkr_wait_vm<0>();
     tkr_process<1>(st, slot, qf, acc);
     finish_tile(t);
+    if (wmax && lane < nq) wmax[(long)lane * nw + gw] = wave_best;
 }
 
 // The group-max scan of <= 1024 queries over the shard: gmax[q][group] = best approximate score of the 16 rows of the group.
 // Returns 1 when a 1024-thread selection is the matching follow-up (streaming / ping-pong scans), 0 for the 256-thread one,
 // negative on error.
+// wmax / nw_out (optional): room for [nq][1024] per-wave maxima; *nw_out = the number of waves when the scan wrote them, else 0
 static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, int64_t rows, int32_t dim,
-                            const void* queries_f16, int32_t nq, float* gmax, hipStream_t st0) {
+                            const void* queries_f16, int32_t nq, float* gmax, hipStream_t st0, float* wmax = nullptr,
+                            int* nw_out = nullptr) {
+    if (nw_out) *nw_out = 0;
     const long ngroups = (rows + TK_G - 1) / TK_G;
     int nqt, nsl; long rps;
     coarse_plan(nq, rows, &nqt, &nsl, &rps);
@@ -891,12 +992,15 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
         }
         // nt on the pool stream (read exactly once): measured 0.2729 -> 0.2466 ms per 64-query search, 0.2382 -> 0.2124 at 16
         static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "0": default cache policy (A/B)
+        static const char* env_h = getenv("UNIIR_TOPK_HIER");          // "0": selection from the full group-max rows (A/B)
+        float* wm = (wmax && nw_out && ncu * 4 <= 1024 && (ngroups + ncu * 4 - 1) / (ncu * 4) <= 64 && !(env_h && env_h[0] == '0')) ? wmax : nullptr;
+        if (wm) *nw_out = ncu * 4;
         if (!(env_nt && env_nt[0] == '0'))
             hipLaunchKernelGGL(topk_stream2_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups);
+                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm);
         else
             hipLaunchKernelGGL(topk_stream2_kernel<0>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups);
+                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm);
         HIP_LAUNCH_CHECK();
         return 1;
     }
@@ -986,9 +1090,10 @@ static int topk_select_after_scan(int sel, const float* gmax, int64_t rows, int3
     return UNIIR_OK;
 }
 
+#define TK_WMAX_BYTES (64 * 1024 * 4 + 256)     // per-wave maxima of the <= 64-query scan: [64][<= 1024 waves] fp32
 extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t rows) {
     if (nq <= 0 || kc <= 0 || rows <= 0) return 0;
-    if (nq <= TK_GPATH_MAXQ) return (int64_t)nq * ((rows + TK_G - 1) / TK_G) * 4 + 256;
+    if (nq <= TK_GPATH_MAXQ) return (int64_t)nq * ((rows + TK_G - 1) / TK_G) * 4 + 256 + TK_WMAX_BYTES;
     int nqt, nsl; long rps;
     coarse_plan(nq, rows, &nqt, &nsl, &rps);
     return (int64_t)nqt * nsl * TK_QT * TK_CAP * (int64_t)sizeof(TkEntry) + (int64_t)nsl * nq * kc * (int64_t)sizeof(TkEntry) + 256;
@@ -1439,7 +1544,7 @@ template <int PARTS, int RW, int DEPTH>
 __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     const unsigned short* __restrict__ pool, const float* __restrict__ pinv, long rows, int dim,
     const unsigned short* __restrict__ queries, const float* __restrict__ gmax, long ngroups, int kc, int gcap,
-    int* __restrict__ cand, float* __restrict__ exact, int stop_after) {
+    int* __restrict__ cand, float* __restrict__ exact, int stop_after, const float* __restrict__ wmax, int nw) {
     // stop_after (timing experiments only, UNIIR_TOPK_TAIL_STOP): 1 = return after the selection, 2 = after the query scaling
     extern __shared__ __attribute__((aligned(16))) char dyn[];       // the gather rings
     __shared__ int sel[2 * TK_MAXKC * TK_G];                         // the selection's output: gcap * 16 row indices, -1 = empty
@@ -1451,7 +1556,10 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     const unsigned short* qr = queries + (long)q * dim;
     // the query's inverse norm (FAISS fvec_renorm_L2 as restated by the oracle: sequential fp32 sum of squares, no fma; see
     // inv_norm_kernel) by lane 0 of wave 0, from a wave-private LDS copy of the query, while the selection's loads are in flight
+    bool normed = false;
     auto qnorm = [&] {
+        if (normed) return;              // (the selection may run twice: the hierarchical one can bail out)
+        normed = true;
         if (w != 0) return;
         for (int c = lane; c < dim / 8; c += 64)
             *reinterpret_cast<u32x4_t*>(qrow + c * 8) = *reinterpret_cast<const u32x4_t*>(qr + c * 8);
@@ -1471,8 +1579,19 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
             s_iq = s > 0.f ? (float)(1.0 / (double)(float)sqrt((double)s)) : 0.f;
         }
     };
-    gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm);     // ends with a barrier
-    if (stop_after == 1) return;
+    // the selection ends with a barrier; behind the stream2 scan it starts from the per-wave maxima (gsel_hier)
+    if (!(wmax && gsel_hier<TKT_THREADS>(gmax + (long)q * ngroups, wmax + (long)q * nw, nw, ngroups, rows, kc, gcap, sel, qnorm)))
+        gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm);
+    const int ngrp = (gcap - part + PARTS - 1) / PARTS;      // this workgroup's share: groups of rank part, part + PARTS, ...
+    const int nth = ngrp * TK_G;                             // thread t -> member t % 16 of its (t / 16)-th group
+    auto stop_here = [&] {                                   // timing experiments: an empty shortlist instead of the re-score
+        for (int t = tid; t < nth; t += TKT_THREADS) {
+            const long o = (long)q * gcap * TK_G + ((t >> 4) * PARTS + part) * TK_G + (t & 15);
+            cand[o] = -1;
+            exact[o] = -INFINITY;
+        }
+    };
+    if (stop_after == 1) { stop_here(); return; }
     {
         const float iq = s_iq;                 // the normalised query, once per workgroup (the oracle's qn[j])
         for (int j = tid; j < dim; j += TKT_THREADS) {
@@ -1481,10 +1600,7 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
         }
     }
     __syncthreads();
-    if (stop_after == 2) return;
-    // this workgroup's share: groups of rank part, part + PARTS, ...; thread t -> member t % 16 of its (t / 16)-th group
-    const int ngrp = (gcap - part + PARTS - 1) / PARTS;
-    const int nth = ngrp * TK_G;
+    if (stop_after == 2) { stop_here(); return; }
     if (w >= RW) return;                                              // no barrier follows
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * dim * 2), 0x00020000);
     const unsigned qn32 = lds_addr32(reinterpret_cast<const char*>(qn));
@@ -1572,7 +1688,7 @@ __global__ __launch_bounds__(1024) void topk_tail_sort_kernel(const float* __res
 // selection + exact re-score + sort behind a finished group-max scan; false when the shape does not fit the fused kernels
 static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int64_t* pool_ids, int64_t rows, int32_t dim,
                               const void* queries_f16, int32_t nq, int32_t kc, int32_t k, const float* gmax, int32_t* cand,
-                              float* exact, float* out_scores, int64_t* out_ids, hipStream_t st) {
+                              float* exact, float* out_scores, int64_t* out_ids, hipStream_t st, const float* wmax, int nw) {
     static const char* env = getenv("UNIIR_TOPK_FUSED_TAIL");          // "0": the round-2 tail (four launches), for A/B
     const long ngroups = (rows + TK_G - 1) / TK_G;
     const int gcap = TK_GMULT * kc;
@@ -1592,7 +1708,7 @@ static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, RW * DEPTH * 8192);                  \
         hipLaunchKernelGGL((topk_tail_select_rescore_kernel<P, RW, DEPTH>), g, b, RW * DEPTH * 8192, st,               \
                            (const unsigned short*)pool_f16, pinv, (long)rows, dim, (const unsigned short*)queries_f16, \
-                           gmax, ngroups, kc, gcap, cand, exact, stop_after);                                          \
+                           gmax, ngroups, kc, gcap, cand, exact, stop_after, nw > 0 ? wmax : nullptr, nw);             \
     } while (0)
     // rings: 3 waves x 4 slices (the interactive regime: 144 slots per workgroup at k = 10) or 5 waves x 2 slices = 96 / 80 KiB
     if (parts == 4) TKT_LAUNCH(4, 3, 4);
@@ -1653,10 +1769,13 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
         const int n = nq - lo < chunk ? nq - lo : chunk;
         const unsigned short* qp = (const unsigned short*)queries_f16 + (long)lo * dim;
         if (n <= TK_GPATH_MAXQ) {       // group-max scan, then the fused tail (selection + query norm + exact re-score | sort)
-            const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, qp, n, gmax, (hipStream_t)stream);
+            // the per-wave maxima live behind the group maxima of this sweep (uniir_topk_workspace_bytes reserves the room)
+            float* wmax = (float*)(((uintptr_t)(gmax + (int64_t)n * ((rows + TK_G - 1) / TK_G)) + 255) & ~(uintptr_t)255);
+            int nw = 0;
+            const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, qp, n, gmax, (hipStream_t)stream, wmax, &nw);
             if (sel < 0) return sel;
             if (sel == 1 && launch_fused_tail(pool_f16, pool_inv_norm, pool_ids, rows, dim, qp, n, kc, k, gmax, cand, exact,
-                                              out_scores + (long)lo * k, out_ids + (long)lo * k, (hipStream_t)stream)) {
+                                              out_scores + (long)lo * k, out_ids + (long)lo * k, (hipStream_t)stream, wmax, nw)) {
                 HIP_LAUNCH_CHECK();
                 continue;
             }
