@@ -7,7 +7,7 @@ cd $R
 timeout 600 python -m pytest tests/test_topk_gpu.py "tests/test_fullsize_gpu.py::test_topk_full_shard_properties" tests/test_bench_paths_gpu.py::test_search_shard_multi_sweep_loop_equals_the_oracle tests/test_pipeline_gpu.py -x -q > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log
 tail -3 $O/pytest.log
-for cfg in "new:" "nohier:UNIIR_TOPK_HIER=0" "stop1:UNIIR_TOPK_TAIL_STOP=1"; do
+for cfg in "new:" "zerotail:ZERO_TAIL=1" "stop1:UNIIR_TOPK_TAIL_STOP=1"; do
   name=${cfg%%:*}; e1=${cfg#*:}
   env $e1 NQS=16,64 timeout 300 python tools/r3/topk_bench.py > $O/tb_$name.txt 2>&1
   echo "== $name"; grep topk $O/tb_$name.txt

@@ -16,6 +16,8 @@ shard = retrieval.PoolShard(pool, torch.arange(n, device=dev))
 lib = _lib.load()
 for nq in [int(x) for x in os.environ.get("NQS", "16,64,128,256,1024").split(",")]:
     q = torch.randn(nq, 768, device=dev).half()
+    if os.environ.get("ZERO_TAIL"):          # experiment: only the first 16 queries carry data (MFMA operand power vs store count)
+        q[16:] = 0
     ws = torch.empty(lib.uniir_topk_ip_workspace_bytes(nq, 10, n), device=dev, dtype=torch.uint8)
     for _ in range(5):
         retrieval.search_shard(shard, q, 10, workspace=ws)

@@ -1561,20 +1561,37 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
         if (normed) return;              // (the selection may run twice: the hierarchical one can bail out)
         normed = true;
         if (w != 0) return;
-        for (int c = lane; c < dim / 8; c += 64)
-            *reinterpret_cast<u32x4_t*>(qrow + c * 8) = *reinterpret_cast<const u32x4_t*>(qr + c * 8);
+        // the 768 squares in parallel (64 lanes), then ONE lane adds them in the oracle's order: the only serial part is the chain of
+        // fp32 additions (the all-in-one-lane form of this took ~7 us -- conversions, multiplies and LDS latency inside the chain --
+        // and was the critical path of the kernel's first phase).  qn[] doubles as the buffer of squares until the scaling below.
+        for (int c = lane; c < dim / 8; c += 64) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(qr + c * 8);
+            *reinterpret_cast<u32x4_t*>(qrow + c * 8) = v;
+            f32x4_t a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = f16_to_f32((unsigned short)(v[e] & 0xffffu));
+                const float hi = f16_to_f32((unsigned short)(v[e] >> 16));
+                const float l2 = __fmul_rn(lo, lo), h2 = __fmul_rn(hi, hi);
+                if (e < 2) { a[2 * e] = l2; a[2 * e + 1] = h2; } else { b[2 * e - 4] = l2; b[2 * e - 3] = h2; }
+            }
+            *reinterpret_cast<f32x4_t*>(qn + c * 8) = a;
+            *reinterpret_cast<f32x4_t*>(qn + c * 8 + 4) = b;
+        }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             float s = 0.f;
-            for (int c = 0; c < dim; c += 8) {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(qrow + c);
+            for (int c = 0; c < dim; c += 16) {          // dim % 64 == 0
+                const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(qn + c), x1 = *reinterpret_cast<const f32x4_t*>(qn + c + 4);
+                const f32x4_t x2 = *reinterpret_cast<const f32x4_t*>(qn + c + 8), x3 = *reinterpret_cast<const f32x4_t*>(qn + c + 12);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float lo = f16_to_f32((unsigned short)(v[e] & 0xffffu));
-                    const float hi = f16_to_f32((unsigned short)(v[e] >> 16));
-                    s = __fadd_rn(s, __fmul_rn(lo, lo));
-                    s = __fadd_rn(s, __fmul_rn(hi, hi));
-                }
+                for (int e = 0; e < 4; ++e) s = __fadd_rn(s, x0[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __fadd_rn(s, x1[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __fadd_rn(s, x2[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __fadd_rn(s, x3[e]);
             }
             s_iq = s > 0.f ? (float)(1.0 / (double)(float)sqrt((double)s)) : 0.f;
         }
