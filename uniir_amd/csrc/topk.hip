@@ -829,20 +829,12 @@ DEVINL void tkr_process(const TkrState& st, int slot, const u32x4_t (&qf)[4][24]
 #undef TKR_STEP
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int AUX>
-__global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned short* __restrict__ pool,
-                                                             const float* __restrict__ pinv, long rows,
-                                                             const unsigned short* __restrict__ queries, int nq,
-                                                             float* __restrict__ gmax, long ngroups,
-                                                             float* __restrict__ wmax) {      // optional [nq][waves]: per-wave maxima
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+// everything a streaming-scan wave sets up before its first pool tile: DMA descriptors / per-lane offsets, and the query fragments
+// (all 64 queries, 96 x 16 bytes per lane) staged through LDS.  Contains two workgroup barriers.
+DEVINL void tkr_prepare(TkrState& st, u32x4_t (&qf)[4][24], char* lds, const unsigned short* __restrict__ pool,
+                        const float* __restrict__ pinv, long rows, const unsigned short* __restrict__ queries, int nq, int w,
+                        int lane) {
     const int li = lane & 15, lg = lane >> 4;
-    // one contiguous range of tiles (groups of 16 rows) per wave, sizes differing by at most one
-    const long gw = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
-    const long lo = gw * ngroups / nw, hi = (gw + 1) * ngroups / nw;      // never empty: the launcher asks for >= 2048 groups
-    TkrState st;
     st.my = lds + w * TKR_WAVE_LDS;
     st.lbase = lds_addr32(st.my);
     st.rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * 1536), 0x00020000);
@@ -861,7 +853,6 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     // times: ~45 us per wave, measured as 244 vs 202 us between 64 and 16 queries' worth of ... the same loads).  So the 64 x 1536
     // bytes of queries are first copied into LDS by LDS-DMA (the rings are not in use yet; 16-byte chunk index ^= (query & 15) on
     // the source side, so that the 16 queries x 4 chunks of a fragment read are conflict-free), then every wave reads all of them.
-    u32x4_t qf[4][24];
     {
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)queries, 0, nq * 1536, 0x00020000);
         // 98 304 bytes = 96 DMA instructions of 1 KiB over 4 waves: instruction i covers LDS bytes [1024 i, +1024): query i * 2 / 3 ...
@@ -887,6 +878,25 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
         }
         __syncthreads();                 // every wave has its fragments: the rings may be filled
     }
+}
+
+template <int AUX>
+__global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned short* __restrict__ pool,
+                                                             const float* __restrict__ pinv, long rows,
+                                                             const unsigned short* __restrict__ queries, int nq,
+                                                             float* __restrict__ gmax, long ngroups,
+                                                             float* __restrict__ wmax,        // optional [nq][waves]: per-wave maxima
+                                                             int exp_store) {   // timing experiments only (wrong results): 1, 2, 3
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    // one contiguous range of tiles (groups of 16 rows) per wave, sizes differing by at most one
+    const long gw = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
+    const long lo = gw * ngroups / nw, hi = (gw + 1) * ngroups / nw;      // never empty: the launcher asks for >= 2048 groups
+    TkrState st;
+    u32x4_t qf[4][24];
+    tkr_prepare(st, qf, lds, pool, pinv, rows, queries, nq, w, lane);
     tkr_issue<0, AUX>(st, lo, 0);
     tkr_issue<1, AUX>(st, lo, 1);
     f32x4_t acc[4];
@@ -912,6 +922,11 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
         }
         const float mine = lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lg * 16 + li = lane
         wave_best = fmaxf(wave_best, mine);
+        if (exp_store == 2) {             // experiment: one coalesced 256-byte store per tile ([group][query] layout)
+            gmax[tile * 64 + lane] = mine;
+            return;
+        }
+        if (exp_store == 3) return;       // experiment: no group-max stores at all
         // Eight consecutive group maxima of a query leave as two 16-byte stores to one 32-byte run (one 4-byte store per lane and
         // tile is 64 scattered requests per tile, 2.8 M per sweep).  The lane's 32 bytes of LDS serve as an indexed register file
         // (asm accesses: the compiler must not order them against the LDS-DMA stream); the octet phase is per lane, so that the
@@ -923,7 +938,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
             asm_wait_lgkm<0>();
             const f32x4_t v0 = __builtin_bit_cast(f32x4_t, s0), v1 = __builtin_bit_cast(f32x4_t, s1);
             const long g0 = tile - k;                        // first group of this lane's octet
-            if (lane < nq) {
+            if (lane < (exp_store == 1 ? 16 : nq)) {
                 float* dst = gmax + (long)lane * ngroups + g0;
                 if (k == 7u && g0 >= lo) {
                     *reinterpret_cast<f32x4_t*>(dst) = v0;
@@ -961,13 +976,233 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     if (wmax && lane < nq) wmax[(long)lane * nw + gw] = wave_best;
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Streaming scan, third generation: the stream2 kernel with a FILTERED output.  Measured on the 64-query scan (round 3): the dense
+// group-max matrix costs 34 of 191 us (no stores at all: 157 us = 6.9 TB/s; one coalesced 256-byte store per tile: 175 us) -- write
+// traffic sprinkled into the read stream is expensive.  So the scan keeps almost nothing:
+//   * every wave stores its first TKF_EARLY tiles densely, one coalesced 256-byte store per tile (early[wave][tile][query]);
+//   * every wave folds its FIRST tile's value into one of 32 bucket maxima per query (atomicMax on an order-preserving key; buckets
+//     of nw / 32 waves) and takes a ticket; wave 0 waits for all tickets and takes, per query, the kc-th largest of the 32 bucket
+//     maxima (a 32-element sorting network in registers): at least kc groups reach that value, so it is a valid lower bound
+//     tau[q] of the kc-th best group maximum (about the 2.5 % quantile);
+//   * from tile TKF_EARLY on a wave appends (value, group) to its private slice of the query's list only when value >= tau[q]:
+//     ~2.5 % of the groups.
+// Exact: every group >= a valid lower bound of the kc-th best is kept; the selection (gsel_sparse) ranks early + list entries.
+// Cross-workgroup hand-offs follow the MI355X guide's recipe: plain stores -> agent release fence -> asm vmcnt(0) -> relaxed agent
+// atomic; consumer: relaxed poll -> agent acquire fence -> plain loads.  Every wait is bounded: on a timeout tau = -inf (everything
+// is appended: slower, still exact).  All workgroups are resident (grid = CUs, one workgroup per CU), so the waits are short.
+#define TKF_EARLY 3
+struct TkFiltCtrl {
+    int ticket, flag, pad[14];
+    float tau[64];
+    unsigned bucket[32][64];      // per query: maximum (as an order-preserving key, 0 = empty) of the first-tile values of 1/32 of the waves
+};
+// float -> unsigned key with the same order (atomicMax on the keys == maximum of the floats); every real value maps above 0
+DEVINL unsigned tkf_key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+DEVINL float tkf_unkey(unsigned k) {
+    return k == 0u ? -INFINITY : __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// wave gw's range of tiles: wave 0 (which computes the thresholds) takes 3 tiles fewer, the rest is split evenly
+DEVINL void tkf_range(long gw, long nw, long ngroups, long& lo, long& hi) {
+    const long base = ngroups / nw, t0 = base > 6 ? base - 3 : base;
+    lo = gw == 0 ? 0 : t0 + (gw - 1) * (ngroups - t0) / (nw - 1);
+    hi = gw == 0 ? t0 : t0 + gw * (ngroups - t0) / (nw - 1);
+}
+template <int I, int J>
+DEVINL void tkf_cas(float (&v)[32]) {      // descending compare-exchange
+    const float a = v[I], b = v[J];
+    v[I] = fmaxf(a, b);
+    v[J] = fminf(a, b);
+}
+template <int K, int J, int I>
+DEVINL void tkf_bitonic_step(float (&v)[32]) {
+    if constexpr (I < 32) {
+        constexpr int L = I ^ J;
+        if constexpr (L > I) {
+            if constexpr ((I & K) == 0) tkf_cas<I, L>(v);
+            else tkf_cas<L, I>(v);
+        }
+        tkf_bitonic_step<K, J, I + 1>(v);
+    }
+}
+template <int K, int J>
+DEVINL void tkf_bitonic_j(float (&v)[32]) {
+    if constexpr (J > 0) {
+        tkf_bitonic_step<K, J, 0>(v);
+        tkf_bitonic_j<K, J / 2>(v);
+    }
+}
+template <int K>
+DEVINL void tkf_bitonic_k(float (&v)[32]) {
+    if constexpr (K <= 32) {
+        tkf_bitonic_j<K, K / 2>(v);
+        tkf_bitonic_k<K * 2>(v);
+    }
+}
+template <int AUX>
+__global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned short* __restrict__ pool,
+                                                             const float* __restrict__ pinv, long rows,
+                                                             const unsigned short* __restrict__ queries, int nq,
+                                                             long ngroups, int kc, TkFiltCtrl* __restrict__ ctrl,
+                                                             float* __restrict__ early, float* __restrict__ ent_val,
+                                                             int* __restrict__ ent_grp, int* __restrict__ ent_cnt, int rmax) {
+    // lists: one private slice of rmax (>= the wave's tiles) entries per (query, wave) -- ent_*[(q * nw + wave) * rmax + i] -- and
+    // ent_cnt[q * nw + wave] entries in it: plain stores, no atomics (a returning atomic would make hipcc drain the DMA queue)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = lane >> 4;
+    const long gw = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
+    long lo, hi;
+    tkf_range(gw, nw, ngroups, lo, hi);
+    TkrState st;
+    u32x4_t qf[4][24];
+    tkr_prepare(st, qf, lds, pool, pinv, rows, queries, nq, w, lane);
+    tkr_issue<0, AUX>(st, lo, 0);
+    tkr_issue<1, AUX>(st, lo, 1);
+    f32x4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float tau = -INFINITY;
+    bool have_tau = false;
+    int npos = 0;                          // entries this lane (query) has appended to this wave's slice
+    auto tile_max = [&](long tile) {       // D: lane -> query j * 16 + (lane & 15), candidates 4 lg + r of the tile
+        const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + TKR_PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
+        asm_wait_lgkm<0>();
+        const f32x4_t iv = __builtin_bit_cast(f32x4_t, ivb);
+        const long r0 = tile * 16 + 4 * lg;
+        float m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x = fmaxf(x, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
+            m[j] = group_max(x);
+            acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        return lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lane
+    };
+    auto publish = [&](int* word, bool add) {     // release everything this wave has stored, then signal
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            if (add) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_store(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto thresholds = [&] {       // wave 0 only, after its own first tile is published
+        int spins = 0;
+        while (__hip_atomic_load(&ctrl->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)nw && spins < 100000) {
+            __builtin_amdgcn_s_sleep(4);
+            ++spins;
+        }
+        float t = -INFINITY;
+        if (__hip_atomic_load(&ctrl->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)nw) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // the 8 KiB of bucket keys come in by LDS-DMA (no registers: this wave holds 500 of them) into the ring slot that is
+            // free right now -- slot 1: tile lo has been consumed, tile lo + 1 sits in slots 2 and 0 -- then 32 LDS reads per lane
+            char* scratch = st.my + 1 * TKR_HALF_BYTES;
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)&ctrl->bucket[0][0], 0, 32 * 64 * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (void __attribute__((address_space(3)))*)(scratch + i * 1024), 16,
+                                                         (unsigned)(i * 1024 + lane * 16), 0, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned sb = lds_addr32(scratch) + lane * 4;
+            float bm[32];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) {
+                unsigned kv;
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(kv) : "v"(sb), "i"(b * 256));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bm[b] = tkf_unkey(kv);
+            }
+            tkf_bitonic_k<2>(bm);                          // descending
+#pragma unroll
+            for (int b = 0; b < 32; ++b) t = (b == kc - 1) ? bm[b] : t;       // kc <= 32 (launcher)
+        }
+        ctrl->tau[lane] = t;
+        publish(&ctrl->flag, false);
+        tau = t;
+        have_tau = true;
+    };
+    auto finish_tile = [&](long tile) {
+        const float mine = tile_max(tile);
+        const long ti = tile - lo;
+        if (ti < TKF_EARLY) {
+            early[(((gw * TKF_EARLY) + ti) << 6) + lane] = lane < nq ? mine : -INFINITY;
+            if (ti == 0) {
+                (void)__hip_atomic_fetch_max(&ctrl->bucket[(gw << 5) / nw][lane], tkf_key(lane < nq ? mine : -INFINITY),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish(&ctrl->ticket, true);
+                if (gw == 0) thresholds();
+            }
+            return;
+        }
+        if (!have_tau) {
+            int spins = 0;
+            while (!__hip_atomic_load(&ctrl->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && spins < 100000) {
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+            }
+            if (__hip_atomic_load(&ctrl->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                tau = ctrl->tau[lane];
+            }                                              // else: timed out, tau stays -inf (append everything)
+            have_tau = true;
+        }
+        if (lane < nq && mine >= tau && npos < rmax) {
+            const long o = ((long)lane * nw + gw) * rmax + npos;
+            ent_val[o] = mine;
+            ent_grp[o] = (int)tile;
+            ++npos;
+        }
+    };
+    int slot = 0;
+    long t = lo;
+    for (; t + 1 < hi; ++t) {
+        tkr_issue<0, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);
+        tkr_wait_vm<25>();
+        tkr_process<0>(st, slot, qf, acc);
+        slot = slot == 2 ? 0 : slot + 1;
+        tkr_issue<1, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);
+        tkr_wait_vm<25>();
+        tkr_process<1>(st, slot, qf, acc);
+        slot = slot == 2 ? 0 : slot + 1;
+        finish_tile(t);
+    }
+    tkr_wait_vm<12>();
+    tkr_process<0>(st, slot, qf, acc);
+    slot = slot == 2 ? 0 : slot + 1;
+    tkr_wait_vm<0>();
+    tkr_process<1>(st, slot, qf, acc);
+    finish_tile(t);
+    if (lane < nq) ent_cnt[(long)lane * nw + gw] = npos;
+}
+
 // The group-max scan of <= 1024 queries over the shard: gmax[q][group] = best approximate score of the 16 rows of the group.
 // Returns 1 when a 1024-thread selection is the matching follow-up (streaming / ping-pong scans), 0 for the 256-thread one,
 // negative on error.
-// wmax / nw_out (optional): room for [nq][1024] per-wave maxima; *nw_out = the number of waves when the scan wrote them, else 0
+// the filtered scan's outputs (topk_stream3_kernel): control words, early tiles, per-query lists; nw = waves of the scan
+struct TkSparse {
+    TkFiltCtrl* ctrl;
+    float* early;
+    float* ent_val;
+    int* ent_grp;
+    int* ent_cnt;
+    int rmax, nw, kc;
+};
+#define TK_SPARSE_EARLY_BYTES (1024L * TKF_EARLY * 64 * 4)
+#define TK_SPARSE_LIST_BYTES(ngroups) (64L * 1024 * ((ngroups) / 1024 + 4) * 4)   // >= 64 queries x waves x rmax entries: waves <= 1024, rmax = ngroups / waves + 2
+// wmax / nw_out (optional): room for [nq][1024] per-wave maxima; *nw_out = the number of waves when the scan wrote them, else 0.
+// sparse (optional, with kc set): the caller can consume the filtered output -> the scan may run as topk_stream3_kernel and then
+// returns 2 (nothing is written to gmax).
 static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, int64_t rows, int32_t dim,
                             const void* queries_f16, int32_t nq, float* gmax, hipStream_t st0, float* wmax = nullptr,
-                            int* nw_out = nullptr) {
+                            int* nw_out = nullptr, TkSparse* sparse = nullptr) {
     if (nw_out) *nw_out = 0;
     const long ngroups = (rows + TK_G - 1) / TK_G;
     int nqt, nsl; long rps;
@@ -992,15 +1227,40 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
         }
         // nt on the pool stream (read exactly once): measured 0.2729 -> 0.2466 ms per 64-query search, 0.2382 -> 0.2124 at 16
         static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "0": default cache policy (A/B)
+        static const char* env_f = getenv("UNIIR_TOPK_FILTER");        // "0": dense group-max output (the stream2 scan), for A/B
+        static const char* env_nt0 = getenv("UNIIR_TOPK_NT");
+        if (sparse && !(env_f && env_f[0] == '0') && ngroups >= 8L * ncu * 4 && (ncu * 4) % 32 == 0 && ncu * 4 <= 1024 &&
+            sparse->kc <= 32) {
+            sparse->nw = ncu * 4;
+            sparse->rmax = (int)(ngroups / (ncu * 4) + 2);            // >= every wave's tile count (tkf_range)
+            if (hipMemsetAsync(sparse->ctrl, 0, sizeof(TkFiltCtrl), st0) != hipSuccess) return UNIIR_ELAUNCH;
+            static PerDeviceOnce attr_s3;
+            if (attr_s3.first()) {
+                (void)hipFuncSetAttribute((const void*)topk_stream3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
+                (void)hipFuncSetAttribute((const void*)topk_stream3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
+            }
+            if (!(env_nt0 && env_nt0[0] == '0'))
+                hipLaunchKernelGGL(topk_stream3_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
+                                   pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, ngroups, sparse->kc,
+                                   sparse->ctrl, sparse->early, sparse->ent_val, sparse->ent_grp, sparse->ent_cnt, sparse->rmax);
+            else
+                hipLaunchKernelGGL(topk_stream3_kernel<0>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
+                                   pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, ngroups, sparse->kc,
+                                   sparse->ctrl, sparse->early, sparse->ent_val, sparse->ent_grp, sparse->ent_cnt, sparse->rmax);
+            HIP_LAUNCH_CHECK();
+            return 2;
+        }
         static const char* env_h = getenv("UNIIR_TOPK_HIER");          // "0": selection from the full group-max rows (A/B)
+        static const char* env_x = getenv("UNIIR_TOPK_EXP_STORE");
+        const int exp_store = env_x ? atoi(env_x) : 0;
         float* wm = (wmax && nw_out && ncu * 4 <= 1024 && (ngroups + ncu * 4 - 1) / (ncu * 4) <= 64 && !(env_h && env_h[0] == '0')) ? wmax : nullptr;
         if (wm) *nw_out = ncu * 4;
         if (!(env_nt && env_nt[0] == '0'))
             hipLaunchKernelGGL(topk_stream2_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm);
+                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm, exp_store);
         else
             hipLaunchKernelGGL(topk_stream2_kernel<0>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm);
+                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm, exp_store);
         HIP_LAUNCH_CHECK();
         return 1;
     }
@@ -1093,7 +1353,13 @@ static int topk_select_after_scan(int sel, const float* gmax, int64_t rows, int3
 #define TK_WMAX_BYTES (64 * 1024 * 4 + 256)     // per-wave maxima of the <= 64-query scan: [64][<= 1024 waves] fp32
 extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t rows) {
     if (nq <= 0 || kc <= 0 || rows <= 0) return 0;
-    if (nq <= TK_GPATH_MAXQ) return (int64_t)nq * ((rows + TK_G - 1) / TK_G) * 4 + 256 + TK_WMAX_BYTES;
+    if (nq <= TK_GPATH_MAXQ) {
+        const int64_t ngroups = (rows + TK_G - 1) / TK_G;
+        const int64_t dense = (int64_t)nq * ngroups * 4 + 256 + TK_WMAX_BYTES;
+        // the filtered scan of <= 64 queries: control words, early tiles, per-query (value, group) lists with room for every group
+        const int64_t sparse = 1024 + TK_SPARSE_EARLY_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngroups) + 64 * 1024 * 4;
+        return nq <= 64 && sparse > dense ? sparse : dense;
+    }
     int nqt, nsl; long rps;
     coarse_plan(nq, rows, &nqt, &nsl, &rps);
     return (int64_t)nqt * nsl * TK_QT * TK_CAP * (int64_t)sizeof(TkEntry) + (int64_t)nsl * nq * kc * (int64_t)sizeof(TkEntry) + 256;
@@ -1466,6 +1732,147 @@ DEVINL float rescore_wave(const unsigned short* __restrict__ pool, const unsigne
     return s;
 }
 
+// Selection behind the filtered scan (topk_stream3_kernel): a query's candidates are the nw x TKF_EARLY densely stored early tiles
+// plus its list of appended (value, group) entries.  Same scheme as gsel_body: per-thread maxima -> quarter-wave threshold (the
+// threads hold disjoint sets of groups) -> everything above it collected in LDS -> ranked exactly by (value desc, group asc) -> the
+// kc best plus the ties of the kc-th, at most gcap groups.  Overflow of the collection (massive exact ties, e.g. an all-zero
+// query) falls back to one extraction per round.  Ends with a barrier.
+template <int BS, class F>
+DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap, const float* __restrict__ early,
+                        const float* __restrict__ ent_val, const int* __restrict__ ent_grp, const int* __restrict__ ent_cnt,
+                        int rmax, int* out, F&& mid) {
+    __shared__ float qmax[64];
+    __shared__ float sval[TK_SELCAP];
+    __shared__ int sgrp[TK_SELCAP];
+    __shared__ int scnt;
+    __shared__ float stau0, stau;
+    __shared__ float rs[BS / 64];
+    __shared__ int rg[BS / 64];
+    __shared__ float wsel;
+    __shared__ int isel;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
+    long lo = 0, hi = 0;
+    if (tid < nw) tkf_range(tid, nw, ngroups, lo, hi);
+    float ev[TKF_EARLY];
+#pragma unroll
+    for (int f = 0; f < TKF_EARLY; ++f) ev[f] = tid < nw ? early[(((long)tid * TKF_EARLY + f) << 6) + q] : -INFINITY;
+    // thread tid holds wave tid's early tiles and wave tid's slice of the list
+    int cntq = tid < nw ? ent_cnt[(long)q * nw + tid] : 0;
+    if (cntq > rmax) cntq = rmax;
+    const float* lv = ent_val + ((long)q * nw + tid) * rmax;
+    const int* lgp = ent_grp + ((long)q * nw + tid) * rmax;
+    float mx = -INFINITY;
+    for (int e = 0; e < cntq; ++e) mx = fmaxf(mx, lv[e]);
+    mid();
+#pragma unroll
+    for (int f = 0; f < TKF_EARLY; ++f) mx = fmaxf(mx, ev[f]);
+    if (tid == 0) { scnt = 0; stau0 = -INFINITY; stau = -INFINITY; }
+    const float qm = row16_max(mx);
+    if ((tid & 15) == 0) qmax[tid >> 4] = qm;
+    __syncthreads();
+    if (tid < 64) {
+        const float x = qmax[tid];
+        int rank = 0;
+        for (int t = 0; t < 64; ++t) {
+            const float o = qmax[t];
+            rank += (o > x || (o == x && t < tid)) ? 1 : 0;
+        }
+        if (rank == min(kc, 64) - 1) stau0 = x;
+    }
+    __syncthreads();
+    const float t0 = stau0;
+#pragma unroll
+    for (int f = 0; f < TKF_EARLY; ++f)
+        if (ev[f] >= t0 && ev[f] > -INFINITY) {
+            const int pos = atomicAdd(&scnt, 1);
+            if (pos < TK_SELCAP) { sval[pos] = ev[f]; sgrp[pos] = (int)(lo + f); }
+        }
+    for (int e = 0; e < cntq; ++e) {
+        const float x = lv[e];
+        if (x >= t0 && x > -INFINITY) {
+            const int pos = atomicAdd(&scnt, 1);
+            if (pos < TK_SELCAP) { sval[pos] = x; sgrp[pos] = lgp[e]; }
+        }
+    }
+    __syncthreads();
+    const int n = scnt;
+    if (n <= TK_SELCAP) {
+        for (int e = tid; e < n; e += BS) {
+            const float x = sval[e];
+            const int gi = sgrp[e];
+            int rank = 0;
+            for (int t = 0; t < n; ++t) {
+                const float o = sval[t];
+                const int og = sgrp[t];
+                rank += (o > x || (o == x && og < gi)) ? 1 : 0;
+            }
+            if (rank == min(kc, n) - 1) stau = x;
+        }
+        __syncthreads();
+        const float tt = stau;
+        for (int e = tid; e < n; e += BS) {
+            const float x = sval[e];
+            const int gi = sgrp[e];
+            int rank = 0;
+            for (int t = 0; t < n; ++t) {
+                const float o = sval[t];
+                const int og = sgrp[t];
+                rank += (o > x || (o == x && og < gi)) ? 1 : 0;
+            }
+            if (rank < gcap && x >= tt) {
+                for (int m = 0; m < TK_G; ++m) {
+                    const long row = (long)gi * TK_G + m;
+                    out[rank * TK_G + m] = row < rows ? (int)row : -1;
+                }
+            }
+        }
+    } else {
+        // one extraction per round over the thread's own entries: the best one strictly after (last_s, last_g)
+        float last_s = INFINITY, tk = -INFINITY;
+        int last_g = -1;
+        for (int j = 0; j < gcap; ++j) {
+            float bs = -INFINITY;
+            int bg = 0x7fffffff;
+            auto offer = [&](float x, int gi) {
+                const bool after = (x < last_s) || (x == last_s && gi > last_g);
+                if (x > -INFINITY && after && (x > bs || (x == bs && gi < bg))) { bs = x; bg = gi; }
+            };
+#pragma unroll
+            for (int f = 0; f < TKF_EARLY; ++f) offer(ev[f], (int)(lo + f));
+            for (int e = 0; e < cntq; ++e) offer(lv[e], lgp[e]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float os = __shfl_xor(bs, o, 64);
+                const int og = __shfl_xor(bg, o, 64);
+                if (os > bs || (os == bs && og < bg)) { bs = os; bg = og; }
+            }
+            if (lane == 0) { rs[w] = bs; rg[w] = bg; }
+            __syncthreads();
+            if (tid == 0) {
+                float fs = rs[0];
+                int fg = rg[0];
+                for (int k2 = 1; k2 < BS / 64; ++k2)
+                    if (rs[k2] > fs || (rs[k2] == fs && rg[k2] < fg)) { fs = rs[k2]; fg = rg[k2]; }
+                wsel = fs;
+                isel = fg;
+            }
+            __syncthreads();
+            last_s = wsel;
+            last_g = isel;
+            __syncthreads();
+            if (last_g == 0x7fffffff || last_s == -INFINITY) break;
+            if (j == kc - 1) tk = last_s;
+            if (j >= kc && last_s < tk) break;
+            if (tid < TK_G) {
+                const long row = (long)last_g * TK_G + tid;
+                out[j * TK_G + tid] = row < rows ? (int)row : -1;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // The same exact re-score with the candidate rows gathered by LDS-DMA (buffer_load_dwordx4 ... lds) into a wave-private ring of
 // DEPTH slices (64 rows x 128 bytes = 8 KiB each): DEPTH - 1 slices are in flight while one is walked, at no register cost -- the
 // register-staged gather above exposes one HBM round trip per 128-byte slice (12 per row: ~2 us each, 25 us per re-score).  Layout:
@@ -1544,7 +1951,9 @@ template <int PARTS, int RW, int DEPTH>
 __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     const unsigned short* __restrict__ pool, const float* __restrict__ pinv, long rows, int dim,
     const unsigned short* __restrict__ queries, const float* __restrict__ gmax, long ngroups, int kc, int gcap,
-    int* __restrict__ cand, float* __restrict__ exact, int stop_after, const float* __restrict__ wmax, int nw) {
+    int* __restrict__ cand, float* __restrict__ exact, int stop_after, const float* __restrict__ wmax, int nw,
+    const float* __restrict__ early, const float* __restrict__ ent_val, const int* __restrict__ ent_grp,
+    const int* __restrict__ ent_cnt, int ent_rmax) {
     // stop_after (timing experiments only, UNIIR_TOPK_TAIL_STOP): 1 = return after the selection, 2 = after the query scaling
     extern __shared__ __attribute__((aligned(16))) char dyn[];       // the gather rings
     __shared__ int sel[2 * TK_MAXKC * TK_G];                         // the selection's output: gcap * 16 row indices, -1 = empty
@@ -1596,8 +2005,11 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
             s_iq = s > 0.f ? (float)(1.0 / (double)(float)sqrt((double)s)) : 0.f;
         }
     };
-    // the selection ends with a barrier; behind the stream2 scan it starts from the per-wave maxima (gsel_hier)
-    if (!(wmax && gsel_hier<TKT_THREADS>(gmax + (long)q * ngroups, wmax + (long)q * nw, nw, ngroups, rows, kc, gcap, sel, qnorm)))
+    // the selection ends with a barrier; behind the filtered stream3 scan it reads the early tiles + the query's list
+    // (gsel_sparse), behind the stream2 scan it starts from the per-wave maxima (gsel_hier)
+    if (early)
+        gsel_sparse<TKT_THREADS>(q, nw, ngroups, rows, kc, gcap, early, ent_val, ent_grp, ent_cnt, ent_rmax, sel, qnorm);
+    else if (!(wmax && gsel_hier<TKT_THREADS>(gmax + (long)q * ngroups, wmax + (long)q * nw, nw, ngroups, rows, kc, gcap, sel, qnorm)))
         gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm);
     const int ngrp = (gcap - part + PARTS - 1) / PARTS;      // this workgroup's share: groups of rank part, part + PARTS, ...
     const int nth = ngrp * TK_G;                             // thread t -> member t % 16 of its (t / 16)-th group
@@ -1702,17 +2114,25 @@ __global__ __launch_bounds__(1024) void topk_tail_sort_kernel(const float* __res
     }
 }
 
-// selection + exact re-score + sort behind a finished group-max scan; false when the shape does not fit the fused kernels
-static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int64_t* pool_ids, int64_t rows, int32_t dim,
-                              const void* queries_f16, int32_t nq, int32_t kc, int32_t k, const float* gmax, int32_t* cand,
-                              float* exact, float* out_scores, int64_t* out_ids, hipStream_t st, const float* wmax, int nw) {
+// can the fused tail (selection + query norm + exact re-score | sort) serve this search?
+static bool fused_tail_ok(int64_t rows, int32_t dim, int32_t kc) {
     static const char* env = getenv("UNIIR_TOPK_FUSED_TAIL");          // "0": the round-2 tail (four launches), for A/B
     const long ngroups = (rows + TK_G - 1) / TK_G;
     const int gcap = TK_GMULT * kc;
     if ((env && env[0] == '0') || dim % 64 || dim > 4096 || ngroups % 2 || ngroups > 1024L * 2 * TK_SELREG ||
         gcap * TK_G > TKT_SORTCAP || gcap > 2 * TK_MAXKC)
         return false;
-    if (rows * dim * 2 >= (1L << 31)) return false;                  // the gather's 31-bit buffer bound
+    return rows * dim * 2 < (1L << 31);                                // the gather's 31-bit buffer bound
+}
+// selection + exact re-score + sort behind a finished scan (dense gmax [+ wave maxima], or the filtered output `sp`); false when
+// the shape does not fit the fused kernels
+static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int64_t* pool_ids, int64_t rows, int32_t dim,
+                              const void* queries_f16, int32_t nq, int32_t kc, int32_t k, const float* gmax, int32_t* cand,
+                              float* exact, float* out_scores, int64_t* out_ids, hipStream_t st, const float* wmax, int nw,
+                              const TkSparse* sp = nullptr) {
+    const long ngroups = (rows + TK_G - 1) / TK_G;
+    const int gcap = TK_GMULT * kc;
+    if (!fused_tail_ok(rows, dim, kc)) return false;
     const int parts = nq <= 64 ? 4 : nq <= 128 ? 2 : 1;
     static const char* env_stop = getenv("UNIIR_TOPK_TAIL_STOP");     // timing experiments: results are garbage when set
     const int stop_after = env_stop ? atoi(env_stop) : 0;
@@ -1725,7 +2145,9 @@ static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, RW * DEPTH * 8192);                  \
         hipLaunchKernelGGL((topk_tail_select_rescore_kernel<P, RW, DEPTH>), g, b, RW * DEPTH * 8192, st,               \
                            (const unsigned short*)pool_f16, pinv, (long)rows, dim, (const unsigned short*)queries_f16, \
-                           gmax, ngroups, kc, gcap, cand, exact, stop_after, nw > 0 ? wmax : nullptr, nw);             \
+                           gmax, ngroups, kc, gcap, cand, exact, stop_after, (!sp && nw > 0) ? wmax : nullptr,         \
+                           sp ? sp->nw : nw, sp ? sp->early : nullptr, sp ? sp->ent_val : nullptr,                     \
+                           sp ? sp->ent_grp : nullptr, sp ? sp->ent_cnt : nullptr, sp ? sp->rmax : 0);                 \
     } while (0)
     // rings: 3 waves x 4 slices (the interactive regime: 144 slots per workgroup at k = 10) or 5 waves x 2 slices = 96 / 80 KiB
     if (parts == 4) TKT_LAUNCH(4, 3, 4);
@@ -1786,16 +2208,30 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
         const int n = nq - lo < chunk ? nq - lo : chunk;
         const unsigned short* qp = (const unsigned short*)queries_f16 + (long)lo * dim;
         if (n <= TK_GPATH_MAXQ) {       // group-max scan, then the fused tail (selection + query norm + exact re-score | sort)
-            // the per-wave maxima live behind the group maxima of this sweep (uniir_topk_workspace_bytes reserves the room)
-            float* wmax = (float*)(((uintptr_t)(gmax + (int64_t)n * ((rows + TK_G - 1) / TK_G)) + 255) & ~(uintptr_t)255);
+            // the per-wave maxima live behind the group maxima of this sweep (uniir_topk_workspace_bytes reserves the room); the
+            // filtered scan's outputs take the same region instead
+            const int64_t ngr = (rows + TK_G - 1) / TK_G;
+            float* wmax = (float*)(((uintptr_t)(gmax + (int64_t)n * ngr) + 255) & ~(uintptr_t)255);
+            TkSparse sp;
+            sp.ctrl = (TkFiltCtrl*)ws;
+            sp.early = (float*)(ws + 1024);
+            sp.ent_val = (float*)(ws + 1024 + TK_SPARSE_EARLY_BYTES);
+            sp.ent_grp = (int*)(ws + 1024 + TK_SPARSE_EARLY_BYTES + TK_SPARSE_LIST_BYTES(ngr));
+            sp.ent_cnt = (int*)(ws + 1024 + TK_SPARSE_EARLY_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngr));
+            sp.kc = kc;
+            sp.nw = sp.rmax = 0;
+            const bool fused = fused_tail_ok(rows, dim, kc);
             int nw = 0;
-            const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, qp, n, gmax, (hipStream_t)stream, wmax, &nw);
+            const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, qp, n, gmax, (hipStream_t)stream, wmax, &nw,
+                                             (fused && n <= 64) ? &sp : nullptr);
             if (sel < 0) return sel;
-            if (sel == 1 && launch_fused_tail(pool_f16, pool_inv_norm, pool_ids, rows, dim, qp, n, kc, k, gmax, cand, exact,
-                                              out_scores + (long)lo * k, out_ids + (long)lo * k, (hipStream_t)stream, wmax, nw)) {
+            if (sel >= 1 && launch_fused_tail(pool_f16, pool_inv_norm, pool_ids, rows, dim, qp, n, kc, k, gmax, cand, exact,
+                                              out_scores + (long)lo * k, out_ids + (long)lo * k, (hipStream_t)stream, wmax, nw,
+                                              sel == 2 ? &sp : nullptr)) {
                 HIP_LAUNCH_CHECK();
                 continue;
             }
+            if (sel == 2) return UNIIR_ELAUNCH;        // (cannot happen: the filtered scan is only chosen when the fused tail fits)
             rc = topk_select_after_scan(sel, gmax, rows, n, kc, cand, (hipStream_t)stream);
             if (rc) return rc;
         } else {
