@@ -1195,6 +1195,8 @@ struct TkSparse {
     int* ent_cnt;
     int rmax, nw, kc;
 };
+#define TK_SPARSE_CTRL_BYTES 16384L                 // >= sizeof(TkFiltCtrl)
+static_assert(sizeof(TkFiltCtrl) <= TK_SPARSE_CTRL_BYTES, "control block outgrew its slot");
 #define TK_SPARSE_EARLY_BYTES (1024L * TKF_EARLY * 64 * 4)
 #define TK_SPARSE_LIST_BYTES(ngroups) (64L * 1024 * ((ngroups) / 1024 + 4) * 4)   // >= 64 queries x waves x rmax entries: waves <= 1024, rmax = ngroups / waves + 2
 // wmax / nw_out (optional): room for [nq][1024] per-wave maxima; *nw_out = the number of waves when the scan wrote them, else 0.
@@ -1357,7 +1359,7 @@ extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t ro
         const int64_t ngroups = (rows + TK_G - 1) / TK_G;
         const int64_t dense = (int64_t)nq * ngroups * 4 + 256 + TK_WMAX_BYTES;
         // the filtered scan of <= 64 queries: control words, early tiles, per-query (value, group) lists with room for every group
-        const int64_t sparse = 1024 + TK_SPARSE_EARLY_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngroups) + 64 * 1024 * 4;
+        const int64_t sparse = TK_SPARSE_CTRL_BYTES + TK_SPARSE_EARLY_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngroups) + 64 * 1024 * 4;
         return nq <= 64 && sparse > dense ? sparse : dense;
     }
     int nqt, nsl; long rps;
@@ -2214,10 +2216,10 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
             float* wmax = (float*)(((uintptr_t)(gmax + (int64_t)n * ngr) + 255) & ~(uintptr_t)255);
             TkSparse sp;
             sp.ctrl = (TkFiltCtrl*)ws;
-            sp.early = (float*)(ws + 1024);
-            sp.ent_val = (float*)(ws + 1024 + TK_SPARSE_EARLY_BYTES);
-            sp.ent_grp = (int*)(ws + 1024 + TK_SPARSE_EARLY_BYTES + TK_SPARSE_LIST_BYTES(ngr));
-            sp.ent_cnt = (int*)(ws + 1024 + TK_SPARSE_EARLY_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngr));
+            sp.early = (float*)(ws + TK_SPARSE_CTRL_BYTES);
+            sp.ent_val = (float*)(ws + TK_SPARSE_CTRL_BYTES + TK_SPARSE_EARLY_BYTES);
+            sp.ent_grp = (int*)(ws + TK_SPARSE_CTRL_BYTES + TK_SPARSE_EARLY_BYTES + TK_SPARSE_LIST_BYTES(ngr));
+            sp.ent_cnt = (int*)(ws + TK_SPARSE_CTRL_BYTES + TK_SPARSE_EARLY_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngr));
             sp.kc = kc;
             sp.nw = sp.rmax = 0;
             const bool fused = fused_tail_ok(rows, dim, kc);
