@@ -988,13 +988,16 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
 //   * from tile TKF_EARLY on a wave appends (value, group) to its private slice of the query's list only when value >= tau[q]:
 //     ~2.5 % of the groups.
 // Exact: every group >= a valid lower bound of the kc-th best is kept; the selection (gsel_sparse) ranks early + list entries.
-// Cross-workgroup hand-offs follow the MI355X guide's recipe: plain stores -> agent release fence -> asm vmcnt(0) -> relaxed agent
-// atomic; consumer: relaxed poll -> agent acquire fence -> plain loads.  Every wait is bounded: on a timeout tau = -inf (everything
-// is appended: slower, still exact).  All workgroups are resident (grid = CUs, one workgroup per CU), so the waits are short.
+// Cross-workgroup traffic is atomics only, no fences (a release fence per wave -- buffer_wbl2, 1024 of them at once -- made the
+// tickets trickle in over ~40 us: measured 210 us for this kernel against 165 us for the dense stream2 scan on the same box): the
+// bucket maxima are RETURNING agent-scope atomics (the wave waits for the return, then takes its ticket), wave 0 reads them with
+// sc0 sc1 loads, and a threshold is published as ONE 4-byte atomic store per query that is its own flag (key != 0).  Every wait is
+// bounded: on a timeout tau = -inf (everything is appended: slower, still exact).  All workgroups are resident (grid = CUs, one
+// workgroup per CU), so the waits are short.
 #define TKF_EARLY 3
 struct TkFiltCtrl {
-    int ticket, flag, pad[14];
-    float tau[64];
+    int ticket, pad[15];
+    unsigned tauk[64];            // per query: key of the threshold, 0 = not published yet (the datum is its own flag)
     unsigned bucket[32][64];      // per query: maximum (as an order-preserving key, 0 = empty) of the first-tile values of 1/32 of the waves
 };
 // float -> unsigned key with the same order (atomicMax on the keys == maximum of the floats); every real value maps above 0
@@ -1085,15 +1088,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
         }
         return lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lane
     };
-    auto publish = [&](int* word, bool add) {     // release everything this wave has stored, then signal
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            if (add) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else __hip_atomic_store(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    auto thresholds = [&] {       // wave 0 only, after its own first tile is published
+    auto thresholds = [&] {       // wave 0 only, after its own first tile is in its bucket
         int spins = 0;
         while (__hip_atomic_load(&ctrl->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)nw && spins < 100000) {
             __builtin_amdgcn_s_sleep(4);
@@ -1101,15 +1096,15 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
         }
         float t = -INFINITY;
         if (__hip_atomic_load(&ctrl->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)nw) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            // the 8 KiB of bucket keys come in by LDS-DMA (no registers: this wave holds 500 of them) into the ring slot that is
-            // free right now -- slot 1: tile lo has been consumed, tile lo + 1 sits in slots 2 and 0 -- then 32 LDS reads per lane
+            // the 8 KiB of bucket keys come in by LDS-DMA (no registers: this wave holds 500 of them; sc0 sc1: past L1 and the
+            // XCD's L2, to where the atomics were performed) into the ring slot that is free right now -- slot 1: tile lo has been
+            // consumed, tile lo + 1 sits in slots 2 and 0 -- then 32 LDS reads per lane
             char* scratch = st.my + 1 * TKR_HALF_BYTES;
             const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)&ctrl->bucket[0][0], 0, 32 * 64 * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (void __attribute__((address_space(3)))*)(scratch + i * 1024), 16,
-                                                         (unsigned)(i * 1024 + lane * 16), 0, 0, 0);
+                                                         (unsigned)(i * 1024 + lane * 16), 0, 0, 17);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned sb = lds_addr32(scratch) + lane * 4;
             float bm[32];
@@ -1124,8 +1119,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
 #pragma unroll
             for (int b = 0; b < 32; ++b) t = (b == kc - 1) ? bm[b] : t;       // kc <= 32 (launcher)
         }
-        ctrl->tau[lane] = t;
-        publish(&ctrl->flag, false);
+        __hip_atomic_store(&ctrl->tauk[lane], tkf_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tau = t;
         have_tau = true;
     };
@@ -1135,23 +1129,26 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
         if (ti < TKF_EARLY) {
             early[(((gw * TKF_EARLY) + ti) << 6) + lane] = lane < nq ? mine : -INFINITY;
             if (ti == 0) {
-                (void)__hip_atomic_fetch_max(&ctrl->bucket[(gw << 5) / nw][lane], tkf_key(lane < nq ? mine : -INFINITY),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                publish(&ctrl->ticket, true);
+                // this wave's first-tile value into its bucket: a RETURNING atomic, so that the ticket below is taken after it has
+                // been performed (the wave waits for the returned value)
+                const unsigned old = __hip_atomic_fetch_max(&ctrl->bucket[(gw << 5) / nw][lane], tkf_key(lane < nq ? mine : -INFINITY),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::"v"(old) : "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&ctrl->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (gw == 0) thresholds();
             }
             return;
         }
         if (!have_tau) {
+            unsigned kv = 0u;
             int spins = 0;
-            while (!__hip_atomic_load(&ctrl->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && spins < 100000) {
+            while (true) {
+                kv = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(kv != 0u) || spins >= 100000) break;
                 __builtin_amdgcn_s_sleep(2);
                 ++spins;
             }
-            if (__hip_atomic_load(&ctrl->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                tau = ctrl->tau[lane];
-            }                                              // else: timed out, tau stays -inf (append everything)
+            tau = kv != 0u ? tkf_unkey(kv) : -INFINITY;          // timed out: append everything
             have_tau = true;
         }
         if (lane < nq && mine >= tau && npos < rmax) {
