@@ -120,7 +120,7 @@ def _two_call_search(shard, queries, k):
 
 
 @pytest.mark.parametrize("n,nq,d,k", [(70001, 64, 768, 10), (30000, 7, 512, 50), (9000, 300, 256, 10), (40, 5, 64, 10),
-                                      (70000, 1100, 768, 10), (140030, 64, 768, 10), (200000, 9, 768, 20)])
+                                      (70000, 1100, 768, 10), (280030, 64, 768, 10), (262144, 9, 768, 20)])
 def test_single_call_search_equals_the_op_level_sequence_bit_for_bit(n, nq, d, k):
     """uniir_topk_ip (one call: query norms + per-chunk scan, selection, re-score, sort) == the op-level entry points called
     one by one, scores and ids, incl. zero rows, duplicate ties, a ragged last group, -1 padding and > 1024 queries"""
@@ -182,10 +182,10 @@ def _oracle_topk_mt(pool, ids, queries, k):
 
 @pytest.mark.parametrize("n,nq,k", [(40030, 1, 10), (40030, 37, 10), (65536, 64, 10), (40003, 64, 10), (40030, 64, 50),
                                     (40030, 100, 10), (40030, 128, 10), (40030, 200, 10), (40030, 300, 50), (40030, 700, 10),
-                                    (140030, 64, 10), (140030, 5, 10), (262144, 33, 24)])
+                                    (280030, 64, 10), (280030, 5, 10), (262144, 33, 24)])
 def test_round3_scan_and_fused_tail_equal_the_c_oracle(n, nq, k):
     """round 3 kernels against oracle.c (reference mbeir_retriever.py:188-232), scores bit-exact and ids identical:
-    >= 8192 groups (140 030 / 262 144 rows) and k <= 24: the FILTERED scan topk_stream3_kernel (early tiles + thresholds from the
+    >= 16384 groups (280 030 / 262 144 rows) and k <= 24: the FILTERED scan topk_stream3_kernel (early tiles + thresholds from the
     waves' first tiles + per-wave lists) and gsel_sparse, incl. duplicate rows (ties at the threshold) and a ragged last tile;
     <= 64 queries: topk_stream2_kernel (queries in registers, pool by LDS-DMA; needs >= 2048 groups) incl. a ragged last tile
     (40030 = 2501 x 16 + 14) and an odd group count (40003 -> 2501 groups: the round-2 tail behind the new scan);
@@ -200,7 +200,7 @@ def test_round3_scan_and_fused_tail_equal_the_c_oracle(n, nq, k):
     pool[2000:2003] = pool[5]
     if n > 100000:                                # 40 more copies of one row, spread over the whole shard: one query's top hits all tie
         where = torch.randperm(n, device=DEV, generator=g)[:40]
-        pool[where] = pool[5]
+        pool[where] = pool[5].clone().repeat(40, 1)
     queries = torch.randn(nq, 768, device=DEV, generator=g).half()
     queries[0] = pool[5]
     ids = torch.randperm(n, device=DEV, generator=g).to(torch.int64) * 5 + 123

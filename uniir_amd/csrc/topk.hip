@@ -994,9 +994,10 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
 // sc0 sc1 loads, and a threshold is published as ONE 4-byte atomic store per query that is its own flag (key != 0).  Every wait is
 // bounded: on a timeout tau = -inf (everything is appended: slower, still exact).  All workgroups are resident (grid = CUs, one
 // workgroup per CU), so the waits are short.
-#define TKF_EARLY 3
+#define TKF_EARLY 3          // tiles every wave stores densely, whatever happens
+#define TKF_EMAX 12          // ... and up to this many while the thresholds are not out yet (then it waits)
 struct TkFiltCtrl {
-    int ticket, pad[15];
+    int ticket[8], pad[8];        // first-tile tickets, one word per blockIdx & 7 (a single word serialises 1024 atomics: ~12 us)
     unsigned tauk[64];            // per query: key of the threshold, 0 = not published yet (the datum is its own flag)
     unsigned bucket[32][64];      // per query: maximum (as an order-preserving key, 0 = empty) of the first-tile values of 1/32 of the waves
 };
@@ -1072,6 +1073,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
     float tau = -INFINITY;
     bool have_tau = false;
     int npos = 0;                          // entries this lane (query) has appended to this wave's slice
+    int nearly = 0;                        // tiles this wave has stored densely (wave-uniform)
     auto tile_max = [&](long tile) {       // D: lane -> query j * 16 + (lane & 15), candidates 4 lg + r of the tile
         const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + TKR_PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
         asm_wait_lgkm<0>();
@@ -1089,13 +1091,19 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
         return lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lane
     };
     auto thresholds = [&] {       // wave 0 only, after its own first tile is in its bucket
+        auto tickets = [&] {
+            int sum = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += __hip_atomic_load(&ctrl->ticket[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return sum;
+        };
         int spins = 0;
-        while (__hip_atomic_load(&ctrl->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)nw && spins < 100000) {
-            __builtin_amdgcn_s_sleep(4);
+        while (tickets() < (int)nw && spins < 100000) {
+            __builtin_amdgcn_s_sleep(2);
             ++spins;
         }
         float t = -INFINITY;
-        if (__hip_atomic_load(&ctrl->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)nw) {
+        if (tickets() >= (int)nw) {
             // the 8 KiB of bucket keys come in by LDS-DMA (no registers: this wave holds 500 of them; sc0 sc1: past L1 and the
             // XCD's L2, to where the atomics were performed) into the ring slot that is free right now -- slot 1: tile lo has been
             // consumed, tile lo + 1 sits in slots 2 and 0 -- then 32 LDS reads per lane
@@ -1126,30 +1134,35 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
     auto finish_tile = [&](long tile) {
         const float mine = tile_max(tile);
         const long ti = tile - lo;
-        if (ti < TKF_EARLY) {
-            early[(((gw * TKF_EARLY) + ti) << 6) + lane] = lane < nq ? mine : -INFINITY;
+        if (ti >= TKF_EARLY && !have_tau) {
+            // thresholds out yet?  One look per tile up to tile TKF_EMAX (meanwhile the tile is stored densely like the first
+            // ones), then a bounded wait
+            unsigned kv = 0u;
+            int spins = 0;
+            while (true) {
+                kv = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(kv != 0u) || ti < TKF_EMAX || spins >= 100000) break;
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+            }
+            if (__all(kv != 0u) || ti >= TKF_EMAX) {
+                tau = kv != 0u ? tkf_unkey(kv) : -INFINITY;      // timed out: append everything
+                have_tau = true;
+            }
+        }
+        if (!have_tau) {               // ti < TKF_EARLY, or the thresholds are not out and ti < TKF_EMAX
+            early[(((gw * TKF_EMAX) + ti) << 6) + lane] = lane < nq ? mine : -INFINITY;
+            nearly = (int)ti + 1;
             if (ti == 0) {
                 // this wave's first-tile value into its bucket: a RETURNING atomic, so that the ticket below is taken after it has
                 // been performed (the wave waits for the returned value)
                 const unsigned old = __hip_atomic_fetch_max(&ctrl->bucket[(gw << 5) / nw][lane], tkf_key(lane < nq ? mine : -INFINITY),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("" ::"v"(old) : "memory");
-                if (lane == 0) __hip_atomic_fetch_add(&ctrl->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_fetch_add(&ctrl->ticket[blockIdx.x & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (gw == 0) thresholds();
             }
             return;
-        }
-        if (!have_tau) {
-            unsigned kv = 0u;
-            int spins = 0;
-            while (true) {
-                kv = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all(kv != 0u) || spins >= 100000) break;
-                __builtin_amdgcn_s_sleep(2);
-                ++spins;
-            }
-            tau = kv != 0u ? tkf_unkey(kv) : -INFINITY;          // timed out: append everything
-            have_tau = true;
         }
         if (lane < nq && mine >= tau && npos < rmax) {
             const long o = ((long)lane * nw + gw) * rmax + npos;
@@ -1178,6 +1191,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
     tkr_process<1>(st, slot, qf, acc);
     finish_tile(t);
     if (lane < nq) ent_cnt[(long)lane * nw + gw] = npos;
+    if (lane == 0) reinterpret_cast<int*>(early + (nw * TKF_EMAX << 6))[gw] = nearly;
 }
 
 // The group-max scan of <= 1024 queries over the shard: gmax[q][group] = best approximate score of the 16 rows of the group.
@@ -1194,7 +1208,7 @@ struct TkSparse {
 };
 #define TK_SPARSE_CTRL_BYTES 16384L                 // >= sizeof(TkFiltCtrl)
 static_assert(sizeof(TkFiltCtrl) <= TK_SPARSE_CTRL_BYTES, "control block outgrew its slot");
-#define TK_SPARSE_EARLY_BYTES (1024L * TKF_EARLY * 64 * 4)
+#define TK_SPARSE_EARLY_BYTES (1024L * TKF_EMAX * 64 * 4 + 1024L * 4)     // early tiles + the number of them per wave
 #define TK_SPARSE_LIST_BYTES(ngroups) (64L * 1024 * ((ngroups) / 1024 + 4) * 4)   // >= 64 queries x waves x rmax entries: waves <= 1024, rmax = ngroups / waves + 2
 // wmax / nw_out (optional): room for [nq][1024] per-wave maxima; *nw_out = the number of waves when the scan wrote them, else 0.
 // sparse (optional, with kc set): the caller can consume the filtered output -> the scan may run as topk_stream3_kernel and then
@@ -1228,7 +1242,7 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
         static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "0": default cache policy (A/B)
         static const char* env_f = getenv("UNIIR_TOPK_FILTER");        // "0": dense group-max output (the stream2 scan), for A/B
         static const char* env_nt0 = getenv("UNIIR_TOPK_NT");
-        if (sparse && !(env_f && env_f[0] == '0') && ngroups >= 8L * ncu * 4 && (ncu * 4) % 32 == 0 && ncu * 4 <= 1024 &&
+        if (sparse && !(env_f && env_f[0] == '0') && ngroups >= 16L * ncu * 4 && (ncu * 4) % 32 == 0 && ncu * 4 <= 1024 &&
             sparse->kc <= 32) {
             sparse->nw = ncu * 4;
             sparse->rmax = (int)(ngroups / (ncu * 4) + 2);            // >= every wave's tile count (tkf_range)
@@ -1753,9 +1767,10 @@ DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap
     for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
     long lo = 0, hi = 0;
     if (tid < nw) tkf_range(tid, nw, ngroups, lo, hi);
-    float ev[TKF_EARLY];
+    const int ne = tid < nw ? reinterpret_cast<const int*>(early + ((long)nw * TKF_EMAX << 6))[tid] : 0;   // this wave's dense tiles
+    float ev[TKF_EMAX];
 #pragma unroll
-    for (int f = 0; f < TKF_EARLY; ++f) ev[f] = tid < nw ? early[(((long)tid * TKF_EARLY + f) << 6) + q] : -INFINITY;
+    for (int f = 0; f < TKF_EMAX; ++f) ev[f] = f < ne ? early[(((long)tid * TKF_EMAX + f) << 6) + q] : -INFINITY;
     // thread tid holds wave tid's early tiles and wave tid's slice of the list
     int cntq = tid < nw ? ent_cnt[(long)q * nw + tid] : 0;
     if (cntq > rmax) cntq = rmax;
@@ -1765,7 +1780,7 @@ DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap
     for (int e = 0; e < cntq; ++e) mx = fmaxf(mx, lv[e]);
     mid();
 #pragma unroll
-    for (int f = 0; f < TKF_EARLY; ++f) mx = fmaxf(mx, ev[f]);
+    for (int f = 0; f < TKF_EMAX; ++f) mx = fmaxf(mx, ev[f]);
     if (tid == 0) { scnt = 0; stau0 = -INFINITY; stau = -INFINITY; }
     const float qm = row16_max(mx);
     if ((tid & 15) == 0) qmax[tid >> 4] = qm;
@@ -1782,7 +1797,7 @@ DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap
     __syncthreads();
     const float t0 = stau0;
 #pragma unroll
-    for (int f = 0; f < TKF_EARLY; ++f)
+    for (int f = 0; f < TKF_EMAX; ++f)
         if (ev[f] >= t0 && ev[f] > -INFINITY) {
             const int pos = atomicAdd(&scnt, 1);
             if (pos < TK_SELCAP) { sval[pos] = ev[f]; sgrp[pos] = (int)(lo + f); }
@@ -1838,7 +1853,7 @@ DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap
                 if (x > -INFINITY && after && (x > bs || (x == bs && gi < bg))) { bs = x; bg = gi; }
             };
 #pragma unroll
-            for (int f = 0; f < TKF_EARLY; ++f) offer(ev[f], (int)(lo + f));
+            for (int f = 0; f < TKF_EMAX; ++f) offer(ev[f], (int)(lo + f));
             for (int e = 0; e < cntq; ++e) offer(lv[e], lgp[e]);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
