@@ -198,9 +198,9 @@ def test_round3_scan_and_fused_tail_equal_the_c_oracle(n, nq, k):
     pool[17] = 0                                  # zero row: inverse norm 0, score 0
     pool[n - 1] = pool[5]                         # duplicates incl. the very last row (ragged tile): ties broken by id
     pool[2000:2003] = pool[5]
-    if n > 100000:                                # 40 more copies of one row, spread over the whole shard: one query's top hits all tie
-        where = torch.randperm(n, device=DEV, generator=g)[:40]
-        pool[where] = pool[5].clone().repeat(40, 1)
+    if n > 100000:       # 16 more copies of one row, spread over the whole shard: one query's top hits all tie (21 tied groups: more
+        where = torch.randperm(n, device=DEV, generator=g)[:16]      # than kc = 18, fewer than the 36 the selection keeps)
+        pool[where] = pool[5].clone().repeat(16, 1)
     queries = torch.randn(nq, 768, device=DEV, generator=g).half()
     queries[0] = pool[5]
     ids = torch.randperm(n, device=DEV, generator=g).to(torch.int64) * 5 + 123

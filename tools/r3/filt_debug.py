@@ -19,7 +19,7 @@ ws = torch.zeros(lib.uniir_topk_ip_workspace_bytes(nq, 10, n), device=dev, dtype
 retrieval.search_shard(shard, q, 10, workspace=ws)
 torch.cuda.synchronize()
 ngr = (n + 15) // 16
-CTRL, EARLY = 16384, 1024 * 12 * 64 * 4 + 1024 * 4
+CTRL = 16384
 LIST = 64 * 1024 * (ngr // 1024 + 4) * 4
 raw = ws.cpu().numpy()
 ctrl = raw[:CTRL].view(np.uint32)
@@ -36,11 +36,7 @@ def unkey(k):
 
 
 print("tau[:8]", [round(unkey(k), 4) for k in tauk[:8]])
-off = CTRL + EARLY + 2 * LIST
+off = CTRL + 2 * LIST
 cnt = raw[off:off + 64 * 1024 * 4].view(np.int32).reshape(64, 1024)
 print("list entries per query: mean %.1f max %d; per (query, wave) max %d; total %d of %d groups x queries" %
       (cnt.sum(1).mean(), cnt.sum(1).max(), cnt.max(), cnt.sum(), ngr * 64))
-early = raw[CTRL:CTRL + 1024 * 12 * 64 * 4].view(np.float32).reshape(1024, 12, 64)[:, :3]
-ne = raw[CTRL + 1024 * 12 * 64 * 4:CTRL + EARLY].view(np.int32)
-print("dense tiles per wave: min %d mean %.2f max %d" % (ne.min(), ne.mean(), ne.max()))
-print("early tile maxima: mean %.4f max %.4f" % (early[:, :, :nq].mean(), early[:, :, :nq].max()))

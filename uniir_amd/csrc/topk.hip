@@ -779,6 +779,7 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
 #define TKR_PINV_OFF (3 * TKR_HALF_BYTES)
 #define TKR_STAGE_OFF (TKR_PINV_OFF + 512)
 #define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 2048)
+#define TKR3_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 3072)      // stream3: 12 parked maxima per lane instead of the octet staging
 template <int N>
 DEVINL void tkr_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N));
@@ -831,11 +832,12 @@ DEVINL void tkr_process(const TkrState& st, int slot, const u32x4_t (&qf)[4][24]
 }
 // everything a streaming-scan wave sets up before its first pool tile: DMA descriptors / per-lane offsets, and the query fragments
 // (all 64 queries, 96 x 16 bytes per lane) staged through LDS.  Contains two workgroup barriers.
+template <int WAVE_LDS>
 DEVINL void tkr_prepare(TkrState& st, u32x4_t (&qf)[4][24], char* lds, const unsigned short* __restrict__ pool,
                         const float* __restrict__ pinv, long rows, const unsigned short* __restrict__ queries, int nq, int w,
                         int lane) {
     const int li = lane & 15, lg = lane >> 4;
-    st.my = lds + w * TKR_WAVE_LDS;
+    st.my = lds + w * WAVE_LDS;
     st.lbase = lds_addr32(st.my);
     st.rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * 1536), 0x00020000);
     st.ri = __builtin_amdgcn_make_buffer_rsrc((void*)pinv, 0, (int)(rows * 4), 0x00020000);
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     const long lo = gw * ngroups / nw, hi = (gw + 1) * ngroups / nw;      // never empty: the launcher asks for >= 2048 groups
     TkrState st;
     u32x4_t qf[4][24];
-    tkr_prepare(st, qf, lds, pool, pinv, rows, queries, nq, w, lane);
+    tkr_prepare<TKR_WAVE_LDS>(st, qf, lds, pool, pinv, rows, queries, nq, w, lane);
     tkr_issue<0, AUX>(st, lo, 0);
     tkr_issue<1, AUX>(st, lo, 1);
     f32x4_t acc[4];
@@ -980,22 +982,21 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
 // Streaming scan, third generation: the stream2 kernel with a FILTERED output.  Measured on the 64-query scan (round 3): the dense
 // group-max matrix costs 34 of 191 us (no stores at all: 157 us = 6.9 TB/s; one coalesced 256-byte store per tile: 175 us) -- write
 // traffic sprinkled into the read stream is expensive.  So the scan keeps almost nothing:
-//   * every wave stores its first TKF_EARLY tiles densely, one coalesced 256-byte store per tile (early[wave][tile][query]);
+//   * until the thresholds are out (~30 us: 8 - 9 tiles) a wave parks its tiles' maxima in LDS, 12 per lane;
 //   * every wave folds its FIRST tile's value into one of 32 bucket maxima per query (atomicMax on an order-preserving key; buckets
 //     of nw / 32 waves) and takes a ticket; wave 0 waits for all tickets and takes, per query, the kc-th largest of the 32 bucket
 //     maxima (a 32-element sorting network in registers): at least kc groups reach that value, so it is a valid lower bound
 //     tau[q] of the kc-th best group maximum (about the 2.5 % quantile);
-//   * from tile TKF_EARLY on a wave appends (value, group) to its private slice of the query's list only when value >= tau[q]:
-//     ~2.5 % of the groups.
-// Exact: every group >= a valid lower bound of the kc-th best is kept; the selection (gsel_sparse) ranks early + list entries.
+//   * a wave appends (value, group) to its private slice of the query's list only when value >= tau[q] (the parked tiles as
+//     soon as tau is known): ~2.5 % of the groups.
+// Exact: every group >= a valid lower bound of the kc-th best is kept; the selection (gsel_sparse) ranks the list entries.
 // Cross-workgroup traffic is atomics only, no fences (a release fence per wave -- buffer_wbl2, 1024 of them at once -- made the
 // tickets trickle in over ~40 us: measured 210 us for this kernel against 165 us for the dense stream2 scan on the same box): the
 // bucket maxima are RETURNING agent-scope atomics (the wave waits for the return, then takes its ticket), wave 0 reads them with
 // sc0 sc1 loads, and a threshold is published as ONE 4-byte atomic store per query that is its own flag (key != 0).  Every wait is
 // bounded: on a timeout tau = -inf (everything is appended: slower, still exact).  All workgroups are resident (grid = CUs, one
 // workgroup per CU), so the waits are short.
-#define TKF_EARLY 3          // tiles every wave stores densely, whatever happens
-#define TKF_EMAX 12          // ... and up to this many while the thresholds are not out yet (then it waits)
+#define TKF_EMAX 12          // tiles a wave can park in LDS while the thresholds are not out yet (then it waits)
 struct TkFiltCtrl {
     int ticket[8], pad[8];        // first-tile tickets, one word per blockIdx & 7 (a single word serialises 1024 atomics: ~12 us)
     unsigned tauk[64];            // per query: key of the threshold, 0 = not published yet (the datum is its own flag)
@@ -1051,8 +1052,8 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
                                                              const float* __restrict__ pinv, long rows,
                                                              const unsigned short* __restrict__ queries, int nq,
                                                              long ngroups, int kc, TkFiltCtrl* __restrict__ ctrl,
-                                                             float* __restrict__ early, float* __restrict__ ent_val,
-                                                             int* __restrict__ ent_grp, int* __restrict__ ent_cnt, int rmax) {
+                                                             float* __restrict__ ent_val, int* __restrict__ ent_grp,
+                                                             int* __restrict__ ent_cnt, int rmax) {
     // lists: one private slice of rmax (>= the wave's tiles) entries per (query, wave) -- ent_*[(q * nw + wave) * rmax + i] -- and
     // ent_cnt[q * nw + wave] entries in it: plain stores, no atomics (a returning atomic would make hipcc drain the DMA queue)
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1064,7 +1065,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
     tkf_range(gw, nw, ngroups, lo, hi);
     TkrState st;
     u32x4_t qf[4][24];
-    tkr_prepare(st, qf, lds, pool, pinv, rows, queries, nq, w, lane);
+    tkr_prepare<TKR3_WAVE_LDS>(st, qf, lds, pool, pinv, rows, queries, nq, w, lane);
     tkr_issue<0, AUX>(st, lo, 0);
     tkr_issue<1, AUX>(st, lo, 1);
     f32x4_t acc[4];
@@ -1073,7 +1074,9 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
     float tau = -INFINITY;
     bool have_tau = false;
     int npos = 0;                          // entries this lane (query) has appended to this wave's slice
-    int nearly = 0;                        // tiles this wave has stored densely (wave-uniform)
+    unsigned kvp = 0u;                     // the threshold word as of the top of the current iteration (0 = not out yet)
+    unsigned old0 = 0u;                    // return value of the first tile's bucket atomic
+    const unsigned stg = st.lbase + TKR_STAGE_OFF + lane * 4;      // [TKF_EMAX][64] floats: this lane's maxima of the tiles before tau
     auto tile_max = [&](long tile) {       // D: lane -> query j * 16 + (lane & 15), candidates 4 lg + r of the tile
         const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + TKR_PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
         asm_wait_lgkm<0>();
@@ -1090,7 +1093,15 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
         }
         return lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lane
     };
-    auto thresholds = [&] {       // wave 0 only, after its own first tile is in its bucket
+    auto append = [&](float v, long tile) {
+        if (lane < nq && v >= tau && npos < rmax) {
+            const long o = ((long)lane * nw + gw) * rmax + npos;
+            ent_val[o] = v;
+            ent_grp[o] = (int)tile;
+            ++npos;
+        }
+    };
+    auto thresholds = [&](int free_slot) {       // wave 0 only, after its own ticket
         auto tickets = [&] {
             int sum = 0;
 #pragma unroll
@@ -1105,9 +1116,8 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
         float t = -INFINITY;
         if (tickets() >= (int)nw) {
             // the 8 KiB of bucket keys come in by LDS-DMA (no registers: this wave holds 500 of them; sc0 sc1: past L1 and the
-            // XCD's L2, to where the atomics were performed) into the ring slot that is free right now -- slot 1: tile lo has been
-            // consumed, tile lo + 1 sits in slots 2 and 0 -- then 32 LDS reads per lane
-            char* scratch = st.my + 1 * TKR_HALF_BYTES;
+            // XCD's L2, to where the atomics were performed) into the ring slot that has just been consumed, then 32 LDS reads
+            char* scratch = st.my + free_slot * TKR_HALF_BYTES;
             const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)&ctrl->bucket[0][0], 0, 32 * 64 * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -1128,52 +1138,52 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
             for (int b = 0; b < 32; ++b) t = (b == kc - 1) ? bm[b] : t;       // kc <= 32 (launcher)
         }
         __hip_atomic_store(&ctrl->tauk[lane], tkf_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tau = t;
-        have_tau = true;
+        kvp = tkf_key(t);
     };
-    auto finish_tile = [&](long tile) {
+    // Until the thresholds are out a wave parks its tiles' maxima in LDS (TKF_EMAX per lane; asm accesses like the fragment reads);
+    // the threshold word is LOADED at the top of an iteration and LOOKED AT at its end, so the poll never drains the DMA queue
+    // (a load that is waited for right away costs a full vmcnt(0): measured -- 8 polling tiles per wave -- as ~25 us per scan).
+    auto finish_tile = [&](long tile, int free_slot) {
         const float mine = tile_max(tile);
         const long ti = tile - lo;
-        if (ti >= TKF_EARLY && !have_tau) {
-            // thresholds out yet?  One look per tile up to tile TKF_EMAX (meanwhile the tile is stored densely like the first
-            // ones), then a bounded wait
-            unsigned kv = 0u;
-            int spins = 0;
-            while (true) {
-                kv = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all(kv != 0u) || ti < TKF_EMAX || spins >= 100000) break;
-                __builtin_amdgcn_s_sleep(2);
-                ++spins;
-            }
-            if (__all(kv != 0u) || ti >= TKF_EMAX) {
-                tau = kv != 0u ? tkf_unkey(kv) : -INFINITY;      // timed out: append everything
-                have_tau = true;
-            }
-        }
-        if (!have_tau) {               // ti < TKF_EARLY, or the thresholds are not out and ti < TKF_EMAX
-            early[(((gw * TKF_EMAX) + ti) << 6) + lane] = lane < nq ? mine : -INFINITY;
-            nearly = (int)ti + 1;
-            if (ti == 0) {
-                // this wave's first-tile value into its bucket: a RETURNING atomic, so that the ticket below is taken after it has
-                // been performed (the wave waits for the returned value)
-                const unsigned old = __hip_atomic_fetch_max(&ctrl->bucket[(gw << 5) / nw][lane], tkf_key(lane < nq ? mine : -INFINITY),
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("" ::"v"(old) : "memory");
+        if (!have_tau) {
+            if (ti == 0)       // first tile -> this wave's bucket (returning atomic: the ticket is taken once it has come back)
+                old0 = __hip_atomic_fetch_max(&ctrl->bucket[(gw << 5) / nw][lane], tkf_key(lane < nq ? mine : -INFINITY),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ti == 1) {
+                asm volatile("" ::"v"(old0) : "memory");
                 if (lane == 0) __hip_atomic_fetch_add(&ctrl->ticket[blockIdx.x & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (gw == 0) thresholds();
+                if (gw == 0) thresholds(free_slot);
             }
-            return;
+            if (!__all(kvp != 0u) && ti >= TKF_EMAX) {        // the park is full: wait (bounded)
+                int spins = 0;
+                while (true) {
+                    kvp = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(kvp != 0u) || spins >= 100000) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    ++spins;
+                }
+            }
+            if (__all(kvp != 0u) || ti >= TKF_EMAX) {
+                tau = kvp != 0u ? tkf_unkey(kvp) : -INFINITY;        // timed out: keep everything
+                have_tau = true;
+                for (long j = 0; j < ti; ++j) {                      // the parked tiles
+                    unsigned pv;
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(pv) : "v"(stg + (unsigned)j * 256u));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    append(__uint_as_float(pv), lo + j);
+                }
+            } else {
+                asm volatile("ds_write_b32 %0, %1" ::"v"(stg + (unsigned)ti * 256u), "v"(mine) : "memory");
+                return;
+            }
         }
-        if (lane < nq && mine >= tau && npos < rmax) {
-            const long o = ((long)lane * nw + gw) * rmax + npos;
-            ent_val[o] = mine;
-            ent_grp[o] = (int)tile;
-            ++npos;
-        }
+        append(mine, tile);
     };
     int slot = 0;
     long t = lo;
     for (; t + 1 < hi; ++t) {
+        if (!have_tau) kvp = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tkr_issue<0, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);
         tkr_wait_vm<25>();
         tkr_process<0>(st, slot, qf, acc);
@@ -1182,25 +1192,24 @@ __global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned sho
         tkr_wait_vm<25>();
         tkr_process<1>(st, slot, qf, acc);
         slot = slot == 2 ? 0 : slot + 1;
-        finish_tile(t);
+        finish_tile(t, slot == 0 ? 2 : slot - 1);
     }
+    if (!have_tau) kvp = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tkr_wait_vm<12>();
     tkr_process<0>(st, slot, qf, acc);
     slot = slot == 2 ? 0 : slot + 1;
     tkr_wait_vm<0>();
     tkr_process<1>(st, slot, qf, acc);
-    finish_tile(t);
+    finish_tile(t, slot);
     if (lane < nq) ent_cnt[(long)lane * nw + gw] = npos;
-    if (lane == 0) reinterpret_cast<int*>(early + (nw * TKF_EMAX << 6))[gw] = nearly;
 }
 
 // The group-max scan of <= 1024 queries over the shard: gmax[q][group] = best approximate score of the 16 rows of the group.
 // Returns 1 when a 1024-thread selection is the matching follow-up (streaming / ping-pong scans), 0 for the 256-thread one,
 // negative on error.
-// the filtered scan's outputs (topk_stream3_kernel): control words, early tiles, per-query lists; nw = waves of the scan
+// the filtered scan's outputs (topk_stream3_kernel): control words, per-(query, wave) lists; nw = waves of the scan
 struct TkSparse {
     TkFiltCtrl* ctrl;
-    float* early;
     float* ent_val;
     int* ent_grp;
     int* ent_cnt;
@@ -1208,7 +1217,6 @@ struct TkSparse {
 };
 #define TK_SPARSE_CTRL_BYTES 16384L                 // >= sizeof(TkFiltCtrl)
 static_assert(sizeof(TkFiltCtrl) <= TK_SPARSE_CTRL_BYTES, "control block outgrew its slot");
-#define TK_SPARSE_EARLY_BYTES (1024L * TKF_EMAX * 64 * 4 + 1024L * 4)     // early tiles + the number of them per wave
 #define TK_SPARSE_LIST_BYTES(ngroups) (64L * 1024 * ((ngroups) / 1024 + 4) * 4)   // >= 64 queries x waves x rmax entries: waves <= 1024, rmax = ngroups / waves + 2
 // wmax / nw_out (optional): room for [nq][1024] per-wave maxima; *nw_out = the number of waves when the scan wrote them, else 0.
 // sparse (optional, with kc set): the caller can consume the filtered output -> the scan may run as topk_stream3_kernel and then
@@ -1249,17 +1257,17 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
             if (hipMemsetAsync(sparse->ctrl, 0, sizeof(TkFiltCtrl), st0) != hipSuccess) return UNIIR_ELAUNCH;
             static PerDeviceOnce attr_s3;
             if (attr_s3.first()) {
-                (void)hipFuncSetAttribute((const void*)topk_stream3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
-                (void)hipFuncSetAttribute((const void*)topk_stream3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
+                (void)hipFuncSetAttribute((const void*)topk_stream3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR3_WAVE_LDS);
+                (void)hipFuncSetAttribute((const void*)topk_stream3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR3_WAVE_LDS);
             }
             if (!(env_nt0 && env_nt0[0] == '0'))
-                hipLaunchKernelGGL(topk_stream3_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
+                hipLaunchKernelGGL(topk_stream3_kernel<2>, dim3(ncu), dim3(256), 4 * TKR3_WAVE_LDS, st0, (const unsigned short*)pool_f16,
                                    pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, ngroups, sparse->kc,
-                                   sparse->ctrl, sparse->early, sparse->ent_val, sparse->ent_grp, sparse->ent_cnt, sparse->rmax);
+                                   sparse->ctrl, sparse->ent_val, sparse->ent_grp, sparse->ent_cnt, sparse->rmax);
             else
-                hipLaunchKernelGGL(topk_stream3_kernel<0>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
+                hipLaunchKernelGGL(topk_stream3_kernel<0>, dim3(ncu), dim3(256), 4 * TKR3_WAVE_LDS, st0, (const unsigned short*)pool_f16,
                                    pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, ngroups, sparse->kc,
-                                   sparse->ctrl, sparse->early, sparse->ent_val, sparse->ent_grp, sparse->ent_cnt, sparse->rmax);
+                                   sparse->ctrl, sparse->ent_val, sparse->ent_grp, sparse->ent_cnt, sparse->rmax);
             HIP_LAUNCH_CHECK();
             return 2;
         }
@@ -1369,8 +1377,8 @@ extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t ro
     if (nq <= TK_GPATH_MAXQ) {
         const int64_t ngroups = (rows + TK_G - 1) / TK_G;
         const int64_t dense = (int64_t)nq * ngroups * 4 + 256 + TK_WMAX_BYTES;
-        // the filtered scan of <= 64 queries: control words, early tiles, per-query (value, group) lists with room for every group
-        const int64_t sparse = TK_SPARSE_CTRL_BYTES + TK_SPARSE_EARLY_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngroups) + 64 * 1024 * 4;
+        // the filtered scan of <= 64 queries: control words, per-(query, wave) (value, group) lists with room for every group, counts
+        const int64_t sparse = TK_SPARSE_CTRL_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngroups) + 64 * 1024 * 4;
         return nq <= 64 && sparse > dense ? sparse : dense;
     }
     int nqt, nsl; long rps;
@@ -1745,15 +1753,14 @@ DEVINL float rescore_wave(const unsigned short* __restrict__ pool, const unsigne
     return s;
 }
 
-// Selection behind the filtered scan (topk_stream3_kernel): a query's candidates are the nw x TKF_EARLY densely stored early tiles
-// plus its list of appended (value, group) entries.  Same scheme as gsel_body: per-thread maxima -> quarter-wave threshold (the
+// Selection behind the filtered scan (topk_stream3_kernel): a query's candidates are its appended (value, group) entries, one
+// slice per wave of the scan.  Same scheme as gsel_body: per-thread maxima -> quarter-wave threshold (the
 // threads hold disjoint sets of groups) -> everything above it collected in LDS -> ranked exactly by (value desc, group asc) -> the
 // kc best plus the ties of the kc-th, at most gcap groups.  Overflow of the collection (massive exact ties, e.g. an all-zero
 // query) falls back to one extraction per round.  Ends with a barrier.
 template <int BS, class F>
-DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap, const float* __restrict__ early,
-                        const float* __restrict__ ent_val, const int* __restrict__ ent_grp, const int* __restrict__ ent_cnt,
-                        int rmax, int* out, F&& mid) {
+DEVINL void gsel_sparse(int q, int nw, long rows, int kc, int gcap, const float* __restrict__ ent_val,
+                        const int* __restrict__ ent_grp, const int* __restrict__ ent_cnt, int rmax, int* out, F&& mid) {
     __shared__ float qmax[64];
     __shared__ float sval[TK_SELCAP];
     __shared__ int sgrp[TK_SELCAP];
@@ -1765,13 +1772,7 @@ DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap
     __shared__ int isel;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
-    long lo = 0, hi = 0;
-    if (tid < nw) tkf_range(tid, nw, ngroups, lo, hi);
-    const int ne = tid < nw ? reinterpret_cast<const int*>(early + ((long)nw * TKF_EMAX << 6))[tid] : 0;   // this wave's dense tiles
-    float ev[TKF_EMAX];
-#pragma unroll
-    for (int f = 0; f < TKF_EMAX; ++f) ev[f] = f < ne ? early[(((long)tid * TKF_EMAX + f) << 6) + q] : -INFINITY;
-    // thread tid holds wave tid's early tiles and wave tid's slice of the list
+    // thread tid holds wave tid's slice of the list (disjoint sets of groups per thread)
     int cntq = tid < nw ? ent_cnt[(long)q * nw + tid] : 0;
     if (cntq > rmax) cntq = rmax;
     const float* lv = ent_val + ((long)q * nw + tid) * rmax;
@@ -1779,8 +1780,6 @@ DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap
     float mx = -INFINITY;
     for (int e = 0; e < cntq; ++e) mx = fmaxf(mx, lv[e]);
     mid();
-#pragma unroll
-    for (int f = 0; f < TKF_EMAX; ++f) mx = fmaxf(mx, ev[f]);
     if (tid == 0) { scnt = 0; stau0 = -INFINITY; stau = -INFINITY; }
     const float qm = row16_max(mx);
     if ((tid & 15) == 0) qmax[tid >> 4] = qm;
@@ -1796,12 +1795,6 @@ DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap
     }
     __syncthreads();
     const float t0 = stau0;
-#pragma unroll
-    for (int f = 0; f < TKF_EMAX; ++f)
-        if (ev[f] >= t0 && ev[f] > -INFINITY) {
-            const int pos = atomicAdd(&scnt, 1);
-            if (pos < TK_SELCAP) { sval[pos] = ev[f]; sgrp[pos] = (int)(lo + f); }
-        }
     for (int e = 0; e < cntq; ++e) {
         const float x = lv[e];
         if (x >= t0 && x > -INFINITY) {
@@ -1852,8 +1845,6 @@ DEVINL void gsel_sparse(int q, int nw, long ngroups, long rows, int kc, int gcap
                 const bool after = (x < last_s) || (x == last_s && gi > last_g);
                 if (x > -INFINITY && after && (x > bs || (x == bs && gi < bg))) { bs = x; bg = gi; }
             };
-#pragma unroll
-            for (int f = 0; f < TKF_EMAX; ++f) offer(ev[f], (int)(lo + f));
             for (int e = 0; e < cntq; ++e) offer(lv[e], lgp[e]);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -1966,8 +1957,7 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     const unsigned short* __restrict__ pool, const float* __restrict__ pinv, long rows, int dim,
     const unsigned short* __restrict__ queries, const float* __restrict__ gmax, long ngroups, int kc, int gcap,
     int* __restrict__ cand, float* __restrict__ exact, int stop_after, const float* __restrict__ wmax, int nw,
-    const float* __restrict__ early, const float* __restrict__ ent_val, const int* __restrict__ ent_grp,
-    const int* __restrict__ ent_cnt, int ent_rmax) {
+    const float* __restrict__ ent_val, const int* __restrict__ ent_grp, const int* __restrict__ ent_cnt, int ent_rmax) {
     // stop_after (timing experiments only, UNIIR_TOPK_TAIL_STOP): 1 = return after the selection, 2 = after the query scaling
     extern __shared__ __attribute__((aligned(16))) char dyn[];       // the gather rings
     __shared__ int sel[2 * TK_MAXKC * TK_G];                         // the selection's output: gcap * 16 row indices, -1 = empty
@@ -2019,10 +2009,10 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
             s_iq = s > 0.f ? (float)(1.0 / (double)(float)sqrt((double)s)) : 0.f;
         }
     };
-    // the selection ends with a barrier; behind the filtered stream3 scan it reads the early tiles + the query's list
-    // (gsel_sparse), behind the stream2 scan it starts from the per-wave maxima (gsel_hier)
-    if (early)
-        gsel_sparse<TKT_THREADS>(q, nw, ngroups, rows, kc, gcap, early, ent_val, ent_grp, ent_cnt, ent_rmax, sel, qnorm);
+    // the selection ends with a barrier; behind the filtered stream3 scan it reads the query's lists (gsel_sparse), behind the
+    // stream2 scan it starts from the per-wave maxima (gsel_hier)
+    if (ent_val)
+        gsel_sparse<TKT_THREADS>(q, nw, rows, kc, gcap, ent_val, ent_grp, ent_cnt, ent_rmax, sel, qnorm);
     else if (!(wmax && gsel_hier<TKT_THREADS>(gmax + (long)q * ngroups, wmax + (long)q * nw, nw, ngroups, rows, kc, gcap, sel, qnorm)))
         gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm);
     const int ngrp = (gcap - part + PARTS - 1) / PARTS;      // this workgroup's share: groups of rank part, part + PARTS, ...
@@ -2160,8 +2150,8 @@ static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int
         hipLaunchKernelGGL((topk_tail_select_rescore_kernel<P, RW, DEPTH>), g, b, RW * DEPTH * 8192, st,               \
                            (const unsigned short*)pool_f16, pinv, (long)rows, dim, (const unsigned short*)queries_f16, \
                            gmax, ngroups, kc, gcap, cand, exact, stop_after, (!sp && nw > 0) ? wmax : nullptr,         \
-                           sp ? sp->nw : nw, sp ? sp->early : nullptr, sp ? sp->ent_val : nullptr,                     \
-                           sp ? sp->ent_grp : nullptr, sp ? sp->ent_cnt : nullptr, sp ? sp->rmax : 0);                 \
+                           sp ? sp->nw : nw, sp ? sp->ent_val : nullptr, sp ? sp->ent_grp : nullptr,                   \
+                           sp ? sp->ent_cnt : nullptr, sp ? sp->rmax : 0);                                             \
     } while (0)
     // rings: 3 waves x 4 slices (the interactive regime: 144 slots per workgroup at k = 10) or 5 waves x 2 slices = 96 / 80 KiB
     if (parts == 4) TKT_LAUNCH(4, 3, 4);
@@ -2228,10 +2218,9 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
             float* wmax = (float*)(((uintptr_t)(gmax + (int64_t)n * ngr) + 255) & ~(uintptr_t)255);
             TkSparse sp;
             sp.ctrl = (TkFiltCtrl*)ws;
-            sp.early = (float*)(ws + TK_SPARSE_CTRL_BYTES);
-            sp.ent_val = (float*)(ws + TK_SPARSE_CTRL_BYTES + TK_SPARSE_EARLY_BYTES);
-            sp.ent_grp = (int*)(ws + TK_SPARSE_CTRL_BYTES + TK_SPARSE_EARLY_BYTES + TK_SPARSE_LIST_BYTES(ngr));
-            sp.ent_cnt = (int*)(ws + TK_SPARSE_CTRL_BYTES + TK_SPARSE_EARLY_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngr));
+            sp.ent_val = (float*)(ws + TK_SPARSE_CTRL_BYTES);
+            sp.ent_grp = (int*)(ws + TK_SPARSE_CTRL_BYTES + TK_SPARSE_LIST_BYTES(ngr));
+            sp.ent_cnt = (int*)(ws + TK_SPARSE_CTRL_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngr));
             sp.kc = kc;
             sp.nw = sp.rmax = 0;
             const bool fused = fused_tail_ok(rows, dim, kc);
