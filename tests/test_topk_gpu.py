@@ -185,8 +185,9 @@ def _oracle_topk_mt(pool, ids, queries, k):
                                     (280030, 64, 10), (280030, 5, 10), (262144, 33, 24)])
 def test_round3_scan_and_fused_tail_equal_the_c_oracle(n, nq, k):
     """round 3 kernels against oracle.c (reference mbeir_retriever.py:188-232), scores bit-exact and ids identical:
-    >= 16384 groups (280 030 / 262 144 rows) and k <= 24: the FILTERED scan topk_stream3_kernel (early tiles + thresholds from the
-    waves' first tiles + per-wave lists) and gsel_sparse, incl. duplicate rows (ties at the threshold) and a ragged last tile;
+    >= 16384 groups (280 030 / 262 144 rows) and k <= 24 with UNIIR_TOPK_FILTER=1 in the environment: the FILTERED scan
+    topk_stream3_kernel (thresholds from the waves' first tiles + per-wave lists) and gsel_sparse, incl. duplicate rows (ties at the
+    threshold) and a ragged last tile -- an experiment that is off by default (it passed these cases when it was on);
     <= 64 queries: topk_stream2_kernel (queries in registers, pool by LDS-DMA; needs >= 2048 groups) incl. a ragged last tile
     (40030 = 2501 x 16 + 14) and an odd group count (40003 -> 2501 groups: the round-2 tail behind the new scan);
     65..128 queries: the ping-pong scan without its padded query half; > 128: the full tile; behind all of them the fused tail

@@ -1248,9 +1248,14 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
         }
         // nt on the pool stream (read exactly once): measured 0.2729 -> 0.2466 ms per 64-query search, 0.2382 -> 0.2124 at 16
         static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "0": default cache policy (A/B)
-        static const char* env_f = getenv("UNIIR_TOPK_FILTER");        // "0": dense group-max output (the stream2 scan), for A/B
+        // MEASURED (round 3, same box, 64 queries x 700 k rows): dense stream2 scan 189 us; this filtered scan 183 us with the
+        // waiting tiles stored densely (but the selection then reads 8 x more and loses the 6 us again), 210 us with them parked in
+        // LDS; without ANY group-max store the scan takes 156 us.  The ~30 us until the thresholds are out (first tiles of 1024
+        // waves + 65 k bucket atomics + tickets) cover a fifth of the scan, and the bookkeeping around them eats the rest of the gain.
+        // The output volume does drop 40 x (1 100 of 43 750 groups per query).  Kept as an experiment: UNIIR_TOPK_FILTER=1.
+        static const char* env_f = getenv("UNIIR_TOPK_FILTER");        // "1": the filtered scan (experiment)
         static const char* env_nt0 = getenv("UNIIR_TOPK_NT");
-        if (sparse && !(env_f && env_f[0] == '0') && ngroups >= 16L * ncu * 4 && (ncu * 4) % 32 == 0 && ncu * 4 <= 1024 &&
+        if (sparse && env_f && env_f[0] == '1' && ngroups >= 16L * ncu * 4 && (ncu * 4) % 32 == 0 && ncu * 4 <= 1024 &&
             sparse->kc <= 32) {
             sparse->nw = ncu * 4;
             sparse->rmax = (int)(ngroups / (ncu * 4) + 2);            // >= every wave's tile count (tkf_range)
