@@ -166,21 +166,27 @@ def cpu_retrieval_baseline(d=768, k=10):
 # ------------------------------------------------------------------------------------------------------------------
 def bench_retrieval(dev, n=700_000, d=768, k=10, full=True):
     """brute-force top-10 over one GPU's 700k x 768 fp16 shard of the 5.6M pool (configs[3]); whole search incl. the exact
-    re-score.  q64: interactive / HBM-bound; q1024: one MFMA sweep; q100000: config 4's per-GPU work (98 sweeps)"""
+    re-score.  q16 / q64: interactive, HBM-bound (queries in registers, pool streamed once); q128 / q256: still one pass over the
+    pool (ping-pong MFMA scan, <= 128 queries without the padded half of the query tile); q1024: one MFMA sweep; q100000:
+    config 4's per-GPU work (98 sweeps).  The workspace is allocated once per query count (search_shard would otherwise
+    torch.empty it per call) and 5 untimed searches precede the timed ones."""
     from uniir_amd import retrieval
     g = torch.Generator(device=dev).manual_seed(2023)
     pool = torch.randn(n, d, generator=g, device=dev).half()
     shard = retrieval.PoolShard(pool, torch.arange(n, device=dev))
     out = {}
-    for nq in ((64, 1024, 16384, 100_000) if full else (64, 1024)):
+    from uniir_amd import _lib
+    for nq in ((16, 64, 128, 256, 1024, 16384, 100_000) if full else (64, 1024)):
         q = torch.randn(nq, d, generator=g, device=dev).half()
-        retrieval.search_shard(shard, q, k)
+        ws = torch.empty(_lib.load().uniir_topk_ip_workspace_bytes(nq, k, n), device=dev, dtype=torch.uint8)
+        for _ in range(5 if nq <= 1024 else 1):
+            retrieval.search_shard(shard, q, k, workspace=ws)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 10 if nq <= 1024 else (2 if nq <= 16384 else 1)
+        iters = 30 if nq <= 256 else (10 if nq <= 1024 else (2 if nq <= 16384 else 1))
         e0.record()
         for _ in range(iters):
-            retrieval.search_shard(shard, q, k)
+            retrieval.search_shard(shard, q, k, workspace=ws)
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / iters

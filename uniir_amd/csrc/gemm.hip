@@ -4,6 +4,7 @@
 #include "gemm_core.h"
 #include "gemm_core256.h"
 #include "gemm_core_pp.h"
+#include "gemm_core_pp2.h"
 #include "../../include/uniir_hip.h"
 #include <stdlib.h>
 
@@ -184,13 +185,13 @@ DEVINL int epi_col(int j, int w, int wn) {
 
 // copy-out of one 128-row fp32 pass: thread -> rows r0 + 8 it, one 16-B chunk; EPI / ACT are compile-time so that the
 // loop body carries no per-element branching
-template <int EPI, int ACT>
+template <int EPI, int ACT, int SRCSTEP = 8192>      // SRCSTEP: LDS bytes between the thread's rows (8 rows of the staged image)
 DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long offa, long rstep, long rstep_aux, bool full,
                          bool colok, int rows_left, f32x4_t& csum, int mrow) {
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
         if (full || (colok && 8 * it < rows_left)) {
-            f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + it * 8192);
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + it * SRCSTEP);
             const long off = off0 + it * rstep;
             if (EPI == UNIIR_EPI_RESID_F32) {
                 if (p.row_scale) v *= p.row_scale[mrow + 8 * it];
@@ -223,13 +224,13 @@ DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long of
 }
 
 // bf16 copy-out with the activation copy (EPI_BIAS_ACT): C <- f, C2 <- act(f)
-template <int ACT>
+template <int ACT, int SRCSTEP = 8192>
 DEVINL void epi_bf16_copy_act(const char* src, unsigned short* c1, unsigned short* c2, long rstep, bool full, bool colok,
                               int rows_left, bool skip_f) {
 #pragma unroll 2
     for (int it = 0; it < 16; ++it) {
         if (full || (colok && 16 * it < rows_left)) {
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + it * 8192);
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + it * SRCSTEP);
             if (!skip_f) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1));
             u32x4_t g;
 #pragma unroll
@@ -373,6 +374,163 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
             }
         }
     }
+}
+
+// Epilogue of the 256x128 (4-wave, two workgroups per CU) tile of gemm_core_pp2.h, staged through the workgroup's 80 KiB of LDS like
+// epilogue256_staged: bf16 outputs in one pass (image [256][128] bf16, 256-B rows, 16-B chunk ^= row & 15), fp32 math in two passes
+// of 128 rows (image [128][128] f32, 512-B rows, 16-B chunk ^= row & 7).  Accumulator map: acc[4h + i][2h' + j] at rows
+// 128h + 64wr + 16i, cols 64h' + 32wc + 16j (wr = w >> 1, wc = w & 1).
+DEVINL void epilogue128_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int m0, int n0, char* lds, int epi) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int li = lane & 15, lg = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const bool full = (m0 + 256 <= p.M) && (n0 + 128 <= p.N);
+    const f32x4_t alpha4 = {p.alpha, p.alpha, p.alpha, p.alpha};
+    int nl[4];
+    f32x4_t bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        nl[j] = (j >> 1) * 64 + wc * 32 + (j & 1) * 16 + 4 * lg;
+        const int n = n0 + nl[j];
+        bv[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    if (epi == UNIIR_EPI_BF16 || epi == UNIIR_EPI_BIAS_ACT) {
+        char* sj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sj[j] = lds + li * 256 + (((nl[j] >> 3) ^ li) << 4) + ((nl[j] & 7) << 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rb = ((i >> 2) * 128 + wr * 64 + (i & 3) * 16) * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4_t v = acc[i][j] * alpha4 + bv[j];
+                const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2_t*>(sj[j] + rb) = o;
+            }
+        }
+        __syncthreads();
+        // thread -> (row r0 + 16 it, 16-B chunk ch): 16 threads cover a row's 256 bytes
+        const int r0 = tid >> 4, ch = tid & 15;
+        const char* src = lds + r0 * 256 + ((ch ^ r0) << 4);
+        const long off0 = (long)(m0 + r0) * p.ldc + n0 + ch * 8;
+        unsigned short* c1 = (unsigned short*)p.C + off0;
+        unsigned short* c2 = (unsigned short*)p.C2 + off0;
+        const long rstep = 16L * p.ldc;
+        const bool colok = n0 + ch * 8 < p.N;
+        const int rows_left = p.M - m0 - r0;
+        const bool act = epi == UNIIR_EPI_BIAS_ACT;
+        if (!act) {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                if (full || (colok && 16 * it < rows_left)) {
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + it * 4096);
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1));
+                }
+                c1 += rstep;
+            }
+        } else if (p.act == UNIIR_ACT_QUICKGELU) {
+            epi_bf16_copy_act<UNIIR_ACT_QUICKGELU, 4096>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
+        } else if (p.act == UNIIR_ACT_GELU_ERF) {
+            epi_bf16_copy_act<UNIIR_ACT_GELU_ERF, 4096>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
+        } else {
+            epi_bf16_copy_act<UNIIR_ACT_RELU, 4096>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
+        }
+        return;
+    }
+    // fp32 math on the way out: two passes of 128 rows; every wave stages its tiles 4h .. 4h + 3 in pass h
+    char* sj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sj[j] = lds + li * 512 + (((nl[j] >> 2) ^ (li & 7)) << 4);
+    const int r0 = tid >> 5, ch = tid & 31;       // copy-out: row r0 + 8 it of the pass, 16-B chunk ch (4 floats)
+    const char* src = lds + r0 * 512 + ((ch ^ (r0 & 7)) << 4);
+    const bool colok = n0 + ch * 4 < p.N;
+    const long rstep = 8L * p.ldc, rstep_aux = 8L * p.ldaux;
+    f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int rb = (wr * 64 + ii * 16) * 512;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(sj[j] + rb) = acc[4 * h + ii][j] * alpha4 + bv[j];
+        }
+        __syncthreads();
+        const int mrow = m0 + 128 * h + r0;
+        const long off0 = (long)mrow * p.ldc + n0 + ch * 4;
+        const long offa = (long)mrow * p.ldaux + n0 + ch * 4;
+        const int rows_left = p.M - mrow;
+        if (epi == UNIIR_EPI_RESID_F32)
+            epi_f32_copy<UNIIR_EPI_RESID_F32, 0, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
+        else if (epi == UNIIR_EPI_F32)
+            epi_f32_copy<UNIIR_EPI_F32, 0, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
+        else if (p.act == UNIIR_ACT_QUICKGELU)
+            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_QUICKGELU, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
+        else if (p.act == UNIIR_ACT_GELU_ERF)
+            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_GELU_ERF, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
+        else
+            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_RELU, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
+    }
+    if (p.colsum) {
+        // this thread's 4 columns (ch = tid & 31) summed over its rows of both passes; 8 threads share a column group
+        __syncthreads();
+        f32x4_t* red = reinterpret_cast<f32x4_t*>(lds);
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 32) {
+            f32x4_t s = red[tid];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) s += red[tid + 32 * k];
+            const int n = n0 + tid * 4;
+            if (n < p.N) {
+                unsafeAtomicAdd(p.colsum + n + 0, s[0]);
+                unsafeAtomicAdd(p.colsum + n + 1, s[1]);
+                unsafeAtomicAdd(p.colsum + n + 2, s[2]);
+                unsafeAtomicAdd(p.colsum + n + 3, s[3]);
+            }
+        }
+    }
+}
+
+// 256x128 tile, 4 waves, two workgroups per CU (gemm_core_pp2.h): no split-K (the weight-gradient GEMMs stay on the 256x256 kernel)
+#define PP2_LDS_BYTES (5 * 16384)
+template <typename Elem, bool A_TMAJ, bool B_TMAJ>
+__global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(GemmKArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    // row-major over (row panel, column panel) with the column panel fastest: the workgroups of a CU / an XCD share A row panels
+    const int mt = id / p.tiles_n, nt = id - mt * p.tiles_n;
+    const int m0 = mt * 256, n0 = nt * 128;
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    glds_mainloop_pp2<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, 0, p.K, lds, acc);
+    epilogue128_staged(p, acc, m0, n0, lds, p.epilogue);
+}
+
+template <typename Elem>
+static int launch_pp2(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 127) / 128;
+    const dim3 g(a.tiles_m * a.tiles_n), b(256);
+#define LAUNCH2(AT, BT)                                                                                      \
+    do {                                                                                                     \
+        static PerDeviceOnce attr_set;                                                                       \
+        if (attr_set.first())                                                                                \
+            (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<Elem, AT, BT>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PP2_LDS_BYTES);            \
+        hipLaunchKernelGGL((gemm_pp2_kernel<Elem, AT, BT>), g, b, PP2_LDS_BYTES, st, a);                     \
+    } while (0)
+    if (!a_tmaj && !b_tmaj) LAUNCH2(false, false);
+    else if (!a_tmaj && b_tmaj) LAUNCH2(false, true);
+    else if (a_tmaj && !b_tmaj) LAUNCH2(true, false);
+    else LAUNCH2(true, true);
+#undef LAUNCH2
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
 }
 
 // LDS-DMA GEMM (gemm_core256.h): block tile (128*WM) x (64*WN), K step BK.  Used when K % BK == 0.
@@ -574,6 +732,11 @@ static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t s
         if (pp_eligible(a, a_tmaj, b_tmaj)) {
 #ifndef UNIIR_EXP_BUILD
             if (a.a_rowsum && std::is_same<Elem, ElemBF16>::value) return launch_glds_rowsum(a, st);
+            // the 256x128 two-workgroups-per-CU kernel: forward / dgrad shapes (no split-K, no atomics), opt-in while it is measured
+            static const char* env2 = getenv("UNIIR_GEMM_PP2");       // "1": all eligible; "2": only K <= 1024
+            if (env2 && (env2[0] == '1' || (env2[0] == '2' && a.K <= 1024)) && a.k_splits == 1 && !a.slab &&
+                a.epilogue != UNIIR_EPI_ATOMIC_F32 && a.N >= 128)
+                return launch_pp2<Elem>(a, a_tmaj, b_tmaj, st);
 #endif
             return launch_glds<Elem, 2, 4, 64, 2>(a, a_tmaj, b_tmaj, st);
         }
