@@ -167,7 +167,7 @@ def cpu_retrieval_baseline(d=768, k=10):
 def bench_retrieval(dev, n=700_000, d=768, k=10, full=True):
     """brute-force top-10 over one GPU's 700k x 768 fp16 shard of the 5.6M pool (configs[3]); whole search incl. the exact
     re-score.  q16 / q64: interactive, HBM-bound (queries in registers, pool streamed once); q128 / q256: still one pass over the
-    pool (ping-pong MFMA scan, <= 128 queries without the padded half of the query tile); q1024: one MFMA sweep; q100000:
+    pool (64 register-resident queries per wave, 2 / 4 waves share one LDS ring of pool tiles); q1024: one MFMA sweep; q100000:
     config 4's per-GPU work (98 sweeps).  The workspace is allocated once per query count (search_shard would otherwise
     torch.empty it per call) and 5 untimed searches precede the timed ones."""
     from uniir_amd import retrieval
@@ -384,6 +384,79 @@ class _DryRunTrainer:
         return {"loss": torch.tensor(0.0 if ok else float("nan"))}
 
 
+class BoardSampler:
+    """Shader clock and board power of the GPU under the timed steps, read from the amdgpu hwmon files (sysfs, no subprocess) by a
+    background thread every 50 ms.  Context for the roofline: the MI355X's 2.5 PF bf16 figure is at 2.4 GHz; with random operands
+    the matrix pipe runs against the board power cap and the sustained clock is what the chip can actually offer the kernels.
+    Best effort: returns None when the files are not visible in this container."""
+
+    def __init__(self, local_rank):
+        import glob
+        import threading
+        self.rows = []
+        self._stop = threading.Event()
+        self._thread = None
+        cands = []
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            f = os.path.join(h, "freq1_input")
+            pw = next((os.path.join(h, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
+            if os.path.exists(f):
+                cands.append((h, f, pw))
+        self.cands = cands
+        self.pick = None
+        try:        # match the torch device by PCI address when both sides expose it
+            pr = torch.cuda.get_device_properties(local_rank)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for i, (h, _, _) in enumerate(cands):
+                if want in os.path.realpath(os.path.join(h, "..", "..")):
+                    self.pick = i
+        except Exception:
+            pass
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def start(self):
+        import threading
+        if not self.cands:
+            return
+
+        def loop():
+            while not self._stop.is_set():
+                self.rows.append([(self._read(f), self._read(pw) if pw else None) for _, f, pw in self.cands])
+                self._stop.wait(0.05)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+        if not self.rows:
+            return None
+        ncard = len(self.cands)
+        mean_pw = [sum((r[i][1] or 0.0) for r in self.rows) / len(self.rows) for i in range(ncard)]
+        i = self.pick if self.pick is not None else max(range(ncard), key=lambda j: mean_pw[j])
+        clk = [r[i][0] / 1e6 for r in self.rows if r[i][0]]
+        pw = [r[i][1] / 1e6 for r in self.rows if r[i][1]]
+        cap = self._read(os.path.join(self.cands[i][0], "power1_cap"))
+        if not clk:
+            return None
+        mean_clk = sum(clk) / len(clk)
+        return {"sclk_mhz_mean": round(mean_clk, 1), "sclk_mhz_min": round(min(clk), 1), "sclk_mhz_max": round(max(clk), 1),
+                "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_cap_w": round(cap / 1e6, 1) if cap else None,
+                "samples": len(clk), "peak_at_mean_clock_tflops": round(MFMA_PEAK_BF16 / 1e12 * mean_clk / 2400.0, 1),
+                "note": "amdgpu hwmon freq1_input / power1_average sampled every 50 ms over the timed steps (rank 0's GPU); "
+                        "peak_at_mean_clock = 2.5 PF x mean clock / 2.4 GHz: what the matrix pipe can deliver at the clock the "
+                        "power management sustained (roofline.peak stays the 2.4-GHz figure)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -452,13 +525,16 @@ def main():
     for _ in range(args.warmup):
         out = trainer.train_step(batch)
     barrier()
+    board = BoardSampler(local_rank) if (ops is not None and rank == 0) else None
     if ops is not None and rank == 0:
         ops.gemm_timing_start()
+        board.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = trainer.train_step(batch)
     barrier()
     dt = time.perf_counter() - t0
+    board_rec = board.stop() if board is not None else None
     if ops is not None and rank == 0:
         timing = ops.gemm_timing_stop()          # (flop, seconds, launches) of the sampled GEMM launches
     loss = float(out["loss"].detach())
@@ -507,7 +583,8 @@ def main():
                     "traffic": traffic, "traffic_note": traffic_note, "launches_timed": nsamp,
                     "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} uniir_gemm calls of the timed region bracketed by HIP events on the "
                                 "launch stream inside the library (uniir_gemm_timing; 2 event records per sampled launch)",
-                    "end_to_end_frac": round(value * FLOP_PER_PAIR[args.model] / (world * MFMA_PEAK_BF16), 4)}
+                    "end_to_end_frac": round(value * FLOP_PER_PAIR[args.model] / (world * MFMA_PEAK_BF16), 4),
+                    "board": board_rec}
         result = {
             "metric": "query+cand pairs/sec in-batch contrastive (CLIP_SF-L)", "value": round(value, 2),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

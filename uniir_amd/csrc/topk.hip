@@ -780,6 +780,12 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
 #define TKR_STAGE_OFF (TKR_PINV_OFF + 512)
 #define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 2048)
 #define TKR3_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 3072)      // stream3: 12 parked maxima per lane instead of the octet staging
+// v_max_f32 without the canonicalising self-max hipcc puts in front of fmaxf on values it cannot see the origin of (swap results)
+DEVINL float tk5_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int N>
 DEVINL void tkr_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N));
@@ -912,17 +918,30 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
         const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + TKR_PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
         asm_wait_lgkm<0>();
         const f32x4_t iv = __builtin_bit_cast(f32x4_t, ivb);
-        const long r0 = tile * 16 + 4 * lg;
         float m[4];
+        if (tile * 16 + 16 <= rows) {                              // every tile but a ragged last one: no row masks
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = -INFINITY;
+            for (int j = 0; j < 4; ++j)
+                m[j] = tk5_max(tk5_max(acc[j][0] * iv[0], acc[j][1] * iv[1]), tk5_max(acc[j][2] * iv[2], acc[j][3] * iv[3]));
+        } else {
+            const long r0 = tile * 16 + 4 * lg;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x = fmaxf(x, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
-            m[j] = group_max(x);
-            acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) {
+                float x = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x = fmaxf(x, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
+                m[j] = x;
+            }
         }
-        const float mine = lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lg * 16 + li = lane
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // the four row reductions as one reduce-scatter (see topk_stream5_kernel): lane -> the maximum of query lg * 16 + li = lane
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[0]), __float_as_uint(m[2]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[1]), __float_as_uint(m[3]), false, false);
+        const float r02 = tk5_max(__uint_as_float(s02[0]), __uint_as_float(s02[1]));
+        const float r13 = tk5_max(__uint_as_float(s13[0]), __uint_as_float(s13[1]));
+        const auto sq = __builtin_amdgcn_permlane16_swap(__float_as_uint(r02), __float_as_uint(r13), false, false);
+        const float mine = tk5_max(__uint_as_float(sq[0]), __uint_as_float(sq[1]));
         wave_best = fmaxf(wave_best, mine);
         if (exp_store == 2) {             // experiment: one coalesced 256-byte store per tile ([group][query] layout)
             gmax[tile * 64 + lane] = mine;
@@ -997,7 +1016,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
 // consecutive ranges of the same  v * ngroups / NV  partition the 64-query kernel uses.
 template <int QW>
 struct Tk4 {
-    static constexpr int NS = QW == 2 ? 6 : 10;
+    static constexpr int NS = QW == 2 ? 6 : 10;               // (QW = 1 only borrows PER: Tk5)
     static constexpr int D = NS - 1;
     static constexpr int PER = 12 / QW;
     static constexpr int WAIT = (D - 1) * PER + (D - 1) / 2;
@@ -1029,6 +1048,7 @@ DEVINL void tk4_issue(const Tk4State& st, long tile, bool live, int slot) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rp, (void __attribute__((address_space(3)))*)(dst + (I) * 1024), 16,  \
                                                  ((I) & 1) ? vo : ve, (((st.w * PER + (I)) >> 1) * 128) + HALF * 768, 0, AUX);
     TK4_DMA(0) TK4_DMA(1) TK4_DMA(2) TK4_DMA(3) TK4_DMA(4) TK4_DMA(5)
+    TK4_DMA(6) TK4_DMA(7) TK4_DMA(8) TK4_DMA(9) TK4_DMA(10) TK4_DMA(11)
 #undef TK4_DMA
     if (HALF == 0) {
         if ((threadIdx.x & 63) < 16)
@@ -1181,6 +1201,221 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream4_kernel(const unsigned
         slot = slot == C::NS - 1 ? 0 : slot + 1;
         finish_tile(t);
     }
+    tkr_wait_vm<0>();                                              // the trailing dummies (and the last stores)
+}
+
+// c += a x q (v_mfma_f32_16x16x32_f16) with the query fragment in an AGPR (IN_A) or a VGPR
+template <bool IN_A>
+DEVINL void tk5_mfma(const u32x4_t& a, const u32x4_t& q, f32x4_t& c) {
+    if constexpr (IN_A) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(q));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(q));
+}
+// The same scan with ROLLING fragment registers (see the loop): one barrier per half-tile in the middle of its MFMAs.  D is even
+// here (the wait in the middle of half-tile h is for h + 1, with h + 2 .. h + D - 1 still in flight: D - 2 half-tiles,
+// (D - 2) / 2 inverse-norm DMAs).
+template <int QW>
+struct Tk5 {
+    static constexpr int NS = QW == 1 ? 3 : QW == 2 ? 5 : 9;          // QW = 1: four single-wave workgroups per CU, private rings
+    static constexpr int D = NS - 1;
+    static constexpr int PER = 12 / QW;
+    static constexpr int WAIT = (D - 2) * PER + (D - 2) / 2;
+    static constexpr int WAIT0 = (D - 1) * PER + (D - 2) / 2;        // prologue: half-tile 0 of 0 .. D - 1
+    static constexpr int RING = NS * TKR_HALF_BYTES;
+    static constexpr int PRIV = 512 + 2048;
+    static constexpr int LDS = RING + QW * PRIV;
+    static constexpr int VR = QW;
+};
+template <int QW, int AUX>
+__global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned short* __restrict__ pool,
+                                                                 const float* __restrict__ pinv, long rows,
+                                                                 const unsigned short* __restrict__ queries, int nq,
+                                                                 float* __restrict__ gmax, long ngroups,
+                                                                 float* __restrict__ wmax) {     // optional [nq][4 ncu] maxima
+    using C = Tk5<QW>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    // 32-bit range arithmetic: ngroups < 2^31 / 1536 / 16 and nv <= 1024 (launcher), so v * ngroups < 2^27
+    const unsigned nv = gridDim.x * C::VR, ng32 = (unsigned)ngroups;
+    const unsigned v0 = blockIdx.x * C::VR;
+    const long lo = v0 * ng32 / nv, hi = (v0 + C::VR) * ng32 / nv;             // >= VR tiles (the launcher asks for >= 2048 groups)
+    Tk4State st;
+    st.w = w;
+    st.ring = lds;
+    st.priv = lds + C::RING + w * C::PRIV;
+    st.rbase = lds_addr32(st.ring);
+    st.pbase = lds_addr32(st.priv);
+    st.rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * 1536), 0x00020000);
+    st.ri = __builtin_amdgcn_make_buffer_rsrc((void*)pinv, 0, (int)(rows * 4), 0x00020000);
+    {
+        const int r8 = lane >> 3, c8 = lane & 7;
+        const int row0 = r8, row1 = 8 + r8;
+        const unsigned vb0 = (unsigned)(row0 * 1536 + ((c8 ^ ((row0 >> 1) & 7)) << 4));
+        const unsigned vb1 = (unsigned)(row1 * 1536 + ((c8 ^ ((row1 >> 1) & 7)) << 4));
+        const bool odd_first = ((w * C::PER) & 1) != 0;          // QW = 4: waves 1 and 3 start on an odd instruction
+        st.ve = odd_first ? vb1 : vb0;
+        st.vo = odd_first ? vb0 : vb1;
+        st.vpi = (unsigned)((lane & 15) * 4);
+        const int g = (li >> 1) & 7;
+        st.la0 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + (((0 + lg) ^ g) << 4));
+        st.la1 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + (((4 + lg) ^ g) << 4));
+    }
+    // this wave's 64 queries -> registers, 16 at a time through a private 24-KiB piece of the (still unused) ring
+    u32x4_t qf[4][24];
+    {
+        const unsigned qb = 64u * w;                               // queries >= nq are out of bounds: zeros
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)queries, 0, nq * 1536, 0x00020000);
+        char* mine = lds + w * 24576;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const unsigned b = 1024u * i + 16u * lane;
+                const unsigned qq = b / 1536u, p = (b % 1536u) >> 4;                // query 16 j + qq of this wave, chunk position p
+                const unsigned src = (qb + 16u * j + qq) * 1536u + (((p & ~15u) | ((p ^ qq) & 15u)) << 4);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (void __attribute__((address_space(3)))*)(mine + 1024 * i), 16, src, 0, 0, 0);
+            }
+            tkr_wait_vm<0>();                                      // (hipcc does not order plain LDS loads behind LDS-DMA by itself)
+            // plain LDS loads: the compiler knows when their results are valid (they move on into AGPRs)
+#pragma unroll
+            for (int s = 0; s < 24; ++s) {
+                const int c = 4 * s + lg;
+                qf[j][s] = *reinterpret_cast<const u32x4_t*>(mine + li * 1536 + (((c & ~15) | ((c ^ li) & 15)) << 4));
+            }
+            asm_wait_lgkm<0>();                                    // ... and the next round's DMA must not overtake them
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                                  // every wave is done with its staging piece: the ring may fill
+    __builtin_amdgcn_sched_barrier(0);
+    const long nh = 2 * (hi - lo);
+    // half-tiles 0 .. D - 1 (D even: whole tiles)
+#pragma unroll
+    for (int h = 0; h < C::D; ++h) {
+        const long tile = lo + (h >> 1);
+        if (h & 1) tk4_issue<QW, 1, AUX>(st, tile, h < nh, h);
+        else tk4_issue<QW, 0, AUX>(st, tile, h < nh, h);
+    }
+    f32x4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int qi = 64 * w + lane;                                  // this lane's query in the group-max matrix
+    float best = -INFINITY;
+    unsigned vcur = v0;
+    long vhi = (v0 + 1) * ng32 / nv;
+    const unsigned stg = st.pbase + 512 + lane * 32;
+    const unsigned qoff = (unsigned)(((long)qi * ngroups) & 3);
+    auto finish_tile = [&](long tile) {
+        // (the MFMAs are inline asm: the compiler's hazard recogniser does not see them -- their results are read >= 100 cycles later,
+        // behind this LDS round trip)
+        const u32x4_t ivb = asm_ds_read_b128<0>(st.pbase + (unsigned)(tile & 7) * 64 + lg * 16);
+        asm volatile("s_nop 7\n\ts_nop 7");
+        asm_wait_lgkm<0>();
+        const f32x4_t iv = __builtin_bit_cast(f32x4_t, ivb);
+        float m[4];
+        if (tile * 16 + 16 <= rows) {                              // every tile but a ragged last one: no row masks
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                m[j] = tk5_max(tk5_max(acc[j][0] * iv[0], acc[j][1] * iv[1]), tk5_max(acc[j][2] * iv[2], acc[j][3] * iv[3]));
+        } else {
+            const long r0 = tile * 16 + 4 * lg;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x = fmaxf(x, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
+                m[j] = x;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // maxima over the four 16-lane rows for the four query tiles at once, as a reduce-scatter: after the 32-lane swap the lower
+        // half of the wave owns tiles 0 / 1, the upper half tiles 2 / 3; after the 16-lane swap row lg owns tile lg, i.e. the lane
+        // holds the group maximum of query 16 lg + li = its own query (6 instructions instead of 4 full reductions and a select)
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[0]), __float_as_uint(m[2]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[1]), __float_as_uint(m[3]), false, false);
+        const float r02 = tk5_max(__uint_as_float(s02[0]), __uint_as_float(s02[1]));
+        const float r13 = tk5_max(__uint_as_float(s13[0]), __uint_as_float(s13[1]));
+        const auto sq = __builtin_amdgcn_permlane16_swap(__float_as_uint(r02), __float_as_uint(r13), false, false);
+        const float mine = tk5_max(__uint_as_float(sq[0]), __uint_as_float(sq[1]));
+        best = fmaxf(best, mine);
+        if (tile == vhi - 1) {                                     // end of a virtual wave's range
+            if (wmax && qi < nq) wmax[(long)qi * nv + vcur] = best;
+            best = -INFINITY;
+            ++vcur;
+            vhi = (vcur + 1) * ng32 / nv;
+        }
+        const unsigned k = ((unsigned)tile + qoff) & 7u;
+        asm volatile("ds_write_b32 %0, %1" ::"v"(stg + k * 4u), "v"(mine) : "memory");
+        if (k == 7u || tile == hi - 1) {
+            const u32x4_t s0 = asm_ds_read_b128<0>(stg), s1 = asm_ds_read_b128<16>(stg);
+            asm_wait_lgkm<0>();
+            const f32x4_t v0 = __builtin_bit_cast(f32x4_t, s0), v1 = __builtin_bit_cast(f32x4_t, s1);
+            const long g0 = tile - k;
+            if (qi < nq) {
+                float* dst = gmax + (long)qi * ngroups + g0;
+                if (k == 7u && g0 >= lo) {
+                    *reinterpret_cast<f32x4_t*>(dst) = v0;
+                    *reinterpret_cast<f32x4_t*>(dst + 4) = v1;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (i <= (int)k && g0 + i >= lo) dst[i] = i < 4 ? v0[i] : v1[i - 4];
+                }
+            }
+        }
+    };
+    // Rolling fragment registers: a[0..5] (k-steps 0..5 of a half-tile) are re-loaded for half-tile h + 1 as soon as the MFMAs of
+    // half-tile h have issued past them, a[6..11] at the top of h: LDS latency, the DMA issue and the barrier all sit under
+    // MFMAs of the same wave (one wave per SIMD: nobody else could hide them).
+    u32x4_t a[12];
+#define TK5_READ6(F, SB)                                                                                       \
+    a[6 * F + 0] = asm_ds_read_b128<(3 * F + 0) * 2048>((SB) + st.la0); a[6 * F + 1] = asm_ds_read_b128<(3 * F + 0) * 2048>((SB) + st.la1); \
+    a[6 * F + 2] = asm_ds_read_b128<(3 * F + 1) * 2048>((SB) + st.la0); a[6 * F + 3] = asm_ds_read_b128<(3 * F + 1) * 2048>((SB) + st.la1); \
+    a[6 * F + 4] = asm_ds_read_b128<(3 * F + 2) * 2048>((SB) + st.la0); a[6 * F + 5] = asm_ds_read_b128<(3 * F + 2) * 2048>((SB) + st.la1); \
+    __builtin_amdgcn_sched_barrier(0);
+    // The MFMAs are written out: 64 of the 96 query fragments are pinned to AGPRs and go into the MFMA as its B operand directly
+    // (left to itself hipcc parks ~230 registers of them in AGPRs as well but copies four registers back per use:
+    // v_accvgpr_read x 4 in front of most MFMAs -- issue slots a one-wave-per-SIMD kernel does not have to spare).
+#define TK5_MFMA(J, HALF, SH) tk5_mfma<((J) * 24 + 12 * (HALF) + (SH) < 64)>(a[SH], qf[J][12 * (HALF) + (SH)], acc[J]);
+#define TK5_STEP(HALF, SH, W)                                                                                   \
+    asm_wait_lgkm<W>();                                                                                        \
+    TK5_MFMA(0, HALF, SH) TK5_MFMA(1, HALF, SH) TK5_MFMA(2, HALF, SH) TK5_MFMA(3, HALF, SH)
+    // one half-tile: `slot` holds it, its first six fragments are already on their way (or there)
+#define TK5_HALF(HALF, TILE_NEXT, LIVE)                                                                         \
+    {                                                                                                          \
+        const unsigned sb = st.rbase + slot * TKR_HALF_BYTES;                                                  \
+        TK5_READ6(1, sb)                                                                                       \
+        TK5_STEP(HALF, 0, 6) TK5_STEP(HALF, 1, 6) TK5_STEP(HALF, 2, 6) TK5_STEP(HALF, 3, 6) TK5_STEP(HALF, 4, 6) TK5_STEP(HALF, 5, 6) \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        tkr_wait_vm<C::WAIT>();                                                                                \
+        pp_barrier();                                                                                          \
+        tk4_issue<QW, HALF, AUX>(st, TILE_NEXT, LIVE, slot == 0 ? C::NS - 1 : slot - 1);                       \
+        slot = slot == C::NS - 1 ? 0 : slot + 1;                                                               \
+        const unsigned sn = st.rbase + slot * TKR_HALF_BYTES;                                                  \
+        TK5_READ6(0, sn)                                                                                       \
+        TK5_STEP(HALF, 6, 11) TK5_STEP(HALF, 7, 10) TK5_STEP(HALF, 8, 9) TK5_STEP(HALF, 9, 8) TK5_STEP(HALF, 10, 7) TK5_STEP(HALF, 11, 6) \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    int slot = 0;
+    long h = 0;
+    tkr_wait_vm<C::WAIT0>();
+    pp_barrier();
+    {
+        const unsigned s0 = st.rbase;
+        TK5_READ6(0, s0)
+        asm_wait_lgkm<0>();
+    }
+    for (long t = lo; t < hi; ++t, h += 2) {
+        TK5_HALF(0, t + C::D / 2, h + C::D < nh)
+        TK5_HALF(1, t + C::D / 2, h + 1 + C::D < nh)
+        finish_tile(t);
+    }
+#undef TK5_HALF
+#undef TK5_STEP
+#undef TK5_MFMA
+#undef TK5_READ6
     tkr_wait_vm<0>();                                              // the trailing dummies (and the last stores)
 }
 
@@ -1427,6 +1662,15 @@ static_assert(sizeof(TkFiltCtrl) <= TK_SPARSE_CTRL_BYTES, "control block outgrew
 // wmax / nw_out (optional): room for [nq][1024] per-wave maxima; *nw_out = the number of waves when the scan wrote them, else 0.
 // sparse (optional, with kc set): the caller can consume the filtered output -> the scan may run as topk_stream3_kernel and then
 // returns 2 (nothing is written to gmax).
+template <int QW, int A>
+static void launch_stream5(int nv, hipStream_t st0, const void* pool_f16, const float* pool_inv_norm, long rows,
+                           const void* queries_f16, int nq, float* gmax, long ngroups, float* wm) {
+    static PerDeviceOnce attr;
+    if (attr.first())
+        (void)hipFuncSetAttribute((const void*)topk_stream5_kernel<QW, A>, hipFuncAttributeMaxDynamicSharedMemorySize, Tk5<QW>::LDS);
+    hipLaunchKernelGGL((topk_stream5_kernel<QW, A>), dim3(nv / QW), dim3(64 * QW), Tk5<QW>::LDS, st0, (const unsigned short*)pool_f16,
+                       pool_inv_norm, rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm);
+}
 static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, int64_t rows, int32_t dim,
                             const void* queries_f16, int32_t nq, float* gmax, hipStream_t st0, float* wmax = nullptr,
                             int* nw_out = nullptr, TkSparse* sparse = nullptr) {
@@ -1487,6 +1731,13 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
         const int exp_store = env_x ? atoi(env_x) : 0;
         float* wm = (wmax && nw_out && ncu * 4 <= 1024 && (ngroups + ncu * 4 - 1) / (ncu * 4) <= 64 && !(env_h && env_h[0] == '0')) ? wmax : nullptr;
         if (wm) *nw_out = ncu * 4;
+        static const char* env_s5 = getenv("UNIIR_TOPK_STREAM5");      // "1": the rolling-register kernel, one wave per workgroup
+        if (env_s5 && env_s5[0] == '1' && exp_store == 0) {
+            if (!(env_nt && env_nt[0] == '0')) launch_stream5<1, 2>(ncu * 4, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+            else launch_stream5<1, 0>(ncu * 4, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+            HIP_LAUNCH_CHECK();
+            return 1;
+        }
         if (!(env_nt && env_nt[0] == '0'))
             hipLaunchKernelGGL(topk_stream2_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
                                pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm, exp_store);
@@ -1517,7 +1768,8 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
     static const char* env_s4 = getenv("UNIIR_TOPK_STREAM4");    // "0": the ping-pong GEMM scan instead (A/B)
     // MEASURED (round 3, 700 k rows): 128 queries: scan 203 us vs 247 us (ping-pong GEMM scan); 256 queries (QW = 4): 332 vs 322 us
     // -- one 4-wave workgroup per CU marches in lockstep (all four read LDS, then all four multiply) -> "4": experiment only
-    const int s4_max = (env_s4 && env_s4[0] == '4') ? 256 : 128;
+    // with the rolling-register kernel (stream5): 256 queries 0.333 ms vs 0.376 (ping-pong) -> default up to 256; "2": up to 128 only
+    const int s4_max = (env_s4 && env_s4[0] == '2') ? 128 : 256;
     if (nq > 64 && nq <= s4_max && dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048 && !(env_s4 && env_s4[0] == '0')) {
         static int ncu4 = 0;
         if (!ncu4) {
@@ -1541,7 +1793,16 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
                            (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, \
                            gmax, ngroups, wm);                                                                                  \
     } while (0)
-        if (nq <= 128) { if (nt) TK4_LAUNCH(2, 2); else TK4_LAUNCH(2, 0); }
+        static const char* env_s5 = getenv("UNIIR_TOPK_STREAM5");    // "0": the first shared-ring kernel (A/B)
+        if (!(env_s5 && env_s5[0] == '0')) {
+            if (nq <= 128) {
+                if (nt) launch_stream5<2, 2>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+                else launch_stream5<2, 0>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+            } else {
+                if (nt) launch_stream5<4, 2>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+                else launch_stream5<4, 0>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+            }
+        } else if (nq <= 128) { if (nt) TK4_LAUNCH(2, 2); else TK4_LAUNCH(2, 0); }
         else { if (nt) TK4_LAUNCH(4, 2); else TK4_LAUNCH(4, 0); }
 #undef TK4_LAUNCH
         HIP_LAUNCH_CHECK();
