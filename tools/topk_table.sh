@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/topk_table.txt
 : > $OUT
-for NQ in 16 64 128 1024; do
+for NQ in 16 64 128 256 1024; do
   rm -rf /tmp/tkp_$NQ
   NQ=$NQ rocprofv3 --kernel-trace --stats -d /tmp/tkp_$NQ -o t -- python $R/tools/topk_prof.py > /dev/null 2>&1
   DB=$(find /tmp/tkp_$NQ -name "*_results.db" | head -1)
