@@ -390,8 +390,9 @@ int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_norm, const i
                        float* out_scores, int64_t* out_ids, void* stream);
 /* The whole search of one pool shard in ONE call -- what the reference's FFI for this path would bind
  * (mbeir_retriever.py:188-232 search_index: faiss.normalize_L2(queries); index.search(queries, k)):
- * per chunk of <= 1024 queries one sweep of the shard (MFMA group-max scan), then group selection + exact re-score and the
- * final sort.  k <= 56.  Same results as coarse + rescore, bit for bit.
+ * per chunk of <= 1024 queries one sweep of the shard (MFMA group-max scan: queries in registers and the pool streamed once for
+ * <= 256 queries, GEMM-shaped above), then a fused group selection + query norm + exact re-score launch and the final sort.
+ * k <= 56.  Same results as coarse + rescore, bit for bit.
  * workspace: uniir_topk_ip_workspace_bytes(nq, k, rows) bytes, 256-B aligned. */
 int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows);
 int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,

@@ -7,6 +7,18 @@
 //            beats the current kc-th best, so after the first tiles almost nothing is appended.
 //   rescore: the shortlist is re-scored in fp32 in the oracle's exact summation order (sequential, no fma;
 //            oracle/topk_oracle.c) and sorted by (score desc, id asc) -> bit-exact distances, identical ids.
+//
+// That is the op-level pair (uniir_topk_coarse / uniir_topk_rescore).  The one-call search uniir_topk_ip (end of this file) runs,
+// per sweep of <= 1024 queries, THREE launches:
+//   scan  : gmax[q][g] = best approximate score of the 16 pool rows of group g.  <= 64 queries: topk_stream2_kernel (queries
+//           in registers, pool streamed through wave-private LDS-DMA rings); 65..256: topk_stream5_kernel (the ring shared by
+//           2 / 4 waves of 64 register-resident queries each); more: topk_gmax_pp_kernel (ping-pong GEMM core);
+//   tail 1: topk_tail_select_rescore_kernel: the k + 8 best groups per query (hierarchically from the scan's per-wave maxima),
+//           the query's inverse norm, the exact re-score of those groups' rows (LDS-DMA gather);
+//   tail 2: topk_tail_sort_kernel: (score desc, id asc) by rank counting.
+// Exactness: an fp16-product / fp32-accumulate score differs from the oracle's only in summation order, so the true top k rows
+// lie in the k + 8 best groups (ties at the group threshold keep up to 2 (k + 8) groups); the re-score then reproduces the
+// oracle bit for bit.  Switches (A/B, read once): UNIIR_TOPK_{STREAM,STREAM2,STREAM4,STREAM5,PP,NT,HALFN,HIER,FUSED_TAIL,FILTER}.
 #include "gemm_core.h"
 #include "gemm_core256.h"
 #include "gemm_core_pp.h"
