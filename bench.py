@@ -319,7 +319,7 @@ def _free_port():
 
 def self_launch(args, argv):
     """`python bench.py --gpus N` outside a launcher: become `torch.distributed.run` with N ranks of this script"""
-    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+    if not args.dry_run and torch.cuda.device_count() < args.gpus and os.environ.get("UNIIR_BENCH_SHARED_GPU") != "1":
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL needs it)
@@ -479,11 +479,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "RANK" in os.environ and args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    shared = False
     if args.dry_run:
         dev = torch.device("cpu")
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU product path); --dry-run only tests the launcher")
+        # UNIIR_BENCH_SHARED_GPU=1 (tests only): every rank on cuda:0 over gloo -- the whole multi-rank bench path (replica sync,
+        # overlapped reducer, rccl block, checksums) on real device tensors where only one GPU exists; not a measurement
+        shared = os.environ.get("UNIIR_BENCH_SHARED_GPU") == "1"
+        if shared:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -491,7 +497,10 @@ def main():
         if args.dry_run:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if shared:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         if world > 1:

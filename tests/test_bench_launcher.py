@@ -74,3 +74,20 @@ def test_bench_line_schema_on_the_device():
     assert rf["launches_timed"] > 0 and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["traffic"] is None            # profiles/pmc_gemm_traffic.json is the ViT-L/14, 512-pair measurement
     assert abs(r["value"] - 16 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-2 * r["value"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_gpu():
+    """the REAL multi-rank bench path (self-launch, replica sync at the DDP point, overlapped bucketed all-reduce, the rccl block,
+    per-rank checksums) with two ranks on the one GPU a test box has, over gloo (UNIIR_BENCH_SHARED_GPU=1; RCCL cannot put two
+    ranks on one device): ranks seeded differently must end the timed steps with identical parameters"""
+    p, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "16", "--model", "ViT-B/32", "--no-cpu-baseline",
+                     "--no-secondary", "--no-retrieval"], {"UNIIR_BENCH_SHARED_GPU": "1"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, (lines, p.stderr[-2000:])
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 32 and r["config"]["parallelism"] == "dp2"
+    rc = r["rccl"]
+    assert rc["ranks_seen"] == 2 and rc["replicas_identical"] is True and len(rc["replica_checksums"]) == 2
+    assert rc["grad_allreduce"]["collectives_per_step"] >= 1
+    assert abs(r["value"] - 32 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-2 * r["value"]
