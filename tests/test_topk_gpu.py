@@ -192,8 +192,8 @@ def test_round3_scan_and_fused_tail_equal_the_c_oracle(n, nq, k):
     <= 64 queries: topk_stream2_kernel (queries in registers, pool by LDS-DMA; needs >= 2048 groups) incl. a ragged last tile
     (40030 = 2501 x 16 + 14) and an odd group count (40003 -> 2501 groups: the round-2 tail behind the new scan);
     65..256 queries: topk_stream5_kernel (the pool ring shared by 2 / 4 waves of 64 register-resident queries each, rolling
-    fragment registers, MFMAs with AGPR operands; partly filled last wave: 65, 100, 129, 192, 200 queries; its predecessor
-    topk_stream4_kernel and the one-wave form pass the same cases with UNIIR_TOPK_STREAM5=0 / =1 in the environment);
+    fragment registers, MFMAs with AGPR operands; partly filled last wave: 65, 100, 129, 192, 200 queries; its one-wave form
+    passes the <= 64-query cases with UNIIR_TOPK_STREAM5=1 in the environment);
     > 256: the ping-pong GEMM scan; behind all of them the fused tail
     (selection + query norm + exact re-score in one launch with 4 / 2 / 1 workgroups per query, rank-count sort in the second),
     also at k = 50 (116 groups = 1 856 re-score slots per query, several 512-slot rounds per workgroup)."""

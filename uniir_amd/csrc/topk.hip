@@ -1010,32 +1010,24 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// Streaming scan for 65 .. 256 queries: the stream2 kernel with the pool ring SHARED by the QW waves of a workgroup.  Every wave
-// still keeps 64 queries in registers (wave w: queries 64 w ..), so one half-tile of the pool that lands in LDS is multiplied
-// with 64 QW queries: the pool is read from HBM once for up to 256 queries, and no query fragment is ever re-read from LDS (the
-// ping-pong GEMM scan re-reads 64 KiB of them per 256-row pool tile).
-//   QW = 2: 128-thread workgroups, two per CU (2 x 512-register waves each), ring of 6 half-tiles, 5 in flight per workgroup;
-//   QW = 4: 256-thread workgroups, one per CU, ring of 10 half-tiles, 9 in flight.
+// Streaming scan for 65 .. 256 queries (topk_stream5_kernel): the stream2 kernel with the pool ring SHARED by the QW waves of a
+// workgroup.  Every wave still keeps 64 queries in registers (wave w: queries 64 w ..), so one half-tile of the pool that lands in
+// LDS is multiplied with 64 QW queries: the pool is read from HBM once for up to 256 queries, and no query fragment is ever re-read
+// from LDS (the ping-pong GEMM scan re-reads 64 KiB of them per 256-row pool tile).
+//   QW = 2: 128-thread workgroups, two per CU (2 x 512-register waves each); QW = 4: 256-thread workgroups, one per CU.
 // A half-tile (12 DMA instructions) is fetched by all QW waves together (12 / QW instructions each), so the ring needs the
-// workgroup barrier the private rings did without: per half-tile h
-//     wait until MY part of h has landed (counted vmcnt) | s_barrier: everybody's part has, and everybody has finished reading
-//     h - 1 | issue h + D into the slot of h - 1 | multiply h.
-// D = NS - 1 is odd, so the D - 1 half-tiles that may stay in flight at the wait always hold (D - 1) / 2 inverse-norm DMAs
-// (those travel with the first half of a tile, one private copy per wave, a ring of 8 tiles): the count is a constant.  Past
-// the end of the range the loop keeps issuing DMAs whose offset is out of bounds (no memory traffic, zeros into a free slot):
-// the count stays exact without a tail loop.
+// workgroup barrier the private rings did without.  The inverse norms travel with the first half of a tile, one private copy per
+// wave, a ring of 8 tiles.  Past the end of the range the loop keeps issuing DMAs whose offset is out of bounds (no memory
+// traffic, zeros into a free slot): the vmcnt arithmetic stays exact without a tail loop.
 // The per-"wave" maxima for gsel_hier are written per VIRTUAL wave: the workgroup's range is the union of VR = 1024 / workgroups
 // consecutive ranges of the same  v * ngroups / NV  partition the 64-query kernel uses.
+// (A first version -- topk_stream4_kernel, round 3 -- waited, passed the barrier, issued the next DMA and only then read and
+// multiplied the half-tile: 128 queries 203 us, but 256 queries 332 us vs 322 us for the GEMM-shaped scan, because one wave per
+// SIMD cannot hide its own LDS latency that way.  The rolling-register loop below replaced it: 181 / ~275 us.)
+// Tk4 only carries the DMA split (PER) the issue helper needs.
 template <int QW>
 struct Tk4 {
-    static constexpr int NS = QW == 2 ? 6 : 10;               // (QW = 1 only borrows PER: Tk5)
-    static constexpr int D = NS - 1;
-    static constexpr int PER = 12 / QW;
-    static constexpr int WAIT = (D - 1) * PER + (D - 1) / 2;
-    static constexpr int RING = NS * TKR_HALF_BYTES;
-    static constexpr int PRIV = 512 + 2048;                 // per wave: 8 tiles' inverse norms (64 B each) + the octet staging
-    static constexpr int LDS = RING + QW * PRIV;
-    static constexpr int VR = QW;                            // virtual waves per workgroup: grid = 4 ncu / QW workgroups
+    static constexpr int PER = 12 / QW;          // DMA instructions per wave and half-tile
 };
 struct Tk4State {
     __amdgpu_buffer_rsrc_t rp, ri;
@@ -1069,162 +1061,17 @@ DEVINL void tk4_issue(const Tk4State& st, long tile, bool live, int slot) {
     }
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int QW, int AUX>
-__global__ __launch_bounds__(64 * QW, 1) void topk_stream4_kernel(const unsigned short* __restrict__ pool,
-                                                                 const float* __restrict__ pinv, long rows,
-                                                                 const unsigned short* __restrict__ queries, int nq,
-                                                                 float* __restrict__ gmax, long ngroups,
-                                                                 float* __restrict__ wmax) {     // optional [nq][4 ncu] maxima
-    using C = Tk4<QW>;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lg = lane >> 4;
-    // 32-bit range arithmetic: ngroups < 2^31 / 1536 / 16 and nv <= 1024 (launcher), so v * ngroups < 2^27
-    const unsigned nv = gridDim.x * C::VR, ng32 = (unsigned)ngroups;
-    const unsigned v0 = blockIdx.x * C::VR;
-    const long lo = v0 * ng32 / nv, hi = (v0 + C::VR) * ng32 / nv;             // >= VR tiles (the launcher asks for >= 2048 groups)
-    Tk4State st;
-    st.w = w;
-    st.ring = lds;
-    st.priv = lds + C::RING + w * C::PRIV;
-    st.rbase = lds_addr32(st.ring);
-    st.pbase = lds_addr32(st.priv);
-    st.rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * 1536), 0x00020000);
-    st.ri = __builtin_amdgcn_make_buffer_rsrc((void*)pinv, 0, (int)(rows * 4), 0x00020000);
-    {
-        const int r8 = lane >> 3, c8 = lane & 7;
-        const int row0 = r8, row1 = 8 + r8;
-        const unsigned vb0 = (unsigned)(row0 * 1536 + ((c8 ^ ((row0 >> 1) & 7)) << 4));
-        const unsigned vb1 = (unsigned)(row1 * 1536 + ((c8 ^ ((row1 >> 1) & 7)) << 4));
-        const bool odd_first = ((w * C::PER) & 1) != 0;          // QW = 4: waves 1 and 3 start on an odd instruction
-        st.ve = odd_first ? vb1 : vb0;
-        st.vo = odd_first ? vb0 : vb1;
-        st.vpi = (unsigned)((lane & 15) * 4);
-        const int g = (li >> 1) & 7;
-        st.la0 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + (((0 + lg) ^ g) << 4));
-        st.la1 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + (((4 + lg) ^ g) << 4));
-    }
-    // this wave's 64 queries -> registers, 16 at a time through a private 24-KiB piece of the (still unused) ring
-    u32x4_t qf[4][24];
-    {
-        const unsigned qb = 64u * w;                               // queries >= nq are out of bounds: zeros
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)queries, 0, nq * 1536, 0x00020000);
-        char* mine = lds + w * 24576;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int i = 0; i < 24; ++i) {
-                const unsigned b = 1024u * i + 16u * lane;
-                const unsigned qq = b / 1536u, p = (b % 1536u) >> 4;                // query 16 j + qq of this wave, chunk position p
-                const unsigned src = (qb + 16u * j + qq) * 1536u + (((p & ~15u) | ((p ^ qq) & 15u)) << 4);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (void __attribute__((address_space(3)))*)(mine + 1024 * i), 16, src, 0, 0, 0);
-            }
-            tkr_wait_vm<0>();                                      // (hipcc does not order plain LDS loads behind LDS-DMA by itself)
-            // plain LDS loads: the compiler knows when their results are valid (they move on into AGPRs)
-#pragma unroll
-            for (int s = 0; s < 24; ++s) {
-                const int c = 4 * s + lg;
-                qf[j][s] = *reinterpret_cast<const u32x4_t*>(mine + li * 1536 + (((c & ~15) | ((c ^ li) & 15)) << 4));
-            }
-            asm_wait_lgkm<0>();                                    // ... and the next round's DMA must not overtake them
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                                  // every wave is done with its staging piece: the ring may fill
-    __builtin_amdgcn_sched_barrier(0);
-    const long nh = 2 * (hi - lo);
-    // half-tiles 0 .. D - 1 (D odd: the last one is a first half)
-#pragma unroll
-    for (int h = 0; h < C::D; ++h) {
-        const long tile = lo + (h >> 1);
-        if (h & 1) tk4_issue<QW, 1, AUX>(st, tile, h < nh, h);
-        else tk4_issue<QW, 0, AUX>(st, tile, h < nh, h);
-    }
-    f32x4_t acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int qi = 64 * w + lane;                                  // this lane's query in the group-max matrix
-    float best = -INFINITY;
-    unsigned vcur = v0;
-    long vhi = (v0 + 1) * ng32 / nv;
-    const unsigned stg = st.pbase + 512 + lane * 32;
-    const unsigned qoff = (unsigned)(((long)qi * ngroups) & 3);
-    TkrState ps;                                                   // tkr_process reads: ring base + per-lane fragment offsets
-    ps.lbase = st.rbase;
-    ps.la0 = st.la0;
-    ps.la1 = st.la1;
-    auto finish_tile = [&](long tile) {
-        const u32x4_t ivb = asm_ds_read_b128<0>(st.pbase + (unsigned)(tile & 7) * 64 + lg * 16);
-        asm_wait_lgkm<0>();
-        const f32x4_t iv = __builtin_bit_cast(f32x4_t, ivb);
-        const long r0 = tile * 16 + 4 * lg;
-        float m[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x = fmaxf(x, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
-            m[j] = group_max(x);
-            acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-        const float mine = lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];
-        best = fmaxf(best, mine);
-        if (tile == vhi - 1) {                                     // end of a virtual wave's range
-            if (wmax && qi < nq) wmax[(long)qi * nv + vcur] = best;
-            best = -INFINITY;
-            ++vcur;
-            vhi = (vcur + 1) * ng32 / nv;
-        }
-        const unsigned k = ((unsigned)tile + qoff) & 7u;
-        asm volatile("ds_write_b32 %0, %1" ::"v"(stg + k * 4u), "v"(mine) : "memory");
-        if (k == 7u || tile == hi - 1) {
-            const u32x4_t s0 = asm_ds_read_b128<0>(stg), s1 = asm_ds_read_b128<16>(stg);
-            asm_wait_lgkm<0>();
-            const f32x4_t v0 = __builtin_bit_cast(f32x4_t, s0), v1 = __builtin_bit_cast(f32x4_t, s1);
-            const long g0 = tile - k;
-            if (qi < nq) {
-                float* dst = gmax + (long)qi * ngroups + g0;
-                if (k == 7u && g0 >= lo) {
-                    *reinterpret_cast<f32x4_t*>(dst) = v0;
-                    *reinterpret_cast<f32x4_t*>(dst + 4) = v1;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (i <= (int)k && g0 + i >= lo) dst[i] = i < 4 ? v0[i] : v1[i - 4];
-                }
-            }
-        }
-    };
-    int slot = 0;
-    long h = 0;
-    for (long t = lo; t < hi; ++t, h += 2) {
-        // first half of tile t: h + D is the second half of tile t + (D - 1) / 2
-        tkr_wait_vm<C::WAIT>();
-        pp_barrier();
-        tk4_issue<QW, 1, AUX>(st, t + (C::D - 1) / 2, h + C::D < nh, slot == 0 ? C::NS - 1 : slot - 1);
-        tkr_process<0>(ps, slot, qf, acc);
-        slot = slot == C::NS - 1 ? 0 : slot + 1;
-        // second half: h + 1 + D is the first half of tile t + (D + 1) / 2
-        tkr_wait_vm<C::WAIT>();
-        pp_barrier();
-        tk4_issue<QW, 0, AUX>(st, t + (C::D + 1) / 2, h + 1 + C::D < nh, slot == 0 ? C::NS - 1 : slot - 1);
-        tkr_process<1>(ps, slot, qf, acc);
-        slot = slot == C::NS - 1 ? 0 : slot + 1;
-        finish_tile(t);
-    }
-    tkr_wait_vm<0>();                                              // the trailing dummies (and the last stores)
-}
-
 // c += a x q (v_mfma_f32_16x16x32_f16) with the query fragment in an AGPR (IN_A) or a VGPR
 template <bool IN_A>
 DEVINL void tk5_mfma(const u32x4_t& a, const u32x4_t& q, f32x4_t& c) {
     if constexpr (IN_A) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(q));
     else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(q));
 }
-// The same scan with ROLLING fragment registers (see the loop): one barrier per half-tile in the middle of its MFMAs.  D is even
-// here (the wait in the middle of half-tile h is for h + 1, with h + 2 .. h + D - 1 still in flight: D - 2 half-tiles,
-// (D - 2) / 2 inverse-norm DMAs).
+// The shared-ring scan with ROLLING fragment registers (see the loop): a ring of NS half-tiles, D = NS - 1 of them in flight, ONE
+// barrier per half-tile, in the middle of its MFMAs:
+//     [reads of k-steps 6..11 of h] [MFMAs 0..5 of h] | wait: MY part of h + 1 has landed | s_barrier: everybody's has, and
+//     everybody is done with h - 1 | issue h + D into the slot of h - 1 | [reads of k-steps 0..5 of h + 1] [MFMAs 6..11 of h]
+// D is even: at the wait h + 2 .. h + D - 1 may stay in flight = D - 2 half-tiles with (D - 2) / 2 inverse-norm DMAs -- a constant.
 template <int QW>
 struct Tk5 {
     static constexpr int NS = QW == 1 ? 3 : QW == 2 ? 5 : 9;          // QW = 1: four single-wave workgroups per CU, private rings
@@ -1777,10 +1624,9 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
         return 1;
     }
     // 65 .. 256 queries, dim 768: the shared-ring streaming scan (queries in registers, 64 per wave)
-    static const char* env_s4 = getenv("UNIIR_TOPK_STREAM4");    // "0": the ping-pong GEMM scan instead (A/B)
-    // MEASURED (round 3, 700 k rows): 128 queries: scan 203 us vs 247 us (ping-pong GEMM scan); 256 queries (QW = 4): 332 vs 322 us
-    // -- one 4-wave workgroup per CU marches in lockstep (all four read LDS, then all four multiply) -> "4": experiment only
-    // with the rolling-register kernel (stream5): 256 queries 0.333 ms vs 0.376 (ping-pong) -> default up to 256; "2": up to 128 only
+    static const char* env_s4 = getenv("UNIIR_TOPK_STREAM4");    // "0": the ping-pong GEMM scan instead (A/B; the name is historic)
+    // MEASURED (round 3, 700 k rows, whole search): 128 queries 0.224-0.239 ms vs 0.280-0.291 (ping-pong GEMM scan), 256 queries
+    // 0.331-0.345 vs 0.376; "2": up to 128 queries only
     const int s4_max = (env_s4 && env_s4[0] == '2') ? 128 : 256;
     if (nq > 64 && nq <= s4_max && dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048 && !(env_s4 && env_s4[0] == '0')) {
         static int ncu4 = 0;
@@ -1796,27 +1642,13 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
         const int nv = ncu4 * 4;
         float* wm = (wmax && nw_out && nv <= 1024 && (ngroups + nv - 1) / nv <= 64 && !(env_h4 && env_h4[0] == '0')) ? wmax : nullptr;
         if (wm) *nw_out = nv;
-#define TK4_LAUNCH(QW, A)                                                                                                       \
-    do {                                                                                                                        \
-        static PerDeviceOnce attr;                                                                                              \
-        if (attr.first())                                                                                                       \
-            (void)hipFuncSetAttribute((const void*)topk_stream4_kernel<QW, A>, hipFuncAttributeMaxDynamicSharedMemorySize, Tk4<QW>::LDS); \
-        hipLaunchKernelGGL((topk_stream4_kernel<QW, A>), dim3(nv / QW), dim3(64 * QW), Tk4<QW>::LDS, st0,                      \
-                           (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, \
-                           gmax, ngroups, wm);                                                                                  \
-    } while (0)
-        static const char* env_s5 = getenv("UNIIR_TOPK_STREAM5");    // "0": the first shared-ring kernel (A/B)
-        if (!(env_s5 && env_s5[0] == '0')) {
-            if (nq <= 128) {
-                if (nt) launch_stream5<2, 2>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-                else launch_stream5<2, 0>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-            } else {
-                if (nt) launch_stream5<4, 2>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-                else launch_stream5<4, 0>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-            }
-        } else if (nq <= 128) { if (nt) TK4_LAUNCH(2, 2); else TK4_LAUNCH(2, 0); }
-        else { if (nt) TK4_LAUNCH(4, 2); else TK4_LAUNCH(4, 0); }
-#undef TK4_LAUNCH
+        if (nq <= 128) {
+            if (nt) launch_stream5<2, 2>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+            else launch_stream5<2, 0>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+        } else {
+            if (nt) launch_stream5<4, 2>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+            else launch_stream5<4, 0>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+        }
         HIP_LAUNCH_CHECK();
         return 1;
     }
