@@ -1089,7 +1089,8 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
                                                                  const float* __restrict__ pinv, long rows,
                                                                  const unsigned short* __restrict__ queries, int nq,
                                                                  float* __restrict__ gmax, long ngroups,
-                                                                 float* __restrict__ wmax) {     // optional [nq][4 ncu] maxima
+                                                                 float* __restrict__ wmax,       // optional [nq][4 ncu] maxima
+                                                                 int exp_fin) {   // timing experiments only (wrong results): 1 = no tile epilogue
     using C = Tk5<QW>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1269,7 +1270,13 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
     for (long t = lo; t < hi; ++t, h += 2) {
         TK5_HALF(0, t + C::D / 2, h + C::D < nh)
         TK5_HALF(1, t + C::D / 2, h + 1 + C::D < nh)
-        finish_tile(t);
+        if (exp_fin == 1) {
+            asm_wait_lgkm<0>();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        } else {
+            finish_tile(t);
+        }
     }
 #undef TK5_HALF
 #undef TK5_STEP
@@ -1524,11 +1531,13 @@ static_assert(sizeof(TkFiltCtrl) <= TK_SPARSE_CTRL_BYTES, "control block outgrew
 template <int QW, int A>
 static void launch_stream5(int nv, hipStream_t st0, const void* pool_f16, const float* pool_inv_norm, long rows,
                            const void* queries_f16, int nq, float* gmax, long ngroups, float* wm) {
+    static const char* env_x = getenv("UNIIR_TOPK_EXP_FIN");       // timing experiment: skip the per-tile epilogue (wrong results)
+    const int exp_fin = env_x ? atoi(env_x) : 0;
     static PerDeviceOnce attr;
     if (attr.first())
         (void)hipFuncSetAttribute((const void*)topk_stream5_kernel<QW, A>, hipFuncAttributeMaxDynamicSharedMemorySize, Tk5<QW>::LDS);
     hipLaunchKernelGGL((topk_stream5_kernel<QW, A>), dim3(nv / QW), dim3(64 * QW), Tk5<QW>::LDS, st0, (const unsigned short*)pool_f16,
-                       pool_inv_norm, rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm);
+                       pool_inv_norm, rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm, exp_fin);
 }
 static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, int64_t rows, int32_t dim,
                             const void* queries_f16, int32_t nq, float* gmax, hipStream_t st0, float* wmax = nullptr,
