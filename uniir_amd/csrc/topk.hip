@@ -792,6 +792,14 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
 #define TKR_STAGE_OFF (TKR_PINV_OFF + 512)
 #define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 2048)
 #define TKR3_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 3072)      // stream3: 12 parked maxima per lane instead of the octet staging
+// group-max stores of the streaming scans: -DUNIIR_GMAX_NT=1 builds them as non-temporal stores.  MEASURED (round 3, same box, whole
+// search): 64 queries 0.2233 / 0.2059 ms (default) vs 0.2288 / 0.2095 (nt); 128 queries 0.2360 / 0.2236 vs 0.2652 / 0.2450 -- the
+// 32-byte runs want the L2's write combining; default stays.
+#if defined(UNIIR_GMAX_NT) && UNIIR_GMAX_NT
+#define TK_GST(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define TK_GST(ptr, v) (*(ptr) = (v))
+#endif
 // v_max_f32 without the canonicalising self-max hipcc puts in front of fmaxf on values it cannot see the origin of (swap results)
 DEVINL float tk5_max(float a, float b) {
     float r;
@@ -974,8 +982,8 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
             if (lane < (exp_store == 1 ? 16 : nq)) {
                 float* dst = gmax + (long)lane * ngroups + g0;
                 if (k == 7u && g0 >= lo) {
-                    *reinterpret_cast<f32x4_t*>(dst) = v0;
-                    *reinterpret_cast<f32x4_t*>(dst + 4) = v1;
+                    TK_GST(reinterpret_cast<f32x4_t*>(dst), v0);
+                    TK_GST(reinterpret_cast<f32x4_t*>(dst + 4), v1);
                 } else {                                     // head of the wave's range / end of the range: the groups this wave computed
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
@@ -1216,8 +1224,8 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
             if (qi < nq) {
                 float* dst = gmax + (long)qi * ngroups + g0;
                 if (k == 7u && g0 >= lo) {
-                    *reinterpret_cast<f32x4_t*>(dst) = v0;
-                    *reinterpret_cast<f32x4_t*>(dst + 4) = v1;
+                    TK_GST(reinterpret_cast<f32x4_t*>(dst), v0);
+                    TK_GST(reinterpret_cast<f32x4_t*>(dst + 4), v1);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
