@@ -1165,48 +1165,29 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
         if (h & 1) tk4_issue<QW, 1, AUX>(st, tile, h < nh, h);
         else tk4_issue<QW, 0, AUX>(st, tile, h < nh, h);
     }
-    f32x4_t acc[4];
+    // two accumulator sets: the tile being multiplied and the previous one, whose maxima are taken UNDER the current tile's MFMAs
+    f32x4_t accA[4], accB[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) accA[j] = accB[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int qi = 64 * w + lane;                                  // this lane's query in the group-max matrix
     float best = -INFINITY;
     unsigned vcur = v0;
     long vhi = (v0 + 1) * ng32 / nv;
     const unsigned stg = st.pbase + 512 + lane * 32;
     const unsigned qoff = (unsigned)(((long)qi * ngroups) & 3);
-    auto finish_tile = [&](long tile) {
-        // (the MFMAs are inline asm: the compiler's hazard recogniser does not see them -- their results are read >= 100 cycles later,
-        // behind this LDS round trip)
-        const u32x4_t ivb = asm_ds_read_b128<0>(st.pbase + (unsigned)(tile & 7) * 64 + lg * 16);
-        asm volatile("s_nop 7\n\ts_nop 7");
-        asm_wait_lgkm<0>();
-        const f32x4_t iv = __builtin_bit_cast(f32x4_t, ivb);
-        float m[4];
-        if (tile * 16 + 16 <= rows) {                              // every tile but a ragged last one: no row masks
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                m[j] = tk5_max(tk5_max(acc[j][0] * iv[0], acc[j][1] * iv[1]), tk5_max(acc[j][2] * iv[2], acc[j][3] * iv[3]));
-        } else {
-            const long r0 = tile * 16 + 4 * lg;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x = fmaxf(x, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
-                m[j] = x;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        // maxima over the four 16-lane rows for the four query tiles at once, as a reduce-scatter: after the 32-lane swap the lower
-        // half of the wave owns tiles 0 / 1, the upper half tiles 2 / 3; after the 16-lane swap row lg owns tile lg, i.e. the lane
-        // holds the group maximum of query 16 lg + li = its own query (6 instructions instead of 4 full reductions and a select)
+    // maxima over the four 16-lane rows for the four query tiles at once, as a reduce-scatter: after the 32-lane swap the lower half
+    // of the wave owns tiles 0 / 1, the upper half tiles 2 / 3; after the 16-lane swap row lg owns tile lg, i.e. the lane holds the
+    // group maximum of query 16 lg + li = its own query (6 instructions instead of 4 full reductions and a select)
+    auto rows_to_mine = [&](const float (&m)[4]) {
         const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[0]), __float_as_uint(m[2]), false, false);
         const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[1]), __float_as_uint(m[3]), false, false);
         const float r02 = tk5_max(__uint_as_float(s02[0]), __uint_as_float(s02[1]));
         const float r13 = tk5_max(__uint_as_float(s13[0]), __uint_as_float(s13[1]));
         const auto sq = __builtin_amdgcn_permlane16_swap(__float_as_uint(r02), __float_as_uint(r13), false, false);
-        const float mine = tk5_max(__uint_as_float(sq[0]), __uint_as_float(sq[1]));
+        return tk5_max(__uint_as_float(sq[0]), __uint_as_float(sq[1]));
+    };
+    // what follows a tile's group maximum `mine`: the virtual wave's running maximum, the octet staging, the 32-byte stores
+    auto fin_tail = [&](long tile, float mine) {
         best = fmaxf(best, mine);
         if (tile == vhi - 1) {                                     // end of a virtual wave's range
             if (wmax && qi < nq) wmax[(long)qi * nv + vcur] = best;
@@ -1216,6 +1197,20 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
         }
         const unsigned k = ((unsigned)tile + qoff) & 7u;
         asm volatile("ds_write_b32 %0, %1" ::"v"(stg + k * 4u), "v"(mine) : "memory");
+        if (exp_fin >= 2) {      // timing experiments (wrong results): the same bytes as aligned 64-byte (2) / 128-byte (3) runs per lane
+            const unsigned per = exp_fin == 2 ? 16u : 32u;
+            if ((((unsigned)tile) & (per - 1)) == per - 1 && qi < nq) {
+                const u32x4_t s0 = asm_ds_read_b128<0>(stg), s1 = asm_ds_read_b128<16>(stg);
+                asm_wait_lgkm<0>();
+                const f32x4_t v0 = __builtin_bit_cast(f32x4_t, s0), v1 = __builtin_bit_cast(f32x4_t, s1);
+                float* d = reinterpret_cast<float*>(reinterpret_cast<unsigned long>(gmax + (long)qi * ngroups + tile - (per - 1)) & ~(unsigned long)(per * 4 - 1));
+                for (unsigned e = 0; e < per / 8; ++e) {
+                    *reinterpret_cast<f32x4_t*>(d + 8 * e) = v0;
+                    *reinterpret_cast<f32x4_t*>(d + 8 * e + 4) = v1;
+                }
+            }
+            return;
+        }
         if (k == 7u || tile == hi - 1) {
             const u32x4_t s0 = asm_ds_read_b128<0>(stg), s1 = asm_ds_read_b128<16>(stg);
             asm_wait_lgkm<0>();
@@ -1234,6 +1229,31 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
             }
         }
     };
+    // the whole epilogue of a tile in one piece (the last tile of the range -- nothing left to hide it under; the only one that can
+    // be ragged).  The MFMAs are inline asm: the compiler's hazard recogniser does not see them -- their results are read >= 100
+    // cycles later, behind this LDS round trip.
+    auto fin_full = [&](f32x4_t (&ac)[4], long tile) {
+        const u32x4_t ivb = asm_ds_read_b128<0>(st.pbase + (unsigned)(tile & 7) * 64 + lg * 16);
+        asm volatile("s_nop 7\n\ts_nop 7");
+        asm_wait_lgkm<0>();
+        const f32x4_t iv = __builtin_bit_cast(f32x4_t, ivb);
+        float m[4];
+        if (tile * 16 + 16 <= rows) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                m[j] = tk5_max(tk5_max(ac[j][0] * iv[0], ac[j][1] * iv[1]), tk5_max(ac[j][2] * iv[2], ac[j][3] * iv[3]));
+        } else {
+            const long r0 = tile * 16 + 4 * lg;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x = fmaxf(x, (r0 + r < rows) ? ac[j][r] * iv[r] : -INFINITY);
+                m[j] = x;
+            }
+        }
+        fin_tail(tile, rows_to_mine(m));
+    };
     // Rolling fragment registers: a[0..5] (k-steps 0..5 of a half-tile) are re-loaded for half-tile h + 1 as soon as the MFMAs of
     // half-tile h have issued past them, a[6..11] at the top of h: LDS latency, the DMA issue and the barrier all sit under
     // MFMAs of the same wave (one wave per SIMD: nobody else could hide them).
@@ -1246,16 +1266,26 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
     // The MFMAs are written out: 64 of the 96 query fragments are pinned to AGPRs and go into the MFMA as its B operand directly
     // (left to itself hipcc parks ~230 registers of them in AGPRs as well but copies four registers back per use:
     // v_accvgpr_read x 4 in front of most MFMAs -- issue slots a one-wave-per-SIMD kernel does not have to spare).
-#define TK5_MFMA(J, HALF, SH) tk5_mfma<((J) * 24 + 12 * (HALF) + (SH) < 64)>(a[SH], qf[J][12 * (HALF) + (SH)], acc[J]);
-#define TK5_STEP(HALF, SH, W)                                                                                   \
+#define TK5_MFMA(ACC, J, HALF, SH) tk5_mfma<((J) * 24 + 12 * (HALF) + (SH) < 64)>(a[SH], qf[J][12 * (HALF) + (SH)], ACC[J]);
+#define TK5_STEP(ACC, HALF, SH, W)                                                                              \
     asm_wait_lgkm<W>();                                                                                        \
-    TK5_MFMA(0, HALF, SH) TK5_MFMA(1, HALF, SH) TK5_MFMA(2, HALF, SH) TK5_MFMA(3, HALF, SH)
+    TK5_MFMA(ACC, 0, HALF, SH) TK5_MFMA(ACC, 1, HALF, SH) TK5_MFMA(ACC, 2, HALF, SH) TK5_MFMA(ACC, 3, HALF, SH)
+    // The previous tile's epilogue, in pieces that sit between the MFMA groups of the current tile (plain VALU code between two
+    // scheduling barriers: it issues in the shadow of the four MFMAs next to it).  PREV holds the finished tile; its inverse norms
+    // were requested at the top of the first half (TK5_PINV: one more LDS read in flight there, hence X = 1 on that half's
+    // counted waits) and have arrived, in order, before the second half's first wait.
+#define TK5_PINV(TILE) ivb_d = asm_ds_read_b128<0>(st.pbase + (unsigned)((TILE) & 7) * 64 + lg * 16); __builtin_amdgcn_sched_barrier(0);
+#define TK5_FIN(PREV, J)                                                                                        \
+    md[J] = tk5_max(tk5_max(PREV[J][0] * iv_d[0], PREV[J][1] * iv_d[1]), tk5_max(PREV[J][2] * iv_d[2], PREV[J][3] * iv_d[3])); \
+    PREV[J] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // one half-tile: `slot` holds it, its first six fragments are already on their way (or there)
-#define TK5_HALF(HALF, TILE_NEXT, LIVE)                                                                         \
+#define TK5_HALF(ACC, HALF, TILE_NEXT, LIVE, X, PRE, F0, F1, F2, F3, F4)                                        \
     {                                                                                                          \
         const unsigned sb = st.rbase + slot * TKR_HALF_BYTES;                                                  \
         TK5_READ6(1, sb)                                                                                       \
-        TK5_STEP(HALF, 0, 6) TK5_STEP(HALF, 1, 6) TK5_STEP(HALF, 2, 6) TK5_STEP(HALF, 3, 6) TK5_STEP(HALF, 4, 6) TK5_STEP(HALF, 5, 6) \
+        PRE                                                                                                    \
+        TK5_STEP(ACC, HALF, 0, 6 + X) F0 TK5_STEP(ACC, HALF, 1, 6 + X) F1 TK5_STEP(ACC, HALF, 2, 6 + X) F2         \
+        TK5_STEP(ACC, HALF, 3, 6 + X) F3 TK5_STEP(ACC, HALF, 4, 6 + X) F4 TK5_STEP(ACC, HALF, 5, 6 + X)            \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         tkr_wait_vm<C::WAIT>();                                                                                \
         pp_barrier();                                                                                          \
@@ -1263,8 +1293,21 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
         slot = slot == C::NS - 1 ? 0 : slot + 1;                                                               \
         const unsigned sn = st.rbase + slot * TKR_HALF_BYTES;                                                  \
         TK5_READ6(0, sn)                                                                                       \
-        TK5_STEP(HALF, 6, 11) TK5_STEP(HALF, 7, 10) TK5_STEP(HALF, 8, 9) TK5_STEP(HALF, 9, 8) TK5_STEP(HALF, 10, 7) TK5_STEP(HALF, 11, 6) \
+        TK5_STEP(ACC, HALF, 6, 11 + X) TK5_STEP(ACC, HALF, 7, 10 + X) TK5_STEP(ACC, HALF, 8, 9 + X)               \
+        TK5_STEP(ACC, HALF, 9, 8 + X) TK5_STEP(ACC, HALF, 10, 7 + X) TK5_STEP(ACC, HALF, 11, 6 + X)               \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    // one tile into ACC while PREV (tile T - 1, if the range has one) is reduced; ends with PREV's stores
+#define TK5_TILE(ACC, PREV, T)                                                                                  \
+    {                                                                                                          \
+        u32x4_t ivb_d;                                                                                         \
+        float md[4], mine_d;                                                                                   \
+        TK5_HALF(ACC, 0, (T) + C::D / 2, h + C::D < nh, 1, TK5_PINV((T) - 1), , , , , )                         \
+        const f32x4_t iv_d = __builtin_bit_cast(f32x4_t, ivb_d);                                               \
+        TK5_HALF(ACC, 1, (T) + C::D / 2, h + 1 + C::D < nh, 0, , TK5_FIN(PREV, 0), TK5_FIN(PREV, 1), TK5_FIN(PREV, 2), \
+                 TK5_FIN(PREV, 3), mine_d = rows_to_mine(md);)                                        \
+        if ((T) > lo && exp_fin != 1) fin_tail((T) - 1, mine_d);                                               \
+        h += 2;                                                                                                \
     }
     int slot = 0;
     long h = 0;
@@ -1275,18 +1318,21 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
         TK5_READ6(0, s0)
         asm_wait_lgkm<0>();
     }
-    for (long t = lo; t < hi; ++t, h += 2) {
-        TK5_HALF(0, t + C::D / 2, h + C::D < nh)
-        TK5_HALF(1, t + C::D / 2, h + 1 + C::D < nh)
-        if (exp_fin == 1) {
-            asm_wait_lgkm<0>();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        } else {
-            finish_tile(t);
-        }
+    long t = lo;
+    for (; t + 1 < hi; t += 2) {
+        TK5_TILE(accA, accB, t)
+        TK5_TILE(accB, accA, t + 1)
     }
+    if (t < hi) {                                                  // odd range: one more tile into accA, then it is the last
+        TK5_TILE(accA, accB, t)
+        if (exp_fin != 1) fin_full(accA, t);
+    } else if (exp_fin != 1) {
+        fin_full(accB, hi - 1);
+    }
+#undef TK5_TILE
 #undef TK5_HALF
+#undef TK5_FIN
+#undef TK5_PINV
 #undef TK5_STEP
 #undef TK5_MFMA
 #undef TK5_READ6
