@@ -167,9 +167,10 @@ def cpu_retrieval_baseline(d=768, k=10):
 def bench_retrieval(dev, n=700_000, d=768, k=10, full=True):
     """brute-force top-10 over one GPU's 700k x 768 fp16 shard of the 5.6M pool (configs[3]); whole search incl. the exact
     re-score.  q16 / q64: interactive, HBM-bound (queries in registers, pool streamed once); q128 / q256: still one pass over the
-    pool (64 register-resident queries per wave, 2 / 4 waves share one LDS ring of pool tiles); q1024: one MFMA sweep; q100000:
-    config 4's per-GPU work (98 sweeps).  The workspace is allocated once per query count (search_shard would otherwise
-    torch.empty it per call) and 5 untimed searches precede the timed ones."""
+    pool (64 register-resident queries per wave, 2 / 4 waves share one LDS ring of pool tiles); q1024 and more: 256-query sweeps
+    of the same streaming scan (measured faster than one GEMM-shaped 1024-query sweep although the pool is read 4 x); q100000:
+    config 4's per-GPU work.  The workspace is allocated once per query count (search_shard would otherwise torch.empty it per
+    call) and 5 untimed searches precede the timed ones."""
     from uniir_amd import retrieval
     g = torch.Generator(device=dev).manual_seed(2023)
     pool = torch.randn(n, d, generator=g, device=dev).half()
@@ -190,9 +191,10 @@ def bench_retrieval(dev, n=700_000, d=768, k=10, full=True):
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / iters
-        sweeps = -(-nq // retrieval.QUERY_CHUNK)      # the pool shard is read once per query chunk
+        per_sweep = retrieval.sweep_queries(d, n)
+        sweeps = -(-nq // per_sweep)                  # the pool shard is read once per query chunk
         out[f"q{nq}"] = {"M_candidates_per_s": round(n / t / 1e6, 1), "M_scores_per_s": round(nq * n / t / 1e6, 1),
-                         "ms": round(t * 1e3, 3), "sweeps": sweeps, "queries_per_sweep": min(nq, retrieval.QUERY_CHUNK),
+                         "ms": round(t * 1e3, 3), "sweeps": sweeps, "queries_per_sweep": min(nq, per_sweep),
                          "hbm": {"achieved": round(sweeps * n * d * 2 / t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                  "frac": round(sweeps * n * d * 2 / t / HBM_PEAK, 4)},
                          "mfma": {"achieved": round(2.0 * nq * n * d / t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,

@@ -398,9 +398,11 @@ int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows);
 int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
                   int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
                   int64_t* out_ids, void* workspace, int64_t workspace_bytes, void* stream);
-/* queries per sweep inside uniir_topk_ip (default / maximum 1024; 0 restores the default).  Results never depend on it: the hook
- * exists so that tests can drive the sweep loop with small inputs.  Process-wide host setting. */
+/* queries per sweep inside uniir_topk_ip: 0 (default) = automatic -- 256 where the streaming scan applies (dim 768, >= 32768 rows,
+ * shard < 2 GiB), else 1024 = the maximum.  Results never depend on it: the hook exists so that tests can drive the sweep loop with
+ * small inputs, and for tuning.  Process-wide host setting.  uniir_topk_ip_sweep_queries: the value a search of this shape uses. */
 int uniir_topk_set_chunk(int32_t queries_per_sweep);
+int32_t uniir_topk_ip_sweep_queries(int32_t dim, int64_t rows);
 /* k-way merge of per-shard results (score desc, id asc): in [nshard][nq][k] -> out [nq][k] */
 int uniir_topk_merge(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k,
                      float* out_scores, int64_t* out_ids, void* stream);

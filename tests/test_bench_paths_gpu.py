@@ -108,6 +108,35 @@ def test_search_shard_multi_sweep_loop_equals_the_oracle(monkeypatch):
         assert lib.uniir_topk_set_chunk(0) == 0
 
 
+def test_sweep_size_is_automatic_and_both_bulk_scans_equal_the_oracle():
+    """uniir_topk_ip picks 256-query sweeps where the streaming scan applies (dim 768, >= 2048 groups) and 1024 elsewhere; the same
+    700-query search run as 256 + 256 + 188 (streaming scan) and, forced, as one 700-query sweep (GEMM-shaped scan) gives the
+    oracle's scores bit for bit and its ids either way"""
+    from oracle import c_oracle
+    from uniir_amd import _lib, retrieval
+    lib = _lib.load()
+    assert retrieval.sweep_queries(768, 700_000) == 256 and retrieval.sweep_queries(768, 40_030) == 256
+    assert retrieval.sweep_queries(512, 700_000) == 1024 and retrieval.sweep_queries(768, 20_000) == 1024
+    n, d, nq, k = 40_030, 768, 700, 10
+    g = torch.Generator(device=DEV).manual_seed(321)
+    pool = torch.randn(n, d, device=DEV, generator=g).half()
+    pool[n - 1] = pool[5]
+    queries = torch.randn(nq, d, device=DEV, generator=g).half()
+    queries[300] = pool[5]
+    ids = torch.randperm(n, device=DEV, generator=g).to(torch.int64) * 2 + 11
+    ws, wi = c_oracle.topk(pool.cpu().numpy(), ids.cpu().numpy(), queries.cpu().numpy(), k)
+    shard = retrieval.PoolShard(pool, ids)
+    try:
+        for chunk in (0, 1024):
+            assert lib.uniir_topk_set_chunk(chunk) == 0
+            assert retrieval.sweep_queries(768, n) == (256 if chunk == 0 else 1024)
+            s, i = retrieval.search_shard(shard, queries, k)
+            assert np.array_equal(i.cpu().numpy(), wi), chunk
+            assert np.array_equal(s.cpu().numpy(), ws), chunk
+    finally:
+        assert lib.uniir_topk_set_chunk(0) == 0
+
+
 def test_vit_l14_forward_only_modality_masks_against_the_oracle():
     """6 items through the no-grad towers of the headline model: 2 image-only, 2 text-only, 2 pairs (clip_sf.py:61-62: the
     masked tower's output is multiplied by 0, so a masked-out modality must contribute exactly nothing)"""

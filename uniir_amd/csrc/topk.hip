@@ -1582,6 +1582,13 @@ static_assert(sizeof(TkFiltCtrl) <= TK_SPARSE_CTRL_BYTES, "control block outgrew
 // wmax / nw_out (optional): room for [nq][1024] per-wave maxima; *nw_out = the number of waves when the scan wrote them, else 0.
 // sparse (optional, with kc set): the caller can consume the filtered output -> the scan may run as topk_stream3_kernel and then
 // returns 2 (nothing is written to gmax).
+// does the shared-ring streaming scan (topk_stream5_kernel<2 / 4>) take a sweep of nq (65 .. 256) queries over this shard?
+static bool stream_shared_ok(int dim, int64_t rows, int nq) {
+    static const char* env_s4 = getenv("UNIIR_TOPK_STREAM4");    // "0": the ping-pong GEMM scan instead (A/B; the name is historic)
+    const int s4_max = (env_s4 && env_s4[0] == '2') ? 128 : 256;
+    const long ngroups = (rows + TK_G - 1) / TK_G;
+    return nq > 64 && nq <= s4_max && dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048 && !(env_s4 && env_s4[0] == '0');
+}
 template <int QW, int A>
 static void launch_stream5(int nv, hipStream_t st0, const void* pool_f16, const float* pool_inv_norm, long rows,
                            const void* queries_f16, int nq, float* gmax, long ngroups, float* wm) {
@@ -1687,11 +1694,9 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
         return 1;
     }
     // 65 .. 256 queries, dim 768: the shared-ring streaming scan (queries in registers, 64 per wave)
-    static const char* env_s4 = getenv("UNIIR_TOPK_STREAM4");    // "0": the ping-pong GEMM scan instead (A/B; the name is historic)
     // MEASURED (round 3, 700 k rows, whole search): 128 queries 0.224-0.239 ms vs 0.280-0.291 (ping-pong GEMM scan), 256 queries
-    // 0.331-0.345 vs 0.376; "2": up to 128 queries only
-    const int s4_max = (env_s4 && env_s4[0] == '2') ? 128 : 256;
-    if (nq > 64 && nq <= s4_max && dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048 && !(env_s4 && env_s4[0] == '0')) {
+    // 0.318-0.345 vs 0.376; UNIIR_TOPK_STREAM4 = "2": up to 128 queries only, "0": never
+    if (stream_shared_ok(dim, rows, nq)) {
         static int ncu4 = 0;
         if (!ncu4) {
             int d = 0;
@@ -2584,21 +2589,33 @@ static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int
 // latency-bound and one 1024-thread workgroup per query serialises what the three launches spread over the whole chip:
 // 98 us instead of 80 us behind the 217-us scan; at 1024 queries it made no difference.)
 #define TKI_CHUNK_MAX 1024
-static int g_tki_chunk = TKI_CHUNK_MAX;
-#define TKI_CHUNK g_tki_chunk
-// queries per sweep of uniir_topk_ip: 0 restores the default (1024, the most the group-max scan takes).  A smaller value only
-// forces more sweeps (tests of the sweep loop; tuning); results do not depend on it.  Host-side setting, not thread-safe.
+static int g_tki_chunk = 0;             // 0 = automatic
+// queries per sweep of uniir_topk_ip.  0 = automatic: 256 where the 4-wave streaming scan applies (dim 768, a shard the buffer
+// bound can address, >= 2048 groups), else 1024 (the most the GEMM-shaped scan takes).  MEASURED (round 3, 700 k rows, same box,
+// twice): 16 384 queries 20.14 / 20.24 ms in 256-query sweeps vs 20.91 / 20.87 in 1024-query sweeps; 1024 queries 1.267 / 1.270 vs
+// 1.380 / 1.303 -- four streaming sweeps re-read the pool three more times (HBM is not the limit there) and still beat one GEMM-
+// shaped sweep.  An explicit value only changes the number of sweeps (tests of the sweep loop; tuning); results never depend on it.
+// Host-side setting, not thread-safe.
 extern "C" int uniir_topk_set_chunk(int32_t queries_per_sweep) {
     if (queries_per_sweep < 0 || queries_per_sweep > TKI_CHUNK_MAX) return UNIIR_EINVAL;
-    g_tki_chunk = queries_per_sweep == 0 ? TKI_CHUNK_MAX : queries_per_sweep;
+    g_tki_chunk = queries_per_sweep;
     return UNIIR_OK;
 }
-extern "C" int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows) {
-    if (nq <= 0 || k <= 0 || rows <= 0) return 0;
-    const int chunk = nq < TKI_CHUNK ? nq : TKI_CHUNK;
+extern "C" int32_t uniir_topk_ip_sweep_queries(int32_t dim, int64_t rows) {
+    if (g_tki_chunk) return g_tki_chunk;
+    return stream_shared_ok(dim, rows, 256) ? 256 : TKI_CHUNK_MAX;
+}
+static int64_t tki_ws_bytes(int32_t nq, int32_t k, int64_t rows, int chunk_max) {
+    const int chunk = nq < chunk_max ? nq : chunk_max;
     const int kc = k + 8 < TK_MAXKC ? k + 8 : TK_MAXKC;
     const int64_t ncand = uniir_topk_ncand(chunk, kc);
     return uniir_topk_workspace_bytes(chunk, kc, rows) + (int64_t)nq * 4 + 256 + 2 * ((int64_t)chunk * ncand * 4 + 256);
+}
+extern "C" int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows) {
+    if (nq <= 0 || k <= 0 || rows <= 0) return 0;
+    if (g_tki_chunk) return tki_ws_bytes(nq, k, rows, g_tki_chunk);
+    const int64_t a = tki_ws_bytes(nq, k, rows, 256), b = tki_ws_bytes(nq, k, rows, TKI_CHUNK_MAX);     // dim is not known here
+    return a > b ? a : b;
 }
 extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
                              int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
@@ -2610,7 +2627,8 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
         ((uintptr_t)workspace & 255))
         return UNIIR_EALIGN;
     if (workspace_bytes < uniir_topk_ip_workspace_bytes(nq, k, rows)) return UNIIR_EINVAL;
-    const int chunk = nq < TKI_CHUNK ? nq : TKI_CHUNK;
+    const int chunk_max = uniir_topk_ip_sweep_queries(dim, rows);
+    const int chunk = nq < chunk_max ? nq : chunk_max;
     const int kc = k + 8;
     const int ncand = uniir_topk_ncand(chunk, kc);
     char* ws = (char*)workspace;

@@ -33,7 +33,14 @@ def query_inv_norms(queries_f16: torch.Tensor) -> torch.Tensor:
     return inv
 
 
-QUERY_CHUNK = 1024   # queries per sweep of the shard inside uniir_topk_ip (its group-max scan takes <= 1024)
+QUERY_CHUNK = 1024   # the most queries one sweep of the shard takes inside uniir_topk_ip
+
+
+def sweep_queries(dim, rows):
+    """queries per sweep uniir_topk_ip uses on a shard of this shape (256 where the streaming scan applies, else 1024)"""
+    from . import _lib
+    return int(_lib.load().uniir_topk_ip_sweep_queries(int(dim), int(rows)))
+
 MAX_K_DIRECT = 64 - COARSE_MARGIN     # 56: the scan keeps k + 8 <= 64 groups per query
 
 
