@@ -264,3 +264,35 @@ def test_deferred_device_image_transform_through_dataset_collator_prefetcher(tmp
     assert torch.equal(batches["cpu"]["image_mask_batched"], batches["gpu"]["image_mask_batched"])
     assert torch.equal(a, b)
     assert (b[batches["gpu"]["image_mask_batched"] == 0] == 0).all() and batches["gpu"]["image_mask_batched"].sum().item() == 6
+
+
+def test_retriever_shard_loop_with_several_shards_equals_one_shard_and_the_oracle(tmp_path, monkeypatch):
+    """mbeir_retriever.search_index over an index file split into 3 row shards (reference mbeir_retriever.py:98-100, 204-206:
+    the index spread over all visible GPUs) -- on this one-GPU box the three shards share the device (UNIIR_RETRIEVER_SHARDS=3),
+    which still runs the per-shard searches, the stacking on the first shard's device and the k-way merge: distances and ids
+    identical to the single-shard search and to the C oracle over the whole pool"""
+    import numpy as np
+    from common import mbeir_retriever
+    from oracle import c_oracle
+    rng = np.random.default_rng(5)
+    n, d, nq, k = 5_003, 64, 37, 10
+    emb = rng.standard_normal((n, d)).astype(np.float16)
+    emb[4000] = emb[7]                                   # a tie across shards: broken by id
+    ids = (rng.permutation(n).astype(np.int64) * 3 + 5)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    q[3] = emb[7]
+    index_path, q_path = str(tmp_path / "pool.index"), str(tmp_path / "q.npy")
+    with open(index_path, "wb") as f:
+        np.savez(f, emb=emb, ids=ids)
+    np.save(q_path, q)
+    want_s, want_i = c_oracle.topk(emb, ids, q, k)
+    res = {}
+    for shards in ("1", "3"):
+        monkeypatch.setenv("UNIIR_RETRIEVER_SHARDS", shards)
+        mbeir_retriever._SHARD_CACHE.clear()
+        res[shards] = mbeir_retriever.search_index(q_path, index_path, batch_size=16, num_cand_to_retrieve=k)
+        assert len(mbeir_retriever._device_shards(index_path)) == int(shards)
+    mbeir_retriever._SHARD_CACHE.clear()
+    for shards in ("1", "3"):
+        assert np.array_equal(res[shards][1], want_i), shards
+        assert np.array_equal(res[shards][0], want_s), shards

@@ -74,15 +74,20 @@ def _device_shards(cand_index_path):
         _SHARD_CACHE.clear()
         with np.load(cand_index_path) as z:
             emb, ids = z["emb"], z["ids"]
-        ngpu = max(1, torch.cuda.device_count())
+        ndev = max(1, torch.cuda.device_count())
+        # UNIIR_RETRIEVER_SHARDS (tests): that many row shards, placed round-robin on the visible devices -- the N > 1 shard loop
+        # and the merge on a box with one GPU
+        ngpu = int(os.environ.get("UNIIR_RETRIEVER_SHARDS", "0")) or ndev
         per = -(-len(ids) // ngpu)
         shards = []
         for g in range(ngpu):
             lo, hi = min(g * per, len(ids)), min((g + 1) * per, len(ids))
-            dev = torch.device("cuda", g)
+            if hi <= lo:
+                continue
+            dev = torch.device("cuda", g % ndev)
             with torch.cuda.device(dev):
                 shards.append(retrieval.PoolShard(torch.from_numpy(emb[lo:hi]).to(dev), torch.from_numpy(ids[lo:hi]).to(dev)))
-        print(f"Retriever: {len(ids)} documents sharded over {ngpu} GPU(s)")
+        print(f"Retriever: {len(ids)} documents in {len(shards)} shard(s) over {min(ngpu, ndev)} GPU(s)")
         _SHARD_CACHE[key] = shards
     return _SHARD_CACHE[key]
 
