@@ -14,7 +14,8 @@
 #include "../../include/uniir_hip.h"
 #include <stdlib.h>
 
-// K / V / Q / dO of a head are read by exactly one workgroup: -DUNIIR_ATT_NT=1 stages them with the nt policy (A/B build)
+// K / V / Q / dO of a head are read by exactly one workgroup: -DUNIIR_ATT_NT=1 stages them with the nt policy (A/B build).
+// MEASURED (round 3, same box, interleaved twice): step 634.5 / 635.6 ms plain, 637.7 / 637.2 ms nt -> stays off.
 #ifndef UNIIR_ATT_NT
 #define UNIIR_ATT_NT 0
 #endif

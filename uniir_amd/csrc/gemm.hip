@@ -8,10 +8,11 @@
 #include "../../include/uniir_hip.h"
 #include <stdlib.h>
 
-// per-row epilogue operands (residual stream, stashed pre-activation) are read exactly once: -DUNIIR_EPI_NT=1 loads them with the
-// nt policy (A/B build)
+// per-row epilogue operands (residual stream, stashed pre-activation) are read exactly once: loaded with the nt policy.
+// MEASURED (round 3, same box, interleaved twice, ViT-L/14 512-pair step): 634.5 / 635.6 ms with plain loads, 632.9 / 631.9 ms with
+// nt (+0.4 %); -DUNIIR_EPI_NT=0 builds the plain loads.
 #ifndef UNIIR_EPI_NT
-#define UNIIR_EPI_NT 0
+#define UNIIR_EPI_NT 1
 #endif
 #if UNIIR_EPI_NT
 #define EPI_LD(p) __builtin_nontemporal_load(p)
