@@ -326,6 +326,14 @@ int uniir_softce(const float* sim, const float* sim_m, const float* temp, const 
 /* uniir_sgemm with C += instead of C = (dq = dsim[:, :b] p_m + dsim[:, b:] queue^T without a concatenated copy) */
 int uniir_sgemm_acc(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                     float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream);
+/* The same product for a LONG reduction with few output tiles (BLIP: d feat = dsim[b][K] x queue[K][E], K = 57 344): deterministic
+ * split-K -- slices of whole K steps into slabs of the caller's workspace, added in slice order.  Reproducible run to run; differs
+ * from uniir_sgemm's k-ordered chain in the last bits (so the logits never take it).  accumulate != 0: C += alpha * A B.
+ * Falls back to the plain kernel when there is nothing to split. */
+int64_t uniir_sgemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int uniir_sgemm_splitk(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+                       int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [DROPOUT] train-mode dropout / DropPath of the BLIP and T5 stacks.  Masks are counter based: element idx of a call

@@ -61,28 +61,48 @@ def test_blip_queue_logits_and_backward_at_the_real_queue_size(hn):
     want = _oracle_chains(a.cpu().numpy(), torch.cat(cols, 0).cpu().numpy())
     got = out.cpu().numpy()
     assert np.array_equal(got, want), float(np.abs(got - want).max())
-    # backward: d a = sum over blocks of dsim[:, cols] @ block, first block overwrites, the others accumulate
+    # backward: d a = sum over blocks of dsim[:, cols] @ block, first block overwrites, the others accumulate.  The queue block
+    # (a reduction over 57 344 columns into 2 x 6 output tiles) runs as the deterministic split-K form in blip_model; both forms
+    # are checked: the un-split k-ordered chain bit for bit, the split form against the chain restated per slice in slice order
+    from uniir_amd import _lib
+    lib = _lib.load()
     dsim = torch.randn(b, n, device=DEV, generator=g) * 1e-2
-    da = torch.full((b, E), float("nan"), device=DEV)
-    col, first = 0, True
-    for kind, t, arg in blocks:
-        fn = "uniir_sgemm" if first else "uniir_sgemm_acc"
-        if kind == "rows":
-            ops.call(fn, dsim[:, col:], n, 1, t, E, 1, da, E, b, E, arg, 1.0)
-            col += arg
-        else:
-            ops.call(fn, dsim[:, col:], n, 1, t[:, arg:], 1, K, da, E, b, E, K - arg, 1.0)
-            col += K - arg
-        first = False
     dn = dsim.cpu().numpy()
-    want_da, col = None, 0
-    for mat in cols:                                # chain over the block's columns, blocks added in fp32 in call order
-        w = mat.shape[0]
-        part = _oracle_chains(dn[:, col:col + w], mat.t().contiguous().cpu().numpy())
-        want_da = part if want_da is None else (want_da + part).astype(np.float32)
-        col += w
-    got_da = da.cpu().numpy()
-    assert np.array_equal(got_da, want_da), float(np.abs(got_da - want_da).max())
+    for split in (False, True):
+        da = torch.full((b, E), float("nan"), device=DEV)
+        col, first = 0, True
+        for kind, t, arg in blocks:
+            fn = "uniir_sgemm" if first else "uniir_sgemm_acc"
+            if kind == "rows":
+                ops.call(fn, dsim[:, col:], n, 1, t, E, 1, da, E, b, E, arg, 1.0)
+                col += arg
+            elif not split:
+                ops.call(fn, dsim[:, col:], n, 1, t[:, arg:], 1, K, da, E, b, E, K - arg, 1.0)
+                col += K - arg
+            else:
+                ws = torch.empty(int(lib.uniir_sgemm_splitk_workspace_bytes(b, E, K - arg)), device=DEV, dtype=torch.uint8)
+                ops.call("uniir_sgemm_splitk", dsim[:, col:], n, 1, t[:, arg:], 1, K, da, E, b, E, K - arg, 1.0,
+                         0 if first else 1, ws, ws.numel())
+                col += K - arg
+            first = False
+        want_da, col = None, 0
+        for bi, mat in enumerate(cols):              # chain over the block's columns, blocks added in fp32 in call order
+            w = mat.shape[0]
+            mt = mat.t().contiguous().cpu().numpy()
+            if split and bi == len(cols) - 1:        # the library's slicing: ~1024 workgroups, whole 16-column K steps per slice
+                tiles = -(-b // 128) * -(-E // 128)
+                splits = max(1, min(-(-1024 // tiles), w // (16 * 8)))
+                kslice = -(-(w // 16) // splits) * 16
+                part = None
+                for k0 in range(0, w, kslice):
+                    sl = _oracle_chains(dn[:, col + k0:col + min(w, k0 + kslice)], mt[:, k0:min(w, k0 + kslice)])
+                    part = sl if part is None else (part + sl).astype(np.float32)
+            else:
+                part = _oracle_chains(dn[:, col:col + w], mt)
+            want_da = part if want_da is None else (want_da + part).astype(np.float32)
+            col += w
+        got_da = da.cpu().numpy()
+        assert np.array_equal(got_da, want_da), (split, float(np.abs(got_da - want_da).max()))
 
 
 def test_search_shard_multi_sweep_loop_equals_the_oracle(monkeypatch):

@@ -102,6 +102,8 @@ SIGNATURES = {
     "uniir_ema_update": (c_int, [P, P, P, c_i64, c_float, S]),
     "uniir_softce": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, P, P, P, P, P, S]),
     "uniir_sgemm_acc": (c_int, [P, c_i64, c_i64, P, c_i64, c_i64, P, c_i64, c_int, c_int, c_int, c_float, S]),
+    "uniir_sgemm_splitk_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
+    "uniir_sgemm_splitk": (c_int, [P, c_i64, c_i64, P, c_i64, c_i64, P, c_i64, c_int, c_int, c_int, c_float, c_int, P, c_i64, S]),
     "uniir_pool_inv_norms": (c_int, [P, c_i64, c_int, P, S]),
     "uniir_topk_workspace_bytes": (c_i64, [c_int, c_int, c_i64]),
     "uniir_topk_ncand": (c_int, [c_int, c_int]),

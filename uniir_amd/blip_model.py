@@ -22,7 +22,7 @@ import math
 import torch
 from torch import nn
 
-from . import comm, ops
+from . import _lib, comm, ops
 from .clip_model import ALIGN, _Blk, _tower_bwd, _tower_fwd
 
 VIT_CONFIGS = {   # src/models/uniir_blip/backbone/blip.py:229-255 (create_vit)
@@ -474,8 +474,12 @@ class _SoftTargetLossFn(torch.autograd.Function):
                 if kind == "rows":
                     ops.call(fn, dsim[:, col:], n, 1, t, E, 1, da, E, b, E, arg, 1.0)
                     col += arg
-                else:
-                    ops.call(fn, dsim[:, col:], n, 1, t[:, arg:], 1, K, da, E, b, E, K - arg, 1.0)
+                else:       # reduction over the K queue columns, 2 x 6 output tiles: the deterministic split-K form
+                    lib = _lib.load()
+                    need_ws = int(lib.uniir_sgemm_splitk_workspace_bytes(b, E, K - arg))
+                    ws = ops._splitk_workspace(da.device, need_ws, tag="blip_dfeat")
+                    ops.call("uniir_sgemm_splitk", dsim[:, col:], n, 1, t[:, arg:], 1, K, da, E, b, E, K - arg, 1.0,
+                             0 if first else 1, ws, ws.numel())
                     col += K - arg
                 first = False
             return da

@@ -120,9 +120,21 @@ template <bool A_CK, bool B_CK>
 __global__ __launch_bounds__(256) void sgemm128_kernel(const float* __restrict__ A, long sam, long sak,
                                                        const float* __restrict__ B, long sbk, long sbn,
                                                        float* __restrict__ C, long ldc, int M, int N, int K, float alpha_host,
-                                                       const float* __restrict__ alpha_dev, int accumulate) {
+                                                       const float* __restrict__ alpha_dev, int accumulate,
+                                                       float* __restrict__ slab = nullptr, int kslice = 0) {
     __shared__ __attribute__((aligned(16))) float As[SG_BK * SGL_PITCH];
     __shared__ __attribute__((aligned(16))) float Bs[SG_BK * SGL_PITCH];
+    if (slab) {       // split-K: slice blockIdx.z of the reduction -> its own [M][N] slab, un-scaled (sgemm_splitk_reduce_kernel adds them)
+        const int kbeg = blockIdx.z * kslice;
+        A += (long)kbeg * sak;
+        B += (long)kbeg * sbk;
+        K = min(K - kbeg, kslice);
+        C = slab + (long)blockIdx.z * M * N;
+        ldc = N;
+        accumulate = 0;
+        alpha_host = 1.0f;
+        alpha_dev = nullptr;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * SGL_BM, n0 = blockIdx.x * SGL_BN;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
@@ -212,6 +224,67 @@ extern "C" int uniir_sgemm_acc(const float* A, int64_t sam, int64_t sak, const f
                                float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return UNIIR_EINVAL;
     return launch_sgemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, nullptr, (hipStream_t)stream, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Long-reduction form (BLIP: d feat[b][E] = dsim[b][K] x queue[K][E] with K = 57 344 and only 2 x 6 output tiles -- 12 workgroups on
+// 256 CUs, 4.3 ms per call): deterministic split-K.  The reduction is cut into `splits` slices of whole K steps, slice s goes to
+// slab s of a caller-owned workspace, and one pass adds the slabs IN SLICE ORDER (so the result is reproducible run to run; it
+// differs from the un-split k-ordered chain in the last bits, which is why this is a separate entry point and the logits -- whose
+// bit-exactness against the oracle is tested -- never take it).
+__global__ __launch_bounds__(256) void sgemm_splitk_reduce_kernel(const float* __restrict__ slab, int splits, long mn, int N,
+                                                                  float* __restrict__ C, long ldc, float alpha, int accumulate) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= mn) return;
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(slab + i);
+    for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4_t*>(slab + (long)s * mn + i);
+    const long m = i / N, n = i - m * N;              // N % 4 == 0: the four elements share a row
+    float* c = C + m * ldc + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = accumulate ? c[r] + v[r] * alpha : v[r] * alpha;
+}
+static int sgemm_splits(int M, int N, int K) {
+    const long tiles = (long)((M + SGL_BM - 1) / SGL_BM) * ((N + SGL_BN - 1) / SGL_BN);
+    long s = (1024 + tiles - 1) / tiles;               // ~4 workgroups per CU
+    const long max_s = K / (SG_BK * 8);                // >= 8 K steps per slice
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : (int)s;
+}
+extern "C" int64_t uniir_sgemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return (int64_t)sgemm_splits(M, N, K) * M * N * 4;
+}
+extern "C" int uniir_sgemm_splitk(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+                                  int64_t ldc, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    if (!A || !B || !C || !workspace || M <= 0 || N <= 0 || K <= 0) return UNIIR_EINVAL;
+    const bool a_ck = sak == 1, a_cm = sam == 1, b_ck = sbk == 1, b_cn = sbn == 1;
+    auto vec_ok = [](const float* p, long ld, bool contig_k, int ext) {
+        return (((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && (contig_k || ext % 4 == 0);
+    };
+    const int splits = sgemm_splits(M, N, K);
+    // shapes the 128-tile kernel does not take, or nothing to split: the plain kernel
+    if (splits < 2 || K % SG_BK || N % 4 || !(a_ck || a_cm) || !(b_ck || b_cn) || !vec_ok(A, a_ck ? sam : sak, a_ck, M) ||
+        !vec_ok(B, b_ck ? sbn : sbk, b_ck, N))
+        return launch_sgemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, nullptr, (hipStream_t)stream, accumulate);
+    if (((uintptr_t)workspace & 15) || workspace_bytes < uniir_sgemm_splitk_workspace_bytes(M, N, K)) return UNIIR_EINVAL;
+    const int ksteps = K / SG_BK;
+    const int kslice = ((ksteps + splits - 1) / splits) * SG_BK;
+    const int used = (K + kslice - 1) / kslice;        // slices that hold at least one K step
+    hipStream_t st = (hipStream_t)stream;
+    float* slab = (float*)workspace;
+    dim3 grid((N + SGL_BN - 1) / SGL_BN, (M + SGL_BM - 1) / SGL_BM, used);
+#define SGL(AK, BK_) hipLaunchKernelGGL((sgemm128_kernel<AK, BK_>), grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, 1.0f, nullptr, 0, slab, kslice)
+    if (a_ck && b_ck) SGL(true, true);
+    else if (a_ck) SGL(true, false);
+    else if (b_ck) SGL(false, true);
+    else SGL(false, false);
+#undef SGL
+    const long mn = (long)M * N;
+    hipLaunchKernelGGL(sgemm_splitk_reduce_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, slab, used, mn, N, C,
+                       (long)ldc, alpha, accumulate);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
 }
 
 // one block per row: lse, first-argmax, per-row loss and hit.  stats = [lse(b) | loss_i(b) | hit_i(b)]
