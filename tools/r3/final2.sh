@@ -5,7 +5,7 @@ O=$R/gpurun_out/r3final2
 mkdir -p $O
 cd $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"
-bash tools/topk_table.sh > /dev/null 2>&1; cp gpurun_out/topk_table.txt $O/
+true
 python - <<'PY'
 import json
 d=json.loads(open('/root/repo/gpurun_out/r3final2/bench_line.json').read().strip().splitlines()[-1])
