@@ -35,11 +35,15 @@ def test_infonce_full_rank_shape_bit_exact():
     assert abs(loss.item() - l) < 2e-6 * max(1.0, abs(l)) and acc.item() == a
 
 
-@pytest.mark.parametrize("nq", [64, 1024])
-def test_topk_full_shard_properties(nq):
+@pytest.mark.parametrize("nq,n", [(64, 700_000), (1024, 700_000), (128, 700_000), (256, 700_000), (200, 1_398_000), (256, 32_768),
+                                  (130, 32_769)])
+def test_topk_full_shard_properties(nq, n):
+    """size-independent properties at BASELINE's shard size and at the limits of the streaming scans: 1 398 000 rows = the largest
+    shard the 31-bit buffer bound addresses (2 147 328 000 bytes), 32 768 rows = the 2 048 groups they need at least (one more row:
+    a ragged last tile); 64 queries = private rings, 128 / 130 / 200 / 256 = shared rings, 1024 = four 256-query sweeps"""
     from oracle import c_oracle
     from uniir_amd import retrieval
-    n, d, k = 700_000, 768, 10
+    d, k = 768, 10
     g = torch.Generator(device=DEV).manual_seed(11 + nq)
     pool = torch.randn(n, d, device=DEV, generator=g).half()
     queries = torch.randn(nq, d, device=DEV, generator=g).half()
