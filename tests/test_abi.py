@@ -87,3 +87,32 @@ def test_tower_entry_points_plan_and_validate_on_the_host():
     assert lib.uniir_clip_tower_workspace_bytes(ctypes.byref(tt), 8, 1) == -1
     assert lib.uniir_topk_ip_workspace_bytes(100000, 10, 700000) > 1024 * 43750 * 4
     assert lib.uniir_topk_ip(None, None, None, 10, 64, None, 1, 10, None, None, None, 0, None) == -1
+
+
+def test_search_host_logic_sweep_size_and_workspace_sizes():
+    """host-side decisions of the shard search and of the split-K fp32 product (no device work): the automatic sweep size
+    (256 queries where the streaming scans apply: dim 768, >= 2048 groups of 16 rows, a shard under 2 GiB; else 1024), the
+    explicit override, workspace sizes that cover either choice, argument validation"""
+    from uniir_amd import _lib
+    lib = _lib.load()
+    assert lib.uniir_topk_set_chunk(0) == 0
+    assert lib.uniir_topk_ip_sweep_queries(768, 700_000) == 256
+    assert lib.uniir_topk_ip_sweep_queries(768, 32_768) == 256 and lib.uniir_topk_ip_sweep_queries(768, 32_752) == 1024
+    assert lib.uniir_topk_ip_sweep_queries(768, 1_398_101) == 256 and lib.uniir_topk_ip_sweep_queries(768, 1_398_102) == 1024
+    assert lib.uniir_topk_ip_sweep_queries(512, 700_000) == 1024
+    try:
+        assert lib.uniir_topk_set_chunk(64) == 0 and lib.uniir_topk_ip_sweep_queries(768, 700_000) == 64
+        w64 = lib.uniir_topk_ip_workspace_bytes(1000, 10, 700_000)
+        assert lib.uniir_topk_set_chunk(1025) < 0 and lib.uniir_topk_set_chunk(-1) < 0        # rejected, setting unchanged
+        assert lib.uniir_topk_ip_sweep_queries(768, 700_000) == 64
+    finally:
+        assert lib.uniir_topk_set_chunk(0) == 0
+    auto = lib.uniir_topk_ip_workspace_bytes(1000, 10, 700_000)
+    assert auto > w64 > 0                               # automatic: sized for the larger of the 256- and 1024-query layouts
+    assert lib.uniir_topk_ip_workspace_bytes(0, 10, 700_000) == 0 and lib.uniir_topk_ip_workspace_bytes(10, 0, 700_000) == 0
+    # split-K fp32 product: b = 256, E = 768 -> 12 output tiles -> 86 slices of the 57 344-long reduction
+    assert lib.uniir_sgemm_splitk_workspace_bytes(256, 768, 57_344) == 86 * 256 * 768 * 4
+    assert lib.uniir_sgemm_splitk_workspace_bytes(256, 768, 64) == 256 * 768 * 4          # nothing to split: one slab
+    assert lib.uniir_sgemm_splitk_workspace_bytes(0, 768, 64) == 0
+    assert lib.uniir_sgemm_splitk(None, 1, 1, None, 1, 1, None, 1, 4, 4, 16, 1.0, 0, None, 0, None) < 0
+    assert lib.uniir_topk_ip(None, None, None, 10, 768, None, 1, 10, None, None, None, 0, None) < 0
