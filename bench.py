@@ -199,6 +199,8 @@ def bench_retrieval(dev, n=700_000, d=768, k=10, full=True):
                                  "frac": round(sweeps * n * d * 2 / t / HBM_PEAK, 4)},
                          "mfma": {"achieved": round(2.0 * nq * n * d / t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,
                                   "unit": "TFLOP/s", "frac": round(2.0 * nq * n * d / t / MFMA_PEAK_BF16, 4)}}
+    out["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE of the scan kernel, profiles/r03_topk_pmc.txt: "
+                           "1.079 GB fetched per sweep of the 1.075-GB shard (read once), 27.8 MB written at 64 queries, 81.3 MB at 256")
     out["workload"] = (f"top-{k} of {n} x {d} fp16 candidates (one GPU's shard of the 5.6M pool), exact fp32 re-score; "
                        "recall on M-BEIR itself cannot be shown offline (no dataset / checkpoint in the image): exactness is "
                        "pinned against the C oracle instead")
