@@ -179,7 +179,7 @@ def bench_retrieval(dev, n=700_000, d=768, k=10, full=True):
     from uniir_amd import _lib
     for nq in ((16, 64, 128, 256, 1024, 16384, 100_000) if full else (64, 1024)):
         q = torch.randn(nq, d, generator=g, device=dev).half()
-        ws = torch.empty(_lib.load().uniir_topk_ip_workspace_bytes(nq, k, n), device=dev, dtype=torch.uint8)
+        ws = torch.empty(_lib.load().uniir_topk_ip_workspace_bytes_ex(nq, k, n, d), device=dev, dtype=torch.uint8)
         for _ in range(5 if nq <= 1024 else 1):
             retrieval.search_shard(shard, q, k, workspace=ws)
         torch.cuda.synchronize()
@@ -301,6 +301,99 @@ def bench_clip_ff(dev, pairs=256, steps=3, warmup=1):
             "unit": "pairs/s", "ms_per_step": round(dt * 1e3, 2), "pairs_per_gpu": pairs,
             "mfma_frac": round(pairs / dt * FLOP_PER_PAIR["ViT-L/14"] / MFMA_PEAK_BF16, 4),
             "mfma_frac_note": "tower FLOPs only (T5 fusion stack not counted)", "final_loss": round(float(out["loss"].detach()), 4)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1: the other two BASELINE metrics on every rank (configs[2] embedding extraction, configs[3] sharded retrieval)
+# ------------------------------------------------------------------------------------------------------------------
+def _rank_max_seconds(dist, dev, fn, iters):
+    """seconds per call of fn, barrier + synchronize on both sides, maximum over the ranks (the job is as slow as its slowest rank)"""
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    sync()
+    t = torch.tensor([(time.perf_counter() - t0) / iters], device=dev, dtype=torch.float64)
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        return float(h)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
+def bench_retrieval_sharded(dist, dev, rank, world, rows=700_000, d=768, k=10, qcounts=(64, 1024, 100_000), check=False):
+    """configs[3] across the ranks (mbeir_retriever.py:96-100, co.shard = True): every rank holds a `rows` x 768 fp16 shard of the
+    pool resident in HBM (ids disjoint), the job's queries are split contiguously over the ranks, and
+    retrieval.search_resident = all-gather of the queries -> exact top-k on the own shard -> all-gather of the per-shard lists ->
+    k-way merge.  Reported per global query count: whole-search time (max over ranks), M candidates/s over the WORLD x rows pool,
+    and the three exchange / merge pieces timed alone on the same shapes.  check=True (tests): the distributed result must equal
+    one search over the concatenated pool."""
+    from uniir_amd import comm, retrieval
+    g = torch.Generator(device=dev).manual_seed(2023 + rank)
+    pool = torch.randn(rows, d, generator=g, device=dev).half()
+    ids = torch.arange(rows, device=dev, dtype=torch.int64) + rank * rows
+    shard = retrieval.PoolShard(pool, ids)
+    n_total = rows * world
+    seen = torch.ones(1, device=dev)
+    comm.allreduce_sum_(seen)
+    out = {"ranks_seen": int(seen.item()), "rows_per_rank": rows, "pool_rows": n_total, "dim": d, "k": k}
+    for nq in qcounts:
+        gq = torch.Generator(device=dev).manual_seed(7 + nq)          # the same global query set on every rank; each keeps its slice
+        allq = torch.randn(nq, d, generator=gq, device=dev).half()
+        lo, hi = comm.contiguous_shard(nq, world, rank)
+        myq = allq[lo:hi].contiguous()
+        res = retrieval.search_resident(shard, myq, k)                  # warm-up (workspace, attributes)
+        iters = 5 if nq <= 1024 else 1
+        t = _rank_max_seconds(dist, dev, lambda: retrieval.search_resident(shard, myq, k), iters)
+        # the pieces, alone, on this search's shapes
+        t_q = _rank_max_seconds(dist, dev, lambda: comm.all_gather_varlen(myq), 3)
+        loc_s, loc_i = retrieval.search_shard(shard, allq, k)
+        t_g = _rank_max_seconds(dist, dev, lambda: comm.gather_topk(loc_s, loc_i), 3)
+        gs, gi = comm.gather_topk(loc_s, loc_i)
+        t_m = _rank_max_seconds(dist, dev, lambda: retrieval.merge_shards(gs, gi), 3)
+        per_sweep = retrieval.sweep_queries(d, rows)
+        rec = {"ms": round(t * 1e3, 3), "M_candidates_per_s": round(n_total / t / 1e6, 1),
+               "M_scores_per_s": round(nq * n_total / t / 1e6, 1), "queries_per_rank": hi - lo,
+               "sweeps_per_shard": -(-nq // per_sweep),
+               "all_gather_queries_ms": round(t_q * 1e3, 3), "gather_topk_ms": round(t_g * 1e3, 3), "merge_ms": round(t_m * 1e3, 3),
+               "mfma_frac": round(2.0 * nq * n_total * d / t / (world * MFMA_PEAK_BF16), 4),
+               "hbm_frac": round(-(-nq // per_sweep) * n_total * d * 2 / t / (world * HBM_PEAK), 4)}
+        if check:         # == one search over the concatenated pool (rank-major rows), bit for bit
+            allpool, _ = comm.all_gather_varlen(pool)
+            allids, _ = comm.all_gather_varlen(ids)
+            ref_s, ref_i = retrieval.search_shard(retrieval.PoolShard(allpool, allids), myq, k)
+            rec["equals_single_shard_search"] = bool(torch.equal(res[0], ref_s) and torch.equal(res[1], ref_i))
+            del allpool, allids
+        out[f"q{nq}"] = rec
+    out["workload"] = (f"top-{k} of {nq} .. global queries over {world} x {rows} x {d} fp16 candidates, one shard per rank, "
+                       "retrieval.search_resident (queries all-gathered, per-shard exact top-k, lists all-gathered, k-way merge)")
+    return out
+
+
+def bench_embed_sharded(dist, dev, world, model_name, items=2048, steps=3):
+    """configs[2] across the ranks (mbeir_embedder.py:63-116: ContiguousDistributedSampler slices, no collective on the data path):
+    every rank encodes `items` synthetic items per batch forward-only; items/s summed over the ranks = world x items / max time"""
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    model = CLIPScoreFusion(model_name=model_name, device=dev).float().eval()
+    batch = synth_batch(CLIP_CONFIGS[model_name], items // 2, 2023, dev)
+    batch["did_list"] = list(range(items))
+    shape = []
+
+    def run():
+        emb, _ids = model(batch, encode_mbeir_batch=True)
+        shape[:] = list(emb.half().shape)
+    with torch.no_grad():
+        run()
+        t = _rank_max_seconds(dist, dev, run, steps)
+    return {"metric": "embedding items/s (CLIP_SF forward only, fp16 out), summed over the ranks", "value": round(world * items / t, 1),
+            "unit": "items/s", "ms_per_batch": round(t * 1e3, 2), "items_per_batch_per_rank": items, "out_shape": shape,
+            "mfma_frac": round(world * items / t * FLOP_PER_ITEM_FWD[model_name] / (world * MFMA_PEAK_BF16), 4)}
 
 
 def _secondary(name, fn, *a, **kw):
@@ -472,6 +565,10 @@ def main():
     ap.add_argument("--no-retrieval", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the embed / BLIP_FF / CLIP_FF blocks")
     ap.add_argument("--dry-run", action="store_true", help="CPU ranks over gloo with a stand-in step (launcher test)")
+    ap.add_argument("--shard-rows", type=int, default=700_000, help="N > 1: pool rows per rank of the sharded retrieval block")
+    ap.add_argument("--shard-queries", default="64,1024,100000", help="N > 1: global query counts of the sharded retrieval block")
+    ap.add_argument("--embed-items", type=int, default=2048, help="items per batch (and rank) of the embedding block")
+    ap.add_argument("--check-sharded", action="store_true", help="N > 1 (tests): sharded search == single search over the whole pool")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -617,6 +714,15 @@ def main():
     del trainer, model, batch, out
     if dev.type == "cuda":
         torch.cuda.empty_cache()
+    if world > 1 and not args.dry_run:      # every rank takes part (collectives inside); rank 0 reports
+        blocks = {}
+        if not args.no_retrieval:
+            blocks["retrieval"] = _secondary("retrieval", bench_retrieval_sharded, dist, dev, rank, world, args.shard_rows, 768, 10,
+                                             tuple(int(x) for x in args.shard_queries.split(",") if x), args.check_sharded)
+        if not args.no_secondary:
+            blocks["embed"] = _secondary("embed", bench_embed_sharded, dist, dev, world, args.model, args.embed_items)
+        if rank == 0:
+            result.update(blocks)
     if rank == 0 and world == 1 and not args.dry_run:
         if not args.no_retrieval:
             result["retrieval"] = _secondary("retrieval", bench_retrieval, dev)

@@ -401,8 +401,10 @@ int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_norm, const i
  * per chunk of <= 1024 queries one sweep of the shard (MFMA group-max scan: queries in registers and the pool streamed once for
  * <= 256 queries, GEMM-shaped above), then a fused group selection + query norm + exact re-score launch and the final sort.
  * k <= 56.  Same results as coarse + rescore, bit for bit.
- * workspace: uniir_topk_ip_workspace_bytes(nq, k, rows) bytes, 256-B aligned. */
+ * workspace: uniir_topk_ip_workspace_bytes_ex(nq, k, rows, dim) bytes (the exact requirement; the dim-agnostic form is an upper
+ * bound over the sweep widths), 256-B aligned. */
 int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows);
+int64_t uniir_topk_ip_workspace_bytes_ex(int32_t nq, int32_t k, int64_t rows, int32_t dim);
 int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
                   int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
                   int64_t* out_ids, void* workspace, int64_t workspace_bytes, void* stream);

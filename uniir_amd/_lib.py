@@ -123,6 +123,7 @@ SIGNATURES = {
     "uniir_attention_f32_fwd": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, c_int, c_int, c_int, c_int, c_int, c_float, S]),
     "uniir_topk_merge_ex": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, S]),
     "uniir_topk_ip_workspace_bytes": (c_i64, [c_int, c_int, c_i64]),
+    "uniir_topk_ip_workspace_bytes_ex": (c_i64, [c_int, c_int, c_i64, c_int]),
     "uniir_topk_set_chunk": (c_int, [c_int]),
     "uniir_topk_ip_sweep_queries": (c_int, [c_int, c_i64]),
     "uniir_topk_ip": (c_int, [P, P, P, c_i64, c_int, P, c_int, c_int, P, P, P, c_i64, S]),

@@ -10,162 +10,12 @@
 //   S^T = K Q^T   -> lane holds S[q = lane&15][key = 4*(lane>>4) + r]   (v_mfma_f32_16x16x32_bf16)
 //   O^T = V^T P^T -> A operand = V^T via transposing LDS reads, B operand = P^T straight from the S^T
 //                    accumulators (k-slots permuted consistently on both operands).
-#include "common.h"
-#include "../../include/uniir_hip.h"
-#include <stdlib.h>
-
-// K / V / Q / dO of a head are read by exactly one workgroup: -DUNIIR_ATT_NT=1 stages them with the nt policy (A/B build).
-// MEASURED (round 3, same box, interleaved twice): step 634.5 / 635.6 ms plain, 637.7 / 637.2 ms nt -> stays off.
-#ifndef UNIIR_ATT_NT
-#define UNIIR_ATT_NT 0
+#include "attention.h"
+#ifdef UNIIR_EXP_BUILD
+unsigned long long* g_att_stamps = nullptr;
+int g_att_exp = 0;
+extern "C" void uniir_exp_attn_set(void* stamps, int mode) { g_att_stamps = (unsigned long long*)stamps; g_att_exp = mode; }
 #endif
-#if UNIIR_ATT_NT
-#define ATT_LD(p) __builtin_nontemporal_load(p)
-#else
-#define ATT_LD(p) (*(p))
-#endif
-#define ATT_D 64
-#define SCALE_LOG2E 0.18033688011112042f  // (1/sqrt(64)) * log2(e)
-#define ATT_SCALE 0.125f
-#define LN2F 0.6931471805599453f
-#define LOG2EF 1.4426950408889634f
-
-DEVINL int swz_off(int row, int col) {  // byte offset of element (row, col) in a swizzled [rows][64] bf16 tile
-    return row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1));
-}
-
-#define ATT_THREADS 512
-#define ATT_WAVES (ATT_THREADS / 64)
-
-// legacy staging (A/B switch UNIIR_ATTN_LEGACY_STAGE=1): one slice, loads 4 deep, one HBM round trip per 2048 chunks
-template <int NT>
-DEVINL void stage_head(char* lds, const unsigned short* __restrict__ src, long ld, int T, int Tp, int tid) {
-    const int total = Tp * 8;
-    for (int c0 = 0; c0 < total; c0 += 4 * NT) {
-        u32x4_t v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * NT + tid;
-            const int row = min(c >> 3, T - 1), kc = c & 7;
-            v[u] = ATT_LD(reinterpret_cast<const u32x4_t*>(src + (long)row * ld + kc * 8));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * NT + tid;
-            const int row = c >> 3, kc = c & 7;
-            if (c < total) {
-                const u32x4_t z = {0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4_t*>(lds + row * 128 + ((kc ^ (row & 7)) << 4)) = (row < T) ? v[u] : z;
-            }
-        }
-    }
-}
-// stage rows [0, Tp) of TWO [T][64] bf16 head slices (row stride `ld` elements each) into swizzled LDS, zero padded.
-// ALL loads of both slices are issued before the first LDS store (one HBM round trip per staging instead of one per 2048
-// chunks and slice -- four at 257 tokens; the PMC anatomy in profiles/r02_attention_pmc.txt shows the waves parked on
-// exactly these waits); loads come from clamped (always valid) addresses, the zero-select happens at the LDS store.
-// NL = 16-B loads per thread and slice: ceil(Tp * 8 / NT) (<= 8 for Tp <= 512 at 512 threads; the 384-thread backward only
-// runs up to 128 tokens).
-// `mid` runs between the loads and the LDS stores: independent work (the backward's per-row statistics with their own global
-// loads) that then shares the staging's HBM round trip instead of adding one.
-template <int NT, int NL, class F>
-DEVINL void stage_two_n(char* ldsA, const unsigned short* __restrict__ srcA, long ldA, char* ldsB,
-                        const unsigned short* __restrict__ srcB, long ldB, int T, int Tp, int tid, F&& mid) {
-    const int total = Tp * 8;
-    u32x4_t va[NL], vb[NL];
-#pragma unroll
-    for (int u = 0; u < NL; ++u) {
-        const int c = u * NT + tid;
-        const int row = min(c >> 3, T - 1), kc = c & 7;
-        va[u] = ATT_LD(reinterpret_cast<const u32x4_t*>(srcA + (long)row * ldA + kc * 8));
-        vb[u] = ATT_LD(reinterpret_cast<const u32x4_t*>(srcB + (long)row * ldB + kc * 8));
-    }
-    mid();
-#pragma unroll
-    for (int u = 0; u < NL; ++u) {
-        const int c = u * NT + tid;
-        const int row = c >> 3, kc = c & 7;
-        if (c < total) {
-            const u32x4_t z = {0u, 0u, 0u, 0u};
-            const int off = row * 128 + ((kc ^ (row & 7)) << 4);
-            *reinterpret_cast<u32x4_t*>(ldsA + off) = (row < T) ? va[u] : z;
-            *reinterpret_cast<u32x4_t*>(ldsB + off) = (row < T) ? vb[u] : z;
-        }
-    }
-}
-template <int NT, class F>
-DEVINL void stage_two(char* ldsA, const unsigned short* __restrict__ srcA, long ldA, char* ldsB,
-                      const unsigned short* __restrict__ srcB, long ldB, int T, int Tp, int tid, F&& mid) {
-    const int nl = (Tp * 8 + NT - 1) / NT;       // wave-uniform
-    if (nl <= 2) stage_two_n<NT, 2>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
-    else if (nl <= 5) stage_two_n<NT, 5>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
-    else stage_two_n<NT, 8>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, mid);
-}
-template <int NT>
-DEVINL void stage_two(char* ldsA, const unsigned short* __restrict__ srcA, long ldA, char* ldsB,
-                      const unsigned short* __restrict__ srcB, long ldB, int T, int Tp, int tid) {
-    stage_two<NT>(ldsA, srcA, ldA, ldsB, srcB, ldB, T, Tp, tid, [] {});
-}
-// b128 fragment: 8 consecutive d (k-step s) of row r0 + (lane&15)
-DEVINL bf16x8_t frag_rows(const char* lds, int r0, int s, int lane) {
-    const int row = r0 + (lane & 15), kc = s * 4 + (lane >> 4);
-    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(lds + row * 128 + ((kc ^ (row & 7)) << 4)));
-}
-// same fragment straight from global (rows >= T read as zero)
-DEVINL bf16x8_t frag_rows_global(const unsigned short* __restrict__ src, long ld, int r0, int s, int lane, int T) {
-    const int row = r0 + (lane & 15);
-    u32x4_t v = {0u, 0u, 0u, 0u};
-    if (row < T) v = *reinterpret_cast<const u32x4_t*>(src + (long)row * ld + s * 32 + (lane >> 4) * 8);
-    return __builtin_bit_cast(bf16x8_t, v);
-}
-// transposed fragment for column tile dt (16 cols) over the 32-row block starting at rb:
-// lane (i = col = lane&15, g = lane>>4) gets rows {rb+4g+0..3, rb+16+4g+0..3} of column 16*dt + (lane&15)
-DEVINL bf16x8_t frag_cols_tr(const char* lds, int rb, int dt, int lane) {
-    const int t = lane & 15, g = lane >> 4;
-    const int row = rb + 4 * g + (t >> 2), col = 16 * dt + 4 * (t & 3);
-    const s16x4_t lo = lds_read_tr16(lds + swz_off(row, col));
-    const s16x4_t hi = lds_read_tr16(lds + swz_off(row + 16, col));
-    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-    const u32x4_t r = {l2[0], l2[1], h2[0], h2[1]};
-    return __builtin_bit_cast(bf16x8_t, r);
-}
-DEVINL bf16x8_t pack8(const f32x4_t a, const f32x4_t b) {
-    const u32x4_t r = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
-                       pack_bf16x2(b[2], b[3])};
-    return __builtin_bit_cast(bf16x8_t, r);
-}
-DEVINL f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-// Generalised argument block: self-attention on the packed in_proj layout (q|k|v per token, CLIP / BLIP ViT / BERT self)
-// and rectangular cross-attention (BLIP MED: Tq text tokens attending to Tk image tokens) share the kernels.
-struct AttnArgs {
-    const unsigned short* q;      // [batch][Tq] rows, row stride q_ld, head h at column h*64
-    const unsigned short* k;      // [batch][Tk] rows, row stride kv_ld
-    const unsigned short* v;
-    long q_ld, kv_ld;
-    unsigned short* out;          // [batch*Tq][out_ld]
-    long out_ld;
-    float* lse;                   // [batch][H][Tq]
-    const int* klen;              // optional [batch]: keys >= klen[m] are masked (BERT padding mask)
-    int Tq, Tk, H, causal;
-    const unsigned short* dout;   // backward only: [batch*Tq][out_ld]
-    unsigned short* dq;           // [batch][Tq] rows, stride dq_ld
-    unsigned short* dk;           // [batch][Tk] rows, stride dkv_ld
-    unsigned short* dv;
-    long dq_ld, dkv_ld;
-    // T5-style attention (CLIP_FF fusion stack): logits = scale * q.k + rel_emb[rel_bucket[key - query + Tq - 1]][h]
-    float scale;                  // 1/8 for CLIP / BLIP, 1 for T5
-    const float* rel_emb;         // optional [buckets][H] fp32
-    const int* rel_bucket;        // [Tq + Tk - 1] bucket of every key - query offset
-    float* drel;                  // backward, optional: [buckets][H] += d loss / d rel_emb
-    int nbuckets;
-    // attention-probability dropout (BERT attention_probs_dropout_prob, T5 dropout_rate): P V uses P * mask / keep with
-    // mask(seed, ((m H + h) Tq + q) Tk + key) (common.h drop_hash); the softmax statistics stay those of the full P
-    float drop_p;
-    unsigned drop_seed;
-    int legacy_stage;             // 1 = one slice at a time, statistics before it (see launch_attn_bwd for when)
-};
 
 template <bool REL, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
@@ -193,14 +43,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     bf16x8_t qnext[2];
     qnext[0] = frag_rows_global(qbase, a.q_ld, w * 16, 0, lane, Tq);
     qnext[1] = frag_rows_global(qbase, a.q_ld, w * 16, 1, lane, Tq);
-    if (a.legacy_stage) {
+    ATT_STAMP(0);
+    if (ATT_EXP(4)) {
+    } else if (a.legacy_stage) {
         stage_head<ATT_THREADS>(ldsK, kbase, a.kv_ld, Tk, Tkp, tid);
         stage_head<ATT_THREADS>(ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
     } else {
         stage_two<ATT_THREADS>(ldsK, kbase, a.kv_ld, ldsV, vbase, a.kv_ld, Tk, Tkp, tid);
     }
+    ATT_STAMP(1);
     __syncthreads();
-    for (int qt = w; qt < nqt; qt += ATT_WAVES) {
+    ATT_STAMP(2);
+    for (int qt = w; qt < (ATT_EXP(1) ? 0 : nqt); qt += ATT_WAVES) {
         const int q0 = qt * 16, q = q0 + qi;
         bf16x8_t qf[2];
         qf[0] = qnext[0];
@@ -295,7 +149,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
             softmax_pv(kb + 1, sb);
         }
         l_run = group_sum(l_run);
-        if (q < Tq) {
+        if (q < Tq && !ATT_EXP(16)) {
             const float inv = 1.0f / l_run;
             unsigned short* orow = a.out + ((long)m * Tq + q) * a.out_ld + h * ATT_D;
 #pragma unroll
@@ -307,6 +161,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
             if (g == 0) a.lse[((long)m * H + h) * Tq + q] = m_run * LN2F + __logf(l_run);
         }
     }
+    ATT_STAMP(3);
 }
 
 // Backward. Phase 1 (per 16-key tile): dV^T += dO^T P, dK^T += Q^T dS with S = Q K^T oriented [q][key].
@@ -371,14 +226,18 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
                 ddiag[d] = 0.f;
             }
     };
-    if (a.legacy_stage) {
+    ATT_STAMP(0);
+    if (ATT_EXP(4)) {
+    } else if (a.legacy_stage) {
         row_stats();
         stage_head<NT>(bufA, qbase, a.q_ld, Tq, Tqp, tid);
         stage_head<NT>(bufB, dobase, a.out_ld, Tq, Tqp, tid);
     } else {
         stage_two<NT>(bufA, qbase, a.q_ld, bufB, dobase, a.out_ld, Tq, Tqp, tid, row_stats);
     }
+    ATT_STAMP(1);
     __syncthreads();
+    ATT_STAMP(2);
 
     const int li = lane & 15, g = lane >> 4;
     const int nktile = (Tk + 15) >> 4, nqtile = (Tq + 15) >> 4;
@@ -407,7 +266,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
     };
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
     // ---------------- phase 1: dK, dV ----------------
-    for (int kt = w; kt < nktile; kt += NWAVES) {
+    for (int kt = w; kt < (ATT_EXP(1) ? 0 : nktile); kt += NWAVES) {
         const int k0 = kt * 16, key = k0 + li;
         bf16x8_t kf[2], vf[2];
 #pragma unroll
@@ -495,7 +354,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
                 dk[dt] = mfma16(cols_frag(tA[dt] + blk), dsf, dk[dt]);
             }
         }
-        if (key < Tk) {
+        if (key < Tk && !ATT_EXP(16)) {
             unsigned short* krow = dkbase + (long)key * a.dkv_ld;
             unsigned short* vrow = dvbase + (long)key * a.dkv_ld;
 #pragma unroll
@@ -508,16 +367,21 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
             }
         }
     }
+    ATT_STAMP(3);
     __syncthreads();
-    if (a.legacy_stage) {
+    ATT_STAMP(4);
+    if (ATT_EXP(8)) {
+    } else if (a.legacy_stage) {
         stage_head<NT>(bufA, kbase, a.kv_ld, Tk, Tkp, tid);
         stage_head<NT>(bufB, vbase, a.kv_ld, Tk, Tkp, tid);
     } else {
         stage_two<NT>(bufA, kbase, a.kv_ld, bufB, vbase, a.kv_ld, Tk, Tkp, tid);
     }
+    ATT_STAMP(5);
     __syncthreads();
+    ATT_STAMP(6);
     // ---------------- phase 2: dQ ----------------
-    for (int qt = w; qt < nqtile; qt += NWAVES) {
+    for (int qt = w; qt < (ATT_EXP(2) ? 0 : nqtile); qt += NWAVES) {
         const int q0 = qt * 16, q = q0 + li;
         bf16x8_t qf[2], dof[2];
 #pragma unroll
@@ -568,7 +432,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(cols_frag(tA[dt] + blk), dsf, dq[dt]);
         }
-        if (q < Tq) {
+        if (q < Tq && !ATT_EXP(16)) {
             unsigned short* qrow = dqbase + (long)q * a.dq_ld;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -578,6 +442,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
             }
         }
     }
+    ATT_STAMP(7);
     if (REL && a.drel) {      // diagonals -> buckets -> global (one atomic per touched bucket and workgroup)
         __syncthreads();
         float* bsum = lse2;     // phase 2 is over: reuse
@@ -599,8 +464,16 @@ static int attn_legacy_stage(bool backward, int tmax) {
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
     return backward && tmax > 128;
 }
+int launch_attn_fwd_pair(const AttnArgs& a, int batch, hipStream_t st);      // attention_pair.hip; 1 = shape not taken
 static int launch_attn_fwd(const AttnArgs& a0, int batch, hipStream_t st) {
     AttnArgs a = a0;
+#ifdef UNIIR_EXP_BUILD
+    a.stamps = g_att_stamps; a.exp = g_att_exp;
+#endif
+    {   // plain self-attention of 193 .. 288 tokens (CLIP ViT-L/14, BLIP ViT): the persistent pair-tile kernel
+        const int rc = launch_attn_fwd_pair(a, batch, st);
+        if (rc != 1) return rc;
+    }
     a.legacy_stage = attn_legacy_stage(false, a.Tk);
     const int Tkp = (a.Tk + 31) & ~31;
     const int sm = 2 * Tkp * 128 + (a.rel_emb ? (a.Tq + a.Tk) * 4 : 0);
@@ -645,8 +518,16 @@ static int launch_attn_bwd_nt(const AttnArgs& a, int batch, int sm, hipStream_t 
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
+int launch_attn_bwd_pair(const AttnArgs& a, int batch, hipStream_t st);      // attention_pair.hip; 1 = shape not taken
 static int launch_attn_bwd(const AttnArgs& a0, int batch, hipStream_t st) {
     AttnArgs a = a0;
+#ifdef UNIIR_EXP_BUILD
+    a.stamps = g_att_stamps; a.exp = g_att_exp;
+#endif
+    {   // plain self-attention of 193 .. 288 tokens (CLIP ViT-L/14, BLIP ViT): the persistent pair-tile kernel
+        const int rc = launch_attn_bwd_pair(a, batch, st);
+        if (rc != 1) return rc;
+    }
     const int tmax = a.Tq > a.Tk ? a.Tq : a.Tk;
     a.legacy_stage = attn_legacy_stage(true, tmax);
     const int Tqp = (a.Tq + 31) & ~31, Tkp = (a.Tk + 31) & ~31;

@@ -34,26 +34,45 @@
 
 struct TkEntry { float score; int idx; };
 
-// inv_norm[i] = 1/sqrt(sum_j x_j^2), sequential fp32 without fma (matches oracle); 0 for zero rows
+// inv_norm[i] = 1/sqrt(sum_j x_j^2), sequential fp32 without fma (matches oracle); 0 for zero rows.
+// A lane owns a row (the sum is one chain in element order), but the rows are FETCHED by the wave: 64 rows x 128 B per step, eight
+// lanes side by side on a row (whole cache lines, each read once), through a wave-private LDS slab from which every lane then takes
+// its own row's 64 elements.  (Round 3's one-thread-one-row loads at a 1 536-B stride fetched 6.5 GB for a 1.075-GB pool: 0.97 ms.)
+#define TKN_ROW 144      // slab row stride: 128 B + 16 (the lanes' 16-byte reads of their own rows fall on distinct banks)
 __global__ __launch_bounds__(256) void inv_norm_kernel(const unsigned short* __restrict__ x, long n, int dim,
                                                        float* __restrict__ inv) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const unsigned short* r = x + i * dim;
+    __shared__ __attribute__((aligned(16))) char stage[4][64 * TKN_ROW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long row0 = ((long)blockIdx.x * 4 + w) * 64;
+    if (row0 >= n) return;                                  // (whole wave; no workgroup barrier below)
+    char* st = stage[w];
+    const int sub = lane >> 3, ch = lane & 7;
     float s = 0.f;
-    for (int c = 0; c < dim; c += 8) {
-        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(r + c);
+    for (int c0 = 0; c0 < dim; c0 += 64) {
+        const bool live = c0 + ch * 8 < dim;                // the last step of a dim that is not a multiple of 64
+        u32x4_t v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float lo = f16_to_f32((unsigned short)(v[e] & 0xffffu));
-            const float hi = f16_to_f32((unsigned short)(v[e] >> 16));
-            s = __fadd_rn(s, __fmul_rn(lo, lo));
-            s = __fadd_rn(s, __fmul_rn(hi, hi));
+        for (int i = 0; i < 8; ++i) {
+            const long gr = min(row0 + sub + 8 * i, n - 1);
+            v[i] = live ? *reinterpret_cast<const u32x4_t*>(x + gr * dim + c0 + ch * 8) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4_t*>(st + (sub + 8 * i) * TKN_ROW + ch * 16) = v[i];
+        const int nch = min(8, (dim - c0) / 8);
+        for (int c = 0; c < nch; ++c) {
+            const u32x4_t q = *reinterpret_cast<const u32x4_t*>(st + lane * TKN_ROW + c * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = f16_to_f32((unsigned short)(q[e] & 0xffffu));
+                const float hi = f16_to_f32((unsigned short)(q[e] >> 16));
+                s = __fadd_rn(s, __fmul_rn(lo, lo));
+                s = __fadd_rn(s, __fmul_rn(hi, hi));
+            }
         }
     }
     // FAISS fvec_renorm_L2: inv_nr = 1.0 / sqrtf(nr) (double division of a correctly rounded float sqrt). The f32
     // sqrt is taken through f64 (exactly the correctly rounded f32 result) so it cannot be lowered to v_rsq/v_sqrt.
-    inv[i] = s > 0.f ? (float)(1.0 / (double)(float)sqrt((double)s)) : 0.f;
+    if (row0 + lane < n) inv[row0 + lane] = s > 0.f ? (float)(1.0 / (double)(float)sqrt((double)s)) : 0.f;
 }
 
 extern "C" int uniir_pool_inv_norms(const void* x_f16, int64_t n, int32_t dim, float* inv_norm, void* stream) {
@@ -62,7 +81,7 @@ extern "C" int uniir_pool_inv_norms(const void* x_f16, int64_t n, int32_t dim, f
     if (dim % 8) return UNIIR_ESHAPE;
     if ((uintptr_t)x_f16 & 15) return UNIIR_EALIGN;
     hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x_f16, (long)n, dim, inv_norm);
+                       (const unsigned short*)x_f16, (long)n, dim, inv_norm);       // 4 waves x 64 rows per workgroup
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -2617,6 +2636,12 @@ extern "C" int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t 
     const int64_t a = tki_ws_bytes(nq, k, rows, 256), b = tki_ws_bytes(nq, k, rows, TKI_CHUNK_MAX);     // dim is not known here
     return a > b ? a : b;
 }
+// the exact requirement of a search of this shape: the sweep width is a function of (dim, rows), so a dim-768 shard searched in
+// 256-query sweeps needs a quarter of the group-maxima region the dim-agnostic bound reserves (45 MB instead of 179 MB at 700 k rows)
+extern "C" int64_t uniir_topk_ip_workspace_bytes_ex(int32_t nq, int32_t k, int64_t rows, int32_t dim) {
+    if (nq <= 0 || k <= 0 || rows <= 0 || dim <= 0) return 0;
+    return tki_ws_bytes(nq, k, rows, uniir_topk_ip_sweep_queries(dim, rows));
+}
 extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
                              int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
                              int64_t* out_ids, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -2626,7 +2651,7 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
     if (((uintptr_t)pool_f16 & 15) || ((uintptr_t)queries_f16 & 15) || ((uintptr_t)pool_inv_norm & 15) ||
         ((uintptr_t)workspace & 255))
         return UNIIR_EALIGN;
-    if (workspace_bytes < uniir_topk_ip_workspace_bytes(nq, k, rows)) return UNIIR_EINVAL;
+    if (workspace_bytes < uniir_topk_ip_workspace_bytes_ex(nq, k, rows, dim)) return UNIIR_EINVAL;
     const int chunk_max = uniir_topk_ip_sweep_queries(dim, rows);
     const int chunk = nq < chunk_max ? nq : chunk_max;
     const int kc = k + 8;

@@ -52,9 +52,38 @@ def _shard_view(shard, lo, hi):
     return v
 
 
+SUBSHARD_BYTES = 1 << 31     # the streaming scans and the fused tail address a shard's rows through 31-bit buffer offsets
+
+
+def subshard_bounds(n, dim):
+    """Row ranges of the LOGICAL sub-shards a resident shard is searched in: one range while n * dim * 2 < 2 GiB, else equal ranges
+    (starting on 16-row boundaries: aligned inverse norms, whole scan groups) that each stay below it -- 1 398 096 rows at dim 768.
+    The 5.6 M x 768 M-BEIR pool on ONE GPU (8.6 GB, mbeir_retriever.py:196-206 with a single visible device) is 5 such ranges."""
+    if n * dim * 2 < SUBSHARD_BYTES:
+        return [(0, n)]
+    max_rows = ((SUBSHARD_BYTES - 1) // (dim * 2)) // 16 * 16
+    parts = -(-n // max_rows)
+    per = -(-(-(-n // parts)) // 16) * 16
+    return [(lo, min(lo + per, n)) for lo in range(0, n, per)]
+
+
+_WS_CACHE = {}     # device index -> workspace tensor (grown on demand): a search allocates nothing in steady state
+
+
+def _workspace(dev, need):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        _WS_CACHE[key] = ws
+    return ws
+
+
 def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None, workspace=None):
     """Exact top-k of `queries` against one shard -> (scores f32 [q,k] desc, ids int64 [q,k], -1 padded).
-    One C call (uniir_topk_ip: query norms, one sweep of the shard per 1024 queries, fused select + exact re-score + sort).
+    One C call per logical sub-shard (uniir_topk_ip: query norms, one sweep of the rows per 256 / 1024 queries, fused select +
+    exact re-score + sort); a shard of >= 2 GiB is searched as equal sub-shards and merged on (score desc, id asc), which is the
+    search of the whole shard (ids are unique).
     k > 56 (FAISS Flat accepts up to 2048; Recall@100, larger hard-negative mining depths): assembled from row slices of the
     shard, see _search_large_k."""
     from . import _lib
@@ -66,11 +95,15 @@ def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None
                 torch.full((nq, k), -1, device=dev, dtype=torch.int64))
     if k > MAX_K_DIRECT:
         return _search_large_k(shard, queries_f16, k)
+    bounds = subshard_bounds(shard.n, shard.dim)
+    if len(bounds) > 1:
+        res = [search_shard(_shard_view(shard, lo, hi), queries_f16, k, workspace=workspace) for lo, hi in bounds]
+        return merge_shards(torch.stack([r[0] for r in res]), torch.stack([r[1] for r in res]))
     out_s = torch.empty(nq, k, device=dev, dtype=torch.float32)       # every slot is written by the final sort (padding included)
     out_i = torch.empty(nq, k, device=dev, dtype=torch.int64)
-    need = _lib.load().uniir_topk_ip_workspace_bytes(nq, k, shard.n)
+    need = _lib.load().uniir_topk_ip_workspace_bytes_ex(nq, k, shard.n, shard.dim)
     if workspace is None or workspace.numel() < need or workspace.data_ptr() % 256:
-        workspace = torch.empty(need, device=dev, dtype=torch.uint8)
+        workspace = _workspace(dev, need)
     ops.call("uniir_topk_ip", shard.emb, shard.inv_norm, shard.ids, shard.n, shard.dim, queries_f16, nq, k, out_s, out_i,
              workspace, workspace.numel())
     return out_s, out_i
