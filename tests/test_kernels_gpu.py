@@ -197,6 +197,40 @@ def test_attention_fwd_bwd(batch, seq, heads, causal):
         assert e < 1.5e-2, (name, e)
 
 
+@pytest.mark.parametrize("batch,seq,heads", [(37, 257, 16), (30, 197, 12), (1, 257, 1), (3, 222, 2)])
+def test_attention_bwd_pair_kernel_against_the_general_kernel(batch, seq, heads):
+    """the persistent pair-tile backward (csrc/attention_pair.hip: plain self-attention of 257 / 197 tokens; > 256 heads makes
+    every workgroup walk over several heads) against the general backward, reached through the key-length entry point with full
+    key lengths (same mathematics, general code path; 222 tokens is a shape the pair kernel does not take: both calls then run the
+    same kernel).  Same products in the same order, except D = rowsum(dO * O) (summed as a tree instead of a chain) and the odd
+    tile's rows (eight partial sums): differences of one bf16 ulp in < 0.1 % of the elements; and both against fp32 torch"""
+    ops = _ops()
+    torch.manual_seed(31 + seq)
+    W = heads * 64
+    qkv = bf(torch.randn(batch * seq, 3 * W, device=DEV))
+    out, lse = ops.attention_fwd(qkv, batch, seq, heads, 0)
+    do = bf(torch.randn(batch * seq, W, device=DEV))
+    d_pair = torch.full_like(qkv, 5.0)                       # every element must be written
+    ops.attention_bwd(qkv, out, do, lse, batch, seq, heads, 0, dqkv=d_pair)
+    d_gen = torch.full_like(qkv, 3.0)
+    klen = torch.full((batch,), seq, device=DEV, dtype=torch.int32)
+    ops.attention_bwd_ex(qkv, 3 * W, qkv[:, W:], qkv[:, 2 * W:], 3 * W, out, do, lse, d_gen, 3 * W, d_gen[:, W:], d_gen[:, 2 * W:],
+                         3 * W, batch, seq, seq, heads, key_len=klen)
+    assert torch.isfinite(d_pair.float()).all()
+    diff = (d_pair.float() - d_gen.float()).abs()
+    ulp = d_gen.float().abs().clamp_min(2.0 ** -20) * 2.0 ** -7          # one bf16 ulp is <= 2^-7 of the value
+    assert (diff <= ulp).all(), float((diff / ulp).max())
+    assert float((diff > 0).float().mean()) < 1e-3
+    if batch * seq * heads <= 40000:
+        qr = qkv.float().requires_grad_(True)
+        oref, _ = _attn_ref(qr, batch, seq, heads, 0)
+        oref.backward(do.float())
+        g = qr.grad.view(batch * seq, 3, W)
+        d = d_pair.float().view(batch * seq, 3, W)
+        for i, name in enumerate("qkv"):
+            assert rel_err(d[:, i], g[:, i]) < 1.5e-2, name
+
+
 @pytest.mark.parametrize("batch,tq,tk,heads,enc", [(3, 100, 197, 12, 1024), (2, 35, 257, 2, 128), (2, 197, 100, 3, 192)])
 def test_cross_attention_with_key_lengths(batch, tq, tk, heads, enc):
     """BLIP MED cross-attention at its real shapes (med.py:160-232): 100 text queries x 197 image keys, separate Q and

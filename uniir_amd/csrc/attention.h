@@ -128,6 +128,26 @@ DEVINL bf16x8_t pack8(const f32x4_t a, const f32x4_t b) {
 DEVINL f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// 16 rows x 64 columns of gradients (lane = row li, registers: column 16 dt + 4 g + r) -> bf16, 64 contiguous bytes per row and
+// store: v_permlane16_swap exchanges the 8-byte pieces of column tiles (0,1) / (2,3) between the lane rows g = (0,1) / (2,3), so
+// that every lane ends up with 8 consecutive columns starting at 32 p + {0, 16, 8, 24}[g].
+DEVINL void att_store_tile(const f32x4_t (&acc)[4], float scale, unsigned short* rowp, bool valid, int g) {
+    u32x2_t pk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const f32x4_t x = acc[dt] * scale;
+        pk[dt] = u32x2_t{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+    }
+    const int dstart = ((g & 1) << 4) | ((g & 2) << 2);      // {0, 16, 8, 24}[g]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const auto x = __builtin_amdgcn_permlane16_swap(pk[2 * p][0], pk[2 * p + 1][0], false, false);
+        const auto y = __builtin_amdgcn_permlane16_swap(pk[2 * p][1], pk[2 * p + 1][1], false, false);
+        const u32x4_t v = {x[0], y[0], x[1], y[1]};
+        if (valid) *reinterpret_cast<u32x4_t*>(rowp + 32 * p + dstart) = v;
+    }
+}
+
 // Generalised argument block: self-attention on the packed in_proj layout (q|k|v per token, CLIP / BLIP ViT / BERT self)
 // and rectangular cross-attention (BLIP MED: Tq text tokens attending to Tk image tokens) share the kernels.
 struct AttnArgs {

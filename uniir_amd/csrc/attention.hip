@@ -149,17 +149,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
             softmax_pv(kb + 1, sb);
         }
         l_run = group_sum(l_run);
-        if (q < Tq && !ATT_EXP(16)) {
-            const float inv = 1.0f / l_run;
-            unsigned short* orow = a.out + ((long)m * Tq + q) * a.out_ld + h * ATT_D;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const f32x4_t v = o[dt] * inv;
-                u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *reinterpret_cast<u32x2_t*>(orow + 16 * dt + 4 * g) = pk;
-            }
-            if (g == 0) a.lse[((long)m * H + h) * Tq + q] = m_run * LN2F + __logf(l_run);
-        }
+        // rows leave as 16-byte pieces, 64 contiguous bytes per row and store (att_store_tile; round 4: the 8-byte stores at a
+        // row stride cost the 257-token forward 0.14 of its 0.70 ms)
+        const bool live = q < Tq && !ATT_EXP(16);
+        att_store_tile(o, 1.0f / l_run, a.out + ((long)m * Tq + min(q, Tq - 1)) * a.out_ld + h * ATT_D, live, g);
+        if (live && g == 0) a.lse[((long)m * H + h) * Tq + q] = m_run * LN2F + __logf(l_run);
     }
     ATT_STAMP(3);
 }
@@ -354,17 +348,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
                 dk[dt] = mfma16(cols_frag(tA[dt] + blk), dsf, dk[dt]);
             }
         }
-        if (key < Tk && !ATT_EXP(16)) {
-            unsigned short* krow = dkbase + (long)key * a.dkv_ld;
-            unsigned short* vrow = dvbase + (long)key * a.dkv_ld;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const f32x4_t x = dk[dt] * oscale;
-                u32x2_t pk = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
-                *reinterpret_cast<u32x2_t*>(krow + 16 * dt + 4 * g) = pk;
-                u32x2_t pv = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
-                *reinterpret_cast<u32x2_t*>(vrow + 16 * dt + 4 * g) = pv;
-            }
+        {
+            const bool live = key < Tk && !ATT_EXP(16);
+            const long krow = (long)min(key, Tk - 1) * a.dkv_ld;
+            att_store_tile(dk, oscale, dkbase + krow, live, g);
+            att_store_tile(dv, 1.0f, dvbase + krow, live, g);
         }
     }
     ATT_STAMP(3);
@@ -432,15 +420,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(cols_frag(tA[dt] + blk), dsf, dq[dt]);
         }
-        if (q < Tq && !ATT_EXP(16)) {
-            unsigned short* qrow = dqbase + (long)q * a.dq_ld;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const f32x4_t x = dq[dt] * oscale;
-                u32x2_t pk = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
-                *reinterpret_cast<u32x2_t*>(qrow + 16 * dt + 4 * g) = pk;
-            }
-        }
+        att_store_tile(dq, oscale, dqbase + (long)min(q, Tq - 1) * a.dq_ld, q < Tq && !ATT_EXP(16), g);
     }
     ATT_STAMP(7);
     if (REL && a.drel) {      // diagonals -> buckets -> global (one atomic per touched bucket and workgroup)
@@ -464,16 +444,11 @@ static int attn_legacy_stage(bool backward, int tmax) {
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
     return backward && tmax > 128;
 }
-int launch_attn_fwd_pair(const AttnArgs& a, int batch, hipStream_t st);      // attention_pair.hip; 1 = shape not taken
 static int launch_attn_fwd(const AttnArgs& a0, int batch, hipStream_t st) {
     AttnArgs a = a0;
 #ifdef UNIIR_EXP_BUILD
     a.stamps = g_att_stamps; a.exp = g_att_exp;
 #endif
-    {   // plain self-attention of 193 .. 288 tokens (CLIP ViT-L/14, BLIP ViT): the persistent pair-tile kernel
-        const int rc = launch_attn_fwd_pair(a, batch, st);
-        if (rc != 1) return rc;
-    }
     a.legacy_stage = attn_legacy_stage(false, a.Tk);
     const int Tkp = (a.Tk + 31) & ~31;
     const int sm = 2 * Tkp * 128 + (a.rel_emb ? (a.Tq + a.Tk) * 4 : 0);
@@ -603,7 +578,8 @@ extern "C" int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k
     if (batch == 0) return UNIIR_OK;
     if (tq < 1 || tk < 1 || tq > 512 || tk > 512) return UNIIR_ESHAPE;
     if (causal && tq != tk) return UNIIR_ESHAPE;
-    if ((q_ld % 8) || (kv_ld % 8) || (out_ld % 8) || (dq_ld % 4) || (dkv_ld % 4)) return UNIIR_EALIGN;
+    if ((q_ld % 8) || (kv_ld % 8) || (out_ld % 8) || (dq_ld % 8) || (dkv_ld % 8)) return UNIIR_EALIGN;      // 16-byte pieces
+    if (((uintptr_t)dq & 15) || ((uintptr_t)dk & 15) || ((uintptr_t)dv & 15)) return UNIIR_EALIGN;
     AttnArgs a = {};
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
     a.q_ld = q_ld; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = out_ld;

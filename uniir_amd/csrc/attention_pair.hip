@@ -1,20 +1,30 @@
-// Persistent pair-tile attention kernels for PLAIN self-attention (no mask, no dropout, no relative bias, Tq = Tk): the CLIP / BLIP
+// Persistent pair-tile attention BACKWARD for PLAIN self-attention (no mask, no dropout, no relative bias, Tq = Tk): the CLIP / BLIP
 // ViT towers' 257- and 197-token layers (openai/CLIP ResidualAttentionBlock.attention via clip_sf.py:43-47; BLIP
-// vit.py:86-106).  Everything else stays on the general kernels of attention.hip.
+// vit.py:86-106).  Everything else -- and every forward -- stays on the general kernels of attention.hip.
 //
 // Why a second structure (measured, round 4, tools/r4/attn_diag.py on the general backward at 257 tokens x 16 heads x 1024 items,
 // 1.98 ms): with the arithmetic knocked out the kernel still takes 0.80 ms (two stagings + statistics: every operand crosses the
 // fabric twice, 5.07 GB fetched for 2.70 GB of operands), the strided 8-byte gradient stores cost 0.34 ms, and the arithmetic
 // alone 1.30 ms with the 17 sixteen-row tiles dealt 3 / 2 / 2 / .. to the 8 waves.  Here:
 //   * ONE persistent 8-wave workgroup per CU walks over (item, head) pairs; Q, dO, K, V of a head are ALL resident in LDS
-//     (4 x 36 KiB at 257 tokens) and arrive by LDS-DMA (buffer_load .. lds) one phase ahead of their use: K, V while phase 1
-//     computes on Q, dO; the next head's Q, dO while phase 2 computes on K, V.  Every operand is fetched once.
+//     (4 x 36 KiB at 257 tokens) and arrive by LDS-DMA (buffer_load .. lds, issued piece by piece from inside the phase loops) one
+//     phase ahead of their use: K, V while phase 1 computes on Q, dO; the next head's Q, dO while phase 2 computes on K, V.
+//     Every operand is fetched once: rocprofv3 FETCH_SIZE x 2 = 2.70 GB per launch = the algorithmic reads (was 5.07).
 //   * A wave owns a PAIR of 16-row tiles (32 keys in phase 1, 32 queries in phase 2): each LDS fragment feeds two MFMAs (half
-//     the LDS reads per flop of the one-tile kernels) and 16 tiles = 8 pairs balance over the 8 waves; the odd last tile (one
-//     valid row at 257 tokens) is split over the waves along its inner loop, its partial sums meet in a small LDS area.
-//   * Gradient rows leave as 16-byte pieces, 64 contiguous bytes per row and instruction (v_permlane16_swap regrouping).
-// Arithmetic, fragment layouts and the order of every accumulation are those of attention.hip's backward (the pair tiles give
-// bitwise the same dK / dV / dQ rows); the odd tile's rows differ by the order of eight partial sums.
+//     the LDS and MFMA-operand instructions per flop of the one-tile kernels) and 16 tiles = 8 pairs balance over the 8 waves; the
+//     odd last tile (one valid row at 257 tokens) is split over waves 0..3 along its inner loop, its partial sums meet in LDS.
+//   * Gradient rows leave as 16-byte pieces, 64 contiguous bytes per row and instruction (att_store_tile).
+// Result: 1.54-1.59 ms (general kernel 2.0-2.25 ms in the same process), 197 tokens 1.11 vs 1.57-1.66 ms.
+// What bounds it now (rocprofv3 --pmc, tools/r4/attn_pmc.sh): the matrix pipe is busy 33.5 % of the kernel, the vector issue 47 %,
+// LDS 23 %, no bank conflicts -- and the costs ADD: a SIMD with two waves spends 16 cycles per 16x16x32 MFMA, ~4.5 per vector or
+// LDS instruction, ~8 per v_exp, one after the other (per 32 x 32 block and wave: 512 + ~540 in phase 1), so the floor of this
+// structure is the instruction count per logit (2 exp + ~7 vector + 3.5 LDS instructions per 64 logits and phase).  Variants
+// that were measured and did not pay: two-group ping-pong barriers (1.88 ms), LDS reads one MFMA group ahead (kept: 1.62 ->
+// 1.57), de-serialised MFMA pairs (kept, no change: the pipe is not the limit), a forward in the same structure
+// (experiments/attention_pair/fwd_pair.h: 0.70 vs 0.66 ms, the forward's softmax instructions do not shrink with pairing).
+// Arithmetic, fragment layouts and the order of every accumulation are those of attention.hip's backward; D = rowsum(dO * O) is
+// summed as a tree (8 lanes per row) instead of a chain and the odd tile's rows are sums of eight partials: one-bf16-ulp
+// differences in < 0.1 % of the elements (tests/test_kernels_gpu.py).
 #include "attention.h"
 
 #ifdef UNIIR_EXP_BUILD
@@ -98,8 +108,9 @@ struct ApDma {
             const unsigned src = (unsigned)(((lane & 7) ^ (row & 7)) * 16);
             const unsigned va = row < T ? (unsigned)row * lda2 + src : 0x7ffffff0u;
             const unsigned vb = row < T ? (unsigned)row * ldb2 + src : 0x7ffffff0u;
-            ap_dma16(sa, la + (unsigned)j * 1024u, va);
-            ap_dma16(sb, lb + (unsigned)j * 1024u, vb);
+            // (readfirstlane: the values ARE wave-uniform, but the asm operands must be provably so)
+            ap_dma16(sa, __builtin_amdgcn_readfirstlane(la + (unsigned)j * 1024u), va);
+            ap_dma16(sb, __builtin_amdgcn_readfirstlane(lb + (unsigned)j * 1024u), vb);
             j += AP_WAVES;
         }
     }
@@ -118,7 +129,8 @@ DEVINL bf16x8_t ap_frag_global(const unsigned short* __restrict__ src, long ld, 
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-// D[q] = dO[q] . O[q] and lse2[q] = lse[q] log2 e of one head -> stats[0 .. TP) = lse2, stats[TP .. 2 TP) = D.  Thread t takes the
+// D[q] = dO[q] . O[q] and lse2[q] = lse[q] log2 e of one head -> stats[0 .. TP) = lse2, stats[TP .. 2 TP) = -D (negated: the
+// consumers then ADD it, which the compiler turns into v_pk_add_f32; a vector subtraction it splits into scalar v_sub_f32).  Thread t takes the
 // 16-B chunks t, t + 512, ..: the 8 lanes of a row sit side by side (coalesced 128-B rows), their partial dots meet by DPP.
 // Two halves: the loads are issued before a barrier, the arithmetic and the LDS writes run behind it.
 template <int TP>
@@ -157,31 +169,11 @@ struct ApStats {
             const int row = c >> 3;
             if ((c & 7) == 0 && row < T) {
                 stats[row] = lv[u] * LOG2EF;
-                stats[TP + row] = d;
+                stats[TP + row] = -d;
             }
         }
     }
 };
-
-// 16 rows x 64 columns of gradients (lane = row li, registers: column 16 dt + 4 g + r) -> bf16, 64 contiguous bytes per row and
-// store: v_permlane16_swap exchanges the 8-byte pieces of column tiles (0,1) / (2,3) between the lane rows g = (0,1) / (2,3), so
-// that every lane ends up with 8 consecutive columns starting at 32 p + {0, 16, 8, 24}[g].
-DEVINL void ap_store_tile(const f32x4_t (&acc)[4], float scale, unsigned short* rowp, bool valid, int g) {
-    u32x2_t pk[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        const f32x4_t x = acc[dt] * scale;
-        pk[dt] = u32x2_t{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
-    }
-    const int dstart = ((g & 1) << 4) | ((g & 2) << 2);      // {0, 16, 8, 24}[g]
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const auto x = __builtin_amdgcn_permlane16_swap(pk[2 * p][0], pk[2 * p + 1][0], false, false);
-        const auto y = __builtin_amdgcn_permlane16_swap(pk[2 * p][1], pk[2 * p + 1][1], false, false);
-        const u32x4_t v = {x[0], y[0], x[1], y[1]};
-        if (valid) *reinterpret_cast<u32x4_t*>(rowp + 32 * p + dstart) = v;
-    }
-}
 
 // lane-constant byte offsets of the fragment reads inside a swizzled [rows][64] slice (block offsets are multiples of 32 rows =
 // 4096 B and do not touch the swizzle)
@@ -231,6 +223,10 @@ DEVINL bf16x8_t ap_cols(unsigned addr) {      // 32-row block: rows 4 g .., 16 +
 // ---- phase 1 of KT key tiles (keys k0 .. k0 + 16 KT - 1, lane = key column) over the query blocks b_lo, b_lo + b_step, .. < b_hi:
 //   S = Q K^T, dP = dO V^T, P = exp2(c S - lse2), dS = P (dP - D);  dV^T += dO^T P,  dK^T += Q^T dS
 // MASK: some key column of these tiles is padding (the odd tile; pairs are always full, see ap_geom)
+// Every LDS read is issued one MFMA group ahead of its use (measured, round 4: a wave issues ~1 instruction per 4.5 cycles and with
+// the reads placed next to their uses the ~14 LDS round trips per block, ~1000 cycles, were the larger half of a block's 1600-2200):
+//   [statistics + transposed fragments of block b]  S / dP MFMAs (row fragments of b: read during the previous block)
+//   [row fragments of block b + step into the registers the MFMAs have just read]  softmax arithmetic  dV / dK MFMAs
 template <int TP, int KT, bool MASK>
 DEVINL void ap_phase1(unsigned lq, unsigned stats, const ApOff& of, const bf16x8_t (&kf)[KT][2], const bf16x8_t (&vf)[KT][2],
                       int k0, int T, int b_lo, int b_hi, int b_step, f32x4_t (&dv)[KT][4], f32x4_t (&dk)[KT][4], int lane,
@@ -245,152 +241,7 @@ DEVINL void ap_phase1(unsigned lq, unsigned stats, const ApOff& of, const bf16x8
     ba.init(lq, of);
     unsigned sbase = stats + 16 * g;
     asm volatile("" : "+v"(sbase));
-    for (int b = b_lo; b < b_hi; b += b_step) {
-        // one VGPR add per fragment class and block; k-step halves, the dO slice (+ SB) and the second 16 rows are immediates
-        const unsigned blk = (unsigned)b * 4096u;
-        const unsigned r0 = ba.r[0] + blk;
-        const unsigned r1 = ba.r[1] + blk;
-        const unsigned st = sbase + (unsigned)b * 128u;
-        dma.step(lane);
-        f32x4_t sa[2][KT], dp[2][KT];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const bf16x8_t aq0 = ap_rows(r0 + qt * 2048), aq1 = ap_rows(r1 + qt * 2048);
-            const bf16x8_t ad0 = ap_rows(r0 + (SB + qt * 2048)), ad1 = ap_rows(r1 + (SB + qt * 2048));
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                sa[qt][kt] = mfma16(aq1, kf[kt][1], mfma16(aq0, kf[kt][0], zero4));
-                dp[qt][kt] = mfma16(ad1, vf[kt][1], mfma16(ad0, vf[kt][0], zero4));
-            }
-        }
-        // A rows = queries, B columns = keys -> acc[r] = S[q = 32 b + 16 qt + 4 g + r][key = k0 + 16 kt + li]
-        f32x4_t l4[2], d4[2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            l4[qt] = AP_LDS(f32x4_t, st + qt * 64);
-            d4[qt] = AP_LDS(f32x4_t, st + (TP * 4 + qt * 64));
-        }
-        bf16x8_t pf[KT], dsf[KT];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            f32x4_t p[2], ds[2];
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {    // rows q >= T carry lse2 = 1e30: P = 0 without a mask
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[qt][kt][r], SCALE_LOG2E, -l4[qt][r]));
-                    p[qt][r] = MASK ? (kval[kt] ? e : 0.f) : e;
-                    ds[qt][r] = p[qt][r] * (dp[qt][kt][r] - d4[qt][r]);
-                }
-            pf[kt] = pack8(p[0], p[1]);
-            dsf[kt] = pack8(ds[0], ds[1]);
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const unsigned tp = ba.t[dt] + blk;
-            const bf16x8_t tq = ap_cols(tp);
-            const bf16x8_t td = ap_cols(tp + SB);
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                dv[kt][dt] = mfma16(td, pf[kt], dv[kt][dt]);
-                dk[kt][dt] = mfma16(tq, dsf[kt], dk[kt][dt]);
-            }
-        }
-    }
-}
-
-// ---- phase 2 of QT query tiles (lane = query column), one key block:
-//   S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - D);  dQ^T += K^T dS^T        EDGE: the block holds padded keys
-template <int TP, int QT, bool EDGE>
-DEVINL void ap_phase2_block(const ApBase& ba, const bf16x8_t (&qf)[QT][2], const bf16x8_t (&dof)[QT][2],
-                            const float (&mylse)[QT], const float (&myD)[QT], int T, int b, f32x4_t (&dq)[QT][4], int g) {
-    constexpr int SB = TP * 128;
-    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-    const unsigned blk = (unsigned)b * 4096u;
-    const unsigned r0 = ba.r[0] + blk;
-    const unsigned r1 = ba.r[1] + blk;
-    f32x4_t sa[2][QT], dp[2][QT];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const bf16x8_t ak0 = ap_rows(r0 + kt * 2048), ak1 = ap_rows(r1 + kt * 2048);
-        const bf16x8_t av0 = ap_rows(r0 + (SB + kt * 2048)), av1 = ap_rows(r1 + (SB + kt * 2048));
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            sa[kt][qt] = mfma16(ak1, qf[qt][1], mfma16(ak0, qf[qt][0], zero4));
-            dp[kt][qt] = mfma16(av1, dof[qt][1], mfma16(av0, dof[qt][0], zero4));
-        }
-    }
-    // acc[r] = S^T[key = 32 b + 16 kt + 4 g + r][q = lane column]
-    bf16x8_t dsf[QT];
-    const int krem = T - (b * 32 + 4 * g);               // EDGE: key 16 kt + r of this lane's rows is valid iff < krem
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        f32x4_t ds[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[kt][qt][r], SCALE_LOG2E, -mylse[qt]));
-                if (EDGE) e = (kt * 16 + r < krem) ? e : 0.f;
-                ds[kt][r] = e * (dp[kt][qt][r] - myD[qt]);
-            }
-        dsf[qt] = pack8(ds[0], ds[1]);
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t tk = ap_cols(ba.t[dt] + blk);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) dq[qt][dt] = mfma16(tk, dsf[qt], dq[qt][dt]);
-    }
-}
-// the key blocks b_lo, b_lo + b_step, .. < nblk; only the last block (nblk - 1) holds padded keys (T % 32 != 0, see ap_geom)
-template <int TP, int QT>
-DEVINL void ap_phase2(unsigned lk, const ApOff& of, const bf16x8_t (&qf)[QT][2], const bf16x8_t (&dof)[QT][2],
-                      const float (&mylse)[QT], const float (&myD)[QT], int T, int b_lo, int nblk, int b_step,
-                      f32x4_t (&dq)[QT][4], int lane, ApDma& dma) {
-    const int g = lane >> 4;
-    ApBase ba;
-    ba.init(lk, of);
-    int b = b_lo;
-    for (; b < nblk - 1; b += b_step) {
-        dma.step(lane);
-        ap_phase2_block<TP, QT, false>(ba, qf, dof, mylse, myD, T, b, dq, g);
-    }
-    if (b == nblk - 1) {
-        dma.step(lane);
-        ap_phase2_block<TP, QT, true>(ba, qf, dof, mylse, myD, T, b, dq, g);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Ping-pong forms of the pair loops.  Measured with the free-running loops above (round 4, s_memtime stamps): the two waves of a SIMD
-// run the same code in lock step, so their MFMA bursts collide and then their VALU bursts do -- 18 blocks of 515 matrix-pipe cycles
-// took ~20 k ticks per SIMD (46 % pipe utilisation, the second-dispatched wave of every SIMD 20-35 % slower than the first).
-// Here the workgroup's two wave groups (waves 0..3 / 4..7: wave i and i + 4 share a SIMD) run ONE s_barrier apart and every block
-// is two barrier intervals:  A = [MFMAs: products of the previous block's P / dS, then the next block's S / dP]   B = [LDS fragment
-// reads for the next A + the softmax arithmetic + one DMA piece], so that in every interval one wave of a SIMD feeds the matrix
-// pipe while its partner does vector and LDS work (gemm_core_pp.h's schedule; MI355X guide "Two waves per SIMD").
-// Every wave executes the same number of barriers (2 nblk + 2) whether it has a pair (`active`) or not.
-// ---------------------------------------------------------------------------------------------------------------------------------
-DEVINL void ap_bar() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int TP>
-DEVINL void ap_phase1_pp(unsigned lq, unsigned stats, const ApOff& of, const bf16x8_t (&kf)[2][2], const bf16x8_t (&vf)[2][2], int nblk,
-                         bool active, int grp, f32x4_t (&dv)[2][4], f32x4_t (&dk)[2][4], int lane, ApDma& dma) {
-    constexpr int SB = TP * 128;
-    const int g = lane >> 4;
-    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-    ApBase ba;
-    ba.init(lq, of);
-    unsigned sbase = stats + 16 * g;
-    asm volatile("" : "+v"(sbase));
-    bf16x8_t RQ[2][2], RD[2][2], TQ[4], TD[4], pf[2], dsf[2];
-    f32x4_t sa[2][2], dp[2][2];
+    bf16x8_t RQ[2][2], RD[2][2];
     auto load_rows = [&](int b) {
         const unsigned blk = (unsigned)b * 4096u;
         const unsigned r0 = ba.r[0] + blk, r1 = ba.r[1] + blk;
@@ -402,34 +253,9 @@ DEVINL void ap_phase1_pp(unsigned lq, unsigned stats, const ApOff& of, const bf1
             RD[qt][1] = ap_rows(r1 + (SB + qt * 2048));
         }
     };
-    auto load_cols = [&](int b) {
+    if (b_lo < b_hi) load_rows(b_lo);
+    auto body = [&](int b, auto with_dma) {
         const unsigned blk = (unsigned)b * 4096u;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const unsigned tp = ba.t[dt] + blk;
-            TQ[dt] = ap_cols(tp);
-            TD[dt] = ap_cols(tp + SB);
-        }
-    };
-    auto m1 = [&] {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                sa[qt][kt] = mfma16(RQ[qt][1], kf[kt][1], mfma16(RQ[qt][0], kf[kt][0], zero4));
-                dp[qt][kt] = mfma16(RD[qt][1], vf[kt][1], mfma16(RD[qt][0], vf[kt][0], zero4));
-            }
-    };
-    auto m2 = [&] {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                dv[kt][dt] = mfma16(TD[dt], pf[kt], dv[kt][dt]);
-                dk[kt][dt] = mfma16(TQ[dt], dsf[kt], dk[kt][dt]);
-            }
-    };
-    auto valu = [&](int b) {
         const unsigned st = sbase + (unsigned)b * 128u;
         f32x4_t l4[2], d4[2];
 #pragma unroll
@@ -437,51 +263,85 @@ DEVINL void ap_phase1_pp(unsigned lq, unsigned stats, const ApOff& of, const bf1
             l4[qt] = AP_LDS(f32x4_t, st + qt * 64);
             d4[qt] = AP_LDS(f32x4_t, st + (TP * 4 + qt * 64));
         }
+        bf16x8_t TQ[4], TD[4];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int dt = 0; dt < 4; ++dt) {
+            const unsigned tp = ba.t[dt] + blk;
+            TQ[dt] = ap_cols(tp);
+            TD[dt] = ap_cols(tp + SB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the two k-steps of a product are a dependent pair: all first steps, then all second steps (left to itself the compiler
+        // chains every pair back to back through one temporary -- 16 serialised MFMAs at the full latency, measured: the matrix
+        // pipe then paces the loop at 32 instead of 16 cycles per MFMA)
+        f32x4_t sa[2][KT], dp[2][KT];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                sa[qt][kt] = mfma16(RQ[qt][0], kf[kt][0], zero4);
+                dp[qt][kt] = mfma16(RD[qt][0], vf[kt][0], zero4);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                sa[qt][kt] = mfma16(RQ[qt][1], kf[kt][1], sa[qt][kt]);
+                dp[qt][kt] = mfma16(RD[qt][1], vf[kt][1], dp[qt][kt]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (decltype(with_dma)::value) dma.step(lane);
+        if (b + b_step < b_hi) load_rows(b + b_step);
+        __builtin_amdgcn_sched_barrier(0);
+        // A rows = queries, B columns = keys -> acc[r] = S[q = 32 b + 16 qt + 4 g + r][key = k0 + 16 kt + li]
+        bf16x8_t pf[KT], dsf[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            // vector expressions: the compiler emits v_pk_fma / v_pk_add / v_pk_mul (two elements per issue slot; the loops are
+            // bound by the number of instructions a SIMD can issue, ~1 per 4.5 cycles, not by any pipe)
             f32x4_t p[2], ds[2];
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+            for (int qt = 0; qt < 2; ++qt) {     // rows q >= T carry lse2 = 1e30: P = 0 without a mask
+                const f32x4_t arg = __builtin_elementwise_fma(sa[qt][kt], f32x4_t{SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, -l4[qt]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {    // rows q >= T carry lse2 = 1e30: P = 0 without a mask; the pair's keys are all valid
-                    p[qt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[qt][kt][r], SCALE_LOG2E, -l4[qt][r]));
-                    ds[qt][r] = p[qt][r] * (dp[qt][kt][r] - d4[qt][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(arg[r]);
+                    p[qt][r] = MASK ? (kval[kt] ? e : 0.f) : e;
                 }
+                ds[qt] = p[qt] * (dp[qt][kt] + d4[qt]);          // d4 = -D
+            }
             pf[kt] = pack8(p[0], p[1]);
             dsf[kt] = pack8(ds[0], ds[1]);
         }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                dv[kt][dt] = mfma16(TD[dt], pf[kt], dv[kt][dt]);
+                dk[kt][dt] = mfma16(TQ[dt], dsf[kt], dk[kt][dt]);
+            }
     };
-    if (active) load_rows(0);
-    if (grp) ap_bar();                           // group 1 runs one interval behind
-    if (active) m1();
-    ap_bar();
-    for (int b = 0; b < nblk; ++b) {
-        if (active) {                            // B(b)
-            load_cols(b);
-            if (b + 1 < nblk) load_rows(b + 1);
-            valu(b);
-        }
-        dma.step(lane);
-        ap_bar();
-        if (active) {                            // A(b + 1)
-            m2();
-            if (b + 1 < nblk) m1();
-        }
-        ap_bar();
-    }
-    if (!grp) ap_bar();
+    // the DMA pieces go out with the first blocks; the remaining blocks run a loop body without the issue logic (the loops are bound
+    // by instruction issue: ~20 scalar instructions per block for a piece that is not there)
+    int b = b_lo;
+    for (; b < b_hi && dma.j < dma.ninst; b += b_step) body(b, std::true_type{});
+    for (; b < b_hi; b += b_step) body(b, std::false_type{});
 }
 
-template <int TP>
-DEVINL void ap_phase2_pp(unsigned lk, const ApOff& of, const bf16x8_t (&qf)[2][2], const bf16x8_t (&dof)[2][2], const float (&mylse)[2],
-                         const float (&myD)[2], int T, int nblk, bool active, int grp, f32x4_t (&dq)[2][4], int lane, ApDma& dma) {
+// ---- phase 2 of QT query tiles (lane = query column) over the key blocks b_lo, b_lo + b_step, .. < nblk:
+//   S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - D);  dQ^T += K^T dS^T
+// only the last block (nblk - 1) holds padded keys (T % 32 != 0, see ap_geom); LDS reads one MFMA group ahead as in phase 1
+template <int TP, int QT>
+DEVINL void ap_phase2(unsigned lk, const ApOff& of, const bf16x8_t (&qf)[QT][2], const bf16x8_t (&dof)[QT][2],
+                      const float (&mylse)[QT], const float (&myD)[QT], int T, int b_lo, int nblk, int b_step,
+                      f32x4_t (&dq)[QT][4], int lane, ApDma& dma) {
     constexpr int SB = TP * 128;
     const int g = lane >> 4;
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
     ApBase ba;
     ba.init(lk, of);
-    bf16x8_t RK[2][2], RV[2][2], TK[4], dsf[2];
-    f32x4_t sa[2][2], dp[2][2];
+    bf16x8_t RK[2][2], RV[2][2];
     auto load_rows = [&](int b) {
         const unsigned blk = (unsigned)b * 4096u;
         const unsigned r0 = ba.r[0] + blk, r1 = ba.r[1] + blk;
@@ -493,36 +353,48 @@ DEVINL void ap_phase2_pp(unsigned lk, const ApOff& of, const bf16x8_t (&qf)[2][2
             RV[kt][1] = ap_rows(r1 + (SB + kt * 2048));
         }
     };
-    auto load_cols = [&](int b) {
+    if (b_lo < nblk) load_rows(b_lo);
+    auto body = [&](int b, auto with_dma, auto is_edge) {
         const unsigned blk = (unsigned)b * 4096u;
+        bf16x8_t TK[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) TK[dt] = ap_cols(ba.t[dt] + blk);
-    };
-    auto m1 = [&] {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4_t sa[2][QT], dp[2][QT];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                sa[kt][qt] = mfma16(RK[kt][1], qf[qt][1], mfma16(RK[kt][0], qf[qt][0], zero4));
-                dp[kt][qt] = mfma16(RV[kt][1], dof[qt][1], mfma16(RV[kt][0], dof[qt][0], zero4));
+            for (int qt = 0; qt < QT; ++qt) {
+                sa[kt][qt] = mfma16(RK[kt][0], qf[qt][0], zero4);
+                dp[kt][qt] = mfma16(RV[kt][0], dof[qt][0], zero4);
             }
-    };
-    auto m2 = [&] {
+        __builtin_amdgcn_sched_barrier(0);       // (first k-steps, then second k-steps: see phase 1)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) dq[qt][dt] = mfma16(TK[dt], dsf[qt], dq[qt][dt]);
-    };
-    auto valu = [&](int b) {
-        const bool edge = b == nblk - 1;                       // the last block holds the padded keys (T % 32 != 0)
-        const int krem = T - (b * 32 + 4 * g);
+            for (int qt = 0; qt < QT; ++qt) {
+                sa[kt][qt] = mfma16(RK[kt][1], qf[qt][1], sa[kt][qt]);
+                dp[kt][qt] = mfma16(RV[kt][1], dof[qt][1], dp[kt][qt]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (decltype(with_dma)::value) dma.step(lane);
+        if (b + b_step < nblk) load_rows(b + b_step);
+        __builtin_amdgcn_sched_barrier(0);
+        // acc[r] = S^T[key = 32 b + 16 kt + 4 g + r][q = lane column]
+        constexpr bool edge = decltype(is_edge)::value;
+        const int krem = T - (b * 32 + 4 * g);               // key 16 kt + r of this lane's rows is valid iff < krem
+        bf16x8_t dsf[QT];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             f32x4_t ds[2];
+            const f32x4_t sc4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E};
+            const f32x4_t nl4 = {-mylse[qt], -mylse[qt], -mylse[qt], -mylse[qt]}, D4 = {myD[qt], myD[qt], myD[qt], myD[qt]};   // myD = -D
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt) {
+                const f32x4_t arg = __builtin_elementwise_fma(sa[kt][qt], sc4, nl4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[kt][qt][r], SCALE_LOG2E, -mylse[qt]));
+                for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(arg[r]);
+            }
             if (edge) {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -530,33 +402,23 @@ DEVINL void ap_phase2_pp(unsigned lk, const ApOff& of, const bf16x8_t (&qf)[2][2
                     for (int r = 0; r < 4; ++r) ds[kt][r] = (kt * 16 + r < krem) ? ds[kt][r] : 0.f;
             }
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ds[kt][r] = ds[kt][r] * (dp[kt][qt][r] - myD[qt]);
+            for (int kt = 0; kt < 2; ++kt) ds[kt] = ds[kt] * (dp[kt][qt] + D4);
             dsf[qt] = pack8(ds[0], ds[1]);
         }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) dq[qt][dt] = mfma16(TK[dt], dsf[qt], dq[qt][dt]);
     };
-    if (active) load_rows(0);
-    if (grp) ap_bar();
-    if (active) m1();
-    ap_bar();
-    for (int b = 0; b < nblk; ++b) {
-        if (active) {
-            load_cols(b);
-            if (b + 1 < nblk) load_rows(b + 1);
-            valu(b);
-        }
-        dma.step(lane);
-        ap_bar();
-        if (active) {
-            m2();
-            if (b + 1 < nblk) m1();
-        }
-        ap_bar();
-    }
-    if (!grp) ap_bar();
+    int b = b_lo;
+    for (; b < nblk - 1 && dma.j < dma.ninst; b += b_step) body(b, std::true_type{}, std::false_type{});
+    for (; b < nblk - 1; b += b_step) body(b, std::false_type{}, std::false_type{});
+    if (b == nblk - 1) body(b, std::true_type{}, std::true_type{});       // the one block with padded keys
 }
 
+// MEASURED AND DROPPED (round 4): two-group ping-pong forms of the pair loops (waves 0..3 / 4..7 one s_barrier apart, every block =
+// [MFMA interval | LDS + softmax interval]): correct, but 1.88 ms vs 1.62 ms for the free-running loops at 257 tokens x 16 heads x 1024
+// items -- the vector interval (~150 instructions + a DMA piece at ~4.5 cycles per instruction) sets the pace, not the matrix pipe.
 // the waves' partial sums of the odd tile -> its (<= 16) gradient rows: thread t sums 8 consecutive columns of row (t >> 3) % nvl
 // of matrix t / (8 nvl) over the 8 waves, in wave order, and stores them as one 16-byte piece
 DEVINL void ap_reduce_rows(const float* part, int nmat, int nvl, float scale0, unsigned short* const (&dst)[2], long ld, int row0,
@@ -724,7 +586,7 @@ __global__ __launch_bounds__(AP_THREADS, 2) void attn_bwd_pair_kernel(AttnArgs a
         f32x4_t dv[2][4], dk[2][4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dv[0][dt] = dv[1][dt] = dk[0][dt] = dk[1][dt] = zero4;
-        ap_phase1_pp<TP>(aQ, sCur, of1, kfr.kf, kfr.vf, nblk, w < npair, w >> 2, dv, dk, lane1, dma);
+        if (w < npair) ap_phase1<TP, 2, false>(aQ, sCur, of1, kfr.kf, kfr.vf, k0, T, 0, nblk, 1, dv, dk, lane1, dma);
         AP_STAMP(3);
         int tid2 = tid;
         asm volatile("" : "+v"(tid2));
@@ -758,8 +620,8 @@ __global__ __launch_bounds__(AP_THREADS, 2) void attn_bwd_pair_kernel(AttnArgs a
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const int key = k0 + kt * 16 + li2;
-                ap_store_tile(dk[kt], ATT_SCALE, dkbase + (long)key * a.dkv_ld, key < T, g2);
-                ap_store_tile(dv[kt], 1.0f, dvbase + (long)key * a.dkv_ld, key < T, g2);
+                att_store_tile(dk[kt], ATT_SCALE, dkbase + (long)key * a.dkv_ld, key < T, g2);
+                att_store_tile(dv[kt], 1.0f, dvbase + (long)key * a.dkv_ld, key < T, g2);
             }
         }
         AP_STAMP(5);
@@ -798,7 +660,7 @@ __global__ __launch_bounds__(AP_THREADS, 2) void attn_bwd_pair_kernel(AttnArgs a
         f32x4_t dq[2][4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[0][dt] = dq[1][dt] = zero4;
-        ap_phase2_pp<TP>(aK, of3, qf, dof, mylse, myD, T, nblk, w < npair, w >> 2, dq, lane3, dma);
+        if (w < npair) ap_phase2<TP, 2>(aK, of3, qf, dof, mylse, myD, T, 0, nblk, 1, dq, lane3, dma);
         AP_STAMP(9);
         int tid4 = tid;
         asm volatile("" : "+v"(tid4));
@@ -813,7 +675,7 @@ __global__ __launch_bounds__(AP_THREADS, 2) void attn_bwd_pair_kernel(AttnArgs a
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int q = k0 + qt * 16 + li4;
-                ap_store_tile(dq[qt], ATT_SCALE, dqbase + (long)q * a.dq_ld, q < T, g4);
+                att_store_tile(dq[qt], ATT_SCALE, dqbase + (long)q * a.dq_ld, q < T, g4);
             }
         }
         // the next head's key fragments: their round trip lies under the barrier
@@ -831,244 +693,6 @@ __global__ __launch_bounds__(AP_THREADS, 2) void attn_bwd_pair_kernel(AttnArgs a
 // LDS bytes of the backward for TP padded rows and nvl valid rows in the odd tile
 static int ap_bwd_lds(int TP, int nvl) { return 4 * TP * 128 + 4 * TP * 4 + AP_WAVES * 3 * nvl * 64 * 4; }
 
-// =================================================================================================================================
-// Forward.  K, V of a head in LDS, double buffered over heads: the next head's slices arrive by DMA while this one computes.  A wave
-// owns a pair of query tiles (lane = query column, S^T = K Q^T, O^T = V^T P^T with P^T straight from the accumulators, online softmax
-// per tile exactly as in attention.hip -- the pair rows come out bitwise equal); the odd tile's key blocks are dealt to the waves, whose
-// partial (max, sum, O^T) are combined behind the head's barrier.
-// =================================================================================================================================
-template <int QT>
-struct ApFwdState {
-    f32x4_t o[QT][4];
-    float m[QT], l[QT];
-    DEVINL void init() {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            m[qt] = -1e30f;
-            l[qt] = 0.f;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-};
-template <int TP, int QT, bool EDGE>
-DEVINL void ap_fwd_block(const ApBase& ba, const bf16x8_t (&qf)[QT][2], int T, int b, ApFwdState<QT>& st, int g) {
-    constexpr int SB = TP * 128;
-    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-    const unsigned blk = (unsigned)b * 4096u;
-    const unsigned r0 = ba.r[0] + blk;
-    const unsigned r1 = ba.r[1] + blk;
-    f32x4_t sx[2][QT];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const bf16x8_t ak0 = ap_rows(r0 + kt * 2048), ak1 = ap_rows(r1 + kt * 2048);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) sx[kt][qt] = mfma16(ak1, qf[qt][1], mfma16(ak0, qf[qt][0], zero4));
-    }
-    // acc[r] = S^T[key = 32 b + 16 kt + 4 g + r][q = lane column]
-    const int krem = T - (b * 32 + 4 * g);
-    bf16x8_t pf[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        if (EDGE) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sx[kt][qt][r] = (kt * 16 + r < krem) ? sx[kt][qt][r] : -1e30f;
-        }
-        float mx = -1e30f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sx[kt][qt][r]);
-        mx = group_max(mx);
-        const float m_new = fmaxf(st.m[qt], mx * SCALE_LOG2E);
-        if (__any(m_new > st.m[qt])) {
-            const float alpha = __builtin_amdgcn_exp2f(st.m[qt] - m_new);
-            st.l[qt] *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) st.o[qt][dt] = st.o[qt][dt] * alpha;
-            st.m[qt] = m_new;
-        }
-        float sum = 0.f;
-        f32x4_t p[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {      // masked logits (-1e30) underflow to exactly 0; key 0 is valid for every row
-                p[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[kt][qt][r], SCALE_LOG2E, -st.m[qt]));
-                sum += p[kt][r];
-            }
-        st.l[qt] += sum;
-        pf[qt] = pack8(p[0], p[1]);
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t tv = ap_cols(ba.t[dt] + (blk + SB));
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) st.o[qt][dt] = mfma16(tv, pf[qt], st.o[qt][dt]);
-    }
-}
-template <int TP, int QT>
-DEVINL void ap_fwd_blocks(unsigned lk, const ApOff& of, const bf16x8_t (&qf)[QT][2], int T, int b_lo, int nblk, int b_step,
-                          ApFwdState<QT>& st, int lane, ApDma& dma) {
-    const int g = lane >> 4;
-    ApBase ba;
-    ba.init(lk, of);
-    int b = b_lo;
-    for (; b < nblk - 1; b += b_step) {
-        dma.step(lane);
-        ap_fwd_block<TP, QT, false>(ba, qf, T, b, st, g);
-    }
-    if (b == nblk - 1) {
-        dma.step(lane);
-        ap_fwd_block<TP, QT, true>(ba, qf, T, b, st, g);
-    }
-}
-
-#define AP_FPART 68       // floats per (wave, odd-tile row): m, l, 2 unused, O[64]
-
-template <int TP>
-__global__ __launch_bounds__(AP_THREADS, 2) void attn_fwd_pair_kernel(AttnArgs a, ApGeom gm) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int SB = TP * 128;
-    const int T = gm.T, H = a.H, nblk = gm.nblk, npair = gm.npair, nvl = gm.nvl;
-    float* part = reinterpret_cast<float*>(lds + 4 * SB);       // [2 heads][8 waves][nvl][AP_FPART]
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    ApOff of;
-    of.init(lane);
-    const unsigned aL = ap_lds_addr(lds);
-    const int q0 = 32 * w, qL0 = 32 * npair;
-    const int idle = AP_WAVES - npair;      // the odd tile's key blocks: as in the backward
-    const int lb_lo = gm.left ? (idle > 0 ? (w >= npair ? w - npair : nblk) : (w < 4 ? w : nblk)) : nblk;
-    const int lb_step = idle > 0 ? idle : 4;
-    {   // rows T .. TP - 1 of the four slices stay zero (V's padded rows meet P = 0: they must be finite)
-        const int npad = (TP - T) * 8;
-        const u32x4_t z = {0u, 0u, 0u, 0u};
-        for (int c = tid; c < 4 * npad; c += AP_THREADS) {
-            const int sl = c / npad, r = c % npad;
-            *reinterpret_cast<u32x4_t*>(lds + sl * SB + T * 128 + r * 16) = z;
-        }
-    }
-    const unsigned kbytes = (unsigned)((long)(T - 1) * a.kv_ld * 2 + 128);
-    int hd = blockIdx.x;
-    if (hd >= gm.total_heads) return;
-    bf16x8_t qf[2][2], qf1[1][2];
-    {   // first head: its queries, K and V
-        const int m = hd / H, h = hd % H;
-        const unsigned short* qbase = a.q + (long)m * T * a.q_ld + h * ATT_D;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            qf[0][s] = ap_frag_global(qbase, a.q_ld, q0, s, lane, T);
-            qf[1][s] = ap_frag_global(qbase, a.q_ld, q0 + 16, s, lane, T);
-            qf1[0][s] = ap_frag_global(qbase, a.q_ld, qL0, s, lane, T);
-        }
-        ap_wait_vm0();
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { ap_pin(qf[0][s]); ap_pin(qf[1][s]); ap_pin(qf1[0][s]); }
-        ap_stage2(ap_make_srd(a.k + (long)m * T * a.kv_ld + h * ATT_D, kbytes), a.kv_ld,
-                  ap_make_srd(a.v + (long)m * T * a.kv_ld + h * ATT_D, kbytes), a.kv_ld, aL, aL + SB, T, w, lane);
-        ap_wait_vm0();
-        __syncthreads();
-    }
-    int it = 0;
-    for (; hd < gm.total_heads; hd += gridDim.x, ++it) {
-        const int m = hd / H, h = hd % H;
-        const int nh = hd + gridDim.x;
-        const bool more = nh < gm.total_heads;
-        const int m2 = more ? nh / H : m, h2 = more ? nh % H : h;
-        const unsigned cur = aL + (unsigned)(it & 1) * (2 * SB), nxt = aL + (unsigned)((it + 1) & 1) * (2 * SB);
-        float* mypart = part + (it & 1) * (AP_WAVES * nvl * AP_FPART);
-        AP_STAMP(0);
-        // the queries requested at the end of the last head are complete (no DMA is in flight here)
-        ap_wait_vm0();
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { ap_pin(qf[0][s]); ap_pin(qf[1][s]); ap_pin(qf1[0][s]); }
-        int tid1 = tid;
-        asm volatile("" : "+v"(tid1));
-        ApDma dma;     // the next head's K, V into the other buffer (released by the barrier that ended the head before this one)
-        if (more)
-            dma.start(ap_make_srd(a.k + (long)m2 * T * a.kv_ld + h2 * ATT_D, kbytes), a.kv_ld,
-                      ap_make_srd(a.v + (long)m2 * T * a.kv_ld + h2 * ATT_D, kbytes), a.kv_ld, nxt, nxt + SB, T, w);
-        else
-            dma.idle();
-        AP_STAMP(1);
-        if (gm.left) {          // this wave's share of the odd tile: partial (max, sum, O^T) of its key blocks
-            ApFwdState<1> s1;
-            s1.init();
-            ap_fwd_blocks<TP, 1>(cur, of, qf1, T, lb_lo, nblk, lb_step, s1, lane, dma);
-            const float lsum = group_sum(s1.l[0]);
-            const int li = lane & 15, g = lane >> 4;
-            if (li < nvl) {
-                float* p = mypart + (w * nvl + li) * AP_FPART;
-                if (g == 0) {
-                    p[0] = s1.m[0];
-                    p[1] = lsum;
-                }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4_t*>(p + 4 + 16 * dt + 4 * g) = s1.o[0][dt];
-            }
-        }
-        AP_STAMP(2);
-        ApFwdState<2> st;
-        st.init();
-        if (w < npair) ap_fwd_blocks<TP, 2>(cur, of, qf, T, 0, nblk, 1, st, lane, dma);
-        AP_STAMP(3);
-        int tid2 = tid;
-        asm volatile("" : "+v"(tid2));
-        const int lane2 = tid2 & 63, li2 = lane2 & 15, g2 = lane2 >> 4;
-        dma.drain(lane2);
-        ap_wait_vm0();          // the next head's K / V pieces of this wave have landed
-        AP_STAMP(4);
-        if (w < npair) {
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const int q = q0 + qt * 16 + li2;
-                const float lsum = group_sum(st.l[qt]);
-                ap_store_tile(st.o[qt], 1.0f / lsum, a.out + ((long)m * T + q) * a.out_ld + h * ATT_D, q < T, g2);
-                if (g2 == 0 && q < T) a.lse[((long)m * H + h) * T + q] = st.m[qt] * LN2F + __logf(lsum);
-            }
-        }
-        {   // the next head's queries: their round trip lies under the barrier
-            const unsigned short* qbase2 = a.q + (long)m2 * T * a.q_ld + h2 * ATT_D;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                qf[0][s] = ap_frag_global(qbase2, a.q_ld, q0, s, lane2, T);
-                qf[1][s] = ap_frag_global(qbase2, a.q_ld, q0 + 16, s, lane2, T);
-                qf1[0][s] = ap_frag_global(qbase2, a.q_ld, qL0, s, lane2, T);
-            }
-        }
-        AP_STAMP(5);
-        __syncthreads();        // this head's slices released, the next head's visible, the odd tile's partials complete
-        AP_STAMP(6);
-        if (gm.left && tid2 < nvl * 8) {      // combine: thread = (row, 8 columns); the 8 partials in wave order
-            const int rr = tid2 >> 3, c = tid2 & 7;
-            float M = -1e30f;
-            for (int ww = 0; ww < AP_WAVES; ++ww) M = fmaxf(M, mypart[(ww * nvl + rr) * AP_FPART]);
-            float L = 0.f, acc[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-            for (int ww = 0; ww < AP_WAVES; ++ww) {
-                const float* p = mypart + (ww * nvl + rr) * AP_FPART;
-                const float f = __builtin_amdgcn_exp2f(p[0] - M);
-                L += p[1] * f;
-                const f32x4_t x = *reinterpret_cast<const f32x4_t*>(p + 4 + c * 8), y = *reinterpret_cast<const f32x4_t*>(p + 8 + c * 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[e] += x[e] * f;
-                    acc[4 + e] += y[e] * f;
-                }
-            }
-            const float inv = 1.0f / L;
-            const u32x4_t v = {pack_bf16x2(acc[0] * inv, acc[1] * inv), pack_bf16x2(acc[2] * inv, acc[3] * inv),
-                               pack_bf16x2(acc[4] * inv, acc[5] * inv), pack_bf16x2(acc[6] * inv, acc[7] * inv)};
-            *reinterpret_cast<u32x4_t*>(a.out + ((long)m * T + qL0 + rr) * a.out_ld + h * ATT_D + c * 8) = v;
-            if (c == 0) a.lse[((long)m * H + h) * T + qL0 + rr] = M * LN2F + __logf(L);
-        }
-    }
-}
-static int ap_fwd_lds(int TP, int nvl) { return 4 * TP * 128 + 2 * AP_WAVES * nvl * AP_FPART * 4; }
-
 // can the pair kernels take this call?  plain self-attention (the caller checks mask / dropout / bias), 129 .. 288 tokens in one of
 // the instantiated paddings, at most 8 pairs, and the odd tile's partial area within the LDS budget
 static bool ap_geom(int T, ApGeom* gm, int* TP) {
@@ -1084,7 +708,7 @@ static bool ap_geom(int T, ApGeom* gm, int* TP) {
     if (gm->npair > AP_WAVES) return false;
     if (32 * gm->npair > T) return false;                 // every pair is full (no key mask in the pair loops) ...
     if (T % 32 == 0) return false;                        // ... and exactly the last 32-row block holds padding
-    if (ap_bwd_lds(tp, gm->nvl) > 160 * 1024 || ap_fwd_lds(tp, gm->nvl) > 160 * 1024) return false;
+    if (ap_bwd_lds(tp, gm->nvl) > 160 * 1024) return false;
     *TP = tp;
     return true;
 }
@@ -1115,36 +739,6 @@ int launch_attn_bwd_pair(const AttnArgs& a, int batch, hipStream_t st) {      //
     const int grid = gm.total_heads < ncu ? gm.total_heads : ncu;
     if (TP == 288) hipLaunchKernelGGL(attn_bwd_pair_kernel<288>, dim3(grid), dim3(AP_THREADS), sm, st, a, gm);
     else hipLaunchKernelGGL(attn_bwd_pair_kernel<224>, dim3(grid), dim3(AP_THREADS), sm, st, a, gm);
-    HIP_LAUNCH_CHECK();
-    return UNIIR_OK;
-}
-
-int launch_attn_fwd_pair(const AttnArgs& a, int batch, hipStream_t st) {      // returns 1 when the shape is not taken
-    ApGeom gm;
-    int TP;
-    if (a.Tq != a.Tk || a.causal || a.klen || a.rel_emb || a.drop_p > 0.f || !ap_geom(a.Tq, &gm, &TP)) return 1;
-    if ((a.q_ld | a.kv_ld | a.out_ld) % 8) return 1;
-    if ((long)a.Tq * a.q_ld * 2 >= (1L << 31) || (long)a.Tq * a.kv_ld * 2 >= (1L << 31)) return 1;
-    gm.total_heads = batch * a.H;
-    static int ncu = 0;
-    if (!ncu) {
-        int d = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&prop, d) != hipSuccess) return UNIIR_ELAUNCH;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-#ifdef UNIIR_EXP_BUILD
-    if (g_att_exp & 64) return 1;
-#endif
-    const int sm = ap_fwd_lds(TP, gm.nvl);
-    static PerDeviceOnce attr;
-    if (attr.first()) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pair_kernel<288>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pair_kernel<224>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    const int grid = gm.total_heads < ncu ? gm.total_heads : ncu;
-    if (TP == 288) hipLaunchKernelGGL(attn_fwd_pair_kernel<288>, dim3(grid), dim3(AP_THREADS), sm, st, a, gm);
-    else hipLaunchKernelGGL(attn_fwd_pair_kernel<224>, dim3(grid), dim3(AP_THREADS), sm, st, a, gm);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
