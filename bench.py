@@ -115,7 +115,7 @@ def cpu_baseline(model_name):
     sweep = {}
     for th in (8, 16, 32, 64, 128):
         if th <= cores:
-            t, _ = _oracle_step_timer("ViT-B/32", 4, th, 1, 1, 15.0)
+            t, _ = _oracle_step_timer("ViT-B/32", 4, th, 1, 3, 20.0)            # median of 3 after 1 warm-up
             sweep[th] = round(4 / t, 3)
     if not sweep:
         sweep[cores] = round(4 / _oracle_step_timer("ViT-B/32", 4, cores, 1, 1, 15.0)[0], 3)
@@ -128,7 +128,7 @@ def cpu_baseline(model_name):
     return {"value": round(pairs_l / t_l, 3), "unit": "pairs/s", "cores": best, "kind": "port",
             "sample": f"oracle/clip_oracle.py CLIP_SF {model_name} fp32 fwd+bwd+AdamW, {pairs_l} pairs/step, median of {n_l} timed "
                       f"steps after a 2-pair warm-up step on {best} host threads ({cores} logical cores; thread count picked by the sweep)",
-            "thread_sweep": {"workload": "CLIP_SF ViT-B/32, 4 pairs/step, 1 timed step after 1 warm-up, pairs/s by torch.set_num_threads",
+            "thread_sweep": {"workload": "CLIP_SF ViT-B/32, 4 pairs/step, median of 3 timed steps after 1 warm-up, pairs/s by torch.set_num_threads",
                              "pairs_per_s": {str(k): v for k, v in sweep.items()}, "picked": best},
             "config1": {"value": round(32 / t_b, 3), "unit": "pairs/s", "cores": best,
                         "sample": f"BASELINE configs[0] as written: CLIP_SF ViT-B/32, batch 32, fp32, 1 process, median of {n_b} "
@@ -199,11 +199,47 @@ def bench_retrieval(dev, n=700_000, d=768, k=10, full=True):
                                  "frac": round(sweeps * n * d * 2 / t / HBM_PEAK, 4)},
                          "mfma": {"achieved": round(2.0 * nq * n * d / t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,
                                   "unit": "TFLOP/s", "frac": round(2.0 * nq * n * d / t / MFMA_PEAK_BF16, 4)}}
-    out["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE of the scan kernel, profiles/r03_topk_pmc.txt: "
-                           "1.079 GB fetched per sweep of the 1.075-GB shard (read once), 27.8 MB written at 64 queries, 81.3 MB at 256")
+    if n == 700_000 and d == 768:      # a citation of a committed profile of THIS shard shape, not a measurement of this run
+        out["traffic_note"] = ("cited from profiles/r03_topk_pmc.txt (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE of the scan kernel on a "
+                               "700000 x 768 shard): 1.079 GB fetched per sweep of the 1.075-GB shard (read once), 27.8 MB written at 64 "
+                               "queries, 81.3 MB at 256")
     out["workload"] = (f"top-{k} of {n} x {d} fp16 candidates (one GPU's shard of the 5.6M pool), exact fp32 re-score; "
                        "recall on M-BEIR itself cannot be shown offline (no dataset / checkpoint in the image): exactness is "
                        "pinned against the C oracle instead")
+    return out
+
+
+def bench_retrieval_full_pool(dev, n=5_600_000, d=768, k=10):
+    """configs[3] as written on ONE GPU: the whole 5.6 M x 768 fp16 M-BEIR pool (8.6 GB) resident as one shard, searched as 5 logical
+    sub-shards below the 2-GiB buffer bound (retrieval.subshard_bounds) + k-way merge; 64 / 1024 / 100 000 queries"""
+    from uniir_amd import retrieval
+    g = torch.Generator(device=dev).manual_seed(2024)
+    pool = torch.empty(n, d, device=dev, dtype=torch.float16)
+    for lo in range(0, n, 700_000):
+        pool[lo:lo + 700_000] = torch.randn(min(700_000, n - lo), d, generator=g, device=dev).half()
+    shard = retrieval.PoolShard(pool, torch.arange(n, device=dev))
+    parts = retrieval.subshard_bounds(n, d)
+    per_sweep = retrieval.sweep_queries(d, parts[0][1] - parts[0][0])
+    out = {"pool_rows": n, "sub_shards": len(parts), "rows_per_sub_shard": parts[0][1] - parts[0][0]}
+    for nq in (64, 1024, 100_000):
+        q = torch.randn(nq, d, generator=g, device=dev).half()
+        retrieval.search_shard(shard, q, k)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 10 if nq <= 1024 else 1
+        e0.record()
+        for _ in range(iters):
+            retrieval.search_shard(shard, q, k)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / iters
+        sweeps = -(-nq // per_sweep)
+        out[f"q{nq}"] = {"ms": round(t * 1e3, 3), "M_candidates_per_s": round(n / t / 1e6, 1), "M_scores_per_s": round(nq * n / t / 1e6, 1),
+                         "sweeps_per_sub_shard": sweeps,
+                         "hbm": {"achieved": round(sweeps * n * d * 2 / t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                 "frac": round(sweeps * n * d * 2 / t / HBM_PEAK, 4)},
+                         "mfma": {"achieved": round(2.0 * nq * n * d / t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                                  "frac": round(2.0 * nq * n * d / t / MFMA_PEAK_BF16, 4)}}
     return out
 
 
@@ -726,6 +762,8 @@ def main():
     if rank == 0 and world == 1 and not args.dry_run:
         if not args.no_retrieval:
             result["retrieval"] = _secondary("retrieval", bench_retrieval, dev)
+            if isinstance(result["retrieval"], dict) and "error" not in result["retrieval"]:
+                result["retrieval"]["full_pool"] = _secondary("retrieval.full_pool", bench_retrieval_full_pool, dev)
         if not args.no_secondary:
             result["embed"] = _secondary("embed", bench_embed, dev, args.model)
             result["blip_ff_large"] = _secondary("blip_ff_large", bench_blip_ff, dev)

@@ -401,6 +401,9 @@ int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_norm, const i
  * per chunk of <= 1024 queries one sweep of the shard (MFMA group-max scan: queries in registers and the pool streamed once for
  * <= 256 queries, GEMM-shaped above), then a fused group selection + query norm + exact re-score launch and the final sort.
  * k <= 56.  Same results as coarse + rescore, bit for bit.
+ * rows * dim * 2 must stay below 2 GiB (UNIIR_ESHAPE otherwise: the shard is addressed through 31-bit buffer offsets); a larger
+ * resident shard -- the whole 5.6 M x 768 M-BEIR pool on one GPU -- is searched as equal row ranges and merged with
+ * uniir_topk_merge (uniir_amd/retrieval.py subshard_bounds), which is the search of the whole shard.
  * workspace: uniir_topk_ip_workspace_bytes_ex(nq, k, rows, dim) bytes (the exact requirement; the dim-agnostic form is an upper
  * bound over the sweep widths), 256-B aligned. */
 int64_t uniir_topk_ip_workspace_bytes(int32_t nq, int32_t k, int64_t rows);

@@ -15,6 +15,16 @@ What is restated, and from where (paths relative to the UniIR reference tree):
     pinned against the reference class itself, imported with a stub `clip` module (tests/golden g1/g2/g3/g4).
   * optimizer groups + AdamW + cosine: clip_scorefusion/train.py:52-61,195-199,281-284; uniir_clip/engine.py:19-50
     pinned by g10 (the reference's own train_one_epoch run on CPU).
+
+Rounding mode (`with rounding("bf16"):`, round 4).  The reference trains under autocast (engine.py:24-42: half-precision matmuls,
+fp32 master weights and gradients); the device build does the same in bf16.  Inside the context the SAME restatement rounds to bf16
+at the points where the device holds a 16-bit tensor -- GEMM operands (bf16 weight shadows, LayerNorm outputs, the packed q|k|v,
+attention probabilities and outputs, the MLP pre-activation and activation, the patch embedding) and the 16-bit gradient copies the
+backward GEMMs consume (gradients of those tensors, and the copy of the fp32 residual gradient that feeds each dgrad / wgrad) --
+while the residual stream, LayerNorm / softmax statistics, accumulations and master gradients stay fp32.  It exists so that the
+device gradients can be gated at ~1e-2 instead of the 1e-1 an fp32-everywhere oracle forces: what remains between the two is
+summation order and 1-ulp intrinsics, so a parameter that stays above the gate is a bug, not noise.  Outside the context nothing
+changes (fp32 everywhere, the pinned restatement).
 """
 import math
 from collections import OrderedDict
@@ -99,6 +109,116 @@ def init_state_dict(cfg, seed=0, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# bf16 rounding points of the device build (see the module docstring); identities outside `with rounding("bf16")`
+# ------------------------------------------------------------------------------------------------------------
+_ROUND = None
+
+
+class rounding:
+    def __init__(self, mode):
+        if mode not in (None, "bf16"):
+            raise ValueError(mode)
+        self.mode = mode
+
+    def __enter__(self):
+        global _ROUND
+        self.prev, _ROUND = _ROUND, self.mode
+
+    def __exit__(self, *exc):
+        global _ROUND
+        _ROUND = self.prev
+        return False
+
+
+def _r16(x):
+    return x.bfloat16().float()
+
+
+class _Store16(torch.autograd.Function):
+    """a tensor the device holds in bf16: its value and the gradient that comes back for it are both 16-bit"""
+    @staticmethod
+    def forward(ctx, x):
+        return _r16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r16(g)
+
+
+class _Weight16(torch.autograd.Function):
+    """the bf16 shadow of an fp32 master weight (GEMM operand); its gradient is accumulated in fp32"""
+    @staticmethod
+    def forward(ctx, w):
+        return _r16(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _Grad16(torch.autograd.Function):
+    """an fp32 tensor whose incoming gradient reaches the backward GEMMs through a bf16 copy (residual branches, the embedding)"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r16(g)
+
+
+def q16(x):
+    return _Store16.apply(x) if _ROUND else x
+
+
+def w16(w):
+    return _Weight16.apply(w) if _ROUND else w
+
+
+def g16(x):
+    return _Grad16.apply(x) if _ROUND else x
+
+
+class _Attn16(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d) [+ causal]) v on a packed bf16 q|k|v as the device kernels compute it (csrc/attention.hip): fp32
+    logits and statistics, probabilities rounded to bf16 as matrix operands, output rounded to bf16; backward with P recomputed
+    from the stored log-sum-exp, D = rowsum(dO * O), dS = P (dP - D) rounded to bf16, dq / dk / dv rounded to bf16"""
+    @staticmethod
+    def forward(ctx, qkv, heads, causal):
+        N, L, W3 = qkv.shape
+        W = W3 // 3
+        hd = W // heads
+        q, k, v = (t.view(N, L, heads, hd).transpose(1, 2) for t in qkv.split(W, dim=-1))
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        if causal:
+            s = s + torch.full((L, L), float("-inf")).triu_(1)
+        m = s.max(dim=-1, keepdim=True).values
+        pu = torch.exp(s - m)
+        l = pu.sum(dim=-1, keepdim=True)
+        o = _r16((_r16(pu) @ v) / l)
+        ctx.save_for_backward(q, k, v, o, m + torch.log(l))
+        ctx.geom = (N, L, W, heads, hd, causal)
+        return o.transpose(1, 2).reshape(N, L, W)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        N, L, W, heads, hd, causal = ctx.geom
+        do = do.view(N, L, heads, hd).transpose(1, 2)                 # arrives bf16-valued (the out-projection's dgrad output)
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        if causal:
+            s = s + torch.full((L, L), float("-inf")).triu_(1)
+        p = torch.exp(s - lse)
+        D = (do * o).sum(dim=-1, keepdim=True)
+        ds = _r16(p * (do @ v.transpose(-1, -2) - D))
+        dv = _r16(_r16(p).transpose(-1, -2) @ do)
+        dq = _r16((ds @ k) / math.sqrt(hd))
+        dk = _r16((ds.transpose(-1, -2) @ q) / math.sqrt(hd))
+        dqkv = torch.cat([t.transpose(1, 2).reshape(N, L, W) for t in (dq, dk, dv)], dim=-1)
+        return dqkv, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------
 # towers
 # ------------------------------------------------------------------------------------------------------------
 def layer_norm(x, w, b, eps=1e-5):
@@ -114,6 +234,10 @@ def attention(x, sd, p, heads, attn_mask=None):
     """nn.MultiheadAttention(x, x, x, need_weights=False, attn_mask=mask) on [N, L, W] (batch first here)."""
     N, L, W = x.shape
     hd = W // heads
+    if _ROUND:       # x is the bf16 LayerNorm output; packed q|k|v in bf16; the device attention; fp32 out-projection result
+        qkv = q16(x @ w16(sd[f"{p}.attn.in_proj_weight"]).t() + sd[f"{p}.attn.in_proj_bias"])
+        o = _Attn16.apply(qkv, heads, attn_mask is not None)
+        return o @ w16(sd[f"{p}.attn.out_proj.weight"]).t() + sd[f"{p}.attn.out_proj.bias"]
     qkv = x @ sd[f"{p}.attn.in_proj_weight"].t() + sd[f"{p}.attn.in_proj_bias"]
     q, k, v = qkv.split(W, dim=-1)
     q = q.view(N, L, heads, hd).transpose(1, 2)
@@ -128,16 +252,20 @@ def attention(x, sd, p, heads, attn_mask=None):
 
 
 def resblock(x, sd, p, heads, attn_mask=None):
-    x = x + attention(layer_norm(x, sd[f"{p}.ln_1.weight"], sd[f"{p}.ln_1.bias"]), sd, p, heads, attn_mask)
-    h = layer_norm(x, sd[f"{p}.ln_2.weight"], sd[f"{p}.ln_2.bias"])
-    h = quick_gelu(h @ sd[f"{p}.mlp.c_fc.weight"].t() + sd[f"{p}.mlp.c_fc.bias"])
-    return x + (h @ sd[f"{p}.mlp.c_proj.weight"].t() + sd[f"{p}.mlp.c_proj.bias"])
+    # q16 / w16 / g16: identities unless `with rounding("bf16")` (the device's 16-bit tensors, see the module docstring)
+    x = x + g16(attention(q16(layer_norm(x, sd[f"{p}.ln_1.weight"], sd[f"{p}.ln_1.bias"])), sd, p, heads, attn_mask))
+    h = q16(layer_norm(x, sd[f"{p}.ln_2.weight"], sd[f"{p}.ln_2.bias"]))
+    f = q16(h @ w16(sd[f"{p}.mlp.c_fc.weight"]).t() + sd[f"{p}.mlp.c_fc.bias"])      # the stashed pre-activation (bf16 on the device)
+    h = q16(quick_gelu(f))
+    return x + g16(h @ w16(sd[f"{p}.mlp.c_proj.weight"]).t() + sd[f"{p}.mlp.c_proj.bias"])
 
 
 def encode_image(sd, image, cfg, return_tokens=False):
     """VisionTransformer.forward: conv1 -> [cls; patches] + pos -> ln_pre -> blocks -> ln_post(x[:,0]) @ proj."""
     vw, P = cfg["vision_width"], cfg["vision_patch_size"]
-    x = F.conv2d(image, sd["visual.conv1.weight"], stride=P)          # [N, W, g, g]
+    if _ROUND:
+        image = _r16(image)                                           # bf16 patches
+    x = q16(F.conv2d(image, w16(sd["visual.conv1.weight"]), stride=P))   # [N, W, g, g]; bf16 on the device
     x = x.reshape(x.shape[0], vw, -1).permute(0, 2, 1)                # [N, g*g, W]
     cls = sd["visual.class_embedding"].to(x.dtype) + torch.zeros(x.shape[0], 1, vw, dtype=x.dtype)
     x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]
@@ -147,8 +275,8 @@ def encode_image(sd, image, cfg, return_tokens=False):
         x = resblock(x, sd, f"visual.transformer.resblocks.{i}", heads)
     if return_tokens:
         return x
-    x = layer_norm(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"])
-    return x @ sd["visual.proj"]
+    x = q16(layer_norm(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]))
+    return g16(x @ w16(sd["visual.proj"]))
 
 
 def build_attention_mask(L):
@@ -162,8 +290,8 @@ def encode_text(sd, text, cfg):
     for i in range(cfg["transformer_layers"]):
         x = resblock(x, sd, f"transformer.resblocks.{i}", cfg["transformer_heads"], mask)
     x = layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"])
-    x = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]
-    return x @ sd["text_projection"]
+    x = q16(x[torch.arange(x.shape[0]), text.argmax(dim=-1)])
+    return g16(x @ w16(sd["text_projection"]))
 
 
 # ------------------------------------------------------------------------------------------------------------

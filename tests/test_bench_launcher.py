@@ -79,10 +79,11 @@ def test_bench_line_schema_on_the_device():
 @pytest.mark.gpu
 def test_bench_two_ranks_sharing_the_gpu():
     """the REAL multi-rank bench path (self-launch, replica sync at the DDP point, overlapped bucketed all-reduce, the rccl block,
-    per-rank checksums) with two ranks on the one GPU a test box has, over gloo (UNIIR_BENCH_SHARED_GPU=1; RCCL cannot put two
+    per-rank checksums, and the N > 1 retrieval / embedding blocks) with two ranks on the one GPU a test box has, over gloo (UNIIR_BENCH_SHARED_GPU=1; RCCL cannot put two
     ranks on one device): ranks seeded differently must end the timed steps with identical parameters"""
     p, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "16", "--model", "ViT-B/32", "--no-cpu-baseline",
-                     "--no-secondary", "--no-retrieval"], {"UNIIR_BENCH_SHARED_GPU": "1"})
+                     "--shard-rows", "40030", "--shard-queries", "64,300", "--embed-items", "64", "--check-sharded"],
+                    {"UNIIR_BENCH_SHARED_GPU": "1"})
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(lines) == 1, (lines, p.stderr[-2000:])
     r = json.loads(lines[0])
@@ -91,3 +92,16 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert rc["ranks_seen"] == 2 and rc["replicas_identical"] is True and len(rc["replica_checksums"]) == 2
     assert rc["grad_allreduce"]["collectives_per_step"] >= 1
     assert abs(r["value"] - 32 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-2 * r["value"]
+    # the other two BASELINE metrics at N > 1: sharded retrieval (configs[3]) and embedding extraction (configs[2])
+    rt = r["retrieval"]
+    assert "error" not in rt, rt
+    assert rt["ranks_seen"] == 2 and rt["pool_rows"] == 2 * 40030 and rt["rows_per_rank"] == 40030
+    for key, nq in (("q64", 64), ("q300", 300)):
+        q = rt[key]
+        assert q["equals_single_shard_search"] is True         # == one search over the concatenated pool, bit for bit
+        assert q["queries_per_rank"] == nq // 2 and q["ms"] > 0 and q["M_candidates_per_s"] > 0
+        for piece in ("all_gather_queries_ms", "gather_topk_ms", "merge_ms"):
+            assert q[piece] > 0
+    em = r["embed"]
+    assert "error" not in em, em
+    assert em["items_per_batch_per_rank"] == 64 and em["out_shape"] == [64, 512] and em["value"] > 0

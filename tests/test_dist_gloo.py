@@ -153,9 +153,13 @@ def _reducer_worker(rank, world, port, q):
     # a second flat buffer handed over in the middle of backward (CLIP_FF's T5 store): reduced once, reported by finish()
     extra = torch.full((77,), float(rank + 1))
     red.reduce_extra(extra)
-    red.reduce_extra(extra)            # idempotent within a step
+    twice = False
+    try:
+        red.reduce_extra(extra)        # a second contribution after the sum went out is refused, not ignored
+    except RuntimeError:
+        twice = True
     _, extra_done = red.finish()
-    extra_ok = bool((extra == 3.0).all()) and extra.data_ptr() in extra_done
+    extra_ok = twice and bool((extra == 3.0).all()) and extra.data_ptr() in extra_done
     same2 = torch.equal(flat2, red2_in)
     # a range announced twice inside one armed backward is refused AT the second announcement ...
     red.ready(100, 200)

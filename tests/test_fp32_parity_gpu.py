@@ -175,6 +175,23 @@ def test_vit_l14_two_pairs_bf16_against_the_oracle():
     big = {n: e for n, e in errs.items() if e > 1e-1}           # observed worst 5.9e-2 (bias / LayerNorm gradients of 4 items)
     assert not big, big
     assert torch.nn.functional.cosine_similarity(torch.cat(gd), torch.cat(go), dim=0).item() > 0.9995
+    # against the oracle that rounds to bf16 where the device does (rounding("bf16")): every parameter gradient to ~1e-2
+    oracle16 = O.OracleCLIP(cfg, sd)
+    with O.rounding("bf16"):
+        emb_r = O.encode_multimodal_input(oracle16.sd(), cfg, batch["txt_batched"], batch["image_batched"],
+                                          batch["txt_mask_batched"], batch["image_mask_batched"])
+        out_r = O.inbatch_contrastive_loss(emb_r, batch["index_mapping"], oracle16.logit_scale.exp())
+        out_r["loss"].backward()
+    errs16 = {}
+    for n, p in model.clip_model.named_parameters():
+        g = getattr(oracle16, n.replace(".", "__")).grad
+        if g is not None and g.abs().max() > 0:
+            errs16[n] = rel(p.grad, g)
+    worst16 = max(errs16, key=errs16.get)
+    print(f"ViT-L/14 2 pairs vs bf16-rounding oracle: emb rel {rel(emb_d, emb_r):.2e}, worst grad {worst16} {errs16[worst16]:.2e}")
+    assert rel(emb_d, emb_r) < 3e-3, rel(emb_d, emb_r)
+    big16 = {n: e for n, e in errs16.items() if e > 1.5e-2}
+    assert not big16, big16
     # and the fp32 forward of the same architecture: 257-token fp32 attention, K = 588 patch GEMM
     model.eval()
     model.clip_model.precision = "fp32"

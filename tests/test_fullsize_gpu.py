@@ -4,6 +4,7 @@
     seconds here, so the logits are compared bit for bit;
   * brute-force top-10 over one GPU's 700 k x 768 fp16 shard: order, id validity, planted neighbours at rank 1, every
     returned score re-derived bit-exactly by the C oracle on just the returned rows, shard-split + merge == single search;
+    the same over the WHOLE 5.6 M x 768 pool resident on one GPU (logical sub-shards below the 2-GiB buffer bound);
   * the CLIP_SF ViT-L/14 encoder at 1024 items: row independence (a permuted batch gives the permuted embeddings, a
     64-item slice gives the same rows), unit norms after the loss's normalisation, and gradient linearity in the loss."""
 import numpy as np
@@ -70,6 +71,67 @@ def test_topk_full_shard_properties(nq, n):
     b = retrieval.search_shard(retrieval.PoolShard(pool[h:], ids[h:]), queries, k)
     ms, mi = retrieval.merge_shards(torch.stack([a[0], b[0]]), torch.stack([a[1], b[1]]))
     assert torch.equal(ms, s) and torch.equal(mi, i)
+
+
+@pytest.mark.parametrize("nq", [64, 1024])
+def test_topk_whole_mbeir_pool_on_one_gpu(nq):
+    """BASELINE configs[3] as written on ONE GPU (mbeir_retriever.py:196-206 with a single visible device; README.md:126: 5.6 M
+    candidates): a 5.6 M x 768 fp16 pool (8.6 GB) resident as ONE PoolShard.  retrieval.search_shard searches it as 5 logical
+    sub-shards (each below the 2-GiB buffer bound, on the streaming scans) + uniir_topk_merge; checked by the size-independent
+    properties (order, valid unique ids, planted neighbours at rank 1, the C oracle's exact scores on the returned rows) and
+    against the merge of 8 x 700 k searches (the 8-GPU partitioning of the same pool), bit for bit"""
+    from oracle import c_oracle
+    from uniir_amd import retrieval
+    n, d, k = 5_600_000, 768, 10
+    g = torch.Generator(device=DEV).manual_seed(50 + nq)
+    pool = torch.empty(n, d, device=DEV, dtype=torch.float16)
+    for lo in range(0, n, 700_000):                           # generated in slices: no 17-GB fp32 temporary
+        pool[lo:lo + 700_000] = torch.randn(700_000, d, device=DEV, generator=g).half()
+    queries = torch.randn(nq, d, device=DEV, generator=g).half()
+    where = torch.randperm(n, device=DEV, generator=g)[:nq]
+    pool[where] = (queries.float() * 3.0).half()              # planted: same direction, another norm -> cosine 1
+    ids = torch.arange(n, device=DEV, dtype=torch.int64) * 3 + 7
+    shard = retrieval.PoolShard(pool, ids)
+    bounds = retrieval.subshard_bounds(n, d)
+    assert len(bounds) == 5 and all((hi - lo) * d * 2 < 2 ** 31 and lo % 16 == 0 for lo, hi in bounds) and bounds[-1][1] == n
+    s, i = retrieval.search_shard(shard, queries, k)
+    sc, ic = s.cpu().numpy(), i.cpu().numpy()
+    assert (np.diff(sc, axis=1) <= 0).all()
+    assert ((ic - 7) % 3 == 0).all() and (ic >= 7).all() and (ic < 3 * n + 7).all() and all(len(set(r)) == k for r in ic.tolist())
+    assert np.array_equal(ic[:, 0], ids[where].cpu().numpy())
+    assert np.abs(sc[:, 0] - 1.0).max() < 1e-3
+    for qi in range(0, nq, max(1, nq // 8)):                  # the oracle's exact fp32 scores on the returned rows
+        rows = (i[qi] - 7) // 3
+        ws, wi = c_oracle.topk(pool[rows].cpu().numpy(), ids[rows].cpu().numpy(), queries[qi:qi + 1].cpu().numpy(), k)
+        assert np.array_equal(wi[0], ic[qi]) and np.array_equal(ws[0], sc[qi])
+    parts = [retrieval.search_shard(retrieval._shard_view(shard, lo, lo + 700_000), queries, k) for lo in range(0, n, 700_000)]
+    ms, mi = retrieval.merge_shards(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(ms, s) and torch.equal(mi, i)
+
+
+def test_topk_c_abi_refuses_shards_of_2_gib():
+    """uniir_topk_ip addresses a shard through 31-bit buffer offsets: rows * dim * 2 >= 2 GiB is UNIIR_ESHAPE at the C ABI (never
+    a silent slower path); 1 398 096 rows x 768 (the largest sub-shard retrieval.subshard_bounds produces) is accepted"""
+    from uniir_amd import _lib, retrieval
+    lib = _lib.load()
+    d, k, nq = 768, 10, 8
+    n_ok = (2 ** 31 - 1) // (d * 2) // 16 * 16
+    assert n_ok == 1_398_096 and retrieval.subshard_bounds(n_ok, d) == [(0, n_ok)]
+    assert len(retrieval.subshard_bounds(n_ok + 16, d)) == 2
+    n_bad = 1_500_000
+    pool = torch.zeros(n_bad, d, device=DEV, dtype=torch.float16)
+    ids = torch.arange(n_bad, device=DEV)
+    inv = torch.ones(n_bad, device=DEV)
+    q = torch.randn(nq, d, device=DEV).half()
+    out_s, out_i = torch.empty(nq, k, device=DEV), torch.empty(nq, k, device=DEV, dtype=torch.int64)
+    ws = torch.empty(lib.uniir_topk_ip_workspace_bytes(nq, k, n_bad), device=DEV, dtype=torch.uint8)
+    rc = lib.uniir_topk_ip(pool.data_ptr(), inv.data_ptr(), ids.data_ptr(), n_bad, d, q.data_ptr(), nq, k, out_s.data_ptr(),
+                           out_i.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == -2                                           # UNIIR_ESHAPE
+    rc = lib.uniir_topk_ip(pool.data_ptr(), inv.data_ptr(), ids.data_ptr(), n_ok, d, q.data_ptr(), nq, k, out_s.data_ptr(),
+                           out_i.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
 
 
 def test_vit_l14_encoder_row_independence_and_gradient_linearity():
@@ -174,3 +236,19 @@ def test_config1_vit_b32_step_against_the_oracle():
     big = {n: e for n, e in errs.items() if e > 1e-1}           # observed worst 6.5e-2 (a bias gradient summed over 8 items)
     assert not big, big
     assert torch.nn.functional.cosine_similarity(torch.cat(gd), torch.cat(go), dim=0).item() > 0.9995
+    # the same step against the oracle that rounds to bf16 where the device does (oracle/clip_oracle.py rounding("bf16")): what
+    # is left is summation order and 1-ulp intrinsics, so every parameter gradient must agree to ~1e-2 -- a parameter above the
+    # gate would be a bug in a kernel, not rounding noise
+    oracle16 = O.OracleCLIP(cfg, sd)
+    with O.rounding("bf16"):
+        emb_r = O.encode_multimodal_input(oracle16.sd(), cfg, batch["txt_batched"], batch["image_batched"],
+                                          batch["txt_mask_batched"], batch["image_mask_batched"])
+        out_r = O.inbatch_contrastive_loss(emb_r, batch["index_mapping"], oracle16.logit_scale.exp())
+        out_r["loss"].backward()
+    errs16 = {n: rel(p.grad, getattr(oracle16, n.replace(".", "__")).grad) for n, p in model.clip_model.named_parameters()
+              if getattr(oracle16, n.replace(".", "__")).grad is not None}
+    worst16 = max(errs16, key=errs16.get)
+    print("OBS b32 vs bf16-rounding oracle: emb rel", rel(emb_d, emb_r), "worst grad", worst16, errs16[worst16])
+    assert rel(emb_d, emb_r) < 3e-3, rel(emb_d, emb_r)
+    big16 = {n: e for n, e in errs16.items() if e > 1.5e-2}
+    assert not big16, big16

@@ -218,9 +218,9 @@ def test_attention_bwd_pair_kernel_against_the_general_kernel(batch, seq, heads)
                          3 * W, batch, seq, seq, heads, key_len=klen)
     assert torch.isfinite(d_pair.float()).all()
     diff = (d_pair.float() - d_gen.float()).abs()
-    ulp = d_gen.float().abs().clamp_min(2.0 ** -20) * 2.0 ** -7          # one bf16 ulp is <= 2^-7 of the value
-    assert (diff <= ulp).all(), float((diff / ulp).max())
-    assert float((diff > 0).float().mean()) < 1e-3
+    assert float(diff.max()) <= 2.0 ** -8 * float(d_gen.float().abs().max())      # one bf16 ulp of the largest values at most ...
+    assert float((diff > 0).float().mean()) < 1e-3                                  # ... in under 0.1 % of the elements
+    assert rel_err(d_pair, d_gen) < 1e-4
     if batch * seq * heads <= 40000:
         qr = qkv.float().requires_grad_(True)
         oref, _ = _attn_ref(qr, batch, seq, heads, 0)
@@ -550,12 +550,11 @@ def test_device_image_transform_is_bit_exact():
     assert np.array_equal(sq, ((r.transpose(2, 0, 1) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]))
 
 
-def test_gemm_remainder_rows_split_matches_a_reference_on_both_parts():
-    """round 3 (experiment, on with UNIIR_GEMM_REMAINDER=1; without it this is one more large-shape test of every epilogue):
-    260 row panels x 4 column panels = 1040 tiles = 4 rounds of the 256 CUs + 16 tiles -> the last 1024 rows run the
-    general 128-tile kernel in a second launch (csrc/gemm.hip gemm_impl).  Every epilogue of the step, checked separately on the rows
-    of the first launch and on the remainder rows, incl. the outputs the general kernel produces by extra passes (act(aux), column
-    sums) and the per-row operands (resid, row_scale, aux)."""
+def test_gemm_large_shape_every_epilogue_on_two_row_ranges():
+    """260 row panels x 4 column panels = 1040 tiles = 4 rounds of the 256 CUs + 16 tiles (the shape of the N = 1024 GEMMs of the
+    headline step).  Every epilogue of the step, checked separately on the rows of the whole rounds and on the rows of the partial
+    last round, incl. the per-row operands (resid, row_scale, aux).  (Round 3 ran the partial round as a second launch of the
+    128-tile kernel: +0.5 % slower, experiments/gemm_pp2/remainder_launch.inc.)"""
     ops = _ops()
     torch.manual_seed(9)
     M, N, K = 260 * 256, 1024, 512

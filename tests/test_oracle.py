@@ -198,3 +198,33 @@ def test_c_topk_oracle_known_answers():
     assert (np.diff(s, axis=1) <= 0).all()
     s2, i2 = c_oracle.topk(pool[:4], ids[:4], q, k)                  # fewer rows than k: (-inf, -1) padding
     assert (i2[:, 4:] == -1).all() and np.isinf(s2[:, 4:]).all()
+
+
+def test_bf16_rounding_mode_is_a_small_perturbation_of_the_fp32_restatement():
+    """oracle.clip_oracle.rounding("bf16"): the same restatement with the device's 16-bit rounding points -- forward and every
+    parameter gradient stay within bf16 noise of the fp32 run (and differ from it), and nothing changes outside the context"""
+    from oracle import clip_oracle as O
+    cfg = O.tiny_config(vision_width=128, vision_layers=2, transformer_width=64, transformer_heads=1, transformer_layers=2)
+    sd = O.init_state_dict(cfg, seed=4)
+    batch = O.synthetic_batch(cfg, 6, seed=8)
+
+    def run(mode):
+        m = O.OracleCLIP(cfg, sd)
+        with O.rounding(mode):
+            emb = O.encode_multimodal_input(m.sd(), cfg, batch["txt_batched"], batch["image_batched"], batch["txt_mask_batched"],
+                                            batch["image_mask_batched"])
+            out = O.inbatch_contrastive_loss(emb, batch["index_mapping"], m.logit_scale.exp())
+            out["loss"].backward()
+        return emb.detach(), out["loss"].item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    e32, l32, g32 = run(None)
+    e16, l16, g16 = run("bf16")
+    e32b, l32b, _ = run(None)
+    assert torch.equal(e32, e32b) and l32 == l32b                       # the context leaves nothing behind
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+    assert 1e-4 < rel(e16, e32) < 2e-2
+    assert abs(l16 - l32) < 2e-2 * max(1.0, abs(l32))
+    worst = max(rel(g16[n], g32[n]) for n in g32 if g32[n].abs().max() > 0)
+    assert 1e-4 < worst < 1.5e-1, worst
+    flat16 = torch.cat([g16[n].flatten() for n in g32]); flat32 = torch.cat([g32[n].flatten() for n in g32])
+    assert torch.nn.functional.cosine_similarity(flat16, flat32, dim=0).item() > 0.999

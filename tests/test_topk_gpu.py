@@ -186,14 +186,10 @@ def _oracle_topk_mt(pool, ids, queries, k):
                                     (40003, 65, 10), (40030, 129, 10), (40030, 256, 10), (280030, 192, 10), (280030, 128, 24)])
 def test_round3_scan_and_fused_tail_equal_the_c_oracle(n, nq, k):
     """round 3 kernels against oracle.c (reference mbeir_retriever.py:188-232), scores bit-exact and ids identical:
-    >= 16384 groups (280 030 / 262 144 rows) and k <= 24 with UNIIR_TOPK_FILTER=1 in the environment: the FILTERED scan
-    topk_stream3_kernel (thresholds from the waves' first tiles + per-wave lists) and gsel_sparse, incl. duplicate rows (ties at the
-    threshold) and a ragged last tile -- an experiment that is off by default (it passed these cases when it was on);
     <= 64 queries: topk_stream2_kernel (queries in registers, pool by LDS-DMA; needs >= 2048 groups) incl. a ragged last tile
     (40030 = 2501 x 16 + 14) and an odd group count (40003 -> 2501 groups: the round-2 tail behind the new scan);
     65..256 queries: topk_stream5_kernel (the pool ring shared by 2 / 4 waves of 64 register-resident queries each, rolling
-    fragment registers, MFMAs with AGPR operands; partly filled last wave: 65, 100, 129, 192, 200 queries; its one-wave form
-    passes the <= 64-query cases with UNIIR_TOPK_STREAM5=1 in the environment);
+    fragment registers, MFMAs with AGPR operands; partly filled last wave: 65, 100, 129, 192, 200 queries);
     > 256: the ping-pong GEMM scan; behind all of them the fused tail
     (selection + query norm + exact re-score in one launch with 4 / 2 / 1 workgroups per query, rank-count sort in the second),
     also at k = 50 (116 groups = 1 856 re-score slots per query, several 512-slot rounds per workgroup)."""

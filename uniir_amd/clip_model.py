@@ -17,18 +17,9 @@ from torch import nn
 
 from . import _lib, ops
 
-# UNIIR_PY_TOWERS=1: run the CLIP towers as the per-op launch sequence below (what CLIP_FF and BLIP use for their variants)
-# instead of the single-call C towers of csrc/tower.hip -- same kernels, same order; kept for A/B comparisons
-_PY_TOWERS = os.environ.get("UNIIR_PY_TOWERS") == "1"
-
-# UNIIR_TOWER_STREAMS=1: inside `with model.concurrent_towers():` (encode_multimodal_input of the clip_sf mirror) the text
-# tower's forward -- and, through autograd's stream bookkeeping, its backward -- is enqueued on a second HIP stream beside the image
-# tower, so that its small GEMMs (924 tiles = 3.6 rounds of the 256 CUs) could fill the tail rounds of the image tower's kernels.
-# Measured on the headline step (round 3, same box, A/B/A/B): 625.4 / 627.4 ms on one stream, 623.0 / 623.4 ms on two (-0.5 %):
-# the hardware queues barely overlap two kernels that each want the whole chip (1 workgroup of 128 KiB LDS per CU), and the
-# per-kernel durations the roofline is priced on become meaningless when kernels share CUs.  Off by default; the results are
-# identical either way (tests/test_clip_model_gpu.py::test_two_stream_towers_equal_the_single_stream_step).
-_TOWER_STREAMS = os.environ.get("UNIIR_TOWER_STREAMS", "0") == "1"
+# True (tests): run the CLIP towers as the per-op launch sequence below (what CLIP_FF and BLIP use for their variants) instead of
+# the single-call C towers of csrc/tower.hip -- same kernels, same order
+_PY_TOWERS = False
 
 ALIGN = 64  # elements; every parameter starts on a 256-B boundary of the flat buffers
 
@@ -114,39 +105,6 @@ class CLIP(nn.Module):
         # "bf16": MFMA towers, forward + backward (training / fast extraction).  "fp32": the reference's model.float()
         # forward in exact-fp32 MFMA GEMMs + fp32 attention (csrc/fp32_path.hip): reference-precision embeddings, no backward
         self.precision = "bf16"
-        self._side = {}              # device -> (side stream, [pending join events])
-        self._concurrent = 0
-        self._join_target = None
-
-    # ---- two-stream tower execution ----------------------------------------------------------------------------
-    def concurrent_towers(self):
-        """context manager: encode_text calls inside it run on a side stream, concurrently with whatever the caller's stream
-        does next (encode_image); leaving the context makes the caller's stream wait for them (join_towers)"""
-        model = self
-
-        class _Ctx:
-            def __enter__(self):
-                model._concurrent += 1
-
-            def __exit__(self, *exc):
-                model._concurrent -= 1
-                if model._concurrent == 0:
-                    model.join_towers()
-                return False
-
-        return _Ctx()
-
-    def _side_stream(self, dev):
-        ent = self._side.get(dev)
-        if ent is None:
-            ent = self._side[dev] = (torch.cuda.Stream(dev), [])
-        return ent
-
-    def join_towers(self):
-        """the current stream waits for everything enqueued on the side streams so far (forward: before the embeddings are
-        fused; backward: before the gradient all-reduce / AdamW -- NativeAdamW.step calls it)"""
-        for dev, (side, _) in self._side.items():
-            torch.cuda.current_stream(dev).wait_stream(side)
 
     # ---- flat parameter / gradient / bf16-shadow storage -----------------------------------------------------
     def _ensure_flat(self):
@@ -311,20 +269,7 @@ class CLIP(nn.Module):
     def encode_text(self, text):
         self._sync_shadow()
         tok = text.to(torch.int32).contiguous()
-        if not (_TOWER_STREAMS and self._concurrent > 0 and tok.is_cuda and not _PY_TOWERS and self.precision == "bf16"):
-            return _TowerFn.apply(self, "text", tok, self._anchor_for(text.device))
-        main = torch.cuda.current_stream(tok.device)
-        side, _ = self._side_stream(tok.device)
-        side.wait_stream(main)               # the tokens, the weights' bf16 shadow, last step's AdamW: all ordered before
-        self._join_target = main             # the tower's backward makes this stream wait for its gradients (see _TowerFn)
-        try:
-            with torch.cuda.stream(side):    # autograd runs this node's backward on the same stream
-                emb = _TowerFn.apply(self, "text", tok, self._anchor_for(text.device))
-        finally:
-            self._join_target = None
-        tok.record_stream(side)
-        emb.record_stream(main)              # consumed on the caller's stream after join_towers()
-        return emb
+        return _TowerFn.apply(self, "text", tok, self._anchor_for(text.device))
 
     def _anchor_for(self, dev):
         # a leaf that requires grad, so autograd calls the tower backward (parameter grads are written straight
@@ -532,10 +477,6 @@ class _TowerFn(torch.autograd.Function):
         E = cfg["embed_dim"]
         M = inp.shape[0]
         ctx.model, ctx.which, ctx.M = model, which, M
-        # two-stream mode: this tower runs on a side stream; its backward (which autograd enqueues on that same stream, AFTER the
-        # image tower's: later-created nodes run first) ends by making the caller's stream wait, so that whatever follows
-        # loss.backward() on the caller's stream -- reading .grad, the all-reduce, AdamW -- sees the gradients
-        ctx.join_to = getattr(model, "_join_target", None)
         if M == 0:
             return torch.zeros(0, E, device=dev)
         fl = model._flat
@@ -633,8 +574,6 @@ class _TowerFn(torch.autograd.Function):
                                "tower_bwd_blocks")
                     reducer.ready(*model.layer_grad_range(prefix, i))
             _lib.check(lib.uniir_clip_tower_bwd_stem(C.byref(desc), inp.data_ptr(), M, ws.data_ptr(), need, stream), "tower_bwd_stem")
-            if ctx.join_to is not None:
-                ctx.join_to.wait_stream(torch.cuda.current_stream(demb.device))
             return None, None, None, None
         cfg = model.cfg
         fl = model._flat

@@ -172,8 +172,11 @@ class GradReducer:
     def reduce_extra(self, tensor):
         """a further flat gradient buffer that is final now (CLIP_FF's T5 store: its backward ends before the towers' begins):
         one asynchronous all-reduce on the collective stream, overlapped with the rest of backward like the buckets"""
-        if world() == 1 or tensor.data_ptr() in self.extra_done:
+        if world() == 1:
             return
+        if tensor.data_ptr() in self.extra_done:      # a second contribution after the sum went out would diverge silently
+            raise RuntimeError("GradReducer.reduce_extra: this buffer was already reduced in the armed backward (its module ran "
+                               "twice in one step); use arm_overlap(False) for such steps")
         if self._sync_backend():
             allreduce_sum_(tensor)
         else:

@@ -438,12 +438,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
 // Staging policy (A/B on one MI355X, 1024 items, tools/microbench.py MB_ONLY=attn; legacy -> batched):
 //   forward : 257 tokens 0.783 -> 0.760 ms, 197: 0.488 -> 0.487, 77 causal: 0.146 -> 0.132, 50: 0.116 -> 0.095   => always batched
 //   backward: 257 tokens 2.026 -> 2.021 ms, 197: 1.399 -> 1.446 (worse), 77: 0.388 -> 0.359, 50: 0.336 -> 0.294   => batched up to 128 tokens
-// UNIIR_ATTN_LEGACY_STAGE=1 / =0 forces one or the other (experiments).
-static int attn_legacy_stage(bool backward, int tmax) {
-    static const char* e = getenv("UNIIR_ATTN_LEGACY_STAGE");
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-    return backward && tmax > 128;
-}
+static int attn_legacy_stage(bool backward, int tmax) { return backward && tmax > 128; }
 static int launch_attn_fwd(const AttnArgs& a0, int batch, hipStream_t st) {
     AttnArgs a = a0;
 #ifdef UNIIR_EXP_BUILD
@@ -508,8 +503,7 @@ static int launch_attn_bwd(const AttnArgs& a0, int batch, hipStream_t st) {
     const int Tqp = (a.Tq + 31) & ~31, Tkp = (a.Tk + 31) & ~31;
     const int Tmax = Tqp > Tkp ? Tqp : Tkp;
     const int sm = 2 * Tmax * 128 + 2 * Tqp * 4 + (a.rel_emb ? 2 * (a.Tq + a.Tk) * 4 : 0);
-    static const char* e = getenv("UNIIR_ATTN_BWD_THREADS");          // 384 / 512 forces one (experiments)
-    bool six = e ? (e[0] == '3') : tmax <= 128;
+    bool six = tmax <= 128;
     if (six && (Tmax * 8 + 383) / 384 > 8) six = false;      // stage_two holds <= 8 loads per thread and slice: 384 threads stop at 384 tokens
     return six ? launch_attn_bwd_nt<384>(a, batch, sm, st) : launch_attn_bwd_nt<512>(a, batch, sm, st);
 }

@@ -4,7 +4,6 @@
 #include "gemm_core.h"
 #include "gemm_core256.h"
 #include "gemm_core_pp.h"
-#include "gemm_core_pp2.h"
 #include "../../include/uniir_hip.h"
 #include <stdlib.h>
 
@@ -377,162 +376,6 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
     }
 }
 
-// Epilogue of the 256x128 (4-wave, two workgroups per CU) tile of gemm_core_pp2.h, staged through the workgroup's 80 KiB of LDS like
-// epilogue256_staged: bf16 outputs in one pass (image [256][128] bf16, 256-B rows, 16-B chunk ^= row & 15), fp32 math in two passes
-// of 128 rows (image [128][128] f32, 512-B rows, 16-B chunk ^= row & 7).  Accumulator map: acc[4h + i][2h' + j] at rows
-// 128h + 64wr + 16i, cols 64h' + 32wc + 16j (wr = w >> 1, wc = w & 1).
-DEVINL void epilogue128_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int m0, int n0, char* lds, int epi) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int li = lane & 15, lg = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1;
-    const bool full = (m0 + 256 <= p.M) && (n0 + 128 <= p.N);
-    const f32x4_t alpha4 = {p.alpha, p.alpha, p.alpha, p.alpha};
-    int nl[4];
-    f32x4_t bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        nl[j] = (j >> 1) * 64 + wc * 32 + (j & 1) * 16 + 4 * lg;
-        const int n = n0 + nl[j];
-        bv[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    if (epi == UNIIR_EPI_BF16 || epi == UNIIR_EPI_BIAS_ACT) {
-        char* sj[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sj[j] = lds + li * 256 + (((nl[j] >> 3) ^ li) << 4) + ((nl[j] & 7) << 1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int rb = ((i >> 2) * 128 + wr * 64 + (i & 3) * 16) * 256;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4_t v = acc[i][j] * alpha4 + bv[j];
-                const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *reinterpret_cast<u32x2_t*>(sj[j] + rb) = o;
-            }
-        }
-        __syncthreads();
-        // thread -> (row r0 + 16 it, 16-B chunk ch): 16 threads cover a row's 256 bytes
-        const int r0 = tid >> 4, ch = tid & 15;
-        const char* src = lds + r0 * 256 + ((ch ^ r0) << 4);
-        const long off0 = (long)(m0 + r0) * p.ldc + n0 + ch * 8;
-        unsigned short* c1 = (unsigned short*)p.C + off0;
-        unsigned short* c2 = (unsigned short*)p.C2 + off0;
-        const long rstep = 16L * p.ldc;
-        const bool colok = n0 + ch * 8 < p.N;
-        const int rows_left = p.M - m0 - r0;
-        const bool act = epi == UNIIR_EPI_BIAS_ACT;
-        if (!act) {
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                if (full || (colok && 16 * it < rows_left)) {
-                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + it * 4096);
-                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(c1));
-                }
-                c1 += rstep;
-            }
-        } else if (p.act == UNIIR_ACT_QUICKGELU) {
-            epi_bf16_copy_act<UNIIR_ACT_QUICKGELU, 4096>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
-        } else if (p.act == UNIIR_ACT_GELU_ERF) {
-            epi_bf16_copy_act<UNIIR_ACT_GELU_ERF, 4096>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
-        } else {
-            epi_bf16_copy_act<UNIIR_ACT_RELU, 4096>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
-        }
-        return;
-    }
-    // fp32 math on the way out: two passes of 128 rows; every wave stages its tiles 4h .. 4h + 3 in pass h
-    char* sj[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sj[j] = lds + li * 512 + (((nl[j] >> 2) ^ (li & 7)) << 4);
-    const int r0 = tid >> 5, ch = tid & 31;       // copy-out: row r0 + 8 it of the pass, 16-B chunk ch (4 floats)
-    const char* src = lds + r0 * 512 + ((ch ^ (r0 & 7)) << 4);
-    const bool colok = n0 + ch * 4 < p.N;
-    const long rstep = 8L * p.ldc, rstep_aux = 8L * p.ldaux;
-    f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (h) __syncthreads();
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int rb = (wr * 64 + ii * 16) * 512;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(sj[j] + rb) = acc[4 * h + ii][j] * alpha4 + bv[j];
-        }
-        __syncthreads();
-        const int mrow = m0 + 128 * h + r0;
-        const long off0 = (long)mrow * p.ldc + n0 + ch * 4;
-        const long offa = (long)mrow * p.ldaux + n0 + ch * 4;
-        const int rows_left = p.M - mrow;
-        if (epi == UNIIR_EPI_RESID_F32)
-            epi_f32_copy<UNIIR_EPI_RESID_F32, 0, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
-        else if (epi == UNIIR_EPI_F32)
-            epi_f32_copy<UNIIR_EPI_F32, 0, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
-        else if (p.act == UNIIR_ACT_QUICKGELU)
-            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_QUICKGELU, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
-        else if (p.act == UNIIR_ACT_GELU_ERF)
-            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_GELU_ERF, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
-        else
-            epi_f32_copy<UNIIR_EPI_DACT, UNIIR_ACT_RELU, 4096>(p, src, off0, offa, rstep, rstep_aux, full, colok, rows_left, csum, mrow);
-    }
-    if (p.colsum) {
-        // this thread's 4 columns (ch = tid & 31) summed over its rows of both passes; 8 threads share a column group
-        __syncthreads();
-        f32x4_t* red = reinterpret_cast<f32x4_t*>(lds);
-        red[tid] = csum;
-        __syncthreads();
-        if (tid < 32) {
-            f32x4_t s = red[tid];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) s += red[tid + 32 * k];
-            const int n = n0 + tid * 4;
-            if (n < p.N) {
-                unsafeAtomicAdd(p.colsum + n + 0, s[0]);
-                unsafeAtomicAdd(p.colsum + n + 1, s[1]);
-                unsafeAtomicAdd(p.colsum + n + 2, s[2]);
-                unsafeAtomicAdd(p.colsum + n + 3, s[3]);
-            }
-        }
-    }
-}
-
-// 256x128 tile, 4 waves, two workgroups per CU (gemm_core_pp2.h): no split-K (the weight-gradient GEMMs stay on the 256x256 kernel)
-#define PP2_LDS_BYTES (5 * 16384)
-template <typename Elem, bool A_TMAJ, bool B_TMAJ>
-__global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(GemmKArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
-    // row-major over (row panel, column panel) with the column panel fastest: the workgroups of a CU / an XCD share A row panels
-    const int mt = id / p.tiles_n, nt = id - mt * p.tiles_n;
-    const int m0 = mt * 256, n0 = nt * 128;
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    glds_mainloop_pp2<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, 0, p.K, lds, acc);
-    epilogue128_staged(p, acc, m0, n0, lds, p.epilogue);
-}
-
-template <typename Elem>
-static int launch_pp2(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
-    a.tiles_m = (a.M + 255) / 256;
-    a.tiles_n = (a.N + 127) / 128;
-    const dim3 g(a.tiles_m * a.tiles_n), b(256);
-#define LAUNCH2(AT, BT)                                                                                      \
-    do {                                                                                                     \
-        static PerDeviceOnce attr_set;                                                                       \
-        if (attr_set.first())                                                                                \
-            (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<Elem, AT, BT>,                            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, PP2_LDS_BYTES);            \
-        hipLaunchKernelGGL((gemm_pp2_kernel<Elem, AT, BT>), g, b, PP2_LDS_BYTES, st, a);                     \
-    } while (0)
-    if (!a_tmaj && !b_tmaj) LAUNCH2(false, false);
-    else if (!a_tmaj && b_tmaj) LAUNCH2(false, true);
-    else if (a_tmaj && !b_tmaj) LAUNCH2(true, false);
-    else LAUNCH2(true, true);
-#undef LAUNCH2
-    HIP_LAUNCH_CHECK();
-    return UNIIR_OK;
-}
 
 // LDS-DMA GEMM (gemm_core256.h): block tile (128*WM) x (64*WN), K step BK.  Used when K % BK == 0.
 // split-K / wgrad accumulate epilogue for the ping-pong accumulator map
@@ -654,13 +497,8 @@ static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
     using S = GldsShape<WM, WN, BK>;
     a.tiles_m = (a.M + S::BM - 1) / S::BM;
     a.tiles_n = (a.N + S::BN - 1) / S::BN;
-    {
-        static const char* env = getenv("UNIIR_GEMM_RASTER");      // "GM,CW" (tuning); default 8 x 4, "0" = row-major
-        int gm = 8, cw = 4;
-        if (env && sscanf(env, "%d,%d", &gm, &cw) < 2) cw = 4;
-        a.raster_gm = gm;
-        a.raster_cw = cw > 0 ? cw : 4;
-    }
+    a.raster_gm = 8;          // 2-D tile rasterisation: 8 row panels x 4 column panels per XCD working set (round-3 sweep, tools/r3)
+    a.raster_cw = 4;
     const int grid = a.tiles_m * a.tiles_n * a.k_splits;
     dim3 g(grid), b(S::T);
     const size_t sm = S::LDS_BYTES;
@@ -688,13 +526,9 @@ static int launch_glds(GemmKArgs a, int a_tmaj, int b_tmaj, hipStream_t st) {
 }
 
 // shape choice: 0 = general 128x128 register-staged kernel, 1 = 256x256x64 LDS-DMA kernel (1 workgroup / CU)
-static thread_local int g_force_general = 0;     // set around the remainder-rows launch of gemm_impl
 static int gemm_shape(const GemmKArgs& a, int a_tmaj, int b_tmaj) {
-    static const char* force = getenv("UNIIR_GEMM_SHAPE");      // "0": force the general kernel (tests / experiments)
-    if (g_force_general) return 0;
     if (a.K % 64) return 0;
     if (a.M < 256 || a.N < 128) return 0;    // small problems: the 128-tile kernel fills the chip better
-    if (force && force[0] == '0') return 0;
     return 1;
 }
 
@@ -733,11 +567,6 @@ static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t s
         if (pp_eligible(a, a_tmaj, b_tmaj)) {
 #ifndef UNIIR_EXP_BUILD
             if (a.a_rowsum && std::is_same<Elem, ElemBF16>::value) return launch_glds_rowsum(a, st);
-            // the 256x128 two-workgroups-per-CU kernel: forward / dgrad shapes (no split-K, no atomics), opt-in while it is measured
-            static const char* env2 = getenv("UNIIR_GEMM_PP2");       // "1": all eligible; "2": only K <= 1024
-            if (env2 && (env2[0] == '1' || (env2[0] == '2' && a.K <= 1024)) && a.k_splits == 1 && !a.slab &&
-                a.epilogue != UNIIR_EPI_ATOMIC_F32 && a.N >= 128)
-                return launch_pp2<Elem>(a, a_tmaj, b_tmaj, st);
 #endif
             return launch_glds<Elem, 2, 4, 64, 2>(a, a_tmaj, b_tmaj, st);
         }
@@ -854,52 +683,6 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15) || ((uintptr_t)d->C & 15)) return UNIIR_EALIGN;
     if (d->aux && ((d->ldaux % 4) || ((uintptr_t)d->aux & 7))) return UNIIR_EALIGN;
     if (d->bias && ((uintptr_t)d->bias & 15)) return UNIIR_EALIGN;
-    // Tile quantisation (round 3).  One 256x256 workgroup per CU: tiles_m x tiles_n tiles take ceil(tiles / CUs) rounds, and a
-    // last round with a few tiles costs a whole tile time on an almost idle chip -- the ViT-L/14 step has 263 168 = 1028 x 256 rows,
-    // i.e. 16 tiles (N = 1024: out / proj forward, the qkv / fc / out dgrads), 48 (N = 3072) or 64 (N = 4096) left over after
-    // 16 / 48 / 64 full rounds.  When the leftover is at most a quarter round, the row panels that make up whole rounds run the
-    // 256-tile kernel and the remaining rows (1024 here) a second launch of the general 128x128 kernel: 4x the workgroups at a
-    // quarter of the work each, one short round instead of one long one.  Every epilogue is row-wise, so the split is exact.
-    // An experiment that did not pay (see below): kept behind UNIIR_GEMM_REMAINDER=1.
-    if (!g_force_general && !d->a_tmaj && d->k_splits == 1 && d->M % 256 == 0 && d->K % 64 == 0 && d->N >= 128 &&
-        d->epilogue != UNIIR_EPI_ATOMIC_F32) {
-        // MEASURED (round 3, headline step, same box, A/B/A/B): 625.5 / 626.8 ms without the split, 628.5 / 630.5 ms with it -- the
-        // 128-tile kernel's short round plus the extra launch cost more than the idle tail of the 256-tile round they replace.  Off
-        // unless asked for.
-        static const char* env = getenv("UNIIR_GEMM_REMAINDER");      // "1": split the remainder rows off (experiments)
-        static int ncu = 0;
-        if (!ncu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                      ? prop.multiProcessorCount : 256;
-        }
-        const long tm = d->M / 256, tn = (d->N + 255) / 256, tiles = tm * tn, rem = tiles % ncu;
-        if (env && env[0] == '1' && tiles / ncu >= 4 && rem > 0 && rem * 4 <= ncu) {
-            long g = tn, h = ncu;
-            while (h) { const long r = g % h; g = h; h = r; }          // gcd(tn, ncu)
-            const long step = ncu / g, tm_main = tm / step * step;
-            if (tm_main > 0 && tm_main < tm && (tm - tm_main) * 256 <= 4096) {
-                const long m0 = tm_main * 256;
-                const bool c32 = d->epilogue == UNIIR_EPI_RESID_F32 || d->epilogue == UNIIR_EPI_F32;
-                uniir_gemm_desc d1 = *d, d2 = *d;
-                d1.M = (int)m0;
-                d2.M = d->M - (int)m0;
-                d2.A = (const char*)d->A + m0 * d->lda * 2;
-                d2.C = (char*)d->C + m0 * d->ldc * (c32 ? 4 : 2);
-                if (d->C2) d2.C2 = (char*)d->C2 + m0 * (d->epilogue == UNIIR_EPI_DACT ? d->ldaux : d->ldc) * 2;
-                if (d->resid) d2.resid = d->resid + m0 * d->ldc;
-                if (d->aux) d2.aux = (const char*)d->aux + m0 * d->ldaux * 2;
-                if (d->row_scale) d2.row_scale = d->row_scale + m0;
-                int rc = gemm_impl(&d1, stream);
-                if (rc) return rc;
-                g_force_general = 1;
-                rc = gemm_impl(&d2, stream);
-                g_force_general = 0;
-                return rc;
-            }
-        }
-    }
     GemmKArgs a;
     a.A = (const unsigned short*)d->A;
     a.B = (const unsigned short*)d->B;
@@ -924,10 +707,7 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     a.slab = nullptr;
     a.colsum = d->colsum;
     a.a_rowsum = nullptr;
-    {
-        static const char* e = getenv("UNIIR_GEMM_LOOP");   // "1": counted-lgkmcnt double-buffer loop instead of ping-pong
-        a.asm_loop = (e && e[0] == '1') ? 1 : 2;
-    }
+    a.asm_loop = 2;
     hipStream_t st = (hipStream_t)stream;
     if (d->k_splits > 1) {
         // never leave a split empty (an empty split would leave its slab unwritten)
@@ -945,9 +725,8 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     // runs it, otherwise as a separate pass over A
     bool rowsum_fused = false;
     if (d->a_rowsum) {
-        static const char* e = getenv("UNIIR_GEMM_ROWSUM");     // "0": always the separate pass (A/B)
         if (!d->a_tmaj || d->dtype != UNIIR_DT_BF16) return UNIIR_EUNSUPPORTED;     // (the separate pass reads bf16 too)
-        rowsum_fused = !(e && e[0] == '0') && d->dtype == UNIIR_DT_BF16 && d->b_tmaj && pp_eligible(a, d->a_tmaj, d->b_tmaj);
+        rowsum_fused = d->dtype == UNIIR_DT_BF16 && d->b_tmaj && pp_eligible(a, d->a_tmaj, d->b_tmaj);
         if (rowsum_fused) a.a_rowsum = d->a_rowsum;
     }
     int rc;

@@ -190,12 +190,11 @@ static int launch_sgemm(const float* A, long sam, long sak, const float* B, long
                         long ldc, int M, int N, int K, float alpha, const float* alpha_dev, hipStream_t st,
                         int accumulate = 0) {
     // the 128-tile kernel: both operands with one unit stride, 16-byte aligned vectors, whole K steps, enough tiles to matter
-    static const char* env = getenv("UNIIR_SGEMM_SMALL");      // "1": always the 64-tile kernel (A/B experiments)
     const bool a_ck = sak == 1, a_cm = sam == 1, b_ck = sbk == 1, b_cn = sbn == 1;
     auto vec_ok = [](const float* p, long ld, bool contig_k, int ext) {
         return (((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && (contig_k || ext % 4 == 0);
     };
-    const bool big = !(env && env[0] == '1') && K % SG_BK == 0 && M >= 64 && N >= 64 && (long)M * N >= 128L * 128 * 8 &&
+    const bool big = K % SG_BK == 0 && M >= 64 && N >= 64 && (long)M * N >= 128L * 128 * 8 &&
                      (a_ck || a_cm) && (b_ck || b_cn) && vec_ok(A, a_ck ? sam : sak, a_ck, M) && vec_ok(B, b_ck ? sbn : sbk, b_ck, N);
     if (big) {
         dim3 grid((N + SGL_BN - 1) / SGL_BN, (M + SGL_BM - 1) / SGL_BM);

@@ -18,7 +18,8 @@
 //   tail 2: topk_tail_sort_kernel: (score desc, id asc) by rank counting.
 // Exactness: an fp16-product / fp32-accumulate score differs from the oracle's only in summation order, so the true top k rows
 // lie in the k + 8 best groups (ties at the group threshold keep up to 2 (k + 8) groups); the re-score then reproduces the
-// oracle bit for bit.  Switches (A/B, read once): UNIIR_TOPK_{STREAM,STREAM2,STREAM4,STREAM5,PP,NT,HALFN,HIER,FUSED_TAIL,FILTER}.
+// oracle bit for bit.  No run-time switches: the variants that lost their A/B (filtered scan, one-wave rolling-register scan,
+// default-policy pool streams, ...) are described in experiments/topk/README.md.
 #include "gemm_core.h"
 #include "gemm_core256.h"
 #include "gemm_core_pp.h"
@@ -810,7 +811,6 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
 #define TKR_PINV_OFF (3 * TKR_HALF_BYTES)
 #define TKR_STAGE_OFF (TKR_PINV_OFF + 512)
 #define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 2048)
-#define TKR3_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 3072)      // stream3: 12 parked maxima per lane instead of the octet staging
 // group-max stores of the streaming scans: -DUNIIR_GMAX_NT=1 builds them as non-temporal stores.  MEASURED (round 3, same box, whole
 // search): 64 queries 0.2233 / 0.2059 ms (default) vs 0.2288 / 0.2095 (nt); 128 queries 0.2360 / 0.2236 vs 0.2652 / 0.2450 -- the
 // 32-byte runs want the L2's write combining; default stays.
@@ -932,8 +932,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
                                                              const float* __restrict__ pinv, long rows,
                                                              const unsigned short* __restrict__ queries, int nq,
                                                              float* __restrict__ gmax, long ngroups,
-                                                             float* __restrict__ wmax,        // optional [nq][waves]: per-wave maxima
-                                                             int exp_store) {   // timing experiments only (wrong results): 1, 2, 3
+                                                             float* __restrict__ wmax) {      // optional [nq][waves]: per-wave maxima
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -982,11 +981,6 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
         const auto sq = __builtin_amdgcn_permlane16_swap(__float_as_uint(r02), __float_as_uint(r13), false, false);
         const float mine = tk5_max(__uint_as_float(sq[0]), __uint_as_float(sq[1]));
         wave_best = fmaxf(wave_best, mine);
-        if (exp_store == 2) {             // experiment: one coalesced 256-byte store per tile ([group][query] layout)
-            gmax[tile * 64 + lane] = mine;
-            return;
-        }
-        if (exp_store == 3) return;       // experiment: no group-max stores at all
         // Eight consecutive group maxima of a query leave as two 16-byte stores to one 32-byte run (one 4-byte store per lane and
         // tile is 64 scattered requests per tile, 2.8 M per sweep).  The lane's 32 bytes of LDS serve as an indexed register file
         // (asm accesses: the compiler must not order them against the LDS-DMA stream); the octet phase is per lane, so that the
@@ -998,7 +992,7 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
             asm_wait_lgkm<0>();
             const f32x4_t v0 = __builtin_bit_cast(f32x4_t, s0), v1 = __builtin_bit_cast(f32x4_t, s1);
             const long g0 = tile - k;                        // first group of this lane's octet
-            if (lane < (exp_store == 1 ? 16 : nq)) {
+            if (lane < nq) {
                 float* dst = gmax + (long)lane * ngroups + g0;
                 if (k == 7u && g0 >= lo) {
                     TK_GST(reinterpret_cast<f32x4_t*>(dst), v0);
@@ -1116,8 +1110,7 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
                                                                  const float* __restrict__ pinv, long rows,
                                                                  const unsigned short* __restrict__ queries, int nq,
                                                                  float* __restrict__ gmax, long ngroups,
-                                                                 float* __restrict__ wmax,       // optional [nq][4 ncu] maxima
-                                                                 int exp_fin) {   // timing experiments only (wrong results): 1 = no tile epilogue
+                                                                 float* __restrict__ wmax) {     // optional [nq][4 ncu] maxima
     using C = Tk5<QW>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1216,20 +1209,6 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
         }
         const unsigned k = ((unsigned)tile + qoff) & 7u;
         asm volatile("ds_write_b32 %0, %1" ::"v"(stg + k * 4u), "v"(mine) : "memory");
-        if (exp_fin >= 2) {      // timing experiments (wrong results): the same bytes as aligned 64-byte (2) / 128-byte (3) runs per lane
-            const unsigned per = exp_fin == 2 ? 16u : 32u;
-            if ((((unsigned)tile) & (per - 1)) == per - 1 && qi < nq) {
-                const u32x4_t s0 = asm_ds_read_b128<0>(stg), s1 = asm_ds_read_b128<16>(stg);
-                asm_wait_lgkm<0>();
-                const f32x4_t v0 = __builtin_bit_cast(f32x4_t, s0), v1 = __builtin_bit_cast(f32x4_t, s1);
-                float* d = reinterpret_cast<float*>(reinterpret_cast<unsigned long>(gmax + (long)qi * ngroups + tile - (per - 1)) & ~(unsigned long)(per * 4 - 1));
-                for (unsigned e = 0; e < per / 8; ++e) {
-                    *reinterpret_cast<f32x4_t*>(d + 8 * e) = v0;
-                    *reinterpret_cast<f32x4_t*>(d + 8 * e + 4) = v1;
-                }
-            }
-            return;
-        }
         if (k == 7u || tile == hi - 1) {
             const u32x4_t s0 = asm_ds_read_b128<0>(stg), s1 = asm_ds_read_b128<16>(stg);
             asm_wait_lgkm<0>();
@@ -1325,7 +1304,7 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
         const f32x4_t iv_d = __builtin_bit_cast(f32x4_t, ivb_d);                                               \
         TK5_HALF(ACC, 1, (T) + C::D / 2, h + 1 + C::D < nh, 0, , TK5_FIN(PREV, 0), TK5_FIN(PREV, 1), TK5_FIN(PREV, 2), \
                  TK5_FIN(PREV, 3), mine_d = rows_to_mine(md);)                                        \
-        if ((T) > lo && exp_fin != 1) fin_tail((T) - 1, mine_d);                                               \
+        if ((T) > lo) fin_tail((T) - 1, mine_d);                                                                   \
         h += 2;                                                                                                \
     }
     int slot = 0;
@@ -1344,8 +1323,8 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
     }
     if (t < hi) {                                                  // odd range: one more tile into accA, then it is the last
         TK5_TILE(accA, accB, t)
-        if (exp_fin != 1) fin_full(accA, t);
-    } else if (exp_fin != 1) {
+        fin_full(accA, t);
+    } else {
         fin_full(accB, hi - 1);
     }
 #undef TK5_TILE
@@ -1358,344 +1337,64 @@ __global__ __launch_bounds__(64 * QW, 1) void topk_stream5_kernel(const unsigned
     tkr_wait_vm<0>();                                              // the trailing dummies (and the last stores)
 }
 
-// -------------------------------------------------------------------------------------------------------------
-// Streaming scan, third generation: the stream2 kernel with a FILTERED output.  Measured on the 64-query scan (round 3): the dense
-// group-max matrix costs 34 of 191 us (no stores at all: 157 us = 6.9 TB/s; one coalesced 256-byte store per tile: 175 us) -- write
-// traffic sprinkled into the read stream is expensive.  So the scan keeps almost nothing:
-//   * until the thresholds are out (~30 us: 8 - 9 tiles) a wave parks its tiles' maxima in LDS, 12 per lane;
-//   * every wave folds its FIRST tile's value into one of 32 bucket maxima per query (atomicMax on an order-preserving key; buckets
-//     of nw / 32 waves) and takes a ticket; wave 0 waits for all tickets and takes, per query, the kc-th largest of the 32 bucket
-//     maxima (a 32-element sorting network in registers): at least kc groups reach that value, so it is a valid lower bound
-//     tau[q] of the kc-th best group maximum (about the 2.5 % quantile);
-//   * a wave appends (value, group) to its private slice of the query's list only when value >= tau[q] (the parked tiles as
-//     soon as tau is known): ~2.5 % of the groups.
-// Exact: every group >= a valid lower bound of the kc-th best is kept; the selection (gsel_sparse) ranks the list entries.
-// Cross-workgroup traffic is atomics only, no fences (a release fence per wave -- buffer_wbl2, 1024 of them at once -- made the
-// tickets trickle in over ~40 us: measured 210 us for this kernel against 165 us for the dense stream2 scan on the same box): the
-// bucket maxima are RETURNING agent-scope atomics (the wave waits for the return, then takes its ticket), wave 0 reads them with
-// sc0 sc1 loads, and a threshold is published as ONE 4-byte atomic store per query that is its own flag (key != 0).  Every wait is
-// bounded: on a timeout tau = -inf (everything is appended: slower, still exact).  All workgroups are resident (grid = CUs, one
-// workgroup per CU), so the waits are short.
-#define TKF_EMAX 12          // tiles a wave can park in LDS while the thresholds are not out yet (then it waits)
-struct TkFiltCtrl {
-    int ticket[8], pad[8];        // first-tile tickets, one word per blockIdx & 7 (a single word serialises 1024 atomics: ~12 us)
-    unsigned tauk[64];            // per query: key of the threshold, 0 = not published yet (the datum is its own flag)
-    unsigned bucket[32][64];      // per query: maximum (as an order-preserving key, 0 = empty) of the first-tile values of 1/32 of the waves
-};
-// float -> unsigned key with the same order (atomicMax on the keys == maximum of the floats); every real value maps above 0
-DEVINL unsigned tkf_key(float f) {
-    const unsigned b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-DEVINL float tkf_unkey(unsigned k) {
-    return k == 0u ? -INFINITY : __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-// wave gw's range of tiles: wave 0 (which computes the thresholds) takes 3 tiles fewer, the rest is split evenly
-DEVINL void tkf_range(long gw, long nw, long ngroups, long& lo, long& hi) {
-    const long base = ngroups / nw, t0 = base > 6 ? base - 3 : base;
-    lo = gw == 0 ? 0 : t0 + (gw - 1) * (ngroups - t0) / (nw - 1);
-    hi = gw == 0 ? t0 : t0 + gw * (ngroups - t0) / (nw - 1);
-}
-template <int I, int J>
-DEVINL void tkf_cas(float (&v)[32]) {      // descending compare-exchange
-    const float a = v[I], b = v[J];
-    v[I] = fmaxf(a, b);
-    v[J] = fminf(a, b);
-}
-template <int K, int J, int I>
-DEVINL void tkf_bitonic_step(float (&v)[32]) {
-    if constexpr (I < 32) {
-        constexpr int L = I ^ J;
-        if constexpr (L > I) {
-            if constexpr ((I & K) == 0) tkf_cas<I, L>(v);
-            else tkf_cas<L, I>(v);
-        }
-        tkf_bitonic_step<K, J, I + 1>(v);
-    }
-}
-template <int K, int J>
-DEVINL void tkf_bitonic_j(float (&v)[32]) {
-    if constexpr (J > 0) {
-        tkf_bitonic_step<K, J, 0>(v);
-        tkf_bitonic_j<K, J / 2>(v);
-    }
-}
-template <int K>
-DEVINL void tkf_bitonic_k(float (&v)[32]) {
-    if constexpr (K <= 32) {
-        tkf_bitonic_j<K, K / 2>(v);
-        tkf_bitonic_k<K * 2>(v);
-    }
-}
-template <int AUX>
-__global__ __launch_bounds__(256, 1) void topk_stream3_kernel(const unsigned short* __restrict__ pool,
-                                                             const float* __restrict__ pinv, long rows,
-                                                             const unsigned short* __restrict__ queries, int nq,
-                                                             long ngroups, int kc, TkFiltCtrl* __restrict__ ctrl,
-                                                             float* __restrict__ ent_val, int* __restrict__ ent_grp,
-                                                             int* __restrict__ ent_cnt, int rmax) {
-    // lists: one private slice of rmax (>= the wave's tiles) entries per (query, wave) -- ent_*[(q * nw + wave) * rmax + i] -- and
-    // ent_cnt[q * nw + wave] entries in it: plain stores, no atomics (a returning atomic would make hipcc drain the DMA queue)
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lg = lane >> 4;
-    const long gw = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
-    long lo, hi;
-    tkf_range(gw, nw, ngroups, lo, hi);
-    TkrState st;
-    u32x4_t qf[4][24];
-    tkr_prepare<TKR3_WAVE_LDS>(st, qf, lds, pool, pinv, rows, queries, nq, w, lane);
-    tkr_issue<0, AUX>(st, lo, 0);
-    tkr_issue<1, AUX>(st, lo, 1);
-    f32x4_t acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float tau = -INFINITY;
-    bool have_tau = false;
-    int npos = 0;                          // entries this lane (query) has appended to this wave's slice
-    unsigned kvp = 0u;                     // the threshold word as of the top of the current iteration (0 = not out yet)
-    unsigned old0 = 0u;                    // return value of the first tile's bucket atomic
-    const unsigned stg = st.lbase + TKR_STAGE_OFF + lane * 4;      // [TKF_EMAX][64] floats: this lane's maxima of the tiles before tau
-    auto tile_max = [&](long tile) {       // D: lane -> query j * 16 + (lane & 15), candidates 4 lg + r of the tile
-        const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + TKR_PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
-        asm_wait_lgkm<0>();
-        const f32x4_t iv = __builtin_bit_cast(f32x4_t, ivb);
-        const long r0 = tile * 16 + 4 * lg;
-        float m[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x = fmaxf(x, (r0 + r < rows) ? acc[j][r] * iv[r] : -INFINITY);
-            m[j] = group_max(x);
-            acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-        return lg == 0 ? m[0] : lg == 1 ? m[1] : lg == 2 ? m[2] : m[3];     // lane -> query lane
-    };
-    auto append = [&](float v, long tile) {
-        if (lane < nq && v >= tau && npos < rmax) {
-            const long o = ((long)lane * nw + gw) * rmax + npos;
-            ent_val[o] = v;
-            ent_grp[o] = (int)tile;
-            ++npos;
-        }
-    };
-    auto thresholds = [&](int free_slot) {       // wave 0 only, after its own ticket
-        auto tickets = [&] {
-            int sum = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sum += __hip_atomic_load(&ctrl->ticket[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return sum;
-        };
-        int spins = 0;
-        while (tickets() < (int)nw && spins < 100000) {
-            __builtin_amdgcn_s_sleep(2);
-            ++spins;
-        }
-        float t = -INFINITY;
-        if (tickets() >= (int)nw) {
-            // the 8 KiB of bucket keys come in by LDS-DMA (no registers: this wave holds 500 of them; sc0 sc1: past L1 and the
-            // XCD's L2, to where the atomics were performed) into the ring slot that has just been consumed, then 32 LDS reads
-            char* scratch = st.my + free_slot * TKR_HALF_BYTES;
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)&ctrl->bucket[0][0], 0, 32 * 64 * 4, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (void __attribute__((address_space(3)))*)(scratch + i * 1024), 16,
-                                                         (unsigned)(i * 1024 + lane * 16), 0, 0, 17);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned sb = lds_addr32(scratch) + lane * 4;
-            float bm[32];
-#pragma unroll
-            for (int b = 0; b < 32; ++b) {
-                unsigned kv;
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(kv) : "v"(sb), "i"(b * 256));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                bm[b] = tkf_unkey(kv);
-            }
-            tkf_bitonic_k<2>(bm);                          // descending
-#pragma unroll
-            for (int b = 0; b < 32; ++b) t = (b == kc - 1) ? bm[b] : t;       // kc <= 32 (launcher)
-        }
-        __hip_atomic_store(&ctrl->tauk[lane], tkf_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        kvp = tkf_key(t);
-    };
-    // Until the thresholds are out a wave parks its tiles' maxima in LDS (TKF_EMAX per lane; asm accesses like the fragment reads);
-    // the threshold word is LOADED at the top of an iteration and LOOKED AT at its end, so the poll never drains the DMA queue
-    // (a load that is waited for right away costs a full vmcnt(0): measured -- 8 polling tiles per wave -- as ~25 us per scan).
-    auto finish_tile = [&](long tile, int free_slot) {
-        const float mine = tile_max(tile);
-        const long ti = tile - lo;
-        if (!have_tau) {
-            if (ti == 0)       // first tile -> this wave's bucket (returning atomic: the ticket is taken once it has come back)
-                old0 = __hip_atomic_fetch_max(&ctrl->bucket[(gw << 5) / nw][lane], tkf_key(lane < nq ? mine : -INFINITY),
-                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ti == 1) {
-                asm volatile("" ::"v"(old0) : "memory");
-                if (lane == 0) __hip_atomic_fetch_add(&ctrl->ticket[blockIdx.x & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (gw == 0) thresholds(free_slot);
-            }
-            if (!__all(kvp != 0u) && ti >= TKF_EMAX) {        // the park is full: wait (bounded)
-                int spins = 0;
-                while (true) {
-                    kvp = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all(kvp != 0u) || spins >= 100000) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    ++spins;
-                }
-            }
-            if (__all(kvp != 0u) || ti >= TKF_EMAX) {
-                tau = kvp != 0u ? tkf_unkey(kvp) : -INFINITY;        // timed out: keep everything
-                have_tau = true;
-                for (long j = 0; j < ti; ++j) {                      // the parked tiles
-                    unsigned pv;
-                    asm volatile("ds_read_b32 %0, %1" : "=v"(pv) : "v"(stg + (unsigned)j * 256u));
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    append(__uint_as_float(pv), lo + j);
-                }
-            } else {
-                asm volatile("ds_write_b32 %0, %1" ::"v"(stg + (unsigned)ti * 256u), "v"(mine) : "memory");
-                return;
-            }
-        }
-        append(mine, tile);
-    };
-    int slot = 0;
-    long t = lo;
-    for (; t + 1 < hi; ++t) {
-        if (!have_tau) kvp = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tkr_issue<0, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);
-        tkr_wait_vm<25>();
-        tkr_process<0>(st, slot, qf, acc);
-        slot = slot == 2 ? 0 : slot + 1;
-        tkr_issue<1, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);
-        tkr_wait_vm<25>();
-        tkr_process<1>(st, slot, qf, acc);
-        slot = slot == 2 ? 0 : slot + 1;
-        finish_tile(t, slot == 0 ? 2 : slot - 1);
-    }
-    if (!have_tau) kvp = __hip_atomic_load(&ctrl->tauk[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tkr_wait_vm<12>();
-    tkr_process<0>(st, slot, qf, acc);
-    slot = slot == 2 ? 0 : slot + 1;
-    tkr_wait_vm<0>();
-    tkr_process<1>(st, slot, qf, acc);
-    finish_tile(t, slot);
-    if (lane < nq) ent_cnt[(long)lane * nw + gw] = npos;
-}
-
 // The group-max scan of <= 1024 queries over the shard: gmax[q][group] = best approximate score of the 16 rows of the group.
 // Returns 1 when a 1024-thread selection is the matching follow-up (streaming / ping-pong scans), 0 for the 256-thread one,
 // negative on error.
-// the filtered scan's outputs (topk_stream3_kernel): control words, per-(query, wave) lists; nw = waves of the scan
-struct TkSparse {
-    TkFiltCtrl* ctrl;
-    float* ent_val;
-    int* ent_grp;
-    int* ent_cnt;
-    int rmax, nw, kc;
-};
-#define TK_SPARSE_CTRL_BYTES 16384L                 // >= sizeof(TkFiltCtrl)
-static_assert(sizeof(TkFiltCtrl) <= TK_SPARSE_CTRL_BYTES, "control block outgrew its slot");
-#define TK_SPARSE_LIST_BYTES(ngroups) (64L * 1024 * ((ngroups) / 1024 + 4) * 4)   // >= 64 queries x waves x rmax entries: waves <= 1024, rmax = ngroups / waves + 2
 // wmax / nw_out (optional): room for [nq][1024] per-wave maxima; *nw_out = the number of waves when the scan wrote them, else 0.
-// sparse (optional, with kc set): the caller can consume the filtered output -> the scan may run as topk_stream3_kernel and then
-// returns 2 (nothing is written to gmax).
 // does the shared-ring streaming scan (topk_stream5_kernel<2 / 4>) take a sweep of nq (65 .. 256) queries over this shard?
 static bool stream_shared_ok(int dim, int64_t rows, int nq) {
-    static const char* env_s4 = getenv("UNIIR_TOPK_STREAM4");    // "0": the ping-pong GEMM scan instead (A/B; the name is historic)
-    const int s4_max = (env_s4 && env_s4[0] == '2') ? 128 : 256;
     const long ngroups = (rows + TK_G - 1) / TK_G;
-    return nq > 64 && nq <= s4_max && dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048 && !(env_s4 && env_s4[0] == '0');
+    return nq > 64 && nq <= 256 && dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048;
 }
-template <int QW, int A>
+static int tk_cu_count() {
+    static int ncu = 0;
+    if (!ncu) {
+        int d = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&prop, d) != hipSuccess) return -1;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return ncu;
+}
+template <int QW>
 static void launch_stream5(int nv, hipStream_t st0, const void* pool_f16, const float* pool_inv_norm, long rows,
                            const void* queries_f16, int nq, float* gmax, long ngroups, float* wm) {
-    static const char* env_x = getenv("UNIIR_TOPK_EXP_FIN");       // timing experiment: skip the per-tile epilogue (wrong results)
-    const int exp_fin = env_x ? atoi(env_x) : 0;
     static PerDeviceOnce attr;
     if (attr.first())
-        (void)hipFuncSetAttribute((const void*)topk_stream5_kernel<QW, A>, hipFuncAttributeMaxDynamicSharedMemorySize, Tk5<QW>::LDS);
-    hipLaunchKernelGGL((topk_stream5_kernel<QW, A>), dim3(nv / QW), dim3(64 * QW), Tk5<QW>::LDS, st0, (const unsigned short*)pool_f16,
-                       pool_inv_norm, rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm, exp_fin);
+        (void)hipFuncSetAttribute((const void*)topk_stream5_kernel<QW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Tk5<QW>::LDS);
+    hipLaunchKernelGGL((topk_stream5_kernel<QW, 2>), dim3(nv / QW), dim3(64 * QW), Tk5<QW>::LDS, st0, (const unsigned short*)pool_f16,
+                       pool_inv_norm, rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm);
 }
+// The scan of a sweep, by shape (every pool stream is read with the nt policy where a row is read exactly once per sweep:
+// measured 0.2729 -> 0.2466 ms per 64-query search):
+//   <= 64 queries, dim 768, a shard the 31-bit buffer bound addresses, >= 2048 groups : topk_stream2_kernel (queries in registers)
+//   <= 64 queries, dim 768 / 512 otherwise (small shards, CLIP base pools)            : topk_stream_kernel (queries in LDS)
+//   65 .. 256 queries where the first line's conditions hold                           : topk_stream5_kernel<2 / 4>
+//   more queries or other shapes, dim a multiple of 64 and >= 192                      : topk_gmax_pp_kernel (ping-pong GEMM core)
+//   anything else                                                                      : topk_gmax_kernel
 static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, int64_t rows, int32_t dim,
                             const void* queries_f16, int32_t nq, float* gmax, hipStream_t st0, float* wmax = nullptr,
-                            int* nw_out = nullptr, TkSparse* sparse = nullptr) {
+                            int* nw_out = nullptr) {
     if (nw_out) *nw_out = 0;
     const long ngroups = (rows + TK_G - 1) / TK_G;
     int nqt, nsl; long rps;
     coarse_plan(nq, rows, &nqt, &nsl, &rps);
-    static const char* env_st = getenv("UNIIR_TOPK_STREAM");     // "0" disables the streaming scan (experiments)
-    // second-generation streaming scan (queries in registers, pool by LDS-DMA): dim 768, the shard's bytes addressable by the
-    // 31-bit buffer bound, enough tiles that every one of the 4 waves of every workgroup has work
-    static const char* env_s2 = getenv("UNIIR_TOPK_STREAM2");    // "0": the first-generation streaming scan (A/B)
-    if (nq <= 64 && dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048 && !(env_st && env_st[0] == '0') &&
-        !(env_s2 && env_s2[0] == '0')) {
-        static int ncu = 0;
-        if (!ncu) {
-            int d = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&prop, d) != hipSuccess) return UNIIR_ELAUNCH;
-            ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
+    const bool big_dim768 = dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048;
+    if (nq <= 64 && big_dim768) {
+        const int ncu = tk_cu_count();
+        if (ncu < 0) return UNIIR_ELAUNCH;
         static PerDeviceOnce attr_s2;
-        if (attr_s2.first()) {
-            (void)hipFuncSetAttribute((const void*)topk_stream2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
+        if (attr_s2.first())
             (void)hipFuncSetAttribute((const void*)topk_stream2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
-        }
-        // nt on the pool stream (read exactly once): measured 0.2729 -> 0.2466 ms per 64-query search, 0.2382 -> 0.2124 at 16
-        static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "0": default cache policy (A/B)
-        // MEASURED (round 3, same box, 64 queries x 700 k rows): dense stream2 scan 189 us; this filtered scan 183 us with the
-        // waiting tiles stored densely (but the selection then reads 8 x more and loses the 6 us again), 210 us with them parked in
-        // LDS; without ANY group-max store the scan takes 156 us.  The ~30 us until the thresholds are out (first tiles of 1024
-        // waves + 65 k bucket atomics + tickets) cover a fifth of the scan, and the bookkeeping around them eats the rest of the gain.
-        // The output volume does drop 40 x (1 100 of 43 750 groups per query).  Kept as an experiment: UNIIR_TOPK_FILTER=1.
-        static const char* env_f = getenv("UNIIR_TOPK_FILTER");        // "1": the filtered scan (experiment)
-        static const char* env_nt0 = getenv("UNIIR_TOPK_NT");
-        if (sparse && env_f && env_f[0] == '1' && ngroups >= 16L * ncu * 4 && (ncu * 4) % 32 == 0 && ncu * 4 <= 1024 &&
-            sparse->kc <= 32) {
-            sparse->nw = ncu * 4;
-            sparse->rmax = (int)(ngroups / (ncu * 4) + 2);            // >= every wave's tile count (tkf_range)
-            if (hipMemsetAsync(sparse->ctrl, 0, sizeof(TkFiltCtrl), st0) != hipSuccess) return UNIIR_ELAUNCH;
-            static PerDeviceOnce attr_s3;
-            if (attr_s3.first()) {
-                (void)hipFuncSetAttribute((const void*)topk_stream3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR3_WAVE_LDS);
-                (void)hipFuncSetAttribute((const void*)topk_stream3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR3_WAVE_LDS);
-            }
-            if (!(env_nt0 && env_nt0[0] == '0'))
-                hipLaunchKernelGGL(topk_stream3_kernel<2>, dim3(ncu), dim3(256), 4 * TKR3_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                                   pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, ngroups, sparse->kc,
-                                   sparse->ctrl, sparse->ent_val, sparse->ent_grp, sparse->ent_cnt, sparse->rmax);
-            else
-                hipLaunchKernelGGL(topk_stream3_kernel<0>, dim3(ncu), dim3(256), 4 * TKR3_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                                   pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, ngroups, sparse->kc,
-                                   sparse->ctrl, sparse->ent_val, sparse->ent_grp, sparse->ent_cnt, sparse->rmax);
-            HIP_LAUNCH_CHECK();
-            return 2;
-        }
-        static const char* env_h = getenv("UNIIR_TOPK_HIER");          // "0": selection from the full group-max rows (A/B)
-        static const char* env_x = getenv("UNIIR_TOPK_EXP_STORE");
-        const int exp_store = env_x ? atoi(env_x) : 0;
-        float* wm = (wmax && nw_out && ncu * 4 <= 1024 && (ngroups + ncu * 4 - 1) / (ncu * 4) <= 64 && !(env_h && env_h[0] == '0')) ? wmax : nullptr;
+        // the per-wave maxima feed the hierarchical selection of the fused tail
+        float* wm = (wmax && nw_out && ncu * 4 <= 1024 && (ngroups + ncu * 4 - 1) / (ncu * 4) <= 64) ? wmax : nullptr;
         if (wm) *nw_out = ncu * 4;
-        static const char* env_s5 = getenv("UNIIR_TOPK_STREAM5");      // "1": the rolling-register kernel, one wave per workgroup
-        if (env_s5 && env_s5[0] == '1' && exp_store == 0) {
-            if (!(env_nt && env_nt[0] == '0')) launch_stream5<1, 2>(ncu * 4, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-            else launch_stream5<1, 0>(ncu * 4, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-            HIP_LAUNCH_CHECK();
-            return 1;
-        }
-        if (!(env_nt && env_nt[0] == '0'))
-            hipLaunchKernelGGL(topk_stream2_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm, exp_store);
-        else
-            hipLaunchKernelGGL(topk_stream2_kernel<0>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                               pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm, exp_store);
+        hipLaunchKernelGGL(topk_stream2_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
+                           pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm);
         HIP_LAUNCH_CHECK();
         return 1;
     }
-    if (nq <= 64 && (dim == 768 || dim == 512) && !(env_st && env_st[0] == '0')) {
+    if (nq <= 64 && (dim == 768 || dim == 512)) {
         const long nchunks = (ngroups + TKS_CH - 1) / TKS_CH;
         const size_t sms = 64 * (dim * 2 + 16) + 8 * 64 * TKS_CH * 4;
         int grid = 256;
@@ -1714,39 +1413,23 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
     }
     // 65 .. 256 queries, dim 768: the shared-ring streaming scan (queries in registers, 64 per wave)
     // MEASURED (round 3, 700 k rows, whole search): 128 queries 0.224-0.239 ms vs 0.280-0.291 (ping-pong GEMM scan), 256 queries
-    // 0.318-0.345 vs 0.376; UNIIR_TOPK_STREAM4 = "2": up to 128 queries only, "0": never
+    // 0.318-0.345 vs 0.376
     if (stream_shared_ok(dim, rows, nq)) {
-        static int ncu4 = 0;
-        if (!ncu4) {
-            int d = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&prop, d) != hipSuccess) return UNIIR_ELAUNCH;
-            ncu4 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
-        static const char* env_nt4 = getenv("UNIIR_TOPK_NT");
-        static const char* env_h4 = getenv("UNIIR_TOPK_HIER");
-        const bool nt = !(env_nt4 && env_nt4[0] == '0');
-        const int nv = ncu4 * 4;
-        float* wm = (wmax && nw_out && nv <= 1024 && (ngroups + nv - 1) / nv <= 64 && !(env_h4 && env_h4[0] == '0')) ? wmax : nullptr;
+        const int ncu = tk_cu_count();
+        if (ncu < 0) return UNIIR_ELAUNCH;
+        const int nv = ncu * 4;
+        float* wm = (wmax && nw_out && nv <= 1024 && (ngroups + nv - 1) / nv <= 64) ? wmax : nullptr;
         if (wm) *nw_out = nv;
-        if (nq <= 128) {
-            if (nt) launch_stream5<2, 2>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-            else launch_stream5<2, 0>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-        } else {
-            if (nt) launch_stream5<4, 2>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-            else launch_stream5<4, 0>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
-        }
+        if (nq <= 128) launch_stream5<2>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
+        else launch_stream5<4>(nv, st0, pool_f16, pool_inv_norm, (long)rows, queries_f16, nq, gmax, ngroups, wm);
         HIP_LAUNCH_CHECK();
         return 1;
     }
-    static const char* env_pp = getenv("UNIIR_TOPK_PP");         // "0" disables the ping-pong scan (experiments)
-    if (nq > 64 && dim % 64 == 0 && dim >= 192 && !(env_pp && env_pp[0] == '0')) {
+    if (nq > 64 && dim % 64 == 0 && dim >= 192) {
         const int tiles_q = (nq + 255) / 256;
         const long tiles_c = (rows + 255) / 256;
-        static const char* env_hn = getenv("UNIIR_TOPK_HALFN");       // "0": always the full 256-query tile (A/B)
-        static const char* env_nt = getenv("UNIIR_TOPK_NT");          // "0": default cache policy on the pool stream (A/B)
-        const bool halfn = nq <= 128 && !(env_hn && env_hn[0] == '0');
-        const bool nt = nq <= 256 && !(env_nt && env_nt[0] == '0');   // one query tile: every pool row is read exactly once
+        const bool halfn = nq <= 128;         // half-width query tile
+        const bool nt = nq <= 256;            // one query tile: every pool row is read exactly once
 #define TKPP_LAUNCH(H, A)                                                                                                      \
     do {                                                                                                                       \
         static PerDeviceOnce attr;                                                                                             \
@@ -1756,37 +1439,25 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
                            (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, \
                            nq, gmax, ngroups, tiles_q);                                                                        \
     } while (0)
-        if (halfn && nt) TKPP_LAUNCH(true, 2);
-        else if (halfn) TKPP_LAUNCH(true, 0);
+        if (halfn) TKPP_LAUNCH(true, 2);
         else if (nt) TKPP_LAUNCH(false, 2);
         else TKPP_LAUNCH(false, 0);
 #undef TKPP_LAUNCH
         HIP_LAUNCH_CHECK();
         return 1;
     }
-    static const char* env_wm = getenv("UNIIR_TOPK_WM");
-    static const char* env_bl = getenv("UNIIR_TOPK_BLOCKS");
-    const int wmsel = (env_wm && env_wm[0] == '1') ? 1 : 2;
-    const long ct = 128 * wmsel;
-    const long want_blocks = env_bl ? atol(env_bl) : 768;
+    const long ct = 256;
     long tiles = (rows + ct - 1) / ct;
-    long want = (want_blocks + nqt - 1) / nqt;
+    long want = (768 + nqt - 1) / nqt;
     if (want > tiles) want = tiles;
     if (want < 1) want = 1;
     const long tps = (tiles + want - 1) / want;
     rps = tps * ct;
     nsl = (int)((rows + rps - 1) / rps);
-    if (wmsel == 2) {
-        const size_t smg = GldsShape<2, 2, 32>::LDS_BYTES;
-        (void)hipFuncSetAttribute((const void*)topk_gmax_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg);
-        hipLaunchKernelGGL(topk_gmax_kernel<2>, dim3(nsl, nqt), dim3(256), smg, st0, (const unsigned short*)pool_f16,
-                           pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
-    } else {
-        const size_t smg = GldsShape<1, 2, 32>::LDS_BYTES;
-        (void)hipFuncSetAttribute((const void*)topk_gmax_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg);
-        hipLaunchKernelGGL(topk_gmax_kernel<1>, dim3(nsl, nqt), dim3(128), smg, st0, (const unsigned short*)pool_f16,
-                           pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
-    }
+    const size_t smg = GldsShape<2, 2, 32>::LDS_BYTES;
+    (void)hipFuncSetAttribute((const void*)topk_gmax_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg);
+    hipLaunchKernelGGL(topk_gmax_kernel<2>, dim3(nsl, nqt), dim3(256), smg, st0, (const unsigned short*)pool_f16,
+                       pool_inv_norm, (long)rows, dim, (const unsigned short*)queries_f16, nq, rps, gmax, ngroups);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1814,9 +1485,7 @@ extern "C" int64_t uniir_topk_workspace_bytes(int32_t nq, int32_t kc, int64_t ro
     if (nq <= TK_GPATH_MAXQ) {
         const int64_t ngroups = (rows + TK_G - 1) / TK_G;
         const int64_t dense = (int64_t)nq * ngroups * 4 + 256 + TK_WMAX_BYTES(nq <= 256 ? nq : 64);
-        // the filtered scan of <= 64 queries: control words, per-(query, wave) (value, group) lists with room for every group, counts
-        const int64_t sparse = TK_SPARSE_CTRL_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngroups) + 64 * 1024 * 4;
-        return nq <= 64 && sparse > dense ? sparse : dense;
+        return dense;
     }
     int nqt, nsl; long rps;
     coarse_plan(nq, rows, &nqt, &nsl, &rps);
@@ -1828,7 +1497,7 @@ extern "C" int uniir_topk_coarse(const void* pool_f16, const float* pool_inv_nor
                                  float* cand_score, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!pool_f16 || !pool_inv_norm || !queries_f16 || !cand_idx || !workspace) return UNIIR_EINVAL;
     if (rows <= 0 || nq <= 0 || kc <= 0) return UNIIR_EINVAL;
-    if (kc > TK_MAXKC || dim % 32 || dim <= 0 || rows > 0x7fffffffL) return UNIIR_ESHAPE;
+    if (kc > TK_MAXKC || dim % 32 || dim <= 0 || rows > 0x7fffffffL || rows * (int64_t)dim * 2 >= ((int64_t)1 << 31)) return UNIIR_ESHAPE;
     if (((uintptr_t)pool_f16 & 15) || ((uintptr_t)queries_f16 & 15) || ((uintptr_t)pool_inv_norm & 15) ||
         ((uintptr_t)workspace & 15))
         return UNIIR_EALIGN;
@@ -2190,131 +1859,6 @@ DEVINL float rescore_wave(const unsigned short* __restrict__ pool, const unsigne
     return s;
 }
 
-// Selection behind the filtered scan (topk_stream3_kernel): a query's candidates are its appended (value, group) entries, one
-// slice per wave of the scan.  Same scheme as gsel_body: per-thread maxima -> quarter-wave threshold (the
-// threads hold disjoint sets of groups) -> everything above it collected in LDS -> ranked exactly by (value desc, group asc) -> the
-// kc best plus the ties of the kc-th, at most gcap groups.  Overflow of the collection (massive exact ties, e.g. an all-zero
-// query) falls back to one extraction per round.  Ends with a barrier.
-template <int BS, class F>
-DEVINL void gsel_sparse(int q, int nw, long rows, int kc, int gcap, const float* __restrict__ ent_val,
-                        const int* __restrict__ ent_grp, const int* __restrict__ ent_cnt, int rmax, int* out, F&& mid) {
-    __shared__ float qmax[64];
-    __shared__ float sval[TK_SELCAP];
-    __shared__ int sgrp[TK_SELCAP];
-    __shared__ int scnt;
-    __shared__ float stau0, stau;
-    __shared__ float rs[BS / 64];
-    __shared__ int rg[BS / 64];
-    __shared__ float wsel;
-    __shared__ int isel;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
-    // thread tid holds wave tid's slice of the list (disjoint sets of groups per thread)
-    int cntq = tid < nw ? ent_cnt[(long)q * nw + tid] : 0;
-    if (cntq > rmax) cntq = rmax;
-    const float* lv = ent_val + ((long)q * nw + tid) * rmax;
-    const int* lgp = ent_grp + ((long)q * nw + tid) * rmax;
-    float mx = -INFINITY;
-    for (int e = 0; e < cntq; ++e) mx = fmaxf(mx, lv[e]);
-    mid();
-    if (tid == 0) { scnt = 0; stau0 = -INFINITY; stau = -INFINITY; }
-    const float qm = row16_max(mx);
-    if ((tid & 15) == 0) qmax[tid >> 4] = qm;
-    __syncthreads();
-    if (tid < 64) {
-        const float x = qmax[tid];
-        int rank = 0;
-        for (int t = 0; t < 64; ++t) {
-            const float o = qmax[t];
-            rank += (o > x || (o == x && t < tid)) ? 1 : 0;
-        }
-        if (rank == min(kc, 64) - 1) stau0 = x;
-    }
-    __syncthreads();
-    const float t0 = stau0;
-    for (int e = 0; e < cntq; ++e) {
-        const float x = lv[e];
-        if (x >= t0 && x > -INFINITY) {
-            const int pos = atomicAdd(&scnt, 1);
-            if (pos < TK_SELCAP) { sval[pos] = x; sgrp[pos] = lgp[e]; }
-        }
-    }
-    __syncthreads();
-    const int n = scnt;
-    if (n <= TK_SELCAP) {
-        for (int e = tid; e < n; e += BS) {
-            const float x = sval[e];
-            const int gi = sgrp[e];
-            int rank = 0;
-            for (int t = 0; t < n; ++t) {
-                const float o = sval[t];
-                const int og = sgrp[t];
-                rank += (o > x || (o == x && og < gi)) ? 1 : 0;
-            }
-            if (rank == min(kc, n) - 1) stau = x;
-        }
-        __syncthreads();
-        const float tt = stau;
-        for (int e = tid; e < n; e += BS) {
-            const float x = sval[e];
-            const int gi = sgrp[e];
-            int rank = 0;
-            for (int t = 0; t < n; ++t) {
-                const float o = sval[t];
-                const int og = sgrp[t];
-                rank += (o > x || (o == x && og < gi)) ? 1 : 0;
-            }
-            if (rank < gcap && x >= tt) {
-                for (int m = 0; m < TK_G; ++m) {
-                    const long row = (long)gi * TK_G + m;
-                    out[rank * TK_G + m] = row < rows ? (int)row : -1;
-                }
-            }
-        }
-    } else {
-        // one extraction per round over the thread's own entries: the best one strictly after (last_s, last_g)
-        float last_s = INFINITY, tk = -INFINITY;
-        int last_g = -1;
-        for (int j = 0; j < gcap; ++j) {
-            float bs = -INFINITY;
-            int bg = 0x7fffffff;
-            auto offer = [&](float x, int gi) {
-                const bool after = (x < last_s) || (x == last_s && gi > last_g);
-                if (x > -INFINITY && after && (x > bs || (x == bs && gi < bg))) { bs = x; bg = gi; }
-            };
-            for (int e = 0; e < cntq; ++e) offer(lv[e], lgp[e]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float os = __shfl_xor(bs, o, 64);
-                const int og = __shfl_xor(bg, o, 64);
-                if (os > bs || (os == bs && og < bg)) { bs = os; bg = og; }
-            }
-            if (lane == 0) { rs[w] = bs; rg[w] = bg; }
-            __syncthreads();
-            if (tid == 0) {
-                float fs = rs[0];
-                int fg = rg[0];
-                for (int k2 = 1; k2 < BS / 64; ++k2)
-                    if (rs[k2] > fs || (rs[k2] == fs && rg[k2] < fg)) { fs = rs[k2]; fg = rg[k2]; }
-                wsel = fs;
-                isel = fg;
-            }
-            __syncthreads();
-            last_s = wsel;
-            last_g = isel;
-            __syncthreads();
-            if (last_g == 0x7fffffff || last_s == -INFINITY) break;
-            if (j == kc - 1) tk = last_s;
-            if (j >= kc && last_s < tk) break;
-            if (tid < TK_G) {
-                const long row = (long)last_g * TK_G + tid;
-                out[j * TK_G + tid] = row < rows ? (int)row : -1;
-            }
-        }
-    }
-    __syncthreads();
-}
-
 // The same exact re-score with the candidate rows gathered by LDS-DMA (buffer_load_dwordx4 ... lds) into a wave-private ring of
 // DEPTH slices (64 rows x 128 bytes = 8 KiB each): DEPTH - 1 slices are in flight while one is walked, at no register cost -- the
 // register-staged gather above exposes one HBM round trip per 128-byte slice (12 per row: ~2 us each, 25 us per re-score).  Layout:
@@ -2393,9 +1937,7 @@ template <int PARTS, int RW, int DEPTH>
 __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     const unsigned short* __restrict__ pool, const float* __restrict__ pinv, long rows, int dim,
     const unsigned short* __restrict__ queries, const float* __restrict__ gmax, long ngroups, int kc, int gcap,
-    int* __restrict__ cand, float* __restrict__ exact, int stop_after, const float* __restrict__ wmax, int nw,
-    const float* __restrict__ ent_val, const int* __restrict__ ent_grp, const int* __restrict__ ent_cnt, int ent_rmax) {
-    // stop_after (timing experiments only, UNIIR_TOPK_TAIL_STOP): 1 = return after the selection, 2 = after the query scaling
+    int* __restrict__ cand, float* __restrict__ exact, const float* __restrict__ wmax, int nw) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];       // the gather rings
     __shared__ int sel[2 * TK_MAXKC * TK_G];                         // the selection's output: gcap * 16 row indices, -1 = empty
     __shared__ __attribute__((aligned(16))) unsigned short qrow[4096];
@@ -2446,22 +1988,11 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
             s_iq = s > 0.f ? (float)(1.0 / (double)(float)sqrt((double)s)) : 0.f;
         }
     };
-    // the selection ends with a barrier; behind the filtered stream3 scan it reads the query's lists (gsel_sparse), behind the
-    // stream2 scan it starts from the per-wave maxima (gsel_hier)
-    if (ent_val)
-        gsel_sparse<TKT_THREADS>(q, nw, rows, kc, gcap, ent_val, ent_grp, ent_cnt, ent_rmax, sel, qnorm);
-    else if (!(wmax && gsel_hier<TKT_THREADS>(gmax + (long)q * ngroups, wmax + (long)q * nw, nw, ngroups, rows, kc, gcap, sel, qnorm)))
+    // the selection ends with a barrier; behind the streaming scans it starts from the per-wave maxima (gsel_hier)
+    if (!(wmax && gsel_hier<TKT_THREADS>(gmax + (long)q * ngroups, wmax + (long)q * nw, nw, ngroups, rows, kc, gcap, sel, qnorm)))
         gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm);
     const int ngrp = (gcap - part + PARTS - 1) / PARTS;      // this workgroup's share: groups of rank part, part + PARTS, ...
     const int nth = ngrp * TK_G;                             // thread t -> member t % 16 of its (t / 16)-th group
-    auto stop_here = [&] {                                   // timing experiments: an empty shortlist instead of the re-score
-        for (int t = tid; t < nth; t += TKT_THREADS) {
-            const long o = (long)q * gcap * TK_G + ((t >> 4) * PARTS + part) * TK_G + (t & 15);
-            cand[o] = -1;
-            exact[o] = -INFINITY;
-        }
-    };
-    if (stop_after == 1) { stop_here(); return; }
     {
         const float iq = s_iq;                 // the normalised query, once per workgroup (the oracle's qn[j])
         for (int j = tid; j < dim; j += TKT_THREADS) {
@@ -2470,7 +2001,6 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
         }
     }
     __syncthreads();
-    if (stop_after == 2) { stop_here(); return; }
     if (w >= RW) return;                                              // no barrier follows
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * dim * 2), 0x00020000);
     const unsigned qn32 = lds_addr32(reinterpret_cast<const char*>(qn));
@@ -2557,26 +2087,21 @@ __global__ __launch_bounds__(1024) void topk_tail_sort_kernel(const float* __res
 
 // can the fused tail (selection + query norm + exact re-score | sort) serve this search?
 static bool fused_tail_ok(int64_t rows, int32_t dim, int32_t kc) {
-    static const char* env = getenv("UNIIR_TOPK_FUSED_TAIL");          // "0": the round-2 tail (four launches), for A/B
     const long ngroups = (rows + TK_G - 1) / TK_G;
     const int gcap = TK_GMULT * kc;
-    if ((env && env[0] == '0') || dim % 64 || dim > 4096 || ngroups % 2 || ngroups > 1024L * 2 * TK_SELREG ||
-        gcap * TK_G > TKT_SORTCAP || gcap > 2 * TK_MAXKC)
+    if (dim % 64 || dim > 4096 || ngroups % 2 || ngroups > 1024L * 2 * TK_SELREG || gcap * TK_G > TKT_SORTCAP || gcap > 2 * TK_MAXKC)
         return false;
     return rows * dim * 2 < (1L << 31);                                // the gather's 31-bit buffer bound
 }
-// selection + exact re-score + sort behind a finished scan (dense gmax [+ wave maxima], or the filtered output `sp`); false when
-// the shape does not fit the fused kernels
+// selection + exact re-score + sort behind a finished scan (dense gmax [+ wave maxima]); false when the shape does not fit the
+// fused kernels
 static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int64_t* pool_ids, int64_t rows, int32_t dim,
                               const void* queries_f16, int32_t nq, int32_t kc, int32_t k, const float* gmax, int32_t* cand,
-                              float* exact, float* out_scores, int64_t* out_ids, hipStream_t st, const float* wmax, int nw,
-                              const TkSparse* sp = nullptr) {
+                              float* exact, float* out_scores, int64_t* out_ids, hipStream_t st, const float* wmax, int nw) {
     const long ngroups = (rows + TK_G - 1) / TK_G;
     const int gcap = TK_GMULT * kc;
     if (!fused_tail_ok(rows, dim, kc)) return false;
     const int parts = nq <= 64 ? 4 : nq <= 128 ? 2 : 1;
-    static const char* env_stop = getenv("UNIIR_TOPK_TAIL_STOP");     // timing experiments: results are garbage when set
-    const int stop_after = env_stop ? atoi(env_stop) : 0;
     const dim3 g(nq, parts), b(TKT_THREADS);
 #define TKT_LAUNCH(P, RW, DEPTH)                                                                                       \
     do {                                                                                                               \
@@ -2586,9 +2111,7 @@ static bool launch_fused_tail(const void* pool_f16, const float* pinv, const int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, RW * DEPTH * 8192);                  \
         hipLaunchKernelGGL((topk_tail_select_rescore_kernel<P, RW, DEPTH>), g, b, RW * DEPTH * 8192, st,               \
                            (const unsigned short*)pool_f16, pinv, (long)rows, dim, (const unsigned short*)queries_f16, \
-                           gmax, ngroups, kc, gcap, cand, exact, stop_after, (!sp && nw > 0) ? wmax : nullptr,         \
-                           sp ? sp->nw : nw, sp ? sp->ent_val : nullptr, sp ? sp->ent_grp : nullptr,                   \
-                           sp ? sp->ent_cnt : nullptr, sp ? sp->rmax : 0);                                             \
+                           gmax, ngroups, kc, gcap, cand, exact, nw > 0 ? wmax : nullptr, nw);                         \
     } while (0)
     // rings: 3 waves x 4 slices (the interactive regime: 144 slots per workgroup at k = 10) or 5 waves x 2 slices = 96 / 80 KiB
     if (parts == 4) TKT_LAUNCH(4, 3, 4);
@@ -2648,6 +2171,9 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
     if (!pool_f16 || !pool_inv_norm || !queries_f16 || !out_scores || !out_ids || !workspace) return UNIIR_EINVAL;
     if (rows <= 0 || nq <= 0 || k <= 0) return UNIIR_EINVAL;
     if (k + 8 > TK_MAXKC || dim % 64 || dim <= 0 || rows > 0x7fffffffL) return UNIIR_ESHAPE;
+    // a shard is addressed through 31-bit buffer offsets: >= 2 GiB of rows is searched as equal sub-shards by the caller
+    // (retrieval.subshard_bounds: the 5.6 M x 768 pool on one GPU = 5 calls + uniir_topk_merge), never silently by a slower path
+    if (rows * (int64_t)dim * 2 >= ((int64_t)1 << 31)) return UNIIR_ESHAPE;
     if (((uintptr_t)pool_f16 & 15) || ((uintptr_t)queries_f16 & 15) || ((uintptr_t)pool_inv_norm & 15) ||
         ((uintptr_t)workspace & 255))
         return UNIIR_EALIGN;
@@ -2668,29 +2194,17 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
         const int n = nq - lo < chunk ? nq - lo : chunk;
         const unsigned short* qp = (const unsigned short*)queries_f16 + (long)lo * dim;
         if (n <= TK_GPATH_MAXQ) {       // group-max scan, then the fused tail (selection + query norm + exact re-score | sort)
-            // the per-wave maxima live behind the group maxima of this sweep (uniir_topk_workspace_bytes reserves the room); the
-            // filtered scan's outputs take the same region instead
+            // the per-wave maxima live behind the group maxima of this sweep (uniir_topk_workspace_bytes reserves the room)
             const int64_t ngr = (rows + TK_G - 1) / TK_G;
             float* wmax = (float*)(((uintptr_t)(gmax + (int64_t)n * ngr) + 255) & ~(uintptr_t)255);
-            TkSparse sp;
-            sp.ctrl = (TkFiltCtrl*)ws;
-            sp.ent_val = (float*)(ws + TK_SPARSE_CTRL_BYTES);
-            sp.ent_grp = (int*)(ws + TK_SPARSE_CTRL_BYTES + TK_SPARSE_LIST_BYTES(ngr));
-            sp.ent_cnt = (int*)(ws + TK_SPARSE_CTRL_BYTES + 2 * TK_SPARSE_LIST_BYTES(ngr));
-            sp.kc = kc;
-            sp.nw = sp.rmax = 0;
-            const bool fused = fused_tail_ok(rows, dim, kc);
             int nw = 0;
-            const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, qp, n, gmax, (hipStream_t)stream, wmax, &nw,
-                                             (fused && n <= 64) ? &sp : nullptr);
+            const int sel = launch_gmax_scan(pool_f16, pool_inv_norm, rows, dim, qp, n, gmax, (hipStream_t)stream, wmax, &nw);
             if (sel < 0) return sel;
             if (sel >= 1 && launch_fused_tail(pool_f16, pool_inv_norm, pool_ids, rows, dim, qp, n, kc, k, gmax, cand, exact,
-                                              out_scores + (long)lo * k, out_ids + (long)lo * k, (hipStream_t)stream, wmax, nw,
-                                              sel == 2 ? &sp : nullptr)) {
+                                              out_scores + (long)lo * k, out_ids + (long)lo * k, (hipStream_t)stream, wmax, nw)) {
                 HIP_LAUNCH_CHECK();
                 continue;
             }
-            if (sel == 2) return UNIIR_ELAUNCH;        // (cannot happen: the filtered scan is only chosen when the fused tail fits)
             rc = topk_select_after_scan(sel, gmax, rows, n, kc, cand, (hipStream_t)stream);
             if (rc) return rc;
         } else {

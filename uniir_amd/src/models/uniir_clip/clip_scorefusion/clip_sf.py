@@ -45,9 +45,8 @@ class CLIPScoreFusion(nn.Module):
         return img_emb + txt_emb
 
     def encode_multimodal_input(self, txt_tensor, img_tensor, txt_mask, img_mask):
-        with self.clip_model.concurrent_towers():     # text tower on a second HIP stream beside the image tower; joined on exit
-            txt_emb = self.encode_text(txt_tensor)
-            img_emb = self.encode_image(img_tensor)
+        txt_emb = self.encode_text(txt_tensor)
+        img_emb = self.encode_image(img_tensor)
         return FuseFn.apply(txt_emb, img_emb, txt_mask, img_mask)  # txt*mask + img*mask, [batch, embed_dim]
 
     def get_logit_scale(self):

@@ -74,9 +74,6 @@ class NativeAdamW(torch.optim.Optimizer):
         fl = self._buffers()
         world = comm.world() if self.allreduce else 1
         extra_reduced = set()
-        join = getattr(self.clip, "join_towers", None)
-        if join is not None:
-            join()                                 # towers that ran on a side stream (clip_model two-stream mode)
         if world > 1:
             if self.reducer is not None:           # blocks already reduced during backward; now the remainder + wait
                 self.last_collectives, extra_reduced = self.reducer.finish()
