@@ -122,6 +122,12 @@ int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32_t batch, i
 int uniir_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                         void* dqkv, int32_t batch, int32_t seq, int32_t heads, int32_t causal,
                         void* stream);
+/* Packed rows: item m owns rows row_off[m] .. row_off[m + 1] - 1 (its own length <= max_seq) of qkv / out / dqkv; lse stays
+ * [batch][heads][max_seq].  Every live row's result is bitwise that of the dense call on zero-padded-behind items under causal = 1. */
+int uniir_attention_fwd_packed(const void* qkv, void* out, float* lse, const int32_t* row_off, int32_t batch,
+                               int32_t max_seq, int32_t heads, int32_t causal, void* stream);
+int uniir_attention_bwd_packed(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                               const int32_t* row_off, int32_t batch, int32_t max_seq, int32_t heads, int32_t causal, void* stream);
 /* General form: separate Q [batch*tq][q_ld] and K/V [batch*tk][kv_ld] tensors (head h at column h*64) for the BLIP
  * MED cross-attention (uniir_blip/backbone/med.py:160-232 with encoder_hidden_states), and an optional per-item key
  * length (keys >= key_len[m] masked: the BERT padding mask, med.py:687-688 "(1 - mask) * -10000").
@@ -155,6 +161,11 @@ int uniir_text_embed(const int32_t* text, const float* token_emb, const float* p
                      int32_t* eot, int32_t n, int32_t ctx, int32_t width, int32_t vocab, void* stream);
 int uniir_text_embed_bwd(const int32_t* text, const float* dx, float* dtoken_emb, float* dpos,
                          int32_t n, int32_t ctx, int32_t width, int32_t vocab, void* stream);
+/* the same on packed rows: x row row_off[n] + t for t < row_off[n + 1] - row_off[n]; last_row[n] (optional) = the item's last row */
+int uniir_text_embed_packed(const int32_t* text, const float* token_emb, const float* pos_emb, const int32_t* row_off,
+                            float* x, int32_t* last_row, int32_t n, int32_t ctx, int32_t width, int32_t vocab, void* stream);
+int uniir_text_embed_bwd_packed(const int32_t* text, const float* dx, const int32_t* row_off, float* dtoken_emb,
+                                float* dpos, int32_t n, int32_t ctx, int32_t width, int32_t vocab, void* stream);
 /* out[i][:] = x[(i*seq + idx[i])][:] (idx NULL -> 0, the class token): rows for ln_post / ln_final */
 int uniir_gather_rows(const float* x, const int32_t* idx, float* out, int32_t n, int32_t seq,
                       int32_t width, void* stream);
@@ -278,6 +289,22 @@ int uniir_clip_tower_bwd_blocks(const uniir_clip_tower* t, int32_t batch, int32_
                                 int64_t workspace_bytes, void* stream);
 int uniir_clip_tower_bwd_stem(const uniir_clip_tower* t, const void* input, int32_t batch, void* workspace,
                               int64_t workspace_bytes, void* stream);
+/* The TEXT tower on packed rows (exact): only the tokens up to and including each caption's EOT are rows of the residual stream.
+ * Under CLIP's causal mask nothing behind the EOT reaches the pooled feature (clip_sf.py:43-44 -> CLIP.encode_text pools at
+ * argmax(tokens)), so embeddings and activation gradients are bitwise those of the dense calls above and the weight gradients the same
+ * sums without their zero terms (equal up to the order of fp32 additions).  row_off: device int32 [batch + 1], prefix sums of the
+ * live lengths (argmax + 1); live_rows = row_off[batch] as known to the host.  Same workspace discipline as the dense calls. */
+int64_t uniir_clip_tower_workspace_bytes_packed(const uniir_clip_tower* t, int32_t batch, int32_t live_rows,
+                                                int32_t save_for_backward);
+int uniir_clip_tower_fwd_packed(const uniir_clip_tower* t, const void* tokens, int32_t batch, const int32_t* row_off,
+                                int32_t live_rows, float* emb_out, void* workspace, int64_t workspace_bytes,
+                                int32_t save_for_backward, void* stream);
+int uniir_clip_tower_bwd_head_packed(const uniir_clip_tower* t, const float* demb, int32_t batch, const int32_t* row_off,
+                                     int32_t live_rows, void* workspace, int64_t workspace_bytes, void* stream);
+int uniir_clip_tower_bwd_blocks_packed(const uniir_clip_tower* t, int32_t batch, const int32_t* row_off, int32_t live_rows,
+                                       int32_t layer_lo, int32_t layer_hi, void* workspace, int64_t workspace_bytes, void* stream);
+int uniir_clip_tower_bwd_stem_packed(const uniir_clip_tower* t, const void* tokens, int32_t batch, const int32_t* row_off,
+                                     int32_t live_rows, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [FP32] forward path of the encoders in fp32 ("model.float()" of the reference: clip_sf.py:25-26 keeps fp32 weights,

@@ -168,3 +168,45 @@ def test_hard_negative_batch_through_the_model():
     g_o = oracle.visual__proj.grad
     print("OBS hardneg loss diff", abs(out_d["loss"].item() - out_o["loss"].item()), "grad rel", rel(g_d, g_o))
     assert rel(g_d, g_o) < 4e-2, rel(g_d, g_o)                  # observed 1.6e-2
+
+
+def test_packed_text_tower_equals_the_dense_tower():
+    """clip_model.pack_text (default on): the text tower on the rows up to each caption's EOT only (csrc/tower.hip *_packed).  Under
+    the causal mask nothing behind the EOT reaches the pooled feature (clip_sf.py:43-44), so against the dense tower on the same
+    batch: text embeddings bitwise equal; after loss.backward() the gradients of the embeddings' inputs that are activations flow
+    through the same values, so every parameter gradient agrees up to the ORDER of the fp32 sums over rows (the dense wgrad adds
+    exact zeros for the dead rows in between): 1e-5 relative, the positional embedding (summed per position in item order in both
+    forms) bitwise.  Also: an item whose caption fills the context, the embedding-extraction (no-grad) path, and the row counts"""
+    from oracle import clip_oracle as O
+    from uniir_amd import clip_model
+    cfg = O.tiny_config(vision_width=128, vision_layers=1, transformer_width=128, transformer_heads=2, transformer_layers=3)
+    res = {}
+    for packed in (True, False):
+        model, _, O = _build(cfg, seed=5)
+        model.clip_model.pack_text = packed
+        batch = O.synthetic_batch(cfg, 24, seed=33)
+        txt = batch["txt_batched"]
+        ctx = txt.shape[1]
+        txt[3] = torch.randint(1, cfg["vocab_size"] - 2, (ctx,), dtype=torch.int32, generator=torch.Generator().manual_seed(7))
+        txt[3, 0], txt[3, ctx - 1] = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1          # a caption that fills the context
+        dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        model.train()
+        model.clip_model._ensure_flat()
+        model.clip_model.zero_grad()
+        temb = model.clip_model.encode_text(dbatch["txt_batched"])
+        out = model(dbatch)
+        out["loss"].backward()
+        with torch.no_grad():
+            temb_ng = model.clip_model.encode_text(dbatch["txt_batched"])
+        grads = {n: p.grad.detach().clone() for n, p in model.clip_model.named_parameters() if p.grad is not None}
+        res[packed] = (temb.detach().clone(), temb_ng.clone(), float(out["loss"].detach()), grads, model.clip_model.last_text_rows)
+    (e_p, eng_p, l_p, g_p, rows_p), (e_d, eng_d, l_d, g_d, rows_d) = res[True], res[False]
+    assert torch.equal(e_p, e_d) and torch.equal(eng_p, eng_d) and torch.equal(e_p, eng_p)
+    assert l_p == l_d
+    lens = (txt.argmax(dim=-1) + 1)
+    assert rows_p == (int(lens.sum()), txt.shape[0] * txt.shape[1]) and rows_d is None
+    assert torch.equal(g_p["positional_embedding"], g_d["positional_embedding"])
+    for n in g_d:
+        den = g_d[n].norm().clamp_min(1e-20)
+        assert float((g_p[n] - g_d[n]).norm() / den) < 1e-5, n
+

@@ -231,6 +231,43 @@ def test_attention_bwd_pair_kernel_against_the_general_kernel(batch, seq, heads)
             assert rel_err(d[:, i], g[:, i]) < 1.5e-2, name
 
 
+@pytest.mark.parametrize("batch,ctx,heads", [(9, 77, 12), (5, 77, 8), (3, 50, 2)])
+def test_attention_on_packed_rows_equals_the_dense_causal_call(batch, ctx, heads):
+    """uniir_attention_{fwd,bwd}_packed (the CLIP text tower on the rows up to each caption's EOT, csrc/tower.hip *_packed): item m
+    owns rows row_off[m] .. row_off[m + 1] - 1.  Against the dense causal call on the same captions padded to ctx rows (whatever
+    sits behind the EOT cannot reach a live row under the causal mask): outputs, log-sum-exps and gradients of the live rows are
+    bitwise equal"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(41 + batch)
+    W = heads * 64
+    lens = torch.randint(2, ctx + 1, (batch,), generator=g)
+    lens[0], lens[-1] = ctx, 2                                           # a full caption and the shortest one
+    off = torch.zeros(batch + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lens, 0)
+    R = int(off[-1])
+    row_off = off.to(torch.int32).to(DEV)
+    packed = bf(torch.randn(R, 3 * W, device=DEV))
+    dense = bf(torch.randn(batch * ctx, 3 * W, device=DEV))              # garbage behind the EOT
+    live = torch.zeros(batch * ctx, dtype=torch.bool, device=DEV)
+    for m in range(batch):
+        dense[m * ctx:m * ctx + int(lens[m])] = packed[int(off[m]):int(off[m + 1])]
+        live[m * ctx:m * ctx + int(lens[m])] = True
+    out_d, lse_d = ops.attention_fwd(dense, batch, ctx, heads, 1)
+    out_p = torch.full((R, W), 7.0, device=DEV, dtype=torch.bfloat16)
+    lse_p = torch.zeros(batch, heads, ctx, device=DEV)
+    ops.call("uniir_attention_fwd_packed", packed, out_p, lse_p, row_off, batch, ctx, heads, 1)
+    assert torch.equal(out_p, out_d[live])
+    lmask = live.view(batch, 1, ctx).expand(batch, heads, ctx)
+    assert torch.equal(lse_p[lmask], lse_d[lmask])
+    do_p = bf(torch.randn(R, W, device=DEV))
+    do_d = torch.zeros(batch * ctx, W, device=DEV, dtype=torch.bfloat16)      # nothing behind the EOT carries a gradient
+    do_d[live] = do_p
+    dq_d = ops.attention_bwd(dense, out_d, do_d, lse_d, batch, ctx, heads, 1)
+    dq_p = torch.full((R, 3 * W), 5.0, device=DEV, dtype=torch.bfloat16)
+    ops.call("uniir_attention_bwd_packed", packed, out_p, do_p, lse_p, dq_p, row_off, batch, ctx, heads, 1)
+    assert torch.equal(dq_p, dq_d[live])
+
+
 @pytest.mark.parametrize("batch,tq,tk,heads,enc", [(3, 100, 197, 12, 1024), (2, 35, 257, 2, 128), (2, 197, 100, 3, 192)])
 def test_cross_attention_with_key_lengths(batch, tq, tk, heads, enc):
     """BLIP MED cross-attention at its real shapes (med.py:160-232): 100 text queries x 197 image keys, separate Q and

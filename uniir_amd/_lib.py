@@ -60,6 +60,8 @@ SIGNATURES = {
     "uniir_layernorm_bwd_ex": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, P, P, c_int, c_int, c_float, S]),
     "uniir_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_attention_fwd_packed": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_attention_bwd_packed": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_attention_fwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, P, c_int, c_int, c_int, c_int, c_int, c_float,
                                        C.c_uint32, S]),
     "uniir_attention_bwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, P, c_i64, P, P, P, c_i64, P, P, c_i64, c_int, c_int,
@@ -69,6 +71,8 @@ SIGNATURES = {
     "uniir_vit_assemble_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
     "uniir_text_embed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_text_embed_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_text_embed_packed": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "uniir_text_embed_bwd_packed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_gather_rows": (c_int, [P, P, P, c_int, c_int, c_int, S]),
     "uniir_scatter_rows": (c_int, [P, P, P, c_int, c_int, c_int, S]),
     "uniir_act_fwd": (c_int, [P, P, c_i64, c_int, S]),
@@ -118,6 +122,11 @@ SIGNATURES = {
     "uniir_clip_tower_bwd_head": (c_int, [C.POINTER(ClipTower), P, c_int, P, c_i64, S]),
     "uniir_clip_tower_bwd_blocks": (c_int, [C.POINTER(ClipTower), c_int, c_int, c_int, P, c_i64, S]),
     "uniir_clip_tower_bwd_stem": (c_int, [C.POINTER(ClipTower), P, c_int, P, c_i64, S]),
+    "uniir_clip_tower_workspace_bytes_packed": (c_i64, [C.POINTER(ClipTower), c_int, c_int, c_int]),
+    "uniir_clip_tower_fwd_packed": (c_int, [C.POINTER(ClipTower), P, c_int, P, c_int, P, P, c_i64, c_int, S]),
+    "uniir_clip_tower_bwd_head_packed": (c_int, [C.POINTER(ClipTower), P, c_int, P, c_int, P, c_i64, S]),
+    "uniir_clip_tower_bwd_blocks_packed": (c_int, [C.POINTER(ClipTower), c_int, P, c_int, c_int, c_int, P, c_i64, S]),
+    "uniir_clip_tower_bwd_stem_packed": (c_int, [C.POINTER(ClipTower), P, c_int, P, c_int, P, c_i64, S]),
     "uniir_bias_act_f32": (c_int, [P, P, P, c_i64, c_int, c_int, S]),
     "uniir_vit_assemble_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
     "uniir_attention_f32_fwd": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, c_int, c_int, c_int, c_int, c_int, c_float, S]),

@@ -23,6 +23,26 @@ _PY_TOWERS = False
 
 ALIGN = 64  # elements; every parameter starts on a 256-B boundary of the flat buffers
 
+def text_row_offsets(tok):
+    """(row_off int32 [n + 1] on the tokens' device, live rows on the host) of a token batch [n, ctx]: caption i owns
+    argmax(tok[i]) + 1 rows (upstream pools at the EOT = the largest token id, first occurrence).  The host needs the total to size
+    the GEMMs, which costs one device -> host read per NEW batch; a prefetcher that still has the tokens on the host can attach
+    the lengths as `tok._uniir_lens` (host_utils.DevicePrefetcher does).  The result is remembered ON the tensor object (with its
+    version counter), so a batch that is fed repeatedly (benchmarks, gradient accumulation replays) pays the read once; nothing is
+    keyed by address, so a recycled allocation can never produce a stale answer."""
+    hit = getattr(tok, "_uniir_row_off", None)
+    if hit is not None and hit[0] == tok._version and hit[1] == tuple(tok.shape):
+        return hit[2]
+    lens = getattr(tok, "_uniir_lens", None)
+    if lens is None:
+        lens = (tok.argmax(dim=-1) + 1).to(torch.int32).cpu()
+    lens = lens.to(torch.int64)
+    off = torch.zeros(tok.shape[0] + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lens, 0)
+    out = (off.to(torch.int32).to(tok.device), int(off[-1]))
+    tok._uniir_row_off = (tok._version, tuple(tok.shape), out)
+    return out
+
 CLIP_CONFIGS = {
     "ViT-B/32": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
                      context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
@@ -105,6 +125,11 @@ class CLIP(nn.Module):
         # "bf16": MFMA towers, forward + backward (training / fast extraction).  "fp32": the reference's model.float()
         # forward in exact-fp32 MFMA GEMMs + fp32 attention (csrc/fp32_path.hip): reference-precision embeddings, no backward
         self.precision = "bf16"
+        # exact text-row packing (csrc/tower.hip *_packed): the text tower runs on the tokens up to each caption's EOT only.  Rows
+        # behind the EOT never reach the pooled feature under the causal mask (clip_sf.py:43-44), so results are those of the dense
+        # tower (embeddings and activation gradients bitwise, weight gradients up to the order of fp32 additions).
+        self.pack_text = True
+        self.last_text_rows = None      # (live rows, dense rows) of the last packed text-tower call (bench: executed FLOPs)
 
     # ---- flat parameter / gradient / bf16-shadow storage -----------------------------------------------------
     def _ensure_flat(self):
@@ -269,6 +294,8 @@ class CLIP(nn.Module):
     def encode_text(self, text):
         self._sync_shadow()
         tok = text.to(torch.int32).contiguous()
+        if self.pack_text and tok is not text:       # the caller's tensor object carries the remembered row offsets
+            tok._uniir_row_off = (tok._version, tuple(tok.shape), text_row_offsets(text))
         return _TowerFn.apply(self, "text", tok, self._anchor_for(text.device))
 
     def _anchor_for(self, dev):
@@ -496,11 +523,24 @@ class _TowerFn(torch.autograd.Function):
             # the whole tower in one C call (csrc/tower.hip); the workspace is the activation stash of the backward
             lib = _lib.load()
             desc = model.tower_desc(which)
+            emb = torch.empty(M, E, device=dev, dtype=torch.float32)
+            if which == "text" and model.pack_text:
+                # exact packing: only the tokens up to each caption's EOT are rows of the text tower (text_row_offsets)
+                row_off, live = text_row_offsets(inp)
+                need = lib.uniir_clip_tower_workspace_bytes_packed(C.byref(desc), M, live, int(need_grad))
+                if need < 0:
+                    raise RuntimeError("uniir_clip_tower: unsupported tower geometry")
+                ws = torch.empty(need, device=dev, dtype=torch.uint8)
+                _lib.check(lib.uniir_clip_tower_fwd_packed(C.byref(desc), inp.data_ptr(), M, row_off.data_ptr(), live, emb.data_ptr(),
+                                                           ws.data_ptr(), need, int(need_grad), ops._stream()), "clip_tower_fwd_packed")
+                model.last_text_rows = (live, M * cfg["context_length"])
+                if need_grad:
+                    ctx.stash = dict(ws=ws, inp=inp, ctower=True, row_off=row_off, live=live)
+                return emb
             need = lib.uniir_clip_tower_workspace_bytes(C.byref(desc), M, int(need_grad))
             if need < 0:
                 raise RuntimeError("uniir_clip_tower: unsupported tower geometry")
             ws = torch.empty(need, device=dev, dtype=torch.uint8)
-            emb = torch.empty(M, E, device=dev, dtype=torch.float32)
             inp = inp.float().contiguous() if which == "image" else inp
             _lib.check(lib.uniir_clip_tower_fwd(C.byref(desc), inp.data_ptr(), M, emb.data_ptr(), ws.data_ptr(), need,
                                                 int(need_grad), ops._stream()), "clip_tower_fwd")
@@ -563,12 +603,24 @@ class _TowerFn(torch.autograd.Function):
             demb = demb.contiguous().float()
             need = ws.numel()
             reducer = getattr(model, "_grad_reducer", None)
-            _lib.check(lib.uniir_clip_tower_bwd_head(C.byref(desc), demb.data_ptr(), M, ws.data_ptr(), need, stream), "tower_bwd_head")
             L = desc.layers
+            prefix = "visual.transformer" if which == "image" else "transformer"
+            if "row_off" in st:         # the text tower on packed rows
+                ro, live = st["row_off"].data_ptr(), st["live"]
+                _lib.check(lib.uniir_clip_tower_bwd_head_packed(C.byref(desc), demb.data_ptr(), M, ro, live, ws.data_ptr(), need, stream),
+                           "tower_bwd_head_packed")
+                for lo, hi in ([(0, L)] if reducer is None else [(i, i + 1) for i in reversed(range(L))]):
+                    _lib.check(lib.uniir_clip_tower_bwd_blocks_packed(C.byref(desc), M, ro, live, lo, hi, ws.data_ptr(), need, stream),
+                               "tower_bwd_blocks_packed")
+                    if reducer is not None:
+                        reducer.ready(*model.layer_grad_range(prefix, lo))
+                _lib.check(lib.uniir_clip_tower_bwd_stem_packed(C.byref(desc), inp.data_ptr(), M, ro, live, ws.data_ptr(), need, stream),
+                           "tower_bwd_stem_packed")
+                return None, None, None, None
+            _lib.check(lib.uniir_clip_tower_bwd_head(C.byref(desc), demb.data_ptr(), M, ws.data_ptr(), need, stream), "tower_bwd_head")
             if reducer is None:
                 _lib.check(lib.uniir_clip_tower_bwd_blocks(C.byref(desc), M, 0, L, ws.data_ptr(), need, stream), "tower_bwd_blocks")
             else:       # DDP overlap: hand every finished block's weight gradients to the collective stream
-                prefix = "visual.transformer" if which == "image" else "transformer"
                 for i in reversed(range(L)):
                     _lib.check(lib.uniir_clip_tower_bwd_blocks(C.byref(desc), M, i, i + 1, ws.data_ptr(), need, stream),
                                "tower_bwd_blocks")

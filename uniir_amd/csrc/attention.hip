@@ -20,15 +20,23 @@ extern "C" void uniir_exp_attn_set(void* stamps, int mode) { g_att_stamps = (uns
 template <bool REL, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int Tq = a.Tq, Tk = a.Tk, H = a.H, causal = a.causal;
+    const int H = a.H, causal = a.causal;
+    const int m = blockIdx.x / H, h = blockIdx.x % H;
+    // packed rows (a.row_off): item m owns the rows row_off[m] .. row_off[m + 1] - 1 of every tensor (its own length); the
+    // statistics keep the dense [item][head][a.Tq] layout
+    int Tq = a.Tq, Tk = a.Tk;
+    long qr0 = (long)m * Tq, kr0 = (long)m * Tk;
+    if (a.row_off) {
+        qr0 = kr0 = a.row_off[m];
+        Tq = Tk = a.row_off[m + 1] - a.row_off[m];
+    }
     const int Tkp = (Tk + 31) & ~31;
     char* ldsK = lds;
     char* ldsV = lds + Tkp * 128;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar loop control
-    const int m = blockIdx.x / H, h = blockIdx.x % H;
-    const unsigned short* qbase = a.q + (long)m * Tq * a.q_ld + h * ATT_D;
-    const unsigned short* kbase = a.k + (long)m * Tk * a.kv_ld + h * ATT_D;
-    const unsigned short* vbase = a.v + (long)m * Tk * a.kv_ld + h * ATT_D;
+    const unsigned short* qbase = a.q + qr0 * a.q_ld + h * ATT_D;
+    const unsigned short* kbase = a.k + kr0 * a.kv_ld + h * ATT_D;
+    const unsigned short* vbase = a.v + kr0 * a.kv_ld + h * ATT_D;
     const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
     const float sl2 = REL ? a.scale * LOG2EF : SCALE_LOG2E;
     const unsigned dth = DROP ? drop_threshold(a.drop_p) : 0u;
@@ -152,8 +160,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         // rows leave as 16-byte pieces, 64 contiguous bytes per row and store (att_store_tile; round 4: the 8-byte stores at a
         // row stride cost the 257-token forward 0.14 of its 0.70 ms)
         const bool live = q < Tq && !ATT_EXP(16);
-        att_store_tile(o, 1.0f / l_run, a.out + ((long)m * Tq + min(q, Tq - 1)) * a.out_ld + h * ATT_D, live, g);
-        if (live && g == 0) a.lse[((long)m * H + h) * Tq + q] = m_run * LN2F + __logf(l_run);
+        att_store_tile(o, 1.0f / l_run, a.out + (qr0 + min(q, Tq - 1)) * a.out_ld + h * ATT_D, live, g);
+        if (live && g == 0) a.lse[((long)m * H + h) * a.Tq + q] = m_run * LN2F + __logf(l_run);
     }
     ATT_STAMP(3);
 }
@@ -168,8 +176,15 @@ template <bool REL, bool DROP, bool CAUSAL, int NT>
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArgs a) {
     constexpr int NWAVES = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int Tq = a.Tq, Tk = a.Tk, H = a.H;
+    const int H = a.H;
     constexpr bool causal = CAUSAL;
+    const int m = blockIdx.x / H, h = blockIdx.x % H;
+    int Tq = a.Tq, Tk = a.Tk;              // packed rows: see attn_fwd_kernel
+    long qr0 = (long)m * Tq, kr0 = (long)m * Tk;
+    if (a.row_off) {
+        qr0 = kr0 = a.row_off[m];
+        Tq = Tk = a.row_off[m + 1] - a.row_off[m];
+    }
     const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
     const int Tmax = max(Tqp, Tkp);
     char* bufA = lds;                 // Q, later K
@@ -183,16 +198,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
     const unsigned dth = DROP ? drop_threshold(a.drop_p) : 0u;
     const float dks = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar loop control
-    const int m = blockIdx.x / H, h = blockIdx.x % H;
     const unsigned headbase = (unsigned)((((long)m * H + h) * Tq) * Tk);
-    const unsigned short* qbase = a.q + (long)m * Tq * a.q_ld + h * ATT_D;
-    const unsigned short* kbase = a.k + (long)m * Tk * a.kv_ld + h * ATT_D;
-    const unsigned short* vbase = a.v + (long)m * Tk * a.kv_ld + h * ATT_D;
-    const unsigned short* obase = a.out + (long)m * Tq * a.out_ld + h * ATT_D;
-    const unsigned short* dobase = a.dout + (long)m * Tq * a.out_ld + h * ATT_D;
-    unsigned short* dqbase = a.dq + (long)m * Tq * a.dq_ld + h * ATT_D;
-    unsigned short* dkbase = a.dk + (long)m * Tk * a.dkv_ld + h * ATT_D;
-    unsigned short* dvbase = a.dv + (long)m * Tk * a.dkv_ld + h * ATT_D;
+    const unsigned short* qbase = a.q + qr0 * a.q_ld + h * ATT_D;
+    const unsigned short* kbase = a.k + kr0 * a.kv_ld + h * ATT_D;
+    const unsigned short* vbase = a.v + kr0 * a.kv_ld + h * ATT_D;
+    const unsigned short* obase = a.out + qr0 * a.out_ld + h * ATT_D;
+    const unsigned short* dobase = a.dout + qr0 * a.out_ld + h * ATT_D;
+    unsigned short* dqbase = a.dq + qr0 * a.dq_ld + h * ATT_D;
+    unsigned short* dkbase = a.dk + kr0 * a.dkv_ld + h * ATT_D;
+    unsigned short* dvbase = a.dv + kr0 * a.dkv_ld + h * ATT_D;
     const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
 
     auto row_stats = [&] {          // D[q] = dO[q] . O[q], lse2[q] = lse[q] * log2 e; the bias / gradient rows of a T5 head
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
                         d += __uint_as_float(x[e] & 0xffff0000u) * __uint_as_float(y[e] & 0xffff0000u);
                     }
                 }
-                l = a.lse[((long)m * H + h) * Tq + r] * LOG2EF;
+                l = a.lse[((long)m * H + h) * a.Tq + r] * LOG2EF;
             }
             Dq[r] = d;
             lse2[r] = l;
@@ -537,6 +551,42 @@ extern "C" int uniir_attention_bwd(const void* qkv, const void* out, const void*
     a.q_ld = a.kv_ld = 3 * W;
     a.out = (unsigned short*)out; a.out_ld = W; a.lse = const_cast<float*>(lse); a.klen = nullptr;
     a.Tq = a.Tk = seq; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
+    a.dout = (const unsigned short*)dout;
+    a.dq = (unsigned short*)dqkv; a.dk = a.dq + W; a.dv = a.dq + 2 * W;
+    a.dq_ld = a.dkv_ld = 3 * W;
+    return launch_attn_bwd(a, batch, (hipStream_t)stream);
+}
+
+// packed rows: item m owns rows row_off[m] .. row_off[m + 1] - 1 of qkv / out (lengths <= max_seq); lse stays [batch][heads][max_seq].
+// The CLIP text tower on the live rows of its captions only (rows behind a caption's EOT never reach its pooled feature under the
+// causal mask, clip_sf.py:43-44): every live row's result is bitwise that of the dense call.
+extern "C" int uniir_attention_fwd_packed(const void* qkv, void* out, float* lse, const int32_t* row_off, int32_t batch,
+                                          int32_t max_seq, int32_t heads, int32_t causal, void* stream) {
+    if (!qkv || !out || !lse || !row_off || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (max_seq < 1 || max_seq > 512) return UNIIR_ESHAPE;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return UNIIR_EALIGN;
+    const long W = (long)heads * ATT_D;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)qkv; a.k = a.q + W; a.v = a.q + 2 * W;
+    a.q_ld = a.kv_ld = 3 * W;
+    a.out = (unsigned short*)out; a.out_ld = W; a.lse = lse; a.klen = nullptr; a.row_off = row_off;
+    a.Tq = a.Tk = max_seq; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
+    return launch_attn_fwd(a, batch, (hipStream_t)stream);
+}
+extern "C" int uniir_attention_bwd_packed(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                          const int32_t* row_off, int32_t batch, int32_t max_seq, int32_t heads, int32_t causal,
+                                          void* stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || !row_off || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (max_seq < 1 || max_seq > 512) return UNIIR_ESHAPE;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return UNIIR_EALIGN;
+    const long W = (long)heads * ATT_D;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)qkv; a.k = a.q + W; a.v = a.q + 2 * W;
+    a.q_ld = a.kv_ld = 3 * W;
+    a.out = (unsigned short*)out; a.out_ld = W; a.lse = const_cast<float*>(lse); a.klen = nullptr; a.row_off = row_off;
+    a.Tq = a.Tk = max_seq; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
     a.dout = (const unsigned short*)dout;
     a.dq = (unsigned short*)dqkv; a.dk = a.dq + W; a.dv = a.dq + 2 * W;
     a.dq_ld = a.dkv_ld = 3 * W;

@@ -210,6 +210,80 @@ extern "C" int uniir_text_embed_bwd(const int32_t* text, const float* dx, float*
     return UNIIR_OK;
 }
 
+// packed text rows: item n's tokens 0 .. len - 1 (len = row_off[n + 1] - row_off[n]: up to and including its EOT) are the rows
+// row_off[n] .. row_off[n + 1] - 1 of x; last[n] = its EOT row (for uniir_gather_rows / uniir_scatter_rows with seq = 0)
+__global__ __launch_bounds__(256) void text_embed_packed_kernel(const int* __restrict__ text, const float* __restrict__ tok,
+                                                                const float* __restrict__ pos, const int* __restrict__ row_off,
+                                                                float* __restrict__ x, int* __restrict__ last, int n, int ctx,
+                                                                int w, int vocab) {
+    const int wc = w >> 2;
+    const long total = (long)n * ctx * wc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % wc);
+        const long row = i / wc;
+        const int t = (int)(row % ctx), m = (int)(row / ctx);
+        const int r0 = row_off[m], len = row_off[m + 1] - r0;
+        if (t == 0 && c == 0 && last) last[m] = r0 + len - 1;
+        if (t >= len) continue;
+        int id = text[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(tok + (long)id * w + 4 * c);
+        v += *reinterpret_cast<const f32x4_t*>(pos + (long)t * w + 4 * c);
+        *reinterpret_cast<f32x4_t*>(x + (long)(r0 + t) * w + 4 * c) = v;
+    }
+}
+extern "C" int uniir_text_embed_packed(const int32_t* text, const float* token_emb, const float* pos_emb, const int32_t* row_off,
+                                       float* x, int32_t* last_row, int32_t n, int32_t ctx, int32_t width, int32_t vocab,
+                                       void* stream) {
+    if (!text || !token_emb || !pos_emb || !row_off || !x || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    if (width % 4) return UNIIR_ESHAPE;
+    const long total = (long)n * ctx * (width / 4);
+    hipLaunchKernelGGL(text_embed_packed_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, text,
+                       token_emb, pos_emb, row_off, x, last_row, n, ctx, width, vocab);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+__global__ __launch_bounds__(256) void text_embed_bwd_tok_packed_kernel(const int* __restrict__ text, const float* __restrict__ dx,
+                                                                        const int* __restrict__ row_off, float* __restrict__ dtok,
+                                                                        int n, int ctx, int w, int vocab) {
+    const long total = (long)n * ctx * w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int col = (int)(i % w);
+        const long row = i / w;
+        const int t = (int)(row % ctx), m = (int)(row / ctx);
+        const int r0 = row_off[m];
+        if (t >= row_off[m + 1] - r0) continue;
+        int id = text[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        unsafeAtomicAdd(dtok + (long)id * w + col, dx[(long)(r0 + t) * w + col]);
+    }
+}
+__global__ __launch_bounds__(256) void text_embed_bwd_pos_packed_kernel(const float* __restrict__ dx, const int* __restrict__ row_off,
+                                                                        float* __restrict__ dpos, int n, int ctx, int w) {
+    const int t = blockIdx.x;
+    for (int col = blockIdx.y * 256 + threadIdx.x; col < w; col += gridDim.y * 256) {
+        float s = 0.f;
+        for (int im = 0; im < n; ++im) {           // the dense kernel's order over the items; items shorter than t + 1 add nothing
+            const int r0 = row_off[im];
+            if (t < row_off[im + 1] - r0) s += dx[(long)(r0 + t) * w + col];
+        }
+        dpos[(long)t * w + col] += s;
+    }
+}
+extern "C" int uniir_text_embed_bwd_packed(const int32_t* text, const float* dx, const int32_t* row_off, float* dtoken_emb,
+                                           float* dpos, int32_t n, int32_t ctx, int32_t width, int32_t vocab, void* stream) {
+    if (!text || !dx || !row_off || !dtoken_emb || !dpos || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    const long total = (long)n * ctx * width;
+    hipLaunchKernelGGL(text_embed_bwd_tok_packed_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, text,
+                       dx, row_off, dtoken_emb, n, ctx, width, vocab);
+    hipLaunchKernelGGL(text_embed_bwd_pos_packed_kernel, dim3(ctx, (width + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx,
+                       row_off, dpos, n, ctx, width);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x,
                                                           const int* __restrict__ idx,

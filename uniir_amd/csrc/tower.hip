@@ -26,13 +26,17 @@ struct Plan {
     int64_t tmp;
     int64_t g, df, dh, dx, dx2, dxb, dqkv, demb16, dpooled, drows, dx0, dpo, dconv;
     int64_t total;
+    // packed text rows (uniir_clip_tower_*_packed): R = the live rows, item m = rows row_off[m] .. row_off[m + 1] - 1
+    const int32_t* row_off;
 };
 
-Plan plan(const uniir_clip_tower* t, int batch, bool save) {
+// rows < 0: the dense layout (batch x tokens rows)
+Plan plan(const uniir_clip_tower* t, int batch, bool save, int rows = -1, const int32_t* row_off = nullptr) {
     Plan p;
     memset(&p, 0, sizeof(p));
     p.M = batch; p.T = t->tokens; p.W = t->width; p.H = t->heads; p.L = t->layers; p.E = t->embed_dim;
-    p.R = batch * t->tokens; p.G = t->tokens - 1; p.kpad = t->kpad; p.save = save;
+    p.R = rows >= 0 ? rows : batch * t->tokens; p.G = t->tokens - 1; p.kpad = t->kpad; p.save = save;
+    p.row_off = row_off;
     const int64_t R = p.R, W = p.W, M = p.M;
     int64_t cur = 0;
     auto take = [&](int64_t bytes) { const int64_t o = cur; cur += al(bytes); return o; };
@@ -201,7 +205,8 @@ int blocks_fwd(const uniir_clip_tower* t, const Plan& p, char* ws, void* st) {
                                                : stream_in(p, ws, i + 1);
         TRY(uniir_layernorm_fwd(x, W, b.ln1_w, b.ln1_b, l.h1, nullptr, R, W, 1e-5f, st));
         TRY(linear_fwd(l.h1, b.wqkv16, l.qkv, R, 3 * W, W, UNIIR_EPI_BF16, b.bqkv, nullptr, nullptr, st));
-        TRY(uniir_attention_fwd(l.qkv, l.ao, l.lse, p.M, p.T, p.H, t->is_text ? 1 : 0, st));
+        if (p.row_off) TRY(uniir_attention_fwd_packed(l.qkv, l.ao, l.lse, p.row_off, p.M, p.T, p.H, t->is_text ? 1 : 0, st));
+        else TRY(uniir_attention_fwd(l.qkv, l.ao, l.lse, p.M, p.T, p.H, t->is_text ? 1 : 0, st));
         TRY(linear_fwd(l.ao, b.wo16, l.x2, R, W, W, UNIIR_EPI_RESID_F32, b.bo, x, nullptr, st));
         TRY(uniir_layernorm_fwd(l.x2, W, b.ln2_w, b.ln2_b, l.h2, nullptr, R, W, 1e-5f, st));
         if (p.save)      // f (pre-activation) is stashed for the backward; a forward-only pass writes act(f) alone
@@ -219,20 +224,20 @@ float* stream_out(const Plan& p, char* ws) {
     return (float*)(ws + p.x_last);
 }
 
-}  // namespace
-
-extern "C" int64_t uniir_clip_tower_workspace_bytes(const uniir_clip_tower* t, int32_t batch, int32_t save_for_backward) {
-    if (check_tower(t, batch)) return -1;
-    return plan(t, batch, save_for_backward != 0).total;
+// packed calls: a text tower, row_off given, batch <= live rows <= batch x tokens
+int check_packed(const uniir_clip_tower* t, int batch, const int32_t* row_off, int rows) {
+    if (!t->is_text || !row_off) return UNIIR_EINVAL;
+    if (rows < batch || rows > batch * t->tokens) return UNIIR_ESHAPE;
+    return UNIIR_OK;
 }
 
-extern "C" int uniir_clip_tower_fwd(const uniir_clip_tower* t, const void* input, int32_t batch, float* emb_out,
-                                    void* workspace, int64_t workspace_bytes, int32_t save_for_backward, void* stream) {
+int tower_fwd(const uniir_clip_tower* t, const void* input, int32_t batch, const int32_t* row_off, int rows, float* emb_out,
+              void* workspace, int64_t workspace_bytes, int32_t save_for_backward, void* stream) {
     TRY(check_tower(t, batch));
     if (!input || !emb_out || !workspace) return UNIIR_EINVAL;
     if (batch == 0) return UNIIR_OK;
     if ((uintptr_t)workspace & 255) return UNIIR_EALIGN;
-    const Plan p = plan(t, batch, save_for_backward != 0);
+    const Plan p = plan(t, batch, save_for_backward != 0, rows, row_off);
     if (workspace_bytes < p.total) return UNIIR_EINVAL;
     char* ws = (char*)workspace;
     const int M = p.M, T = p.T, W = p.W, R = p.R;
@@ -243,6 +248,10 @@ extern "C" int uniir_clip_tower_fwd(const uniir_clip_tower* t, const void* input
         TRY(linear_fwd(ws + p.patches, t->conv16, ws + p.po, M * p.G, W, t->kpad, UNIIR_EPI_BF16, nullptr, nullptr, nullptr, stream));
         TRY(uniir_vit_assemble(ws + p.po, t->class_emb, t->pos_emb, (float*)(ws + p.x0), M, T, W, stream));
         TRY(uniir_layernorm_fwd((float*)(ws + p.x0), W, t->ln_pre_w, t->ln_pre_b, nullptr, x_in, R, W, 1e-5f, stream));
+    } else if (row_off) {    // packed: only the rows up to each caption's EOT exist; p.eot holds every item's last (= EOT) row
+        TRY(uniir_text_embed_packed((const int32_t*)input, t->token_emb, t->pos_emb, row_off, x_in, (int32_t*)(ws + p.eot), M, T, W,
+                                    t->vocab, stream));
+        eot = (const int32_t*)(ws + p.eot);
     } else {
         TRY(uniir_text_embed((const int32_t*)input, t->token_emb, t->pos_emb, x_in, (int32_t*)(ws + p.eot), M, T, W, t->vocab,
                              stream));
@@ -250,7 +259,7 @@ extern "C" int uniir_clip_tower_fwd(const uniir_clip_tower* t, const void* input
     }
     TRY(blocks_fwd(t, p, ws, stream));
     float* x_out = p.save ? (float*)(ws + p.x_last) : stream_out(p, ws);
-    TRY(uniir_gather_rows(x_out, eot, (float*)(ws + p.rows), M, T, W, stream));
+    TRY(uniir_gather_rows(x_out, eot, (float*)(ws + p.rows), M, row_off ? 0 : T, W, stream));     // (packed: absolute row indices)
     TRY(uniir_layernorm_fwd((float*)(ws + p.rows), W, t->ln_post_w, t->ln_post_b, ws + p.pooled, nullptr, M, W, 1e-5f, stream));
     uniir_gemm_desc d;
     base_desc(d);
@@ -260,12 +269,12 @@ extern "C" int uniir_clip_tower_fwd(const uniir_clip_tower* t, const void* input
 }
 
 // backward, stage 1: projection, ln_post / ln_final, scatter of the pooled row's gradient into the token stream
-extern "C" int uniir_clip_tower_bwd_head(const uniir_clip_tower* t, const float* demb, int32_t batch, void* workspace,
-                                         int64_t workspace_bytes, void* stream) {
+int tower_bwd_head(const uniir_clip_tower* t, const float* demb, int32_t batch, const int32_t* row_off, int rows, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
     TRY(check_tower(t, batch));
     if (!demb || !workspace || !t->g_proj || !t->g_ln_post_w || !t->g_ln_post_b) return UNIIR_EINVAL;
     if (batch == 0) return UNIIR_OK;
-    const Plan p = plan(t, batch, true);
+    const Plan p = plan(t, batch, true, rows, row_off);
     if (workspace_bytes < p.total) return UNIIR_EINVAL;
     char* ws = (char*)workspace;
     const int M = p.M, T = p.T, W = p.W, R = p.R, E = p.E;
@@ -282,8 +291,8 @@ extern "C" int uniir_clip_tower_bwd_head(const uniir_clip_tower* t, const float*
     TRY(uniir_layernorm_bwd((float*)(ws + p.rows), W, t->ln_post_w, ws + p.dpooled, 0, nullptr, (float*)(ws + p.drows), W, nullptr,
                             t->g_ln_post_w, t->g_ln_post_b, nullptr, M, W, 1e-5f, stream));
     if (hipMemsetAsync(ws + p.dx, 0, (size_t)R * W * 4, (hipStream_t)stream) != hipSuccess) return UNIIR_ELAUNCH;
-    TRY(uniir_scatter_rows((float*)(ws + p.drows), t->is_text ? (const int32_t*)(ws + p.eot) : nullptr, (float*)(ws + p.dx), M, T,
-                           W, stream));
+    TRY(uniir_scatter_rows((float*)(ws + p.drows), t->is_text ? (const int32_t*)(ws + p.eot) : nullptr, (float*)(ws + p.dx), M,
+                           row_off ? 0 : T, W, stream));
     TRY(uniir_cast_f32_to_bf16((float*)(ws + p.dx), ws + p.dxb, (int64_t)R * W, stream));
     // bias gradient of the last block's c_proj: column sums of the incoming gradient (the other blocks get theirs from the
     // LayerNorm backward that produces their incoming gradient)
@@ -291,12 +300,12 @@ extern "C" int uniir_clip_tower_bwd_head(const uniir_clip_tower* t, const float*
 }
 
 // backward, stage 2: residual blocks layer_hi-1 ... layer_lo (call with descending ranges that cover [0, layers))
-extern "C" int uniir_clip_tower_bwd_blocks(const uniir_clip_tower* t, int32_t batch, int32_t layer_lo, int32_t layer_hi,
-                                           void* workspace, int64_t workspace_bytes, void* stream) {
+int tower_bwd_blocks(const uniir_clip_tower* t, int32_t batch, const int32_t* row_off, int rows, int32_t layer_lo, int32_t layer_hi,
+                     void* workspace, int64_t workspace_bytes, void* stream) {
     TRY(check_tower(t, batch));
     if (!workspace || layer_lo < 0 || layer_hi > t->layers || layer_lo > layer_hi) return UNIIR_EINVAL;
     if (batch == 0) return UNIIR_OK;
-    const Plan p = plan(t, batch, true);
+    const Plan p = plan(t, batch, true, rows, row_off);
     if (workspace_bytes < p.total) return UNIIR_EINVAL;
     char* ws = (char*)workspace;
     const int W = p.W, R = p.R;
@@ -318,7 +327,8 @@ extern "C" int uniir_clip_tower_bwd_blocks(const uniir_clip_tower* t, int32_t ba
         TRY(uniir_layernorm_bwd(l.x2, W, b.ln2_w, dh, 0, dx, dx2, W, dxb, b.g_ln2_w, b.g_ln2_b, b.g_bo, R, W, 1e-5f, stream));
         TRY(linear_wgrad(t, dxb, l.ao, b.g_wo, R, W, W, stream));
         TRY(linear_dgrad(dxb, b.wo16, dh, R, W, W, nullptr, nullptr, nullptr, stream));                // d attention out
-        TRY(uniir_attention_bwd(l.qkv, l.ao, dh, l.lse, dqkv, p.M, p.T, p.H, t->is_text ? 1 : 0, stream));
+        if (row_off) TRY(uniir_attention_bwd_packed(l.qkv, l.ao, dh, l.lse, dqkv, row_off, p.M, p.T, p.H, t->is_text ? 1 : 0, stream));
+        else TRY(uniir_attention_bwd(l.qkv, l.ao, dh, l.lse, dqkv, p.M, p.T, p.H, t->is_text ? 1 : 0, stream));
         TRY(linear_wgrad(t, dqkv, l.h1, b.g_wqkv, R, 3 * W, W, stream, b.g_bqkv));       // + the in_proj bias gradient
         TRY(linear_dgrad(dqkv, b.wqkv16, dh, R, 3 * W, W, nullptr, nullptr, nullptr, stream));         // d ln_1 out
         TRY(uniir_layernorm_bwd(l.x, W, b.ln1_w, dh, 0, dx2, dx, W, dxb, b.g_ln1_w, b.g_ln1_b,
@@ -328,17 +338,20 @@ extern "C" int uniir_clip_tower_bwd_blocks(const uniir_clip_tower* t, int32_t ba
 }
 
 // backward, stage 3: what feeds the first block (ln_pre + patch embedding, or the token / positional embeddings)
-extern "C" int uniir_clip_tower_bwd_stem(const uniir_clip_tower* t, const void* input, int32_t batch, void* workspace,
-                                         int64_t workspace_bytes, void* stream) {
+int tower_bwd_stem(const uniir_clip_tower* t, const void* input, int32_t batch, const int32_t* row_off, int rows, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
     TRY(check_tower(t, batch));
     if (!workspace || !input) return UNIIR_EINVAL;
     if (batch == 0) return UNIIR_OK;
-    const Plan p = plan(t, batch, true);
+    const Plan p = plan(t, batch, true, rows, row_off);
     if (workspace_bytes < p.total) return UNIIR_EINVAL;
     char* ws = (char*)workspace;
     const int M = p.M, T = p.T, W = p.W, R = p.R;
     if (t->is_text) {
         if (!t->g_token || !t->g_pos) return UNIIR_EINVAL;
+        if (row_off)
+            return uniir_text_embed_bwd_packed((const int32_t*)input, (float*)(ws + p.dx), row_off, t->g_token, t->g_pos, M, T, W,
+                                               t->vocab, stream);
         return uniir_text_embed_bwd((const int32_t*)input, (float*)(ws + p.dx), t->g_token, t->g_pos, M, T, W, t->vocab, stream);
     }
     if (!t->g_conv || !t->g_class || !t->g_pos || !t->g_ln_pre_w || !t->g_ln_pre_b) return UNIIR_EINVAL;
@@ -350,9 +363,68 @@ extern "C" int uniir_clip_tower_bwd_stem(const uniir_clip_tower* t, const void* 
     return uniir_unpad_add((float*)(ws + p.dconv), t->g_conv, W, 3 * t->patch * t->patch, p.kpad, stream);
 }
 
+}  // namespace
+
+extern "C" int64_t uniir_clip_tower_workspace_bytes(const uniir_clip_tower* t, int32_t batch, int32_t save_for_backward) {
+    if (check_tower(t, batch)) return -1;
+    return plan(t, batch, save_for_backward != 0).total;
+}
+extern "C" int uniir_clip_tower_fwd(const uniir_clip_tower* t, const void* input, int32_t batch, float* emb_out,
+                                    void* workspace, int64_t workspace_bytes, int32_t save_for_backward, void* stream) {
+    return tower_fwd(t, input, batch, nullptr, -1, emb_out, workspace, workspace_bytes, save_for_backward, stream);
+}
+extern "C" int uniir_clip_tower_bwd_head(const uniir_clip_tower* t, const float* demb, int32_t batch, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+    return tower_bwd_head(t, demb, batch, nullptr, -1, workspace, workspace_bytes, stream);
+}
+extern "C" int uniir_clip_tower_bwd_blocks(const uniir_clip_tower* t, int32_t batch, int32_t layer_lo, int32_t layer_hi,
+                                           void* workspace, int64_t workspace_bytes, void* stream) {
+    return tower_bwd_blocks(t, batch, nullptr, -1, layer_lo, layer_hi, workspace, workspace_bytes, stream);
+}
+extern "C" int uniir_clip_tower_bwd_stem(const uniir_clip_tower* t, const void* input, int32_t batch, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+    return tower_bwd_stem(t, input, batch, nullptr, -1, workspace, workspace_bytes, stream);
+}
 extern "C" int uniir_clip_tower_bwd(const uniir_clip_tower* t, const void* input, const float* demb, int32_t batch,
                                     void* workspace, int64_t workspace_bytes, void* stream) {
     TRY(uniir_clip_tower_bwd_head(t, demb, batch, workspace, workspace_bytes, stream));
     TRY(uniir_clip_tower_bwd_blocks(t, batch, 0, t->layers, workspace, workspace_bytes, stream));
     return uniir_clip_tower_bwd_stem(t, input, batch, workspace, workspace_bytes, stream);
+}
+
+// ---- the text tower on PACKED rows (exact): only the tokens up to and including each caption's EOT are rows of the residual stream.
+// Under the causal mask nothing behind the EOT reaches the pooled feature (clip_sf.py:43-44; upstream pools at argmax(tokens)), so the
+// embeddings and every activation gradient are bitwise those of the dense call; weight gradients are the same sums over fewer (all
+// the non-zero) terms, i.e. equal up to the order of fp32 additions.  row_off: device int32 [batch + 1], prefix sums of the live
+// lengths (argmax + 1 per caption); live_rows = row_off[batch], known to the host (it sizes the GEMMs and the workspace).
+extern "C" int64_t uniir_clip_tower_workspace_bytes_packed(const uniir_clip_tower* t, int32_t batch, int32_t live_rows,
+                                                           int32_t save_for_backward) {
+    if (check_tower(t, batch) || !t->is_text || live_rows < batch || live_rows > batch * t->tokens) return -1;
+    return plan(t, batch, save_for_backward != 0, live_rows).total;
+}
+extern "C" int uniir_clip_tower_fwd_packed(const uniir_clip_tower* t, const void* tokens, int32_t batch, const int32_t* row_off,
+                                           int32_t live_rows, float* emb_out, void* workspace, int64_t workspace_bytes,
+                                           int32_t save_for_backward, void* stream) {
+    TRY(check_tower(t, batch));
+    TRY(check_packed(t, batch, row_off, live_rows));
+    return tower_fwd(t, tokens, batch, row_off, live_rows, emb_out, workspace, workspace_bytes, save_for_backward, stream);
+}
+extern "C" int uniir_clip_tower_bwd_head_packed(const uniir_clip_tower* t, const float* demb, int32_t batch, const int32_t* row_off,
+                                                int32_t live_rows, void* workspace, int64_t workspace_bytes, void* stream) {
+    TRY(check_tower(t, batch));
+    TRY(check_packed(t, batch, row_off, live_rows));
+    return tower_bwd_head(t, demb, batch, row_off, live_rows, workspace, workspace_bytes, stream);
+}
+extern "C" int uniir_clip_tower_bwd_blocks_packed(const uniir_clip_tower* t, int32_t batch, const int32_t* row_off, int32_t live_rows,
+                                                  int32_t layer_lo, int32_t layer_hi, void* workspace, int64_t workspace_bytes,
+                                                  void* stream) {
+    TRY(check_tower(t, batch));
+    TRY(check_packed(t, batch, row_off, live_rows));
+    return tower_bwd_blocks(t, batch, row_off, live_rows, layer_lo, layer_hi, workspace, workspace_bytes, stream);
+}
+extern "C" int uniir_clip_tower_bwd_stem_packed(const uniir_clip_tower* t, const void* tokens, int32_t batch, const int32_t* row_off,
+                                                int32_t live_rows, void* workspace, int64_t workspace_bytes, void* stream) {
+    TRY(check_tower(t, batch));
+    TRY(check_packed(t, batch, row_off, live_rows));
+    return tower_bwd_stem(t, tokens, batch, row_off, live_rows, workspace, workspace_bytes, stream);
 }

@@ -295,7 +295,14 @@ class DevicePrefetcher:
         with torch.cuda.stream(self.stream):
             for key, value in batch.items():
                 if isinstance(value, torch.Tensor):
+                    lens = None
+                    if key == "txt_batched" and not value.is_cuda and value.dim() == 2 and not value.is_floating_point():
+                        # CLIP token ids still on the host: the live length of every caption (EOT = arg-max id, upstream's
+                        # pooling row) travels with the batch, so that the packed text tower needs no device -> host read
+                        lens = (value.argmax(dim=-1) + 1).to(torch.int32)
                     batch[key] = self._move(value)
+                    if lens is not None:
+                        batch[key]._uniir_lens = lens
                 elif hasattr(value, "to_device"):                                   # clip_front.RawImageBatch
                     batch[key] = value.pin_memory().to_device(self.dev)
                 elif hasattr(value, "input_ids") and hasattr(value, "items"):      # transformers BatchEncoding (BLIP)
