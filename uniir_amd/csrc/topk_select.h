@@ -1,0 +1,261 @@
+// Group selection of the group-max search (device templates): used by topk_gsel_kernel (topk.hip) and by the fused tail kernel
+// (topk_tail.hip).
+#pragma once
+#include "topk.h"
+
+// one block per query: the best groups by (group max desc, group index asc): the kc best plus ties of the kc-th
+// value (at most gcap groups); every member row of those groups becomes a re-score candidate.
+//   pass 1: per-thread maxima -> tau0 = kc-th largest of the 256 thread maxima (a valid lower bound of the kc-th
+//           largest group value: that many distinct groups reach it)
+//   pass 2: groups >= tau0 are collected in LDS (a few dozen), ranked exactly, the best gcap kept.
+// If the collection overflows (massive exact ties) the kernel falls back to one-extraction-per-round selection.
+#define TK_SELCAP 1024
+#define TK_SELREG 24    // float2 loads per thread of the register-resident variant: ngroups <= 1024 * 2 * 24
+// REG (the interactive <= 64-query path, one 1024-thread block per query): the query's group maxima are read ONCE, as
+// back-to-back 8-byte loads that all stay in flight, and both passes (thread maxima, collection above the threshold) run
+// on registers -- the two dependent strided passes over global memory were 40 of the kernel's 62 us at 700 k rows.
+// `out` (gcap * TK_G row indices, -1 = empty) may be global memory (topk_gsel_kernel) or LDS (the fused tail kernel); every
+// thread of the block returns from this function (no early exit: the fused kernel goes on to the re-score).
+template <int BS, bool REG, class F>
+DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int kc, int gcap, int* out, F&& mid) {
+    __shared__ float tmax[BS];
+    __shared__ float bval[TK_SELCAP];
+    __shared__ int bgrp[TK_SELCAP];
+    __shared__ int bcnt;
+    __shared__ float tau0, tau;
+    __shared__ float ss[BS / 64];
+    __shared__ long long si[BS / 64];
+    __shared__ float wsel;
+    __shared__ long long isel;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
+    float mx = -INFINITY;
+    f32x2_t rv[REG ? TK_SELREG : 1];
+    if (REG) {
+#pragma unroll
+        for (int it = 0; it < TK_SELREG; ++it) {
+            const long e = 2L * (it * BS + tid);
+            rv[it] = e < ngroups ? *reinterpret_cast<const f32x2_t*>(g + e) : f32x2_t{-INFINITY, -INFINITY};   // ngroups is even
+        }
+        mid();      // independent work of the caller that rides the round trip of the loads above (the fused tail: the query norm)
+#pragma unroll
+        for (int it = 0; it < TK_SELREG; ++it) mx = fmaxf(mx, fmaxf(rv[it][0], rv[it][1]));
+    } else {
+        mid();
+        for (long e = tid; e < ngroups; e += BS) mx = fmaxf(mx, g[e]);
+    }
+    if (tid == 0) { bcnt = 0; tau0 = -INFINITY; tau = -INFINITY; }
+    if (BS == 1024) {
+        // threshold = the kc-th largest of the 64 quarter-wave maxima (disjoint subsets, so at least kc entries reach it;
+        // ~20-30 entries do at kc = 18).  Ranking all 1024 thread maxima against each other was 1 M compares per block
+        // -- 40 of the kernel's 50 us.
+        const float qm = row16_max(mx);
+        if ((tid & 15) == 0) tmax[tid >> 4] = qm;
+        __syncthreads();
+        if (tid < 64) {
+            const float v = tmax[tid];
+            int rank = 0;
+            for (int t = 0; t < 64; ++t) {
+                const float o = tmax[t];
+                rank += (o > v || (o == v && t < tid)) ? 1 : 0;
+            }
+            if (rank == min(kc, 64) - 1) tau0 = v;
+        }
+    } else {
+        tmax[tid] = mx;
+        __syncthreads();
+        int rank = 0;
+        for (int t = 0; t < BS; ++t) {
+            const float o = tmax[t];
+            rank += (o > mx || (o == mx && t < tid)) ? 1 : 0;
+        }
+        if (rank == kc - 1) tau0 = mx;   // exactly one thread has this rank
+    }
+    __syncthreads();
+    const float t0 = tau0;
+    if (REG) {
+#pragma unroll
+        for (int it = 0; it < TK_SELREG; ++it)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float v = rv[it][h];
+                if (v >= t0 && v > -INFINITY) {
+                    const int pos = atomicAdd(&bcnt, 1);
+                    if (pos < TK_SELCAP) { bval[pos] = v; bgrp[pos] = (int)(2L * (it * BS + tid) + h); }
+                }
+            }
+    } else {
+        for (long e = tid; e < ngroups; e += BS) {
+            const float v = g[e];
+            if (v >= t0 && v > -INFINITY) {
+                const int pos = atomicAdd(&bcnt, 1);
+                if (pos < TK_SELCAP) { bval[pos] = v; bgrp[pos] = (int)e; }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = bcnt;
+    if (n <= TK_SELCAP) {
+        // exact rank of every collected entry by (value desc, group asc)
+        for (int e = tid; e < n; e += BS) {
+            const float v = bval[e];
+            const int gi = bgrp[e];
+            int rank = 0;
+            for (int t = 0; t < n; ++t) {
+                const float o = bval[t];
+                const int og = bgrp[t];
+                rank += (o > v || (o == v && og < gi)) ? 1 : 0;
+            }
+            if (rank == min(kc, n) - 1) tau = v;
+        }
+        __syncthreads();
+        const float tt = tau;
+        for (int e = tid; e < n; e += BS) {
+            const float v = bval[e];
+            const int gi = bgrp[e];
+            int rank = 0;
+            for (int t = 0; t < n; ++t) {
+                const float o = bval[t];
+                const int og = bgrp[t];
+                rank += (o > v || (o == v && og < gi)) ? 1 : 0;
+            }
+            if (rank < gcap && v >= tt) {
+                for (int m = 0; m < TK_G; ++m) {
+                    const long row = (long)gi * TK_G + m;
+                    out[rank * TK_G + m] = row < rows ? (int)row : -1;
+                }
+            }
+        }
+    } else {
+    // fallback: one extraction per round (value desc, group asc), stop after the kc-th value's ties or gcap groups
+    float last_s = INFINITY, tk = -INFINITY;
+    long long last_g = -1;
+    for (int j = 0; j < gcap; ++j) {
+        float bs = -INFINITY;
+        long long bg = 0x7fffffffffffffffLL;
+        for (long e = tid; e < ngroups; e += BS) {
+            const float v = g[e];
+            const bool after = (v < last_s) || (v == last_s && (long long)e > last_g);
+            if (after && (v > bs || (v == bs && (long long)e < bg))) { bs = v; bg = e; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const long long og = __shfl_xor(bg, o, 64);
+            if (os > bs || (os == bs && og < bg)) { bs = os; bg = og; }
+        }
+        if (lane == 0) { ss[w] = bs; si[w] = bg; }
+        __syncthreads();
+        if (tid == 0) {
+            float fs = ss[0]; long long fg = si[0];
+            for (int k = 1; k < BS / 64; ++k) if (ss[k] > fs || (ss[k] == fs && si[k] < fg)) { fs = ss[k]; fg = si[k]; }
+            wsel = fs; isel = fg;
+        }
+        __syncthreads();
+        last_s = wsel; last_g = isel;
+        __syncthreads();
+        if (last_g == 0x7fffffffffffffffLL || last_s == -INFINITY) break;
+        if (j == kc - 1) tk = last_s;
+        if (j >= kc && last_s < tk) break;
+        if (tid < TK_G) {
+            const long row = last_g * TK_G + tid;
+            out[j * TK_G + tid] = row < rows ? (int)row : -1;
+        }
+    }
+    }
+    __syncthreads();
+}
+
+// Hierarchical selection behind the stream2 scan (<= 64 queries): the scan also leaves the maximum of every WAVE's range of groups
+// (wmax[q][nw], nw <= 1024 waves of ~43 consecutive groups).  One value per thread instead of 48: the threshold comes from the
+// wave maxima (the kc-th largest quarter-wave maximum: at least kc waves, hence at least kc groups, reach it), the ~20 waves that
+// reach it hand in their groups (~900 values), the ~20 of those above the threshold are ranked exactly.  Same output as gsel_body
+// (both collect every group >= a valid lower bound of the kc-th best value and rank the collection by (value desc, group asc)).
+// Returns false (workgroup-uniform, nothing written but the -1 fill) when a cap overflows: the caller then runs gsel_body.
+#define TK_HWAVES 128        // candidate waves kept
+template <int BS, class F>
+DEVINL bool gsel_hier(const float* __restrict__ g, const float* __restrict__ wm, int nw, long ngroups, long rows, int kc, int gcap,
+                      int* out, F&& mid) {
+    __shared__ float qmax[64];
+    __shared__ int cwave[TK_HWAVES];
+    __shared__ float hval[TK_SELCAP];
+    __shared__ int hgrp[TK_SELCAP];
+    __shared__ int ccnt, hcnt;
+    __shared__ float htau0, htau;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
+    const float v = tid < nw ? wm[tid] : -INFINITY;
+    mid();
+    if (tid == 0) { ccnt = 0; hcnt = 0; htau0 = -INFINITY; htau = -INFINITY; }
+    const float qm = row16_max(v);
+    if ((tid & 15) == 0) qmax[tid >> 4] = qm;
+    __syncthreads();
+    if (tid < 64) {
+        const float x = qmax[tid];
+        int rank = 0;
+        for (int t = 0; t < 64; ++t) {
+            const float o = qmax[t];
+            rank += (o > x || (o == x && t < tid)) ? 1 : 0;
+        }
+        if (rank == min(kc, 64) - 1) htau0 = x;
+    }
+    __syncthreads();
+    const float t0 = htau0;
+    if (v >= t0 && v > -INFINITY) {
+        const int pos = atomicAdd(&ccnt, 1);
+        if (pos < TK_HWAVES) cwave[pos] = tid;
+    }
+    __syncthreads();
+    const int nc = ccnt;
+    if (nc > TK_HWAVES) return false;
+    // 16 candidate waves per trip: thread -> (candidate tid / 64, group lo + tid % 64) -- a wave's range holds <= 64 groups
+    for (int c0 = 0; c0 < nc; c0 += BS / 64) {
+        const int c = c0 + (tid >> 6);
+        if (c < nc) {
+            const long wv = cwave[c];
+            const long lo = wv * ngroups / nw, hi = (wv + 1) * ngroups / nw;
+            const long e = lo + (tid & 63);
+            if (e < hi) {
+                const float x = g[e];
+                if (x >= t0 && x > -INFINITY) {
+                    const int pos = atomicAdd(&hcnt, 1);
+                    if (pos < TK_SELCAP) { hval[pos] = x; hgrp[pos] = (int)e; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = hcnt;
+    if (n > TK_SELCAP) return false;
+    for (int e = tid; e < n; e += BS) {
+        const float x = hval[e];
+        const int gi = hgrp[e];
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            const float o = hval[t];
+            const int og = hgrp[t];
+            rank += (o > x || (o == x && og < gi)) ? 1 : 0;
+        }
+        if (rank == min(kc, n) - 1) htau = x;
+    }
+    __syncthreads();
+    const float tt = htau;
+    for (int e = tid; e < n; e += BS) {
+        const float x = hval[e];
+        const int gi = hgrp[e];
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            const float o = hval[t];
+            const int og = hgrp[t];
+            rank += (o > x || (o == x && og < gi)) ? 1 : 0;
+        }
+        if (rank < gcap && x >= tt) {
+            for (int m = 0; m < TK_G; ++m) {
+                const long row = (long)gi * TK_G + m;
+                out[rank * TK_G + m] = row < rows ? (int)row : -1;
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
