@@ -21,6 +21,8 @@
 #define LN2F 0.6931471805599453f
 #define LOG2EF 1.4426950408889634f
 
+#define ATT_DEFER 8.0f      // attn_fwd_kernel: a row's reference maximum moves when a logit exceeds it by more than this (log2 units)
+
 DEVINL int swz_off(int row, int col) {  // byte offset of element (row, col) in a swizzled [rows][64] bf16 tile
     return row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1));
 }

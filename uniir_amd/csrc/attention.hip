@@ -74,7 +74,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         f32x4_t o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        float m_run = -1e30f, l_run = 0.f;
+        float m_run = -1e30f;
+        f32x4_t l4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const int kmax = causal ? min(kvalid, q0 + 16) : kvalid;
         const int nkb = max(1, (kmax + 31) >> 5);
         // S^T of a key block is computed one block ahead (its MFMAs overlap the previous block's softmax); the loop is
@@ -90,9 +91,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         auto softmax_pv = [&](int kb, f32x4_t (&st)[2]) {
             // The softmax is VALU-bound (4 waves share a SIMD): logits stay raw (the 1/8 log2 e scale is folded into the
             // exp2 argument with one fma), masks are applied only on blocks that touch a boundary (wave-uniform
-            // test), and the running output is rescaled only when some row's maximum moved.
+            // test), and the reference maximum moves -- and the running output is rescaled -- only when a row needs it.
             const bool edge = kb * 32 + 32 > kvalid || (causal && kb * 32 + 31 > q0);
-            float mx = -1e30f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -109,32 +109,41 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
                         if (key >= kvalid || (causal && key > q)) st[kt][r] = -1e30f;
                     }
             }
+            // DEFERRED MAXIMUM (round 4).  A row's reference m_run only has to be common to the row's four lanes and close enough to
+            // the true maximum that exp2 cannot overflow; it moves only when one of the ROW'S OWN logits exceeds it by more than
+            // ATT_DEFER (2^8: P <= 256, bf16 keeps its relative precision, the fp32 sums have room).  The test is lane-local (4
+            // v_max3 / v_max, one fma, one compare); the ballot folds the four lane groups into one bit per row on the SCALAR unit, and only
+            // a wave with a flagged row runs the cross-lane maximum and the rescale -- after its first block practically never
+            // (round 3 took both on 85-100 % of the blocks: with 16 rows per wave SOME row's maximum nearly always moved).  The
+            // decision is per row, so a row's result does not depend on which rows share its tile (the packed text tower relies on it).
+            float mx = -1e30f;           // (this chain form compiles to four v_max3; a balanced tree gets canonicalising self-maxima)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
-            mx = group_max(mx);
             const float es = REL ? 1.0f : sl2;
-            const float m_new = fmaxf(m_run, mx * es);
-            if (__any(m_new > m_run)) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                l_run *= alpha;
+            const unsigned long long over = __ballot(__builtin_fmaf(mx, es, -m_run) > ATT_DEFER);
+            unsigned rows_over = (unsigned)(over | (over >> 32));
+            rows_over = (rows_over | (rows_over >> 16)) & 0xffffu;
+            if (rows_over) {
+                const float gm = group_max(mx);
+                const float m_new = ((rows_over >> qi) & 1u) ? fmaxf(m_run, gm * es) : m_run;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // exactly 1 for the rows that keep their reference
+                l4 = l4 * alpha;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * alpha;
                 m_run = m_new;
             }
-            float sum = 0.f;
+            // masked logits (-1e30) underflow to exactly 0; key 0 is valid for every row (klen >= 1, causal includes the
+            // diagonal), so m_run is finite from the first block on.  Vector expressions: v_pk_fma_f32 / v_pk_add_f32.
+            // The row sum stays a per-lane vector of four partials until the tile ends.
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt) {
+                const f32x4_t arg = __builtin_elementwise_fma(st[kt], f32x4_t{es, es, es, es}, f32x4_t{-m_run, -m_run, -m_run, -m_run});
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // masked logits (-1e30) underflow to exactly 0; key 0 is valid for every row (klen >= 1, causal
-                    // includes the diagonal), so m_run is finite from the first block on
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], es, -m_run));
-                    st[kt][r] = p;
-                    sum += p;
-                }
-            l_run += sum;      // per-lane partial of the row sum (alpha is uniform across the 4 lanes of a row)
+                for (int r = 0; r < 4; ++r) st[kt][r] = __builtin_amdgcn_exp2f(arg[r]);
+                l4 = l4 + st[kt];
+            }
             if (DROP) {
                 const unsigned rowbase = (unsigned)((((long)m * H + h) * Tq + q) * Tk);
 #pragma unroll
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
             if (kb + 2 < nkb) s_block(kb + 2, sa);
             softmax_pv(kb + 1, sb);
         }
-        l_run = group_sum(l_run);
+        const float l_run = group_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
         // rows leave as 16-byte pieces, 64 contiguous bytes per row and store (att_store_tile; round 4: the 8-byte stores at a
         // row stride cost the 257-token forward 0.14 of its 0.70 ms)
         const bool live = q < Tq && !ATT_EXP(16);
