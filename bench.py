@@ -811,6 +811,8 @@ def main():
             result["retrieval"] = _secondary("retrieval", bench_retrieval, dev)
             if isinstance(result["retrieval"], dict) and "error" not in result["retrieval"]:
                 result["retrieval"]["full_pool"] = _secondary("retrieval.full_pool", bench_retrieval_full_pool, dev)
+                # the CLIP base models' 512-wide embeddings (configs[0]'s model family), same shard size: q64 / q1024
+                result["retrieval"]["dim512"] = _secondary("retrieval.dim512", bench_retrieval, dev, 700_000, 512, 10, False)
         if not args.no_secondary:
             result["embed"] = _secondary("embed", bench_embed, dev, args.model)
             result["blip_ff_large"] = _secondary("blip_ff_large", bench_blip_ff, dev)

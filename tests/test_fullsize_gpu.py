@@ -109,6 +109,37 @@ def test_topk_whole_mbeir_pool_on_one_gpu(nq):
     assert torch.equal(ms, s) and torch.equal(mi, i)
 
 
+def test_topk_700k_pool_of_clip_base_width():
+    """a 700 k x 512 shard (the CLIP base models' embeddings, clip_sf.py with ViT-B/32: embed_dim 512) at BASELINE's shard size:
+    64 queries on the streaming scan, checked by the size-independent properties, the C oracle on the returned rows, the merge of
+    two half-shard searches, and the same queries inside a 200-query search (another scan kernel): identical rows"""
+    from oracle import c_oracle
+    from uniir_amd import retrieval
+    n, d, k, nq = 700_000, 512, 10, 64
+    g = torch.Generator(device=DEV).manual_seed(77)
+    pool = torch.randn(n, d, device=DEV, generator=g).half()
+    queries = torch.randn(200, d, device=DEV, generator=g).half()
+    where = torch.randperm(n, device=DEV, generator=g)[:200]
+    pool[where] = (queries.float() * 2.0).half()
+    ids = torch.arange(n, device=DEV, dtype=torch.int64) * 3 + 7
+    shard = retrieval.PoolShard(pool, ids)
+    s, i = retrieval.search_shard(shard, queries[:nq], k)
+    sc, ic = s.cpu().numpy(), i.cpu().numpy()
+    assert (np.diff(sc, axis=1) <= 0).all() and all(len(set(r)) == k for r in ic.tolist())
+    assert np.array_equal(ic[:, 0], ids[where[:nq]].cpu().numpy()) and np.abs(sc[:, 0] - 1.0).max() < 1e-3
+    for qi in range(0, nq, 8):
+        rows = (i[qi] - 7) // 3
+        ws, wi = c_oracle.topk(pool[rows].cpu().numpy(), ids[rows].cpu().numpy(), queries[qi:qi + 1].cpu().numpy(), k)
+        assert np.array_equal(wi[0], ic[qi]) and np.array_equal(ws[0], sc[qi])
+    half = 350_000
+    a = retrieval.search_shard(retrieval._shard_view(shard, 0, half), queries[:nq], k)
+    b = retrieval.search_shard(retrieval._shard_view(shard, half, n), queries[:nq], k)
+    ms, mi = retrieval.merge_shards(torch.stack([a[0], b[0]]), torch.stack([a[1], b[1]]))
+    assert torch.equal(ms, s) and torch.equal(mi, i)
+    s2, i2 = retrieval.search_shard(shard, queries, k)
+    assert torch.equal(s2[:nq], s) and torch.equal(i2[:nq], i)
+
+
 def test_topk_c_abi_refuses_shards_of_2_gib():
     """uniir_topk_ip addresses a shard through 31-bit buffer offsets: rows * dim * 2 >= 2 GiB is UNIIR_ESHAPE at the C ABI (never
     a silent slower path); 1 398 096 rows x 768 (the largest sub-shard retrieval.subshard_bounds produces) is accepted"""

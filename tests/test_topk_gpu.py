@@ -209,3 +209,28 @@ def test_round3_scan_and_fused_tail_equal_the_c_oracle(n, nq, k):
     ws, wi = _oracle_topk_mt(pool, ids, queries, k)
     assert np.array_equal(i.cpu().numpy(), wi), np.argwhere(i.cpu().numpy() != wi)[:5]
     assert np.array_equal(s.cpu().numpy(), ws)
+
+
+@pytest.mark.parametrize("n,nq,k", [(40030, 1, 10), (40003, 64, 10), (65536, 33, 24), (280030, 64, 10), (40030, 64, 50), (40030, 100, 10)])
+def test_clip_base_width_pools_on_the_streaming_scan_equal_the_c_oracle(n, nq, k):
+    """dim 512 (the CLIP base models' embed_dim: BASELINE configs[0] / clip_sf.py with ViT-B/32) on topk_stream2_kernel<16> (round 4:
+    the register-resident streaming scan templated on dim / 32; before, 512-wide pools took the first-generation scan): scores
+    bit-exact and ids identical to oracle.c, with a zero row, duplicates incl. the last row of a ragged tile, an odd group count,
+    k = 50, and -- 100 queries -- the ping-pong scan the wider sweeps of such a pool still take"""
+    from uniir_amd import retrieval
+    g = torch.Generator(device=DEV).manual_seed(4000 + n + nq)
+    pool = torch.randn(n, 512, device=DEV, generator=g).half()
+    pool[17] = 0
+    pool[n - 1] = pool[5]
+    pool[2000:2003] = pool[5]
+    if n > 100000:
+        where = torch.randperm(n, device=DEV, generator=g)[:16]
+        pool[where] = pool[5].clone().repeat(16, 1)
+    queries = torch.randn(nq, 512, device=DEV, generator=g).half()
+    queries[0] = pool[5]
+    ids = torch.randperm(n, device=DEV, generator=g).to(torch.int64) * 5 + 123
+    s, i = retrieval.search_shard(retrieval.PoolShard(pool, ids), queries, k)
+    ws, wi = _oracle_topk_mt(pool, ids, queries, k)
+    assert np.array_equal(i.cpu().numpy(), wi), np.argwhere(i.cpu().numpy() != wi)[:5]
+    assert np.array_equal(s.cpu().numpy(), ws)
+

@@ -537,10 +537,19 @@ __global__ __launch_bounds__(512) void topk_stream_kernel(const unsigned short* 
 //   * The 16 inverse norms of a tile ride the same DMA queue (one dword LDS-DMA per tile), so vmcnt counting stays exact.
 // LDS image of a half-tile: instruction j (0..11) writes 1 KiB = [8 rows][8 chunks]: rows 8 (j & 1) + (lane >> 3), column block
 // j >> 1 (128 bytes), position lane & 7 holds chunk (lane & 7) ^ g(row).
-#define TKR_HALF_BYTES 12288
-#define TKR_PINV_OFF (3 * TKR_HALF_BYTES)
-#define TKR_STAGE_OFF (TKR_PINV_OFF + 512)
-#define TKR_WAVE_LDS (3 * TKR_HALF_BYTES + 512 + 2048)
+// Round 4: templated on NK = dim / 32 (24: the 768-wide M-BEIR pools of the large models; 16: the 512-wide pools of the CLIP base
+// models, which used to fall back to the first-generation scan): a row is NK * 64 bytes, a half-tile 16 rows x NK * 16 dims =
+// NK / 2 DMA instructions and NK / 2 k-steps, the queries take 4 * NK * 4 registers.
+#define TKR_HALF_BYTES 12288          // dim 768 (the shared-ring scans below are 768-only)
+template <int NK>
+struct Tkr {
+    static constexpr int ROW = NK * 64;                  // bytes per pool row
+    static constexpr int NH = NK / 2;                    // DMA instructions = k-steps per half-tile
+    static constexpr int HALF = NK * 512;                // bytes per half-tile (16 rows x ROW / 2)
+    static constexpr int PINV_OFF = 3 * HALF;
+    static constexpr int STAGE_OFF = PINV_OFF + 512;
+    static constexpr int WAVE_LDS = 3 * HALF + 512 + 2048;
+};
 // group-max stores of the streaming scans: -DUNIIR_GMAX_NT=1 builds them as non-temporal stores.  MEASURED (round 3, same box, whole
 // search): 64 queries 0.2233 / 0.2059 ms (default) vs 0.2288 / 0.2095 (nt); 128 queries 0.2360 / 0.2236 vs 0.2652 / 0.2450 -- the
 // 32-byte runs want the L2's write combining; default stays.
@@ -562,39 +571,46 @@ struct TkrState {
     unsigned lbase;
     char* my;
 };
-template <int HALF, int AUX>      // AUX: cache policy of the pool stream (0 default, 2 = nt: read-once data)
+template <int NK, int HALF, int AUX>      // AUX: cache policy of the pool stream (0 default, 2 = nt: read-once data)
 DEVINL void tkr_issue(const TkrState& st, long tile, int slot) {
+    using K = Tkr<NK>;
     // the position inside the row goes into the SCALAR offset: it is excluded from the bounds check (so the check is exactly "is
     // this row inside the shard": voffset = first line of the row) and, unlike the instruction's immediate offset, is not added
     // to the LDS address as well
-    const unsigned tb = (unsigned)(tile * (16 * 1536));
+    const unsigned tb = (unsigned)(tile * (16 * K::ROW));
     const unsigned v0 = st.vb0 + tb, v1 = st.vb1 + tb;
-    char* dst = st.my + slot * TKR_HALF_BYTES;
-#define TKR_DMA(J)                                                                                                  \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rp, (void __attribute__((address_space(3)))*)(dst + (J) * 1024), 16, \
-                                             ((J) & 1) ? v1 : v0, ((J) >> 1) * 128 + HALF * 768, 0, AUX);
+    char* dst = st.my + slot * K::HALF;
+#define TKR_DMA(J)                                                                                                       \
+    if ((J) < K::NH)                                                                                                     \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rp, (void __attribute__((address_space(3)))*)(dst + (J) * 1024), 16, \
+                                                 ((J) & 1) ? v1 : v0, ((J) >> 1) * 128 + HALF * (K::ROW / 2), 0, AUX);
     TKR_DMA(0) TKR_DMA(1) TKR_DMA(2) TKR_DMA(3) TKR_DMA(4) TKR_DMA(5) TKR_DMA(6) TKR_DMA(7) TKR_DMA(8) TKR_DMA(9) TKR_DMA(10) TKR_DMA(11)
 #undef TKR_DMA
     if (HALF == 0)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(st.ri, (void __attribute__((address_space(3)))*)(st.my + TKR_PINV_OFF + (int)(tile & 1) * 256),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(st.ri, (void __attribute__((address_space(3)))*)(st.my + K::PINV_OFF + (int)(tile & 1) * 256),
                                                  4, st.vpi + (unsigned)(tile * 64), 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int HALF>
-DEVINL void tkr_process(const TkrState& st, int slot, const u32x4_t (&qf)[4][24], f32x4_t (&acc)[4]) {
-    const unsigned sb = st.lbase + slot * TKR_HALF_BYTES;
+template <int NK, int HALF>
+DEVINL void tkr_process(const TkrState& st, int slot, const u32x4_t (&qf)[4][NK], f32x4_t (&acc)[4]) {
+    using K = Tkr<NK>;
+    const unsigned sb = st.lbase + slot * K::HALF;
     const unsigned a0 = sb + st.la0, a1 = sb + st.la1;
-    u32x4_t a[12];
+    u32x4_t a[K::NH];
     a[0] = asm_ds_read_b128<0 * 2048>(a0);  a[1] = asm_ds_read_b128<0 * 2048>(a1);
     a[2] = asm_ds_read_b128<1 * 2048>(a0);  a[3] = asm_ds_read_b128<1 * 2048>(a1);
     a[4] = asm_ds_read_b128<2 * 2048>(a0);  a[5] = asm_ds_read_b128<2 * 2048>(a1);
     a[6] = asm_ds_read_b128<3 * 2048>(a0);  a[7] = asm_ds_read_b128<3 * 2048>(a1);
-    a[8] = asm_ds_read_b128<4 * 2048>(a0);  a[9] = asm_ds_read_b128<4 * 2048>(a1);
-    a[10] = asm_ds_read_b128<5 * 2048>(a0); a[11] = asm_ds_read_b128<5 * 2048>(a1);
+    if constexpr (K::NH > 8) {
+        a[8] = asm_ds_read_b128<4 * 2048>(a0);  a[9] = asm_ds_read_b128<4 * 2048>(a1);
+        a[10] = asm_ds_read_b128<5 * 2048>(a0); a[11] = asm_ds_read_b128<5 * 2048>(a1);
+    }
     __builtin_amdgcn_sched_barrier(0);
-#define TKR_STEP(SH)                                                                              \
-    asm_wait_lgkm<11 - (SH)>();                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] = ElemF16::mfma(a[SH], qf[j][12 * HALF + (SH)], acc[j]);
+#define TKR_STEP(SH)                                                                                  \
+    if constexpr ((SH) < K::NH) {                                                                     \
+        asm_wait_lgkm<K::NH - 1 - (SH) < 0 ? 0 : K::NH - 1 - (SH)>();                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] = ElemF16::mfma(a[SH], qf[j][K::NH * HALF + (SH)], acc[j]); \
+    }
     TKR_STEP(0) TKR_STEP(1) TKR_STEP(2) TKR_STEP(3) TKR_STEP(4) TKR_STEP(5)
     TKR_STEP(6) TKR_STEP(7) TKR_STEP(8) TKR_STEP(9) TKR_STEP(10) TKR_STEP(11)
 #undef TKR_STEP
@@ -602,20 +618,21 @@ DEVINL void tkr_process(const TkrState& st, int slot, const u32x4_t (&qf)[4][24]
 }
 // everything a streaming-scan wave sets up before its first pool tile: DMA descriptors / per-lane offsets, and the query fragments
 // (all 64 queries, 96 x 16 bytes per lane) staged through LDS.  Contains two workgroup barriers.
-template <int WAVE_LDS>
-DEVINL void tkr_prepare(TkrState& st, u32x4_t (&qf)[4][24], char* lds, const unsigned short* __restrict__ pool,
+template <int NK, int WAVE_LDS>
+DEVINL void tkr_prepare(TkrState& st, u32x4_t (&qf)[4][NK], char* lds, const unsigned short* __restrict__ pool,
                         const float* __restrict__ pinv, long rows, const unsigned short* __restrict__ queries, int nq, int w,
                         int lane) {
+    constexpr unsigned ROW = NK * 64;
     const int li = lane & 15, lg = lane >> 4;
     st.my = lds + w * WAVE_LDS;
     st.lbase = lds_addr32(st.my);
-    st.rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * 1536), 0x00020000);
+    st.rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * ROW), 0x00020000);
     st.ri = __builtin_amdgcn_make_buffer_rsrc((void*)pinv, 0, (int)(rows * 4), 0x00020000);
     {
         const int r8 = lane >> 3, c8 = lane & 7;
         const int row0 = r8, row1 = 8 + r8;                                   // even / odd DMA instruction
-        st.vb0 = (unsigned)(row0 * 1536 + ((c8 ^ ((row0 >> 1) & 7)) << 4));
-        st.vb1 = (unsigned)(row1 * 1536 + ((c8 ^ ((row1 >> 1) & 7)) << 4));
+        st.vb0 = (unsigned)(row0 * ROW + ((c8 ^ ((row0 >> 1) & 7)) << 4));
+        st.vb1 = (unsigned)(row1 * ROW + ((c8 ^ ((row1 >> 1) & 7)) << 4));
         st.vpi = (unsigned)((lane & 15) * 4);
         const int g = (li >> 1) & 7;
         st.la0 = (unsigned)((li >> 3) * 1024 + (li & 7) * 128 + (((0 + lg) ^ g) << 4));
@@ -626,16 +643,16 @@ DEVINL void tkr_prepare(TkrState& st, u32x4_t (&qf)[4][24], char* lds, const uns
     // bytes of queries are first copied into LDS by LDS-DMA (the rings are not in use yet; 16-byte chunk index ^= (query & 15) on
     // the source side, so that the 16 queries x 4 chunks of a fragment read are conflict-free), then every wave reads all of them.
     {
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)queries, 0, nq * 1536, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)queries, 0, nq * (int)ROW, 0x00020000);
         // 98 304 bytes = 96 DMA instructions of 1 KiB over 4 waves: instruction i covers LDS bytes [1024 i, +1024): query i * 2 / 3 ...
         // lane -> LDS byte b = 1024 i + 16 lane -> query b / 1536, position p = (b % 1536) / 16, source chunk p ^ (query & 15)
         // (the XOR stays inside the row: 96 chunks = 6 blocks of 16)
 #pragma unroll
-        for (int ii = 0; ii < 24; ++ii) {
+        for (int ii = 0; ii < NK; ++ii) {
             const int i = ii * 4 + w;
             const unsigned b = 1024u * i + 16u * lane;
-            const unsigned qq = b / 1536u, p = (b % 1536u) >> 4;
-            const unsigned src = qq * 1536u + (((p & ~15u) | ((p ^ qq) & 15u)) << 4);        // queries >= nq: out of bounds -> zeros
+            const unsigned qq = b / ROW, p = (b % ROW) >> 4;
+            const unsigned src = qq * ROW + (((p & ~15u) | ((p ^ qq) & 15u)) << 4);        // queries >= nq: out of bounds -> zeros
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (void __attribute__((address_space(3)))*)(lds + 1024 * i), 16, src, 0, 0, 0);
         }
         __syncthreads();                 // hipcc drains the LDS-DMA in front of the barrier
@@ -643,21 +660,22 @@ DEVINL void tkr_prepare(TkrState& st, u32x4_t (&qf)[4][24], char* lds, const uns
         for (int j = 0; j < 4; ++j) {
             const int q = j * 16 + li;
 #pragma unroll
-            for (int s = 0; s < 24; ++s) {
+            for (int s = 0; s < NK; ++s) {
                 const int c = 4 * s + lg;
-                qf[j][s] = *reinterpret_cast<const u32x4_t*>(lds + q * 1536 + (((c & ~15) | ((c ^ q) & 15)) << 4));
+                qf[j][s] = *reinterpret_cast<const u32x4_t*>(lds + q * ROW + (((c & ~15) | ((c ^ q) & 15)) << 4));
             }
         }
         __syncthreads();                 // every wave has its fragments: the rings may be filled
     }
 }
 
-template <int AUX>
+template <int NK, int AUX>
 __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned short* __restrict__ pool,
                                                              const float* __restrict__ pinv, long rows,
                                                              const unsigned short* __restrict__ queries, int nq,
                                                              float* __restrict__ gmax, long ngroups,
                                                              float* __restrict__ wmax) {      // optional [nq][waves]: per-wave maxima
+    using K = Tkr<NK>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -666,19 +684,19 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
     const long gw = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
     const long lo = gw * ngroups / nw, hi = (gw + 1) * ngroups / nw;      // never empty: the launcher asks for >= 2048 groups
     TkrState st;
-    u32x4_t qf[4][24];
-    tkr_prepare<TKR_WAVE_LDS>(st, qf, lds, pool, pinv, rows, queries, nq, w, lane);
-    tkr_issue<0, AUX>(st, lo, 0);
-    tkr_issue<1, AUX>(st, lo, 1);
+    u32x4_t qf[4][NK];
+    tkr_prepare<NK, K::WAVE_LDS>(st, qf, lds, pool, pinv, rows, queries, nq, w, lane);
+    tkr_issue<NK, 0, AUX>(st, lo, 0);
+    tkr_issue<NK, 1, AUX>(st, lo, 1);
     f32x4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float wave_best = -INFINITY;       // maximum over this wave's whole range, per query (gsel_hier starts from these)
-    const unsigned stg = st.lbase + TKR_STAGE_OFF + lane * 32;
+    const unsigned stg = st.lbase + K::STAGE_OFF + lane * 32;
     const unsigned qoff = (unsigned)(((long)lane * ngroups) & 3);     // 16-byte alignment of the stores (octets start on it)
     auto finish_tile = [&](long tile) {
         // D: lane -> query j * 16 + li, candidates 4 lg + r of the tile
-        const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + TKR_PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
+        const u32x4_t ivb = asm_ds_read_b128<0>(st.lbase + K::PINV_OFF + (unsigned)(tile & 1) * 256 + lg * 16);
         asm_wait_lgkm<0>();
         const f32x4_t iv = __builtin_bit_cast(f32x4_t, ivb);
         float m[4];
@@ -730,27 +748,27 @@ __global__ __launch_bounds__(256, 1) void topk_stream2_kernel(const unsigned sho
             }
         }
     };
-    // half-tile h = 2 (tile - lo) + half lives in ring slot h % 3; two half-tiles stay in flight (12 + 13 DMA instructions: the
-    // inverse norms travel with the first half), so every wait is vmcnt(25).  The group-max stores also count in vmcnt: they can
+    // half-tile h = 2 (tile - lo) + half lives in ring slot h % 3; two half-tiles stay in flight (NK / 2 + NK / 2 + 1 DMA instructions:
+    // the inverse norms travel with the first half), so every wait is vmcnt(NK + 1).  The group-max stores also count in vmcnt: they can
     // only make a wait stricter, never looser.
     int slot = 0;
     long t = lo;
     for (; t + 1 < hi; ++t) {
-        tkr_issue<0, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);       // h + 2 -> slot (h + 2) % 3
-        tkr_wait_vm<25>();
-        tkr_process<0>(st, slot, qf, acc);
+        tkr_issue<NK, 0, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);       // h + 2 -> slot (h + 2) % 3
+        tkr_wait_vm<NK + 1>();
+        tkr_process<NK, 0>(st, slot, qf, acc);
         slot = slot == 2 ? 0 : slot + 1;
-        tkr_issue<1, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);
-        tkr_wait_vm<25>();
-        tkr_process<1>(st, slot, qf, acc);
+        tkr_issue<NK, 1, AUX>(st, t + 1, slot == 0 ? 2 : slot - 1);
+        tkr_wait_vm<NK + 1>();
+        tkr_process<NK, 1>(st, slot, qf, acc);
         slot = slot == 2 ? 0 : slot + 1;
         finish_tile(t);
     }
-    tkr_wait_vm<12>();
-    tkr_process<0>(st, slot, qf, acc);
+    tkr_wait_vm<NK / 2>();
+    tkr_process<NK, 0>(st, slot, qf, acc);
     slot = slot == 2 ? 0 : slot + 1;
     tkr_wait_vm<0>();
-    tkr_process<1>(st, slot, qf, acc);
+    tkr_process<NK, 1>(st, slot, qf, acc);
     finish_tile(t);
     if (wmax && lane < nq) wmax[(long)lane * nw + gw] = wave_best;
 }
@@ -1092,8 +1110,8 @@ static void launch_stream5(int nv, hipStream_t st0, const void* pool_f16, const 
 }
 // The scan of a sweep, by shape (every pool stream is read with the nt policy where a row is read exactly once per sweep:
 // measured 0.2729 -> 0.2466 ms per 64-query search):
-//   <= 64 queries, dim 768, a shard the 31-bit buffer bound addresses, >= 2048 groups : topk_stream2_kernel (queries in registers)
-//   <= 64 queries, dim 768 / 512 otherwise (small shards, CLIP base pools)            : topk_stream_kernel (queries in LDS)
+//   <= 64 queries, dim 768 / 512, a shard the 31-bit buffer bound addresses, >= 2048 groups : topk_stream2_kernel<dim / 32>
+//   <= 64 queries, dim 768 / 512 otherwise (small shards)                                    : topk_stream_kernel (queries in LDS)
 //   65 .. 256 queries where the first line's conditions hold                           : topk_stream5_kernel<2 / 4>
 //   more queries or other shapes, dim a multiple of 64 and >= 192                      : topk_gmax_pp_kernel (ping-pong GEMM core)
 //   anything else                                                                      : topk_gmax_kernel
@@ -1104,18 +1122,26 @@ static int launch_gmax_scan(const void* pool_f16, const float* pool_inv_norm, in
     const long ngroups = (rows + TK_G - 1) / TK_G;
     int nqt, nsl; long rps;
     coarse_plan(nq, rows, &nqt, &nsl, &rps);
-    const bool big_dim768 = dim == 768 && rows * 1536 < (1L << 31) && ngroups >= 2048;
-    if (nq <= 64 && big_dim768) {
+    const bool big_stream = (dim == 768 || dim == 512) && rows * dim * 2 < (1L << 31) && ngroups >= 2048;
+    if (nq <= 64 && big_stream) {
         const int ncu = tk_cu_count();
         if (ncu < 0) return UNIIR_ELAUNCH;
-        static PerDeviceOnce attr_s2;
-        if (attr_s2.first())
-            (void)hipFuncSetAttribute((const void*)topk_stream2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TKR_WAVE_LDS);
         // the per-wave maxima feed the hierarchical selection of the fused tail
         float* wm = (wmax && nw_out && ncu * 4 <= 1024 && (ngroups + ncu * 4 - 1) / (ncu * 4) <= 64) ? wmax : nullptr;
         if (wm) *nw_out = ncu * 4;
-        hipLaunchKernelGGL(topk_stream2_kernel<2>, dim3(ncu), dim3(256), 4 * TKR_WAVE_LDS, st0, (const unsigned short*)pool_f16,
-                           pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, ngroups, wm);
+#define TKS2_LAUNCH(NK)                                                                                                             \
+    do {                                                                                                                            \
+        static PerDeviceOnce attr_s2;                                                                                               \
+        if (attr_s2.first())                                                                                                        \
+            (void)hipFuncSetAttribute((const void*)topk_stream2_kernel<NK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                                      4 * Tkr<NK>::WAVE_LDS);                                                                       \
+        hipLaunchKernelGGL((topk_stream2_kernel<NK, 2>), dim3(ncu), dim3(256), 4 * Tkr<NK>::WAVE_LDS, st0,                          \
+                           (const unsigned short*)pool_f16, pool_inv_norm, (long)rows, (const unsigned short*)queries_f16, nq, gmax, \
+                           ngroups, wm);                                                                                            \
+    } while (0)
+        if (dim == 768) TKS2_LAUNCH(24);
+        else TKS2_LAUNCH(16);
+#undef TKS2_LAUNCH
         HIP_LAUNCH_CHECK();
         return 1;
     }
