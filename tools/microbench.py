@@ -63,6 +63,37 @@ def main():
         t = timeit(lambda: ops.linear_wgrad(dy, x, dw))
         print(f"gemm wgrad TN {name}: {t*1e3:.3f} ms  {2*R*N*K/t/1e12:.1f} TF/s")
         del x, w, y, dy, dx, dw
+    # the same shapes with the epilogues the train step runs them with (csrc/tower.hip): the "in-step vs isolated" comparison
+    if not os.environ.get("MB_SKIP_GEMM"):
+        W = 1024
+        x = torch.randn(R, W, device=dev).bfloat16()
+        h4 = torch.randn(R, 4 * W, device=dev).bfloat16()
+        res = torch.randn(R, W, device=dev)
+        res_out = torch.empty(R, W, device=dev)
+        for (N, K, name, inp) in [(3 * W, W, "qkv", x), (4 * W, W, "fc", x), (W, W, "out", x), (W, 4 * W, "proj", h4)]:
+            w = torch.randn(N, K, device=dev).bfloat16()
+            bias = torch.randn(N, device=dev)
+            if name == "qkv":
+                y = torch.empty(R, N, device=dev, dtype=torch.bfloat16)
+                fn = lambda: ops.linear_fwd(inp, w, bias, out=y)
+                what = "bias"
+            elif name == "fc":
+                y, y2 = torch.empty(R, N, device=dev, dtype=torch.bfloat16), torch.empty(R, N, device=dev, dtype=torch.bfloat16)
+                fn = lambda: ops.linear_fwd(inp, w, bias, out=y, epilogue=ops.EPI_BIAS_ACT, C2=y2)
+                what = "bias + GELU, two outputs"
+            else:
+                fn = lambda: ops.linear_fwd(inp, w, bias, out=res_out, epilogue=ops.EPI_RESID_F32, resid=res)
+                what = "bias + fp32 residual in / out"
+            t = timeit(fn)
+            print(f"gemm fwd NT {name} [{what}]: {t*1e3:.3f} ms  {2*R*N*K/t/1e12:.1f} TF/s")
+            del w
+        w2 = torch.randn(W, 4 * W, device=dev).bfloat16()
+        dy = torch.randn(R, W, device=dev).bfloat16()
+        dx, act = torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16), torch.empty(R, 4 * W, device=dev, dtype=torch.bfloat16)
+        cs = torch.zeros(4 * W, device=dev)
+        t = timeit(lambda: ops.linear_dgrad(dy, w2, out=dx, aux=h4, act_out=act, colsum=cs))
+        print(f"gemm dgrad NN proj [x act'(f), act(f) out, column sums]: {t*1e3:.3f} ms  {2*R*W*4*W/t/1e12:.1f} TF/s")
+        del x, h4, res, res_out, w2, dy, dx, act
     # attention
     for (T, H, causal, b) in [(257, 16, 0, items), (77, 12, 1, items)]:
         qkv = torch.randn(b * T, 3 * H * 64, device=dev).bfloat16()
