@@ -614,6 +614,7 @@ def main():
     ap.add_argument("--no-retrieval", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the embed / BLIP_FF / CLIP_FF blocks")
     ap.add_argument("--no-unpacked", action="store_true", help="skip the second timing of the step with the text tower unpacked")
+    ap.add_argument("--no-stash-act", action="store_true", help="A/B: re-materialise the MLP activations in the backward (clip_model.stash_act = False)")
     ap.add_argument("--dry-run", action="store_true", help="CPU ranks over gloo with a stand-in step (launcher test)")
     ap.add_argument("--shard-rows", type=int, default=700_000, help="N > 1: pool rows per rank of the sharded retrieval block")
     ap.add_argument("--shard-queries", default="64,1024,100000", help="N > 1: global query counts of the sharded retrieval block")
@@ -680,6 +681,8 @@ def main():
             from uniir_amd import comm
             comm.sync_replicas(model)
         trainer = NativeTrainer(model, lr=1e-5, t_total=10000)
+        if args.no_stash_act:
+            model.clip_model.stash_act = False
         batch = synth_batch(cfg, args.pairs, 2023 + rank, dev)
 
     for _ in range(args.warmup):
@@ -788,6 +791,9 @@ def main():
                        if not args.dry_run else "DRY RUN: launcher / collective plumbing only, not a measurement",
                        "pairs_per_gpu": args.pairs, "global_batch": global_pairs, "parallelism": f"dp{world}",
                        "final_loss": round(loss, 4),
+                       "mlp_stash": (None if args.dry_run else
+                                     {k: ("f + act(f)" if v else "f") for k, v in model.clip_model.last_stash_act.items()}),
+                       "peak_mem_GB": (round(torch.cuda.max_memory_allocated(dev) / 1e9, 1) if dev.type == "cuda" else None),
                        "batch": "ONE synthetic batch per rank, generated on the device before the timed region and re-used for "
                                 "every step (timing only; the loss therefore collapses)"},
             "roofline": roof,

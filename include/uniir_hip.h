@@ -276,6 +276,14 @@ typedef struct {
     float *g_class, *g_pos, *g_ln_pre_w, *g_ln_pre_b, *g_token, *g_ln_post_w, *g_ln_post_b, *g_proj;
     void* splitk_ws;                          /* optional scratch for the weight-gradient GEMMs' split-K slabs */
     int64_t splitk_ws_bytes;
+    int32_t stash_act;                        /* with save_for_backward: 0 = the MLP's act(f) lives in one scratch buffer and the
+                                                 backward re-materialises it from the stashed pre-activation f inside the c_proj dgrad
+                                                 epilogue; 1 = act(f) is stashed per layer next to f (round 4: +2 bytes x rows x 4 width
+                                                 per layer of workspace; that epilogue loses its second output: 3.31 -> 2.99 ms at ViT-L/14 x
+                                                 1024 items).  Same forward bit for bit; the c_proj weight gradient reads the forward's
+                                                 act(f) instead of the backward's recomputation (equal up to rare one-ulp differences).
+                                                 Part of the workspace layout: every call on one workspace must see the same value */
+    int32_t reserved_;
 } uniir_clip_tower;
 
 int64_t uniir_clip_tower_workspace_bytes(const uniir_clip_tower* t, int32_t batch, int32_t save_for_backward);

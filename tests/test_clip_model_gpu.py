@@ -210,3 +210,31 @@ def test_packed_text_tower_equals_the_dense_tower():
         den = g_d[n].norm().clamp_min(1e-20)
         assert float((g_p[n] - g_d[n]).norm() / den) < 1e-5, n
 
+
+def test_stashed_mlp_activation_changes_nothing():
+    """clip_model.stash_act (uniir_clip_tower.stash_act): the forward keeps act(f) of every MLP per layer instead of re-materialising
+    it in the c_proj dgrad epilogue.  Only where a buffer lives changes: loss and embeddings are bitwise those of the
+    re-materialising run, every parameter gradient agrees to 1e-4 (the c_proj weight gradient reads the forward's act(f) instead of
+    the backward's recomputation of it), both towers, packed text rows"""
+    from oracle import clip_oracle as O
+    cfg = O.tiny_config(vision_width=128, vision_layers=2, transformer_width=128, transformer_heads=2, transformer_layers=2)
+    res = {}
+    for stash in (True, False):
+        model, _, O = _build(cfg, seed=9)
+        model.clip_model.stash_act = stash
+        batch = O.synthetic_batch(cfg, 12, seed=41)
+        dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        model.train()
+        model.clip_model._ensure_flat()
+        model.clip_model.zero_grad()
+        out = model(dbatch)
+        out["loss"].backward()
+        assert model.clip_model.last_stash_act == {"text": stash, "image": stash}
+        with torch.no_grad():
+            emb = model.clip_model.encode_image(dbatch["image_batched"]).clone()
+        res[stash] = (float(out["loss"].detach()), emb,
+                      {n: p.grad.detach().clone() for n, p in model.clip_model.named_parameters() if p.grad is not None})
+    (l1, e1, g1), (l0, e0, g0) = res[True], res[False]
+    assert l1 == l0 and torch.equal(e1, e0)
+    worst = max(float((g1[n] - g0[n]).norm() / g0[n].norm().clamp_min(1e-20)) for n in g0)
+    assert worst < 1e-4, worst          # (act(f) from the forward's epilogue vs from the backward's: equal up to rare single-ulp flips)

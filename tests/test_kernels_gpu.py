@@ -49,7 +49,7 @@ def test_gemm_dgrad_nn(M, N, K):
     assert rel_err(dx, ref) < 4e-3, rel_err(dx, ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 136, 200), (5000, 768, 1024), (263, 384, 64), (4096, 392, 264), (8192, 768, 1024), (16384, 3072, 1024)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 136, 200), (5000, 768, 1024), (263, 384, 64), (4096, 392, 264), (8192, 768, 1024), (16384, 3072, 1024), (35457, 2304, 768)])
 def test_gemm_wgrad_tn_splitk(M, N, K):
     ops = _ops()
     torch.manual_seed(2)
@@ -61,12 +61,14 @@ def test_gemm_wgrad_tn_splitk(M, N, K):
     assert rel_err(dw, ref) < 1e-3, rel_err(dw, ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 768, 1024), (16384, 3072, 1024), (20000, 520, 256), (5000, 1024, 768), (263, 384, 64),
-                                   (1000, 136, 200)])
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 1024), (16384, 3072, 1024), (20000, 520, 256), (5000, 1024, 768), (35457, 2304, 768),
+                                   (263, 384, 64), (1000, 136, 200)])
 def test_gemm_wgrad_with_bias_gradient(M, N, K):
     """uniir_gemm_desc.a_rowsum: the bias gradient (column sums of dy) out of the weight-gradient GEMM's own pass over dy -- inside
-    the 256x256 transposed kernel (first four shapes: several K splits, an N that is not a tile multiple, row sums only from the
-    first column panel) and by the separate pass for problems that run another kernel (last two); accumulates into dbias"""
+    the 256x256 transposed kernel (first five shapes: several K splits, an N that is not a tile multiple, row sums only from the
+    first column panel; reduction lengths that are not a multiple of 64 -- 20000, 5000, and 35457 = the packed text tower's live
+    rows -- run as the multiple-of-64 part on that kernel plus a tail product of the last rows, round 4) and by the separate pass
+    for problems that run another kernel (last two); accumulates into dbias; bitwise repeatable"""
     ops = _ops()
     torch.manual_seed(12)
     dy, x = bf(torch.randn(M, N, device=DEV) + 0.25), bf(torch.randn(M, K, device=DEV))
@@ -76,6 +78,9 @@ def test_gemm_wgrad_with_bias_gradient(M, N, K):
     assert rel_err(dw, dy.float().t() @ x.float()) < 1e-3
     ref = dy.float().sum(0) + 3.0
     assert rel_err(db, ref) < 1e-5, rel_err(db, ref)
+    dw2 = torch.zeros(N, K, device=DEV)
+    ops.linear_wgrad(dy, x, dw2, dbias=torch.zeros(N, device=DEV))
+    assert torch.equal(dw, dw2)
 
 
 def test_gemm_row_sums_need_a_transposed_bf16_operand():
@@ -124,6 +129,40 @@ def test_gemm_epilogues():
     s = torch.sigmoid(1.702 * a)
     dref = (dy.float() @ w2.float()) * (s * (1 + 1.702 * a * (1 - s)))
     assert rel_err(dx, dref) < 5e-3, rel_err(dx, dref)
+
+
+@pytest.mark.parametrize("m,n,k", [(1024, 512, 256), (1000, 520, 192), (300, 264, 136)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm_dact_epilogue_with_and_without_the_second_output(m, n, k, act):
+    """UNIIR_EPI_DACT: dx = (dy @ w) * act'(aux) [+ act(aux) -> C2] [+ column sums]: the forms the towers run (with the second output
+    when act(f) is re-materialised, without it under uniir_clip_tower.stash_act).  Against fp32 torch; the two forms give bitwise the
+    same dx (and the same column sums up to the order of their atomic additions); act(aux) equals the forward's BIAS_ACT second output up to one bf16 ulp on < 0.2 % of the elements; ragged
+    tiles, QuickGELU and erf-GELU"""
+    ops = _ops()
+    torch.manual_seed(31)
+    x, w = bf(torch.randn(m, k, device=DEV)), bf(torch.randn(n, k, device=DEV) * 0.2)
+    b = torch.randn(n, device=DEV)
+    g_fwd = torch.empty(m, n, device=DEV, dtype=torch.bfloat16)
+    f = ops.linear_fwd(x, w, b, epilogue=ops.EPI_BIAS_ACT, C2=g_fwd, act=act)
+    n2 = 256
+    dy, w2 = bf(torch.randn(m, n2, device=DEV)), bf(torch.randn(n2, n, device=DEV) * 0.2)
+    cs1, cs2 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    g_bwd = torch.empty(m, n, device=DEV, dtype=torch.bfloat16)
+    dx1 = ops.linear_dgrad(dy, w2, aux=f, act=act, act_out=g_bwd, colsum=cs1)
+    dx2 = ops.linear_dgrad(dy, w2, aux=f, act=act, colsum=cs2)
+    assert torch.equal(dx1, dx2) and rel_err(cs1, cs2) < 1e-6        # (the column sums meet through atomics: order varies)
+    # act(aux) vs the forward's own act(f): the same function of the same bf16 values, compiled in two epilogues (contraction may
+    # differ before the rounding): at most one bf16 ulp apart, on very few elements
+    diff = (g_bwd.float() - g_fwd.float()).abs()
+    assert float((diff > 0).float().mean()) < 2e-3 and bool((diff <= g_fwd.float().abs() * 2.0 ** -7 + 1e-30).all())
+    a = f.float()
+    if act == 0:
+        sg = torch.sigmoid(1.702 * a)
+        dref = sg * (1 + 1.702 * a * (1 - sg))
+    else:
+        dref = 0.5 * (1 + torch.erf(a * 0.7071067811865476)) + a * 0.3989422804014327 * torch.exp(-0.5 * a * a)
+    exact = (dy.float() @ w2.float()) * dref
+    assert rel_err(dx1, exact) < 4e-3 and rel_err(cs1, exact.sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("rows,width", [(7, 512), (1000, 768), (513, 1024)])

@@ -93,6 +93,10 @@ def main():
         cs = torch.zeros(4 * W, device=dev)
         t = timeit(lambda: ops.linear_dgrad(dy, w2, out=dx, aux=h4, act_out=act, colsum=cs))
         print(f"gemm dgrad NN proj [x act'(f), act(f) out, column sums]: {t*1e3:.3f} ms  {2*R*W*4*W/t/1e12:.1f} TF/s")
+        t = timeit(lambda: ops.linear_dgrad(dy, w2, out=dx, aux=h4, colsum=cs))
+        print(f"gemm dgrad NN proj [x act'(f), column sums; no act(f) output]: {t*1e3:.3f} ms  {2*R*W*4*W/t/1e12:.1f} TF/s")
+        t = timeit(lambda: ops.linear_dgrad(dy, w2, out=dx))
+        print(f"gemm dgrad NN proj [plain, same operands]: {t*1e3:.3f} ms  {2*R*W*4*W/t/1e12:.1f} TF/s")
         del x, h4, res, res_out, w2, dy, dx, act
     # attention
     for (T, H, causal, b) in [(257, 16, 0, items), (77, 12, 1, items)]:

@@ -129,6 +129,11 @@ class CLIP(nn.Module):
         # behind the EOT never reach the pooled feature under the causal mask (clip_sf.py:43-44), so results are those of the dense
         # tower (embeddings and activation gradients bitwise, weight gradients up to the order of fp32 additions).
         self.pack_text = True
+        # act(f) of every MLP kept per layer by the forward (uniir_clip_tower.stash_act) instead of being re-materialised by the c_proj
+        # dgrad epilogue: +2 B x rows x 4 width per layer of workspace (52 GB at ViT-L/14 x 1024 items), bitwise the same results.
+        # None = when the workspace still fits the device's free memory with 16 GiB to spare, True / False = forced.
+        self.stash_act = None
+        self.last_stash_act = {}          # tower -> what the last training forward chose
         self.last_text_rows = None      # (live rows, dense rows) of the last packed text-tower call (bench: executed FLOPs)
 
     # ---- flat parameter / gradient / bf16-shadow storage -----------------------------------------------------
@@ -524,6 +529,22 @@ class _TowerFn(torch.autograd.Function):
             lib = _lib.load()
             desc = model.tower_desc(which)
             emb = torch.empty(M, E, device=dev, dtype=torch.float32)
+
+            def ws_bytes(stash):
+                desc.stash_act = int(stash)
+                if which == "text" and model.pack_text:
+                    return lib.uniir_clip_tower_workspace_bytes_packed(C.byref(desc), M, text_row_offsets(inp)[1], int(need_grad))
+                return lib.uniir_clip_tower_workspace_bytes(C.byref(desc), M, int(need_grad))
+
+            stash = False
+            if need_grad and model.stash_act is not False:
+                stash = True
+                if model.stash_act is None:        # automatic: only where the larger stash leaves 16 GiB of the device free
+                    free, _ = torch.cuda.mem_get_info(dev)
+                    avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                    stash = ws_bytes(True) + (16 << 30) <= avail
+            desc.stash_act = int(stash)
+            model.last_stash_act[which] = bool(stash)
             if which == "text" and model.pack_text:
                 # exact packing: only the tokens up to each caption's EOT are rows of the text tower (text_row_offsets)
                 row_off, live = text_row_offsets(inp)
@@ -535,7 +556,7 @@ class _TowerFn(torch.autograd.Function):
                                                            ws.data_ptr(), need, int(need_grad), ops._stream()), "clip_tower_fwd_packed")
                 model.last_text_rows = (live, M * cfg["context_length"])
                 if need_grad:
-                    ctx.stash = dict(ws=ws, inp=inp, ctower=True, row_off=row_off, live=live)
+                    ctx.stash = dict(ws=ws, inp=inp, ctower=True, row_off=row_off, live=live, stash_act=int(stash))
                 return emb
             need = lib.uniir_clip_tower_workspace_bytes(C.byref(desc), M, int(need_grad))
             if need < 0:
@@ -545,7 +566,7 @@ class _TowerFn(torch.autograd.Function):
             _lib.check(lib.uniir_clip_tower_fwd(C.byref(desc), inp.data_ptr(), M, emb.data_ptr(), ws.data_ptr(), need,
                                                 int(need_grad), ops._stream()), "clip_tower_fwd")
             if need_grad:
-                ctx.stash = dict(ws=ws, inp=inp, ctower=True)
+                ctx.stash = dict(ws=ws, inp=inp, ctower=True, stash_act=int(stash))
             return emb
         if which == "image":
             W, P, L = cfg["vision_width"], cfg["vision_patch_size"], cfg["vision_layers"]
@@ -599,6 +620,7 @@ class _TowerFn(torch.autograd.Function):
         if st.get("ctower"):
             lib = _lib.load()
             desc = model.tower_desc(which)
+            desc.stash_act = st["stash_act"]        # part of the workspace layout: the value the forward ran with
             ws, inp, stream = st["ws"], st["inp"], ops._stream()
             demb = demb.contiguous().float()
             need = ws.numel()

@@ -326,6 +326,10 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
     const bool colok = n0 + ch * 4 < p.N;
     const long rstep = 8L * p.ldc, rstep_aux = 8L * p.ldaux;
     f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
+    // (EPI_DACT's operand loads sit in the copy-out loop, four rows at a time: their round trip is the larger half of this
+    // epilogue's cost -- c_proj dgrad at ViT-L/14 x 1024 items 2.99 ms against 1.91 plain for 2.2 GB more.  Requesting a pass's 16
+    // pieces before it is staged was tried in round 4, as plain loads, staggered over the two passes, on full tiles only, and as asm
+    // loads behind one explicit wait: hipcc answered with 8 .. 140 spilled registers in every instantiation of the kernel, none kept.)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h) __syncthreads();
@@ -683,6 +687,24 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15) || ((uintptr_t)d->C & 15)) return UNIIR_EALIGN;
     if (d->aux && ((d->ldaux % 4) || ((uintptr_t)d->aux & 7))) return UNIIR_EALIGN;
     if (d->bias && ((uintptr_t)d->bias & 15)) return UNIIR_EALIGN;
+    // A weight gradient (C += A^T B, both operands K-major) whose reduction length is not a multiple of the 64-row K step -- the
+    // packed text tower: K = the live rows of the batch -- would fall to the general 128-tile kernel for the WHOLE product (measured,
+    // round 4: 188 us instead of ~45 us per text-tower weight gradient, 9 ms per train step).  The last K % 64 rows are a second,
+    // tiny accumulating product instead; the multiple-of-64 part keeps the LDS-DMA kernel.  Every output element still receives its
+    // additions in one fixed order (slab sum, then one add from the tail's only K step): deterministic.
+    if (d->a_tmaj && d->b_tmaj && d->epilogue == UNIIR_EPI_ATOMIC_F32 && (d->K % 64) && d->K >= 64 * 16 && d->M >= 256 && d->N >= 128) {
+        uniir_gemm_desc head = *d, tail = *d;
+        const int km = d->K / 64 * 64;
+        head.K = km;
+        tail.K = d->K - km;
+        tail.A = (const char*)d->A + (int64_t)km * d->lda * 2;
+        tail.B = (const char*)d->B + (int64_t)km * d->ldb * 2;
+        tail.k_splits = 1;
+        tail.splitk_ws = nullptr;
+        tail.splitk_ws_bytes = 0;
+        const int rc = gemm_impl(&head, stream);
+        return rc ? rc : gemm_impl(&tail, stream);
+    }
     GemmKArgs a;
     a.A = (const unsigned short*)d->A;
     a.B = (const unsigned short*)d->B;
@@ -701,6 +723,7 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
         a.C2 = d->C;
         a.skip_f = 1;
     }
+
     a.tiles_m = (d->M + GEMM_BM - 1) / GEMM_BM;
     a.tiles_n = (d->N + GEMM_BN - 1) / GEMM_BN;
     a.alpha = d->alpha;

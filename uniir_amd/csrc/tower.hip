@@ -20,7 +20,8 @@ struct Plan {
     // head / stem
     int64_t eot, rows, pooled, patches, po, x0;
     // per layer (stride lay_stride when save, 0 otherwise)
-    int64_t lay0, lay_stride, o_x, o_qkv, o_ao, o_lse, o_x2, o_f, o_h1, o_h2;
+    int64_t lay0, lay_stride, o_x, o_qkv, o_ao, o_lse, o_x2, o_f, o_g, o_h1, o_h2;
+    bool stash_act;                 // uniir_clip_tower.stash_act with save: act(f) of every layer is kept in o_g
     int64_t x_last;                 // the residual stream after the last block
     // transients shared by forward and backward (union)
     int64_t tmp;
@@ -57,6 +58,8 @@ Plan plan(const uniir_clip_tower* t, int batch, bool save, int rows = -1, const 
     p.o_lse = ltake((int64_t)M * p.H * p.T * 4);
     p.o_x2 = ltake(R * W * 4);
     p.o_f = save ? ltake(R * 4 * W * 2) : 0;      // the pre-activation is stashed for the backward only
+    p.stash_act = save && t->stash_act != 0;       // ... and (stash_act) act(f) next to it instead of re-materialising it there
+    p.o_g = p.stash_act ? ltake(R * 4 * W * 2) : 0;
     p.o_h1 = ltake(R * W * 2);
     p.o_h2 = ltake(R * W * 2);
     p.lay0 = cur;
@@ -179,13 +182,13 @@ int linear_wgrad(const uniir_clip_tower* t, const void* dy, const void* x, float
 
 struct Lay {
     float *x, *x2, *lse;
-    void *qkv, *ao, *f, *h1, *h2;
+    void *qkv, *ao, *f, *g, *h1, *h2;
 };
 Lay layer_bufs(const Plan& p, char* ws, int i) {
     char* b = ws + p.lay0 + p.lay_stride * i;
     Lay l;
     l.x = (float*)(b + p.o_x); l.qkv = b + p.o_qkv; l.ao = b + p.o_ao; l.lse = (float*)(b + p.o_lse);
-    l.x2 = (float*)(b + p.o_x2); l.f = b + p.o_f; l.h1 = b + p.o_h1; l.h2 = b + p.o_h2;
+    l.x2 = (float*)(b + p.o_x2); l.f = b + p.o_f; l.g = b + p.o_g; l.h1 = b + p.o_h1; l.h2 = b + p.o_h2;
     return l;
 }
 // where the residual stream that ENTERS block i lives (block i's stash slot; the tower output after the last block)
@@ -209,11 +212,12 @@ int blocks_fwd(const uniir_clip_tower* t, const Plan& p, char* ws, void* st) {
         else TRY(uniir_attention_fwd(l.qkv, l.ao, l.lse, p.M, p.T, p.H, t->is_text ? 1 : 0, st));
         TRY(linear_fwd(l.ao, b.wo16, l.x2, R, W, W, UNIIR_EPI_RESID_F32, b.bo, x, nullptr, st));
         TRY(uniir_layernorm_fwd(l.x2, W, b.ln2_w, b.ln2_b, l.h2, nullptr, R, W, 1e-5f, st));
-        if (p.save)      // f (pre-activation) is stashed for the backward; a forward-only pass writes act(f) alone
-            TRY(linear_fwd(l.h2, b.wfc16, l.f, R, 4 * W, W, UNIIR_EPI_BIAS_ACT, b.bfc, nullptr, ws + p.g, st));
+        void* g = p.stash_act ? l.g : (void*)(ws + p.g);
+        if (p.save)       // f (pre-activation) is stashed for the backward; a forward-only pass writes act(f) alone
+            TRY(linear_fwd(l.h2, b.wfc16, l.f, R, 4 * W, W, UNIIR_EPI_BIAS_ACT, b.bfc, nullptr, g, st));
         else
-            TRY(linear_fwd(l.h2, b.wfc16, ws + p.g, R, 4 * W, W, UNIIR_EPI_ACT_ONLY, b.bfc, nullptr, nullptr, st));
-        TRY(linear_fwd(ws + p.g, b.wproj16, xn, R, W, 4 * W, UNIIR_EPI_RESID_F32, b.bproj, l.x2, nullptr, st));
+            TRY(linear_fwd(l.h2, b.wfc16, g, R, 4 * W, W, UNIIR_EPI_ACT_ONLY, b.bfc, nullptr, nullptr, st));
+        TRY(linear_fwd(g, b.wproj16, xn, R, W, 4 * W, UNIIR_EPI_RESID_F32, b.bproj, l.x2, nullptr, st));
     }
     return UNIIR_OK;
 }
@@ -320,8 +324,9 @@ int tower_bwd_blocks(const uniir_clip_tower* t, int32_t batch, const int32_t* ro
         Lay l = layer_bufs(p, ws, i);
         // d(mlp): df = (dx @ Wproj) * act'(f); the same epilogue re-materialises g = act(f) for dWproj and sums df's columns
         // into the c_fc bias gradient
-        TRY(linear_dgrad(dxb, b.wproj16, df, R, W, 4 * W, l.f, g, b.g_bfc, stream));
-        TRY(linear_wgrad(t, dxb, g, b.g_wproj, R, W, 4 * W, stream));
+        // (stash_act: l.g holds act(f) since the forward -- the epilogue writes no second output)
+        TRY(linear_dgrad(dxb, b.wproj16, df, R, W, 4 * W, l.f, p.stash_act ? nullptr : g, b.g_bfc, stream));
+        TRY(linear_wgrad(t, dxb, p.stash_act ? l.g : g, b.g_wproj, R, W, 4 * W, stream));
         TRY(linear_wgrad(t, df, l.h2, b.g_wfc, R, 4 * W, W, stream));
         TRY(linear_dgrad(df, b.wfc16, dh, R, 4 * W, W, nullptr, nullptr, nullptr, stream));            // d ln_2 out
         TRY(uniir_layernorm_bwd(l.x2, W, b.ln2_w, dh, 0, dx, dx2, W, dxb, b.g_ln2_w, b.g_ln2_b, b.g_bo, R, W, 1e-5f, stream));
