@@ -461,3 +461,64 @@ def test_config_loader_takes_the_full_key_set_of_the_reference_yamls(tmp_path):
             assert cfg.retrieval_config.test_datasets_config.correspond_metrics_name == ["Recall@1, Recall@5", "Recall@10"]
         again = yaml.safe_load(OmegaConf.to_yaml(cfg))
         assert again["experiment"]["path_suffix"] == "CLIP_SF/Large/Instruct/InBatch/"
+
+
+def test_logical_sub_shards_of_a_resident_pool():
+    """retrieval.subshard_bounds (round 4): the row ranges a resident shard is searched in.  uniir_topk_ip addresses a shard through
+    31-bit buffer offsets, so every range stays below 2 GiB, starts on a 16-row boundary (aligned inverse norms, whole scan groups),
+    the ranges are equal (the last one shorter) and cover the shard exactly; the 5.6 M x 768 M-BEIR pool on one GPU
+    (mbeir_retriever.py:196-206 with a single visible device) is 5 of them"""
+    from uniir_amd import retrieval
+    assert retrieval.subshard_bounds(700_000, 768) == [(0, 700_000)]
+    assert retrieval.subshard_bounds(1_398_096, 768) == [(0, 1_398_096)]          # 2^31 - 4 608 bytes
+    assert len(retrieval.subshard_bounds(1_398_112, 768)) == 2
+    for n, d in ((5_600_000, 768), (5_600_001, 768), (1_398_112, 768), (9_000_000, 512), (2_100_000, 1024), (40_000_000, 64)):
+        b = retrieval.subshard_bounds(n, d)
+        assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert all(lo % 16 == 0 and 0 < (hi - lo) * d * 2 < 2 ** 31 for lo, hi in b)
+        assert len({hi - lo for lo, hi in b[:-1]}) <= 1 and b[-1][1] - b[-1][0] <= b[0][1] - b[0][0]
+        assert len(b) == -(-n // (((2 ** 31 - 1) // (d * 2)) // 16 * 16)) or len(b) == -(-n * d * 2 // (2 ** 31 - 1))
+    assert len(retrieval.subshard_bounds(5_600_000, 768)) == 5
+
+
+def test_text_row_offsets_of_a_token_batch():
+    """clip_model.text_row_offsets (round 4, the packed text tower): caption i owns argmax(tokens[i]) + 1 rows (upstream pools at
+    the EOT = the largest id, clip_sf.py:43-44 / CLIP.encode_text); int32 prefix sums on the tokens' device + the total on the host;
+    remembered ON the tensor (never by address), recomputed when the tensor is modified in place; lengths attached by a prefetcher
+    (`_uniir_lens`) are used instead of a device read"""
+    from uniir_amd.clip_model import text_row_offsets
+    tok = torch.zeros(4, 77, dtype=torch.int32)
+    for i, n in enumerate((5, 77, 1, 30)):
+        tok[i, :n] = torch.arange(1, n + 1, dtype=torch.int32)      # the largest id sits at position n - 1
+    off, live = text_row_offsets(tok)
+    assert off.dtype == torch.int32 and off.tolist() == [0, 5, 82, 83, 113] and live == 113
+    assert text_row_offsets(tok)[0] is off                            # remembered on the tensor object
+    tok[2, 9] = 1000                                                  # in-place change -> version counter -> recomputed
+    off2, live2 = text_row_offsets(tok)
+    assert off2.tolist() == [0, 5, 82, 92, 122] and live2 == 122
+    other = tok.clone()                                               # a new tensor never inherits an answer
+    other[0, 40] = 2000
+    assert text_row_offsets(other)[0].tolist() == [0, 41, 118, 128, 158]
+    hinted = torch.zeros(3, 77, dtype=torch.int32)
+    hinted._uniir_lens = torch.tensor([7, 8, 9])
+    assert text_row_offsets(hinted)[0].tolist() == [0, 7, 15, 24]
+
+
+def test_executed_flops_of_the_packed_step():
+    """bench.executed_flop_per_pair: the FLOPs the default (packed) train step executes per pair = SURVEY 8(d)'s count with every
+    caption's 77 positions replaced by its live length.  Full-length captions reproduce the 1.052 TFLOP per pair the unpacked step is
+    priced with (text forward 13.30 GFLOP per item); shorter ones are priced lower, by exactly 3 x the text forward difference"""
+    import bench
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    cfg = CLIP_CONFIGS["ViT-L/14"]
+    W, L, E = cfg["transformer_width"], cfg["transformer_layers"], cfg["embed_dim"]
+    text_fwd = lambda n: L * (24.0 * W * W * n + 4.0 * n * n * W) + 2.0 * W * E
+    assert abs(text_fwd(77) - 13.30e9) < 0.01e9
+    full = torch.zeros(8, 77, dtype=torch.int32)
+    full[:, 76] = 49407
+    f, live, dense = bench.executed_flop_per_pair(cfg, full, bench.FLOP_PER_PAIR["ViT-L/14"])
+    assert f == bench.FLOP_PER_PAIR["ViT-L/14"] and live == dense == 8 * 77
+    short = torch.zeros(8, 77, dtype=torch.int32)
+    short[:, 19] = 49407                                              # 20 live rows per caption
+    f2, live2, _ = bench.executed_flop_per_pair(cfg, short, bench.FLOP_PER_PAIR["ViT-L/14"])
+    assert live2 == 160 and abs((f - f2) - 3 * 2 * (text_fwd(77) - text_fwd(20))) < 1.0
