@@ -6,6 +6,13 @@
 // instructions a SIMD issues (213 per 32-key block of two query tiles, 16 of them MFMAs; ~4.5 cycles each, MFMAs 16, and the costs
 // ADD on a SIMD), and pairing tiles halves only the MFMA and LDS instruction counts per flop, not the ~8 softmax instructions per
 // logit.  To paste back: include after ApDma / ApBase in attention_pair.hip and call launch_attn_fwd_pair from launch_attn_fwd.
+// SECOND MEASUREMENT (round 4, after attention.hip's forward got the per-row deferred maximum: 0.61-0.62 ms): this kernel with the same
+// softmax (ApFwdState::l4 as four packed partials, the lane-local threshold test for both tiles, one scalar fold, cross-lane maximum
+// and rescale only for a flagged row -- pair rows still bitwise equal to the general kernel's) compiles to 53 + 16 vector
+// instructions, 16 MFMAs, 12 LDS reads and 42 scalar instructions per 32-key block of two tiles -- per tile what the general kernel
+// issues, minus six LDS reads -- and ran 0.652-0.706 ms at 257 x 16 x 1024 against 0.622 (197 tokens: 0.447 vs 0.447).  Splitting the
+// block loop into a DMA and a no-DMA body (the backward's trick) made hipcc emit 86 vector instructions per block instead of 53.
+// Not kept, again: two co-resident workgroups of the general kernel hide the per-head staging as well as the double buffering here.
 
 // =================================================================================================================================
 // Forward.  K, V of a head in LDS, double buffered over heads: the next head's slices arrive by DMA while this one computes.  A wave

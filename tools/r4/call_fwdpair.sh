@@ -1,0 +1,10 @@
+#!/bin/bash
+# the pair-tile forward with the deferred maximum: bitwise check against the general kernel, tests, timings
+cd /root/repo
+export PYTHONPATH=/root/repo
+mkdir -p gpurun_out/r4
+timeout 300 python tools/r4/attn_pair_check.py > gpurun_out/r4/fwdpair_check.txt 2>&1
+grep -E "fwd vs general|^T=.*b=1024|ALL PAIR" gpurun_out/r4/fwdpair_check.txt | cut -c1-200
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_clip_model_gpu.py tests/test_blip_gpu.py tests/test_clipff_gpu.py tests/test_parity_exact_gpu.py -m gpu -x -q > gpurun_out/r4/fwdpair_pytest.txt 2>&1
+tail -3 gpurun_out/r4/fwdpair_pytest.txt
+MB_ITEMS=1024 MB_SKIP_GEMM=1 timeout 300 python tools/microbench.py 2>&1 | grep -E "^attn"
