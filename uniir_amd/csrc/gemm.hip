@@ -223,6 +223,104 @@ DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long of
     }
 }
 
+// EPI_DACT copy-out of one 128-row pass, EIGHT columns per thread and row (round 4): the operand f, the result and the optional
+// act(f) output are bf16, so four columns per thread meant 8-byte global loads and stores -- half-width requests for 2 x 2.2 GB (+2.2)
+// per c_proj dgrad.  Thread -> rows r0 + 16 it, columns 8 c8 .. 8 c8 + 7: two 16-byte LDS reads (the two chunks of a thread share a
+// bank group: a 2-way conflict on reads that are a small part of this loop), one 16-byte load of f, one 16-byte store (+1).
+template <int ACT>
+DEVINL void epi_dact_copy8(const GemmKArgs& p, const char* src0, const char* src1, long off0, long offa, long rstep, long rstep_aux,
+                           bool full, bool colok, int rows_left, f32x4_t& cs0, f32x4_t& cs1) {
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        if (full || (colok && 16 * it < rows_left)) {
+            f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src0 + it * 16384);
+            f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(src1 + it * 16384);
+            const long oa = offa + it * rstep_aux;
+            const u32x4_t a = EPI_LD(reinterpret_cast<const u32x4_t*>(p.aux + oa));
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = __uint_as_float(a[e] << 16);
+                f[2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] *= act_bwd(f[e], ACT);
+                v1[e] *= act_bwd(f[4 + e], ACT);
+            }
+            const u32x4_t o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+            *reinterpret_cast<u32x4_t*>((unsigned short*)p.C + off0 + it * rstep) = o;
+            if (p.C2) {  // recomputed activation act(aux) for the wgrad of the next linear
+                u32x4_t g2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g2[e] = pack_bf16x2(act_fwd(f[2 * e], ACT), act_fwd(f[2 * e + 1], ACT));
+                *reinterpret_cast<u32x4_t*>((unsigned short*)p.C2 + oa) = g2;
+            }
+            cs0 += v0;
+            cs1 += v1;
+        }
+    }
+}
+
+// The epilogue of the DACT-only instantiation of the ping-pong kernel (gemm_glds_kernel<.., 4>: the c_proj dgrad of the towers).  Its
+// own kernel because the 256x256 kernel sits at 244-246 registers: the same code inside the shared epilogue256_staged spilled ~30
+// registers in EVERY instantiation and slowed the long-K plain dgrads by 7 % (measured, round 4).
+DEVINL void epilogue256_dact8(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int m0, int n0, char* lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int li = lane & 15, lg = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool full = (m0 + 256 <= p.M) && (n0 + 256 <= p.N);
+    const f32x4_t alpha4 = {p.alpha, p.alpha, p.alpha, p.alpha};
+    char* sj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nl = epi_col<true>(j, w, 0) + 4 * lg;
+        sj[j] = lds + li * 1024 + (((nl >> 2) ^ (li & 7)) << 4);
+    }
+    const int r8 = tid >> 5, c8 = tid & 31;      // copy-out: rows r8 + 16 it of the pass, 16-B chunks 2 c8 and 2 c8 + 1 of the fp32 image
+    const char* src8a = lds + r8 * 1024 + (((2 * c8) ^ (r8 & 7)) << 4);
+    const char* src8b = lds + r8 * 1024 + (((2 * c8 + 1) ^ (r8 & 7)) << 4);
+    const bool colok8 = n0 + c8 * 8 < p.N;
+    const long rstep = 16L * p.ldc, rstep_aux = 16L * p.ldaux;
+    f32x4_t cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int rb = ((w >> 2) * 64 + ii * 16) * 1024;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(sj[j] + rb) = acc[4 * h + ii][j] * alpha4;
+        }
+        __syncthreads();
+        const int mrow8 = m0 + 128 * h + r8;
+        const long o8 = (long)mrow8 * p.ldc + n0 + c8 * 8, a8 = (long)mrow8 * p.ldaux + n0 + c8 * 8;
+        const int left8 = p.M - mrow8;
+        if (p.act == UNIIR_ACT_QUICKGELU) epi_dact_copy8<UNIIR_ACT_QUICKGELU>(p, src8a, src8b, o8, a8, rstep, rstep_aux, full, colok8, left8, cs0, cs1);
+        else if (p.act == UNIIR_ACT_GELU_ERF) epi_dact_copy8<UNIIR_ACT_GELU_ERF>(p, src8a, src8b, o8, a8, rstep, rstep_aux, full, colok8, left8, cs0, cs1);
+        else epi_dact_copy8<UNIIR_ACT_RELU>(p, src8a, src8b, o8, a8, rstep, rstep_aux, full, colok8, left8, cs0, cs1);
+    }
+    if (p.colsum) {      // the thread's 8 columns as two chunks, summed over its rows of both passes; 16 threads share them
+        __syncthreads();
+        f32x4_t* red = reinterpret_cast<f32x4_t*>(lds);
+        red[2 * tid] = cs0;
+        red[2 * tid + 1] = cs1;
+        __syncthreads();
+        if (tid < 64) {          // chunk tid = columns 4 tid ..: thread column group tid >> 1, half tid & 1
+            f32x4_t s = red[2 * (tid >> 1) + (tid & 1)];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) s += red[2 * ((tid >> 1) + 32 * k) + (tid & 1)];
+            const int n = n0 + tid * 4;
+            if (n < p.N) {
+                unsafeAtomicAdd(p.colsum + n + 0, s[0]);
+                unsafeAtomicAdd(p.colsum + n + 1, s[1]);
+                unsafeAtomicAdd(p.colsum + n + 2, s[2]);
+                unsafeAtomicAdd(p.colsum + n + 3, s[3]);
+            }
+        }
+    }
+}
+
 // bf16 copy-out with the activation copy (EPI_BIAS_ACT): C <- f, C2 <- act(f)
 template <int ACT, int SRCSTEP = 8192>
 DEVINL void epi_bf16_copy_act(const char* src, unsigned short* c1, unsigned short* c2, long rstep, bool full, bool colok,
@@ -458,7 +556,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     PP_STAMP(0);
-    constexpr bool PP = (WM == 2 && WN == 4 && BK == 64 && (LOOP == 2 || LOOP == 3));
+    constexpr bool PP = (WM == 2 && WN == 4 && BK == 64 && (LOOP == 2 || LOOP == 3 || LOOP == 4));
     if (PP)
         glds_mainloop_pp<Elem, A_TMAJ, B_TMAJ, LOOP == 3>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc,
                                                           p.a_rowsum, nt, p.tiles_n);
@@ -469,6 +567,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
     PP_STAMP(1);
     const int w = threadIdx.x >> 6;
     const int wm = (w / WN) * 128, wn = (w % WN) * 64;
+    if constexpr (LOOP == 4) {      // the DACT-only instantiation (launch_glds_dact): bias-free, no split-K
+        epilogue256_dact8(p, acc, m0, n0, lds);
+        PP_STAMP(2);
+        return;
+    }
     if (WM * WN == 8) {   // 256x256 tile: LDS-staged, fully coalesced epilogue
         if (p.slab) {
             GemmKArgs q = p;
@@ -564,6 +667,23 @@ static int launch_glds_rowsum(GemmKArgs a, hipStream_t st) {
     return UNIIR_OK;
 }
 
+// dx = (dy @ w) * act'(f) [act(f) out] [column sums] on the ping-pong kernel with the 8-column copy-out (bf16, dy K-contiguous, w
+// K-major: the towers' c_proj dgrad)
+static int launch_glds_dact(GemmKArgs a, hipStream_t st) {
+    using S = GldsShape<2, 4, 64>;
+    a.tiles_m = (a.M + S::BM - 1) / S::BM;
+    a.tiles_n = (a.N + S::BN - 1) / S::BN;
+    a.raster_gm = 8;
+    a.raster_cw = 4;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first())
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<ElemBF16, false, true, 2, 4, 64, 4>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+    hipLaunchKernelGGL((gemm_glds_kernel<ElemBF16, false, true, 2, 4, 64, 4>), dim3(a.tiles_m * a.tiles_n), dim3(S::T), S::LDS_BYTES, st, a);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
 template <typename Elem>
 static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t st) {
     const int shape = gemm_shape(a, a_tmaj, b_tmaj);
@@ -571,6 +691,10 @@ static int launch_gemm(const GemmKArgs& a, int a_tmaj, int b_tmaj, hipStream_t s
         if (pp_eligible(a, a_tmaj, b_tmaj)) {
 #ifndef UNIIR_EXP_BUILD
             if (a.a_rowsum && std::is_same<Elem, ElemBF16>::value) return launch_glds_rowsum(a, st);
+            if (a.epilogue == UNIIR_EPI_DACT && std::is_same<Elem, ElemBF16>::value && !a_tmaj && b_tmaj && a.k_splits == 1 &&
+                !a.slab && !a.bias && a.N % 8 == 0 && a.ldc % 8 == 0 && a.ldaux % 8 == 0 && !((uintptr_t)a.aux & 15) &&
+                (!a.C2 || !((uintptr_t)a.C2 & 15)))
+                return launch_glds_dact(a, st);
 #endif
             return launch_glds<Elem, 2, 4, 64, 2>(a, a_tmaj, b_tmaj, st);
         }
