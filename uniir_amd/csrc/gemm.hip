@@ -264,7 +264,9 @@ DEVINL void epi_dact_copy8(const GemmKArgs& p, const char* src0, const char* src
 
 // The epilogue of the DACT-only instantiation of the ping-pong kernel (gemm_glds_kernel<.., 4>: the c_proj dgrad of the towers).  Its
 // own kernel because the 256x256 kernel sits at 244-246 registers: the same code inside the shared epilogue256_staged spilled ~30
-// registers in EVERY instantiation and slowed the long-K plain dgrads by 7 % (measured, round 4).
+// registers in EVERY instantiation and slowed the long-K plain dgrads by 7 % (measured, round 4).  Also measured here: four rows
+// instead of two per unrolled group (no change), and the first four operand pieces of a pass requested before the pass is staged,
+// the copy loop fully unrolled (2.56 -> 5.49 ms: no spills, 209 registers, and a schedule that waits for everything).
 DEVINL void epilogue256_dact8(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int m0, int n0, char* lds) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
