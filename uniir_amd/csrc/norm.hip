@@ -67,6 +67,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy * gamma;  dgamma += dy*xhat; dbeta += dy
+// (Round 4, measured and not kept: lanes owning PAIRS of neighbouring chunks, so that the bf16 operand / result are 16-byte instead
+// of 8-byte accesses -- the change that took 15 % off the GEMM's activation-gradient epilogue: forward 0.295 -> 0.279 ms, backward
+// 0.499 -> 0.494 ms at 263 168 x 1024, inside the box-to-box noise, for 8 spilled registers at the backward's 168-register budget.
+// These kernels are bound by HBM, not by the number of requests.)
 // EXACT: width == 256 * NC (every production width: 512 / 768 / 1024) -- no chunk predication, which is worth 50 VGPRs
 // (202 -> 152 at NC = 4: 3 waves / SIMD instead of 2).  The residual-gradient row is loaded with x and dy at the top of the
 // row (one exposed memory latency per row instead of two).
