@@ -762,7 +762,7 @@ def main():
                 if rec.get("model") == args.model and rec.get("pairs") == args.pairs:
                     traffic, traffic_note = rec["bytes_per_launch"], rec["note"]
             roof = {"bound": "mfma",
-                    "kernel": "gemm_glds_kernel<ElemBF16, {NT,NN,TN}, 2, 4, 64, {2,3}> (256x256x64 ping-pong LDS-DMA MFMA GEMM: "
+                    "kernel": "gemm_glds_kernel<ElemBF16, {NT,NN,TN}, 2, 4, 64, {2,3,4}> (256x256x64 ping-pong LDS-DMA MFMA GEMM: "
                               "forward, dgrad and wgrad of the towers' linear layers)",
                     "achieved": round(gflop / gtime / 1e12, 2) if gtime > 0 else None, "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(gflop / gtime / MFMA_PEAK_BF16, 4) if gtime > 0 else None,
