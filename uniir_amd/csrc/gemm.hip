@@ -13,6 +13,12 @@
 #ifndef UNIIR_EPI_NT
 #define UNIIR_EPI_NT 1
 #endif
+#ifndef EPI_RESID_PIPE
+#define EPI_RESID_PIPE 0     // RESID_F32 full-tile copy-out: pass 1's operand pieces requested under pass 0's copy-out (0: after it)
+#endif
+#ifndef EPI_DACT_PIPE
+#define EPI_DACT_PIPE 0      // DACT full-tile copy-out: both passes' operand pieces requested before pass 0 is staged
+#endif
 #if UNIIR_EPI_NT
 #define EPI_LD(p) __builtin_nontemporal_load(p)
 #else
@@ -38,22 +44,35 @@ struct GemmKArgs {
     int skip_f;                 // EPI_BIAS_ACT without the pre-activation store (UNIIR_EPI_ACT_ONLY: forward-only passes)
     const float* row_scale;     // EPI_RESID_F32: (v + bias) * row_scale[m] + resid (DropPath factor of the row's item), or nullptr
     float* a_rowsum;            // optional [M]: += sum_k A^T[m][k] (transposed-A ping-pong kernel only, see gemm_core_pp.h)
+    int stag_first, stag_p;     // start stagger (uniir_gemm_tune): the first stag_first workgroups start in stag_p phases,
+    unsigned stag_ticks;        // phase i after i * stag_ticks ticks of s_memrealtime (10 ns); 0 = all at once
 };
 
+// Contraction is switched off inside these two and the one fused multiply-add is written out: the same source then gives the same
+// bits in every epilogue instantiation they are inlined into (round 5: the DACT copy-out exists with and without the act(f) output as
+// two template instances, and "dx is bitwise the same either way" is a tested property -- with contraction left to the compiler the
+// instance that also computes act(f) shared subexpressions differently and moved dx by an ulp).
 DEVINL float act_fwd(float x, int act) {
+#pragma clang fp contract(off)
     // __builtin_amdgcn_rcpf: 1 ulp, one instruction (an IEEE division is ~10); the results are rounded to bf16
-    if (act == UNIIR_ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    if (act == UNIIR_ACT_QUICKGELU) {
+        const float t = 1.702f * x;
+        return x * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+    }
     if (act == UNIIR_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
     return fmaxf(x, 0.0f);
 }
 DEVINL float act_bwd(float x, int act) {
+#pragma clang fp contract(off)
     if (act == UNIIR_ACT_QUICKGELU) {
-        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
-        return s * (1.0f + 1.702f * x * (1.0f - s));
+        const float t = 1.702f * x;
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+        return s * __builtin_fmaf(t, 1.0f - s, 1.0f);
     }
     if (act == UNIIR_ACT_GELU_ERF) {
         const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-        return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+        const float h = -0.5f * x;
+        return __builtin_fmaf(x * 0.3989422804014327f, __expf(h * x), cdf);
     }
     return x > 0.0f ? 1.0f : 0.0f;
 }
@@ -223,6 +242,17 @@ DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long of
     }
 }
 
+// buffer addressing for the full-tile copy-outs: one SGPR descriptor per tensor at the TILE's first element, one 32-bit per-lane byte
+// offset shared by every row, the row advance as a scalar offset -- no 64-bit per-lane address per row (16 rows x 3 tensors of them
+// is what pushed the first version of these loops into scratch)
+// LOADS only.  Measured (round 5, tools/r5/dact_dbg.py): 16-byte buffer STORES with a scalar row offset returned corrupted dwords
+// when the next row's VALU rewrote the data registers right behind them -- the ">64-bit VMEM store, then VALU write of its data"
+// hazard, which the compiler's hazard recogniser only pads when soffset is NOT a register -- so the outputs leave through plain
+// global stores from a per-thread pointer.
+typedef __attribute__((ext_vector_type(4))) unsigned int bufu4_t;
+DEVINL __amdgpu_buffer_rsrc_t epi_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, -1, 0x00020000);
+}
 // EPI_DACT copy-out of one 128-row pass, EIGHT columns per thread and row (round 4): the operand f, the result and the optional
 // act(f) output are bf16, so four columns per thread meant 8-byte global loads and stores -- half-width requests for 2 x 2.2 GB (+2.2)
 // per c_proj dgrad.  Thread -> rows r0 + 16 it, columns 8 c8 .. 8 c8 + 7: two 16-byte LDS reads (the two chunks of a thread share a
@@ -262,6 +292,77 @@ DEVINL void epi_dact_copy8(const GemmKArgs& p, const char* src0, const char* src
     }
 }
 
+// the same on a full tile with the pass's eight operand pieces already requested (round 5: see epilogue256_resid_full -- inside the
+// loop above every load is followed by s_waitcnt vmcnt(0) because the act(f)-output option is a branch between the rows)
+template <int ACT, bool HAS_C2>
+DEVINL void epi_dact_copy8_full(const char* src0, const char* src1, char* pC, char* pC2, unsigned soC, unsigned soA, unsigned rowC,
+                                unsigned rowA, const u32x4_t (&a8)[8], f32x4_t& cs0, f32x4_t& cs1) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src0 + it * 16384);
+        f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(src1 + it * 16384);
+        const u32x4_t a = a8[it];
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[2 * e] = __uint_as_float(a[e] << 16);
+            f[2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v0[e] *= act_bwd(f[e], ACT);
+            v1[e] *= act_bwd(f[4 + e], ACT);
+        }
+        const u32x4_t o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+        *reinterpret_cast<u32x4_t*>(pC + (size_t)(soC + 16 * it * rowC)) = o;
+        if (HAS_C2) {
+            u32x4_t g2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g2[e] = pack_bf16x2(act_fwd(f[2 * e], ACT), act_fwd(f[2 * e + 1], ACT));
+            *reinterpret_cast<u32x4_t*>(pC2 + (size_t)(soA + 16 * it * rowA)) = g2;
+        }
+        cs0 += v0;
+        cs1 += v1;
+    }
+}
+template <bool HAS_C2>
+DEVINL void epi_dact_copy8_full_act(int act, const char* src0, const char* src1, char* pC, char* pC2, unsigned soC, unsigned soA,
+                                    unsigned rowC, unsigned rowA, const u32x4_t (&a8)[8], f32x4_t& cs0, f32x4_t& cs1) {
+    if (act == UNIIR_ACT_QUICKGELU) epi_dact_copy8_full<UNIIR_ACT_QUICKGELU, HAS_C2>(src0, src1, pC, pC2, soC, soA, rowC, rowA, a8, cs0, cs1);
+    else if (act == UNIIR_ACT_GELU_ERF) epi_dact_copy8_full<UNIIR_ACT_GELU_ERF, HAS_C2>(src0, src1, pC, pC2, soC, soA, rowC, rowA, a8, cs0, cs1);
+    else epi_dact_copy8_full<UNIIR_ACT_RELU, HAS_C2>(src0, src1, pC, pC2, soC, soA, rowC, rowA, a8, cs0, cs1);
+}
+
+struct DactFull {
+    __amdgpu_buffer_rsrc_t rA;       // operand f: buffer loads (tile base, 32-bit lane offset vA, scalar row offset)
+    char *pC, *pC2;                  // this thread's first element of the outputs (see the note on buffer stores above)
+    unsigned vA, rowC, rowA;
+    const char *src8a, *src8b;
+    int act;
+    bool has_c2;
+};
+template <int H>
+DEVINL void dact8_request(const DactFull& d, u32x4_t (&fa)[8]) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        fa[it] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(d.rA, d.vA, (unsigned)(128 * H + 16 * it) * d.rowA, UNIIR_EPI_NT ? 2 : 0));
+    }
+}
+template <int H>
+DEVINL void dact8_pass_full(const DactFull& d, const f32x4_t (&acc)[8][4], char* const (&sj)[4], f32x4_t alpha4, int w, f32x4_t& cs0,
+                            f32x4_t& cs1, const u32x4_t (&fa)[8]) {
+    if (H) __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int rb = ((w >> 2) * 64 + ii * 16) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(sj[j] + rb) = acc[4 * H + ii][j] * alpha4;
+    }
+    __syncthreads();
+    if (d.has_c2) epi_dact_copy8_full_act<true>(d.act, d.src8a, d.src8b, d.pC, d.pC2, 128u * H * d.rowC, 128u * H * d.rowA, d.rowC, d.rowA, fa, cs0, cs1);
+    else epi_dact_copy8_full_act<false>(d.act, d.src8a, d.src8b, d.pC, d.pC2, 128u * H * d.rowC, 128u * H * d.rowA, d.rowC, d.rowA, fa, cs0, cs1);
+}
+
 // The epilogue of the DACT-only instantiation of the ping-pong kernel (gemm_glds_kernel<.., 4>: the c_proj dgrad of the towers).  Its
 // own kernel because the 256x256 kernel sits at 244-246 registers: the same code inside the shared epilogue256_staged spilled ~30
 // registers in EVERY instantiation and slowed the long-K plain dgrads by 7 % (measured, round 4).  Also measured here: four rows
@@ -285,22 +386,47 @@ DEVINL void epilogue256_dact8(const GemmKArgs& p, const f32x4_t (&acc)[8][4], in
     const bool colok8 = n0 + c8 * 8 < p.N;
     const long rstep = 16L * p.ldc, rstep_aux = 16L * p.ldaux;
     f32x4_t cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+    if (full) {
+        // buffer addressing relative to the tile (see epi_rsrc); the pass's operand pieces are requested before the pass is staged
+        DactFull d;
+        d.rA = epi_rsrc(p.aux + (long)m0 * p.ldaux + n0);
+        d.vA = (unsigned)(r8 * (int)p.ldaux + c8 * 8) * 2u;
+        d.pC = (char*)((unsigned short*)p.C + (long)(m0 + r8) * p.ldc + n0 + c8 * 8);
+        d.pC2 = p.C2 ? (char*)((unsigned short*)p.C2 + (long)(m0 + r8) * p.ldaux + n0 + c8 * 8) : nullptr;
+        d.rowC = (unsigned)p.ldc * 2u;
+        d.rowA = (unsigned)p.ldaux * 2u;
+        d.src8a = src8a; d.src8b = src8b; d.act = p.act; d.has_c2 = p.C2 != nullptr;
+        u32x4_t fa0[8], fa1[8];        // both passes' operand pieces are requested before anything is staged (64 registers)
+        dact8_request<0>(d, fa0);
+#if EPI_DACT_PIPE
+        dact8_request<1>(d, fa1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        dact8_pass_full<0>(d, acc, sj, alpha4, w, cs0, cs1, fa0);
+#if !EPI_DACT_PIPE
+        __builtin_amdgcn_sched_barrier(0);
+        dact8_request<1>(d, fa1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        dact8_pass_full<1>(d, acc, sj, alpha4, w, cs0, cs1, fa1);
+    } else {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (h) __syncthreads();
+        for (int h = 0; h < 2; ++h) {
+            if (h) __syncthreads();
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int rb = ((w >> 2) * 64 + ii * 16) * 1024;
+            for (int ii = 0; ii < 4; ++ii) {
+                const int rb = ((w >> 2) * 64 + ii * 16) * 1024;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(sj[j] + rb) = acc[4 * h + ii][j] * alpha4;
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(sj[j] + rb) = acc[4 * h + ii][j] * alpha4;
+            }
+            __syncthreads();
+            const int mrow8 = m0 + 128 * h + r8;
+            const long o8 = (long)mrow8 * p.ldc + n0 + c8 * 8, a8 = (long)mrow8 * p.ldaux + n0 + c8 * 8;
+            const int left8 = p.M - mrow8;
+            if (p.act == UNIIR_ACT_QUICKGELU) epi_dact_copy8<UNIIR_ACT_QUICKGELU>(p, src8a, src8b, o8, a8, rstep, rstep_aux, full, colok8, left8, cs0, cs1);
+            else if (p.act == UNIIR_ACT_GELU_ERF) epi_dact_copy8<UNIIR_ACT_GELU_ERF>(p, src8a, src8b, o8, a8, rstep, rstep_aux, full, colok8, left8, cs0, cs1);
+            else epi_dact_copy8<UNIIR_ACT_RELU>(p, src8a, src8b, o8, a8, rstep, rstep_aux, full, colok8, left8, cs0, cs1);
         }
-        __syncthreads();
-        const int mrow8 = m0 + 128 * h + r8;
-        const long o8 = (long)mrow8 * p.ldc + n0 + c8 * 8, a8 = (long)mrow8 * p.ldaux + n0 + c8 * 8;
-        const int left8 = p.M - mrow8;
-        if (p.act == UNIIR_ACT_QUICKGELU) epi_dact_copy8<UNIIR_ACT_QUICKGELU>(p, src8a, src8b, o8, a8, rstep, rstep_aux, full, colok8, left8, cs0, cs1);
-        else if (p.act == UNIIR_ACT_GELU_ERF) epi_dact_copy8<UNIIR_ACT_GELU_ERF>(p, src8a, src8b, o8, a8, rstep, rstep_aux, full, colok8, left8, cs0, cs1);
-        else epi_dact_copy8<UNIIR_ACT_RELU>(p, src8a, src8b, o8, a8, rstep, rstep_aux, full, colok8, left8, cs0, cs1);
     }
     if (p.colsum) {      // the thread's 8 columns as two chunks, summed over its rows of both passes; 16 threads share them
         __syncthreads();
@@ -341,6 +467,92 @@ DEVINL void epi_bf16_copy_act(const char* src, unsigned short* c1, unsigned shor
         c1 += rstep;
         c2 += rstep;
     }
+}
+
+// EPI_RESID_F32 on a full tile with a residual operand (the out_proj / c_proj forward of every tower).  Round 5: the generic copy-out
+// above carries its run-time options (row_scale / resid / C2 / partial tiles) as wave-uniform BRANCHES inside the row loop, and with a
+// branch between them hipcc issues ONE residual load per row followed by s_waitcnt vmcnt(0) -- which on gfx9 also drains the previous
+// row's stores: 32 serialised HBM round trips per tile (28 us per tile at 19 GB/s per CU, profiles/r05_epilogue_stamps.txt).  Here the
+// options are compile-time, and a pass's 16 residual pieces are requested up front -- before the pass is even staged -- into 64
+// registers that the main loop's fragments no longer need: one round trip per pass, under the staging.
+struct ResidFull {
+    __amdgpu_buffer_rsrc_t rR;   // residual operand: buffer loads (tile base, 32-bit lane offset voff, scalar row offset)
+    char *pC, *pC2;              // this thread's first element of the outputs
+    unsigned voff, rowb;
+    const char* src;
+    const float* row_scale;      // + first row of the thread
+};
+template <int H, bool HAS_SCALE>
+DEVINL void resid_request(const ResidFull& d, f32x4_t (&r)[16], float (&sc)[HAS_SCALE ? 16 : 1]) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        r[it] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(d.rR, d.voff, (unsigned)(128 * H + 8 * it) * d.rowb, UNIIR_EPI_NT ? 2 : 0));
+        if (HAS_SCALE) sc[it] = d.row_scale[128 * H + 8 * it];
+    }
+}
+template <int H>
+DEVINL void resid_stage(const f32x4_t (&acc)[8][4], const f32x4_t (&bv)[4], char* const (&sj)[4], f32x4_t alpha4, int w) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int rb = ((w >> 2) * 64 + ii * 16) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(sj[j] + rb) = acc[4 * H + ii][j] * alpha4 + bv[j];
+    }
+}
+template <int H, bool HAS_C2, bool HAS_SCALE>
+DEVINL void resid_copy_out(const ResidFull& d, const f32x4_t (&r)[16], const float (&sc)[HAS_SCALE ? 16 : 1], f32x4_t& csum) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const unsigned so = (unsigned)(128 * H + 8 * it) * d.rowb;
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(d.src + it * 8192);
+        if (HAS_SCALE) v *= sc[it];
+        v += r[it];
+        *reinterpret_cast<f32x4_t*>(d.pC + (size_t)so) = v;
+        if (HAS_C2) {
+            const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(d.pC2 + (size_t)(so >> 1)) = o;
+        }
+        csum += v;
+    }
+}
+template <bool HAS_C2, bool HAS_SCALE>
+DEVINL void epilogue256_resid_full(const GemmKArgs& p, const f32x4_t (&acc)[8][4], const f32x4_t (&bv)[4], char* const (&sj)[4],
+                                   int m0, int n0, char* lds, f32x4_t& csum) {
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const f32x4_t alpha4 = {p.alpha, p.alpha, p.alpha, p.alpha};
+    const int r0 = tid >> 6, ch = tid & 63;   // copy-out: row r0 + 8 it of the pass, 16-B chunk ch (4 floats)
+    const long tile = (long)m0 * p.ldc + n0;
+    ResidFull d;
+    d.src = lds + r0 * 1024 + ((ch ^ (r0 & 7)) << 4);
+    d.rR = epi_rsrc(p.resid + tile);
+    d.voff = (unsigned)(r0 * (int)p.ldc + ch * 4) * 4u;
+    d.pC = (char*)((float*)p.C + tile) + d.voff;
+    d.pC2 = HAS_C2 ? (char*)((unsigned short*)p.C2 + tile) + (d.voff >> 1) : nullptr;
+    d.rowb = (unsigned)p.ldc * 4u;
+    d.row_scale = HAS_SCALE ? p.row_scale + m0 + r0 : nullptr;
+    // order: request pass 0's pieces | stage pass 0 | request pass 1's pieces | copy pass 0 out | stage pass 1 | copy pass 1 out --
+    // the second request travels under the first copy-out (64 + 64 operand registers next to the 64 accumulators still to be staged)
+    f32x4_t ra[16], rb[16];
+    float sa[HAS_SCALE ? 16 : 1], sb[HAS_SCALE ? 16 : 1];
+    resid_request<0, HAS_SCALE>(d, ra, sa);
+    resid_stage<0>(acc, bv, sj, alpha4, w);
+    __builtin_amdgcn_sched_barrier(0);
+#if EPI_RESID_PIPE
+    resid_request<1, HAS_SCALE>(d, rb, sb);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    __syncthreads();
+    resid_copy_out<0, HAS_C2, HAS_SCALE>(d, ra, sa, csum);
+#if !EPI_RESID_PIPE
+    __builtin_amdgcn_sched_barrier(0);
+    resid_request<1, HAS_SCALE>(d, rb, sb);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    __syncthreads();
+    resid_stage<1>(acc, bv, sj, alpha4, w);
+    __syncthreads();
+    resid_copy_out<1, HAS_C2, HAS_SCALE>(d, rb, sb, csum);
 }
 
 template <bool PP>
@@ -426,12 +638,19 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
     const bool colok = n0 + ch * 4 < p.N;
     const long rstep = 8L * p.ldc, rstep_aux = 8L * p.ldaux;
     f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
+    // (DropPath's row_scale keeps the generic loop: 32 more registers do not fit next to the two passes' operand pieces)
+    const bool resid_fast = PP && epi == UNIIR_EPI_RESID_F32 && full && p.resid != nullptr && p.row_scale == nullptr;
+    if (resid_fast) {
+        if (p.C2) epilogue256_resid_full<true, false>(p, acc, bv, sj, m0, n0, lds, csum);
+        else epilogue256_resid_full<false, false>(p, acc, bv, sj, m0, n0, lds, csum);
+    }
     // (EPI_DACT's operand loads sit in the copy-out loop, four rows at a time: their round trip is the larger half of this
     // epilogue's cost -- c_proj dgrad at ViT-L/14 x 1024 items 2.99 ms against 1.91 plain for 2.2 GB more.  Requesting a pass's 16
     // pieces before it is staged was tried in round 4, as plain loads, staggered over the two passes, on full tiles only, and as asm
     // loads behind one explicit wait: hipcc answered with 8 .. 140 spilled registers in every instantiation of the kernel, none kept.)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        if (resid_fast) break;
         if (h) __syncthreads();
         if (PP || wm == 128 * h) {
 #pragma unroll
@@ -509,7 +728,11 @@ __device__ unsigned long long g_pp_ts[3 * 65536];
 extern "C" int uniir_debug_read_ts(void* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_ts), (size_t)n * 8) == hipSuccess ? 0 : 1;
 }
+#if PP_TS == 2     // wall-clock stamps (100 MHz)
+#define PP_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 65536) g_pp_ts[3 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
 #define PP_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 65536) g_pp_ts[3 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime()
+#endif
 #else
 #define PP_STAMP(i)
 #endif
@@ -551,6 +774,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
         kbeg = split * per * BK;
         kend = min(p.K, (split + 1) * per * BK);
         if (kbeg >= kend) return;
+    }
+    if (p.stag_ticks && (int)blockIdx.x < p.stag_first) {
+        // One workgroup per CU and equal tiles: without this every CU reaches its epilogue at the same moment, the epilogues' HBM
+        // traffic comes in bursts with the matrix pipes idle, and the main loops run with HBM idle.  Phase groups interleave them.
+        const unsigned ph = (blockIdx.x >> 3) % (unsigned)p.stag_p;          // blockIdx & 7 is the XCD: alternate inside an XCD
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz, independent of the shader clock
+        const unsigned long long d = (unsigned long long)ph * p.stag_ticks;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
     }
     f32x4_t acc[8][4];
 #pragma unroll
@@ -778,6 +1009,36 @@ extern "C" int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launche
     return UNIIR_OK;
 }
 
+// Tuning knobs of the 256x256 kernel's start stagger (experiments / bench sweeps; defaults below are what ships)
+static struct {
+    int phases = 0;          // 0 / 1: off
+    int ns_kstep = 1450;     // estimated main-loop time per 64-wide K step
+    int ns_epi = 6000;       // estimated epilogue time of the tile
+    int min_rounds = 6;      // only when a CU runs at least this many tiles (the stagger costs (phases - 1) / phases of a tile at the end)
+} g_tune;
+extern "C" int uniir_gemm_tune(int32_t key, int32_t value) {
+    switch (key) {
+        case 0: g_tune.phases = value; break;
+        case 1: g_tune.ns_kstep = value; break;
+        case 2: g_tune.ns_epi = value; break;
+        case 3: g_tune.min_rounds = value; break;
+        default: return UNIIR_EINVAL;
+    }
+    return UNIIR_OK;
+}
+static int device_cus() {
+    static int cus[64] = {};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    if (!cus[d]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+        cus[d] = v;
+    }
+    return cus[d];
+}
+
 static int gemm_impl(const uniir_gemm_desc* d, void* stream);
 extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
     const bool sample = g_gt.stride > 0 && d && (++g_gt.counter % g_gt.stride) == 0 && g_gt.n < GT_MAX;
@@ -857,6 +1118,17 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     a.colsum = d->colsum;
     a.a_rowsum = nullptr;
     a.asm_loop = 2;
+    a.stag_first = 0; a.stag_p = 1; a.stag_ticks = 0;
+    if (g_tune.phases > 1 && d->k_splits == 1 && gemm_shape(a, d->a_tmaj, d->b_tmaj) == 1) {
+        const int cus = device_cus();
+        const long tiles = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+        if (tiles >= (long)g_tune.min_rounds * cus) {
+            const long period_ns = (long)(d->K / 64) * g_tune.ns_kstep + g_tune.ns_epi;
+            a.stag_first = cus;
+            a.stag_p = g_tune.phases;
+            a.stag_ticks = (unsigned)(period_ns / g_tune.phases / 10);
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d->k_splits > 1) {
         // never leave a split empty (an empty split would leave its slab unwritten)
