@@ -33,6 +33,7 @@ FLOP_PER_ITEM_FWD = {"ViT-L/14": 175.33e9, "ViT-B/32": 14.78e9}
 BLIP_FF_FLOP_PER_PAIR = 1.212e12
 MFMA_PEAK_BF16 = 2.5e15
 HBM_PEAK = 8.0e12
+ROTATE = 4          # distinct caption batches rotated through the timed train steps
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_gemm_traffic.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes
 
 
@@ -49,10 +50,10 @@ def executed_flop_per_pair(cfg, txt, dense_flop_per_pair):
     return dense_flop_per_pair - 3.0 * (dense - live), float(lens.sum()), txt.shape[0] * ctx
 
 
-def synth_batch(cfg, pairs, seed, device):
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    M = 2 * pairs
-    res, ctx, vocab = cfg["image_resolution"], cfg["context_length"], cfg["vocab_size"]
+def synth_tokens(cfg, M, g):
+    """SURVEY 8(d)'s synthetic captions: [SOT, L random ids, EOT, 0 ...] with L ~ U{5..60} (the EOT is the row's largest id, as
+    upstream's argmax pooling requires): 7..62 live positions of the 77, 34.5 on average"""
+    ctx, vocab = cfg["context_length"], cfg["vocab_size"]
     txt = torch.zeros(M, ctx, dtype=torch.int32)
     L = torch.randint(5, 61, (M,), generator=g)
     body = torch.randint(1, vocab - 2, (M, ctx), generator=g, dtype=torch.int32)
@@ -60,6 +61,22 @@ def synth_batch(cfg, pairs, seed, device):
     txt = torch.where((pos >= 1) & (pos <= L.unsqueeze(1)), body, txt)
     txt[:, 0] = vocab - 2
     txt[torch.arange(M), L + 1] = vocab - 1
+    return txt
+
+
+def attach_caption_lengths(tok_dev, tok_host):
+    """what host_utils.DevicePrefetcher attaches to a token batch it copies to the device: the captions' live lengths, computed on
+    the host copy, so that the packed text tower sizes its launch without a device -> host read"""
+    tok_dev._uniir_lens = (tok_host.argmax(dim=-1) + 1).to(torch.int32)
+    tok_dev._uniir_lens_version = tok_dev._version
+    return tok_dev
+
+
+def synth_batch(cfg, pairs, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    M = 2 * pairs
+    res = cfg["image_resolution"]
+    txt = synth_tokens(cfg, M, g)
     gd = torch.Generator(device=device).manual_seed(seed)
     img = torch.randn(M, 3, res, res, generator=gd, device=device)
     return {
@@ -256,26 +273,70 @@ def bench_retrieval_full_pool(dev, n=5_600_000, d=768, k=10):
     return out
 
 
+VISION_FLOP_PER_ITEM_FWD = {"ViT-L/14": 162.03e9, "ViT-B/32": 8.82e9}       # the image tower's share of the item
+
+
+def text_flop_per_item_fwd(cfg, txt):
+    """executed forward FLOPs of the packed text tower, mean per caption (the formula of executed_flop_per_pair)"""
+    W, Lyr, E = cfg["transformer_width"], cfg["transformer_layers"], cfg["embed_dim"]
+    lens = (txt.argmax(dim=-1) + 1).double().cpu()
+    return float(sum(Lyr * (24.0 * W * W * L + 4.0 * L * L * W) + 2.0 * W * E for L in lens.tolist())) / max(1, txt.shape[0])
+
+
 def bench_embed(dev, model_name="ViT-L/14", items=2048, steps=3):
     """config 3: forward-only embedding extraction through the reference's `model(batch, encode_mbeir_batch=True)` entry +
-    `.half()` per batch (mbeir_embedder.py:54-60), 2048 synthetic items per batch resident in HBM"""
+    `.half()` per batch (mbeir_embedder.py:54-60), 2048 synthetic items per batch resident in HBM, in the three modes BASELINE
+    configs[2] names: pair (both masks 1), image-only and text-only candidates (the collator's black image / empty caption with mask 0,
+    mbeir_dataset.py:427-434).  Each tower runs on its live rows only (clip_sf.compact_masked), the text tower on packed rows;
+    mfma_frac prices the FLOPs EXECUTED (SURVEY 8(d) counts, live caption lengths), mfma_frac_dense_count the reference's
+    both-towers-on-every-item count for the same items/s."""
     from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
     from uniir_amd.clip_model import CLIP_CONFIGS
+    cfg = CLIP_CONFIGS[model_name]
     model = CLIPScoreFusion(model_name=model_name, device=dev).float().eval()
-    batch = synth_batch(CLIP_CONFIGS[model_name], items // 2, 2023, dev)
+    batch = synth_batch(cfg, items // 2, 2023, dev)
     batch["did_list"] = list(range(items))
-    with torch.no_grad():
-        model(batch, encode_mbeir_batch=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            emb, _ids = model(batch, encode_mbeir_batch=True)
-            out = emb.half()
-        torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"metric": "embedding items/s (CLIP_SF-L forward only, fp16 out)", "value": round(items / dt, 1), "unit": "items/s",
-            "ms_per_batch": round(dt * 1e3, 2), "items_per_batch": items, "out_shape": list(out.shape),
-            "mfma_frac": round(items / dt * FLOP_PER_ITEM_FWD[model_name] / MFMA_PEAK_BF16, 4)}
+    host_tok = batch["txt_batched"].cpu()
+    attach_caption_lengths(batch["txt_batched"], host_tok)
+    text_flop = text_flop_per_item_fwd(cfg, host_tok) if model.clip_model.pack_text else FLOP_PER_ITEM_FWD[model_name] - VISION_FLOP_PER_ITEM_FWD[model_name]
+    # the empty caption of an image-only candidate: [SOT, EOT, 0, ...]
+    empty = torch.zeros_like(host_tok)
+    empty[:, 0], empty[:, 1] = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1
+    modes = {"pair": (1, 1), "image_only": (0, 1), "text_only": (1, 0)}
+    out = {}
+    ones = torch.ones(items, dtype=torch.int64)
+    for mode, (tm, im) in modes.items():
+        b = dict(batch)
+        b["txt_mask_batched"] = (ones * tm).to(dev)
+        b["image_mask_batched"] = (ones * im).to(dev)
+        b["txt_mask_batched"]._uniir_host, b["image_mask_batched"]._uniir_host = ones * tm, ones * im     # as the prefetcher does
+        if not tm:
+            b["txt_batched"] = attach_caption_lengths(empty.to(dev), empty)
+        if not im:
+            b["image_batched"] = torch.zeros_like(batch["image_batched"])
+        n = steps if mode != "text_only" else 4 * steps
+        with torch.no_grad():
+            model(b, encode_mbeir_batch=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                emb, _ids = model(b, encode_mbeir_batch=True)
+                half = emb.half()
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        executed = (VISION_FLOP_PER_ITEM_FWD[model_name] if im else 0.0) + (text_flop if tm else 0.0)
+        out[mode] = {"value": round(items / dt, 1), "unit": "items/s", "ms_per_batch": round(dt * 1e3, 2),
+                     "executed_gflop_per_item": round(executed / 1e9, 2),
+                     "mfma_frac": round(items / dt * executed / MFMA_PEAK_BF16, 4),
+                     "mfma_frac_dense_count": round(items / dt * FLOP_PER_ITEM_FWD[model_name] / MFMA_PEAK_BF16, 4)}
+        del b
+    res = {"metric": "embedding items/s (CLIP_SF-L forward only, fp16 out)", "value": out["pair"]["value"], "unit": "items/s",
+           "ms_per_batch": out["pair"]["ms_per_batch"], "items_per_batch": items, "out_shape": list(half.shape),
+           "mfma_frac": out["pair"]["mfma_frac"],
+           "mfma_frac_note": "pair mode, executed FLOPs (vision 162.03 GFLOP + the packed text tower at the captions' live lengths)",
+           "modes": out, "precision": getattr(model.clip_model, "precision", "bf16"),
+           "masked_rows": "compacted (each tower runs on its mask-1 rows only)" if model.compact_masked else "dense"}
+    return res
 
 
 def _blip_synth(pairs, L, vocab, seed, device):
@@ -430,8 +491,13 @@ def bench_embed_sharded(dist, dev, world, model_name, items=2048, steps=3):
     from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
     from uniir_amd.clip_model import CLIP_CONFIGS
     model = CLIPScoreFusion(model_name=model_name, device=dev).float().eval()
-    batch = synth_batch(CLIP_CONFIGS[model_name], items // 2, 2023, dev)
+    cfg = CLIP_CONFIGS[model_name]
+    batch = synth_batch(cfg, items // 2, 2023, dev)
     batch["did_list"] = list(range(items))
+    host_tok = batch["txt_batched"].cpu()
+    attach_caption_lengths(batch["txt_batched"], host_tok)
+    executed = VISION_FLOP_PER_ITEM_FWD[model_name] + (text_flop_per_item_fwd(cfg, host_tok) if model.clip_model.pack_text
+                                                        else FLOP_PER_ITEM_FWD[model_name] - VISION_FLOP_PER_ITEM_FWD[model_name])
     shape = []
 
     def run():
@@ -442,7 +508,8 @@ def bench_embed_sharded(dist, dev, world, model_name, items=2048, steps=3):
         t = _rank_max_seconds(dist, dev, run, steps)
     return {"metric": "embedding items/s (CLIP_SF forward only, fp16 out), summed over the ranks", "value": round(world * items / t, 1),
             "unit": "items/s", "ms_per_batch": round(t * 1e3, 2), "items_per_batch_per_rank": items, "out_shape": shape,
-            "mfma_frac": round(world * items / t * FLOP_PER_ITEM_FWD[model_name] / (world * MFMA_PEAK_BF16), 4)}
+            "mfma_frac": round(world * items / t * executed / (world * MFMA_PEAK_BF16), 4),
+            "mfma_frac_note": "pair mode, executed FLOPs (packed text tower at the captions' live lengths)"}
 
 
 def _secondary(name, fn, *a, **kw):
@@ -684,17 +751,38 @@ def main():
         if args.no_stash_act:
             model.clip_model.stash_act = False
         batch = synth_batch(cfg, args.pairs, 2023 + rank, dev)
+        # The timed loop rotates ROTATE distinct caption batches (distinct token tensors, different lengths; the 0.6-GB image tensor
+        # is shared -- three more of them do not fit next to the 265-GiB activation stash).  Each arrives the way the train loop's
+        # DevicePrefetcher delivers it: on the device, with the captions' live lengths attached on the host side; the row offsets
+        # remembered on the tensor object are dropped before every step, so the per-batch host work of the packed text tower (prefix
+        # sums + the 4-KB offset copy) is inside the timed region.
+        gtok = torch.Generator(device="cpu").manual_seed(9000 + rank)
+        tok_hosts = [batch["txt_batched"].cpu()] + [synth_tokens(cfg, 2 * args.pairs, gtok) for _ in range(ROTATE - 1)]
+        tok_devs = [attach_caption_lengths(t.to(dev), t) for t in tok_hosts]
 
+    def next_batch(i):
+        if batch is None:
+            return None
+        tok = tok_devs[i % ROTATE]
+        if hasattr(tok, "_uniir_row_off"):
+            del tok._uniir_row_off
+        batch["txt_batched"] = tok
+        return batch
+
+    step_no = 0
     for _ in range(args.warmup):
-        out = trainer.train_step(batch)
+        out = trainer.train_step(next_batch(step_no))
+        step_no += 1
     barrier()
     board = BoardSampler(local_rank) if (ops is not None and rank == 0) else None
     if ops is not None and rank == 0:
         ops.gemm_timing_start()
         board.start()
     t0 = time.perf_counter()
+    timed_from = step_no
     for _ in range(args.steps):
-        out = trainer.train_step(batch)
+        out = trainer.train_step(next_batch(step_no))
+        step_no += 1
     barrier()
     dt = time.perf_counter() - t0
     board_rec = board.stop() if board is not None else None
@@ -714,12 +802,12 @@ def main():
         model.clip_model.pack_text = False
         out = None
         torch.cuda.empty_cache()     # the text workspace changes size: let the 182 GiB vision stash be re-cut from a clean pool
-        for _ in range(max(1, args.warmup)):
-            trainer.train_step(batch)
+        for i in range(max(1, args.warmup)):
+            trainer.train_step(next_batch(i))
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            trainer.train_step(batch)
+        for i in range(args.steps):
+            trainer.train_step(next_batch(timed_from + i))
         barrier()
         tu = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         if world > 1:
@@ -753,8 +841,11 @@ def main():
             roof = None
         else:
             packed_on = bool(getattr(model.clip_model, "pack_text", False))
-            flop_pair, live_rows, dense_rows = (executed_flop_per_pair(cfg, batch["txt_batched"], FLOP_PER_PAIR[args.model])
-                                                if packed_on else (FLOP_PER_PAIR[args.model], 0, 0))
+            if packed_on:       # executed FLOPs: mean over the caption batches of the timed steps
+                per = [executed_flop_per_pair(cfg, tok_hosts[(timed_from + i) % ROTATE], FLOP_PER_PAIR[args.model]) for i in range(args.steps)]
+                flop_pair, live_rows, dense_rows = (sum(x[j] for x in per) / len(per) for j in range(3))
+            else:
+                flop_pair, live_rows, dense_rows = FLOP_PER_PAIR[args.model], 0, 0
             gflop, gtime, nsamp = timing
             traffic, traffic_note = None, "no rocprofv3 --pmc record for this configuration under profiles/"
             if os.path.exists(PMC_FILE):
@@ -773,7 +864,8 @@ def main():
                     "end_to_end_note": ("value x EXECUTED FLOPs per pair / peak: the text tower runs on the rows up to each caption's "
                                         "EOT only (exact: rows behind the EOT never reach the pooled feature under the causal mask); "
                                         f"{flop_pair / 1e12:.4f} TFLOP per pair executed vs {FLOP_PER_PAIR[args.model] / 1e12:.3f} "
-                                        f"with 77 positions per caption; text rows {int(live_rows)} of {int(dense_rows)}")
+                                        f"with 77 positions per caption; text rows {int(live_rows)} of {int(dense_rows)} (mean over the "
+                                        "timed steps' caption batches)")
                     if packed_on else "value x SURVEY 8(d) FLOPs per pair / peak",
                     "end_to_end_frac_unpacked": (round(global_pairs * args.steps / unpacked * FLOP_PER_PAIR[args.model]
                                                        / (world * MFMA_PEAK_BF16), 4) if unpacked else None),
@@ -794,8 +886,12 @@ def main():
                        "mlp_stash": (None if args.dry_run else
                                      {k: ("f + act(f)" if v else "f") for k, v in model.clip_model.last_stash_act.items()}),
                        "peak_mem_GB": (round(torch.cuda.max_memory_allocated(dev) / 1e9, 1) if dev.type == "cuda" else None),
-                       "batch": "ONE synthetic batch per rank, generated on the device before the timed region and re-used for "
-                                "every step (timing only; the loss therefore collapses)"},
+                       "batch": (f"{ROTATE} synthetic caption batches per rank (distinct token tensors; captions [SOT, L ids, EOT] with "
+                                 "L ~ U{5..60}, 7..62 live positions of 77) rotated through the timed steps over ONE shared image "
+                                 "tensor, all resident in HBM before the timed region; every token batch carries its host-side caption "
+                                 "lengths the way host_utils.DevicePrefetcher attaches them, and its cached row offsets are dropped "
+                                 "before each step: the packed text tower's per-batch host work is inside the timed region, no "
+                                 "device -> host read is")},
             "roofline": roof,
         }
         if rccl is not None:

@@ -186,3 +186,71 @@ def test_vit_l14_forward_only_modality_masks_against_the_oracle():
         rel = ((emb_d[r] - emb_o[r]).norm() / emb_o[r].norm()).item()
         assert rel < 1.2e-2, (r, rel)                                  # bf16 towers vs the fp32 oracle (observed ~6e-3 on pairs)
     assert torch.equal(emb_g, emb_d)
+
+
+def test_mask_compacted_towers_equal_the_dense_towers_forward_and_backward():
+    """Round 5: CLIP_SF runs each tower on the rows whose modality mask is 1 only (clip_sf.encode_multimodal_input,
+    compact_masked = True; the reference runs both towers on every item and multiplies by the masks, clip_sf.py:53-63).
+    Embeddings and the loss are BITWISE those of the dense path (x * 0 + y == y); every parameter gradient equals the dense one up to
+    the order of fp32 additions (the dense path adds exact zeros for the dead rows in between).  ViT-B/32, 16 items: image-only,
+    text-only, pairs, and one row with both masks 0 (sized so that the dense and the compacted towers run the same kernel class: below
+    256 rows uniir_gemm sums bias gradients from the ROUNDED bf16 result in a separate pass, which is a 3e-3 difference of its own); plus a batch in which NO row has an image (empty image tower launch), and the
+    prefetcher's host-side mask / caption-length hints against the device -> host fallback."""
+    from oracle import clip_oracle as O
+    from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    cfg = CLIP_CONFIGS["ViT-B/32"]
+    sd = O.init_state_dict(cfg, seed=5)
+    config = SimpleNamespace(model=SimpleNamespace(gather_embeddings=False), data_config=SimpleNamespace(in_batch_neg_num=0))
+    os.environ["UNIIR_ALLOW_RANDOM_INIT"] = "1"
+    model = CLIPScoreFusion("ViT-B/32", device=DEV, config=config)
+    model.clip_model.load_state_dict(sd, strict=True)
+    model.train()
+    b = O.synthetic_batch(cfg, 8, seed=17)                            # 16 items = 8 (query, candidate) pairs
+    txt, img = b["txt_batched"].to(DEV), b["image_batched"].to(DEV)
+    tmask = torch.tensor([1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 1])
+    imask = torch.tensor([0, 1, 1, 0, 1, 1, 0, 0, 1, 1, 0, 1, 1, 0, 1, 1])   # item 7: neither modality (an all-zero embedding)
+
+    def run(compact, hints):
+        model.compact_masked = compact
+        model.zero_grad()
+        t, tm, im = txt.clone(), tmask.to(DEV), imask.to(DEV)
+        if hints:                       # what host_utils.DevicePrefetcher attaches
+            t._uniir_lens = (b["txt_batched"].argmax(dim=-1) + 1).to(torch.int32)
+            t._uniir_lens_version = t._version
+            tm._uniir_host, im._uniir_host = tmask.clone(), imask.clone()
+        batch = {"txt_batched": t, "image_batched": img, "txt_mask_batched": tm, "image_mask_batched": im,
+                 "index_mapping": b["index_mapping"]}
+        emb = model.encode_multimodal_input(t, img, tm, im)
+        out = model(batch)
+        out["loss"].backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.clip_model.named_parameters()}
+        return emb.detach().clone(), out["loss"].detach().clone(), grads
+
+    emb_d, loss_d, g_d = run(False, False)
+    for hints in (False, True):
+        emb_c, loss_c, g_c = run(True, hints)
+        assert torch.equal(emb_c, emb_d) and torch.equal(loss_c, loss_d), hints
+        assert bool((emb_c[7] == 0).all())
+        worst = max(((float((g_c[n] - g_d[n]).abs().max()) / (float(g_d[n].abs().max()) + 1e-12)), n) for n in g_d)
+        assert worst[0] <= 2e-5, (worst, hints)
+    # no image anywhere: the image tower is launched on zero rows
+    model.eval()
+    with torch.no_grad():
+        tm0, im0 = torch.ones(16, dtype=torch.int64, device=DEV), torch.zeros(16, dtype=torch.int64, device=DEV)
+        model.compact_masked = False
+        e_dense = model.encode_multimodal_input(txt, img, tm0, im0)
+        model.compact_masked = True
+        e_comp = model.encode_multimodal_input(txt, img, tm0, im0)
+    assert torch.equal(e_dense, e_comp)
+    # a stale caption-length hint (tokens edited in place after the prefetch) is ignored, not trusted
+    from uniir_amd.clip_model import text_row_offsets
+    t = txt.clone()
+    t._uniir_lens = torch.full((16,), 77, dtype=torch.int32)
+    t._uniir_lens_version = t._version
+    t[0, 0] += 0                                                       # in-place write: bumps the version
+    assert text_row_offsets(t)[1] == int((txt.argmax(dim=-1) + 1).sum())
+    t2 = txt.clone()
+    t2._uniir_lens = torch.zeros(16, dtype=torch.int32)               # out of range: ignored
+    t2._uniir_lens_version = t2._version
+    assert text_row_offsets(t2)[1] == int((txt.argmax(dim=-1) + 1).sum())

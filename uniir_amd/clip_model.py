@@ -23,24 +23,46 @@ _PY_TOWERS = False
 
 ALIGN = 64  # elements; every parameter starts on a 256-B boundary of the flat buffers
 
+def _tensor_version(t):
+    try:
+        return t._version
+    except RuntimeError:            # inference tensors (torch.inference_mode) have no version counter: never cache on them
+        return None
+
+
 def text_row_offsets(tok):
     """(row_off int32 [n + 1] on the tokens' device, live rows on the host) of a token batch [n, ctx]: caption i owns
     argmax(tok[i]) + 1 rows (upstream pools at the EOT = the largest token id, first occurrence).  The host needs the total to size
     the GEMMs, which costs one device -> host read per NEW batch; a prefetcher that still has the tokens on the host can attach
-    the lengths as `tok._uniir_lens` (host_utils.DevicePrefetcher does).  The result is remembered ON the tensor object (with its
-    version counter), so a batch that is fed repeatedly (benchmarks, gradient accumulation replays) pays the read once; nothing is
-    keyed by address, so a recycled allocation can never produce a stale answer."""
+    the lengths as `tok._uniir_lens` (+ `tok._uniir_lens_version`; host_utils.DevicePrefetcher does).  The hint is used only if it is
+    a host tensor of n lengths in [1, ctx] attached to THIS version of the tensor -- anything else (tokens modified in place after the
+    prefetch, a foreign attribute) falls back to the device read, so a stale hint can never size or index the packed kernels.  The
+    result is remembered ON the tensor object (with its version counter), so a batch that is fed repeatedly (benchmarks, gradient
+    accumulation replays) pays the read once; nothing is keyed by address, so a recycled allocation can never produce a stale answer."""
+    ver = _tensor_version(tok)
     hit = getattr(tok, "_uniir_row_off", None)
-    if hit is not None and hit[0] == tok._version and hit[1] == tuple(tok.shape):
+    if hit is not None and ver is not None and hit[0] == ver and hit[1] == tuple(tok.shape):
         return hit[2]
+    n, ctx = tok.shape
     lens = getattr(tok, "_uniir_lens", None)
+    if lens is not None:
+        ok = (isinstance(lens, torch.Tensor) and not lens.is_cuda and lens.dim() == 1 and lens.shape[0] == n
+              and not lens.is_floating_point() and getattr(tok, "_uniir_lens_version", ver) == ver)
+        if ok:
+            lens = lens.to(torch.int64)
+            ok = n == 0 or bool(((lens >= 1) & (lens <= ctx)).all())
+        if not ok:
+            lens = None
     if lens is None:
-        lens = (tok.argmax(dim=-1) + 1).to(torch.int32).cpu()
-    lens = lens.to(torch.int64)
-    off = torch.zeros(tok.shape[0] + 1, dtype=torch.int64)
+        lens = (tok.argmax(dim=-1) + 1).to(torch.int64).cpu()          # always in [1, ctx]
+    off = torch.zeros(n + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(lens, 0)
     out = (off.to(torch.int32).to(tok.device), int(off[-1]))
-    tok._uniir_row_off = (tok._version, tuple(tok.shape), out)
+    if ver is not None:
+        try:
+            tok._uniir_row_off = (ver, tuple(tok.shape), out)
+        except Exception:
+            pass
     return out
 
 CLIP_CONFIGS = {
@@ -300,7 +322,9 @@ class CLIP(nn.Module):
         self._sync_shadow()
         tok = text.to(torch.int32).contiguous()
         if self.pack_text and tok is not text:       # the caller's tensor object carries the remembered row offsets
-            tok._uniir_row_off = (tok._version, tuple(tok.shape), text_row_offsets(text))
+            ver = _tensor_version(tok)
+            if ver is not None:
+                tok._uniir_row_off = (ver, tuple(tok.shape), text_row_offsets(text))
         return _TowerFn.apply(self, "text", tok, self._anchor_for(text.device))
 
     def _anchor_for(self, dev):

@@ -300,9 +300,15 @@ class DevicePrefetcher:
                         # CLIP token ids still on the host: the live length of every caption (EOT = arg-max id, upstream's
                         # pooling row) travels with the batch, so that the packed text tower needs no device -> host read
                         lens = (value.argmax(dim=-1) + 1).to(torch.int32)
+                    host_mask = value if (key in ("txt_mask_batched", "image_mask_batched") and not value.is_cuda) else None
                     batch[key] = self._move(value)
                     if lens is not None:
                         batch[key]._uniir_lens = lens
+                        batch[key]._uniir_lens_version = batch[key]._version     # the hint dies with an in-place edit
+                    if host_mask is not None:
+                        # the modality masks stay readable on the host: CLIP_SF runs each tower on its live rows only
+                        # (clip_sf.encode_multimodal_input) and needs their number to size the launch
+                        batch[key]._uniir_host = host_mask
                 elif hasattr(value, "to_device"):                                   # clip_front.RawImageBatch
                     batch[key] = value.pin_memory().to_device(self.dev)
                 elif hasattr(value, "input_ids") and hasattr(value, "items"):      # transformers BatchEncoding (BLIP)

@@ -9,6 +9,7 @@ import torch
 from torch import nn
 
 from uniir_amd import clip_front
+from uniir_amd.clip_model import _tensor_version
 from uniir_amd.losses import FuseFn, HardNegNCEFn, InBatchNCEFn
 
 
@@ -44,9 +45,46 @@ class CLIPScoreFusion(nn.Module):
     def fuse_embeddings(self, img_emb, txt_emb):
         return img_emb + txt_emb
 
+    # The reference runs BOTH towers on every item and multiplies by the modality masks (clip_sf.py:53-63); the collator feeds a
+    # black image / an empty caption where a modality is absent (mbeir_dataset.py:427-434).  M-BEIR candidate pools are mostly
+    # single-modality, and the image tower is 92 % of an item's FLOPs, so here each tower runs on the rows whose mask is 1 only
+    # (gather -> tower -> scatter into zeros) and the same fused mask-and-add follows: x * 0 + y == y for finite x, so the result
+    # is bitwise the dense one whenever the dense path's masked-out tower output is finite (tests/test_bench_paths_gpu.py).
+    # Weight gradients lose the exact zeros of the masked rows, i.e. equal the dense ones up to fp32 summation order.
+    compact_masked = True
+
+    @staticmethod
+    def _live_rows(mask):
+        """(None if every row is live, else the int64 HOST index tensor of the live rows).  The host copy of the mask comes from
+        the prefetcher (`mask._uniir_host`, host_utils.DevicePrefetcher) when there is one; otherwise one device -> host read."""
+        host = getattr(mask, "_uniir_host", None)
+        if not isinstance(host, torch.Tensor) or host.is_cuda or host.shape != mask.shape:
+            host = mask.detach().to("cpu")
+        live = torch.nonzero(host != 0).flatten()
+        return None if live.numel() == host.numel() else live
+
+    def _encode_live(self, encode, inp, mask):
+        live_host = self._live_rows(mask)
+        if live_host is None:
+            return encode(inp)
+        live = live_host.to(inp.device, non_blocking=True)
+        sub = inp.index_select(0, live)
+        lens = getattr(inp, "_uniir_lens", None)                        # caption lengths travel with the rows (packed text tower)
+        if isinstance(lens, torch.Tensor) and not lens.is_cuda and lens.dim() == 1 and lens.shape[0] == inp.shape[0] \
+                and _tensor_version(inp) is not None and getattr(inp, "_uniir_lens_version", None) == _tensor_version(inp):
+            sub._uniir_lens = lens[live_host]
+            sub._uniir_lens_version = _tensor_version(sub)
+        emb_live = encode(sub)                                          # [n_live, E]; n_live == 0 is legal
+        full = torch.zeros(inp.shape[0], emb_live.shape[1], device=emb_live.device, dtype=emb_live.dtype)
+        return full.index_copy(0, live, emb_live)                       # differentiable scatter: dead rows stay exact zeros
+
     def encode_multimodal_input(self, txt_tensor, img_tensor, txt_mask, img_mask):
-        txt_emb = self.encode_text(txt_tensor)
-        img_emb = self.encode_image(img_tensor)
+        if self.compact_masked:
+            txt_emb = self._encode_live(self.encode_text, txt_tensor, txt_mask)
+            img_emb = self._encode_live(self.encode_image, img_tensor, img_mask)
+        else:
+            txt_emb = self.encode_text(txt_tensor)
+            img_emb = self.encode_image(img_tensor)
         return FuseFn.apply(txt_emb, img_emb, txt_mask, img_mask)  # txt*mask + img*mask, [batch, embed_dim]
 
     def get_logit_scale(self):
