@@ -89,9 +89,6 @@ int uniir_gemm(const uniir_gemm_desc* d, void* stream);
  * synchronise) returns the sums over the sampled launches: 2 M N K, elapsed ms, count.  Single measuring thread. */
 int uniir_gemm_timing(int32_t stride);
 int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launches);
-/* tuning knob of the 256x256 kernel's start stagger (csrc/gemm.hip): key 0 = phases (0 / 1: off), 1 = estimated
- * ns per 64-wide K step, 2 = estimated ns per epilogue, 3 = minimum tiles per CU.  Host-side state, single configuring thread. */
-int uniir_gemm_tune(int32_t key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] building block 2: LayerNorm over the last dim (fp32 statistics, CLIP eps 1e-5).

@@ -56,7 +56,6 @@ SIGNATURES = {
     "uniir_gemm": (c_int, [C.POINTER(GemmDesc), S]),
     "uniir_gemm_timing": (c_int, [c_int]),
     "uniir_gemm_timing_read": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
-    "uniir_gemm_tune": (c_int, [c_int, c_int]),
     "uniir_layernorm_fwd": (c_int, [P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
     "uniir_layernorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
     "uniir_layernorm_bwd_ex": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, P, P, c_int, c_int, c_float, S]),

@@ -13,12 +13,6 @@
 #ifndef UNIIR_EPI_NT
 #define UNIIR_EPI_NT 1
 #endif
-#ifndef EPI_RESID_PIPE
-#define EPI_RESID_PIPE 0     // RESID_F32 full-tile copy-out: pass 1's operand pieces requested under pass 0's copy-out (0: after it)
-#endif
-#ifndef EPI_DACT_PIPE
-#define EPI_DACT_PIPE 0      // DACT full-tile copy-out: both passes' operand pieces requested before pass 0 is staged
-#endif
 #if UNIIR_EPI_NT
 #define EPI_LD(p) __builtin_nontemporal_load(p)
 #else
@@ -44,8 +38,6 @@ struct GemmKArgs {
     int skip_f;                 // EPI_BIAS_ACT without the pre-activation store (UNIIR_EPI_ACT_ONLY: forward-only passes)
     const float* row_scale;     // EPI_RESID_F32: (v + bias) * row_scale[m] + resid (DropPath factor of the row's item), or nullptr
     float* a_rowsum;            // optional [M]: += sum_k A^T[m][k] (transposed-A ping-pong kernel only, see gemm_core_pp.h)
-    int stag_first, stag_p;     // start stagger (uniir_gemm_tune): the first stag_first workgroups start in stag_p phases,
-    unsigned stag_ticks;        // phase i after i * stag_ticks ticks of s_memrealtime (10 ns); 0 = all at once
 };
 
 // Contraction is switched off inside these two and the one fused multiply-add is written out: the same source then gives the same
@@ -396,18 +388,13 @@ DEVINL void epilogue256_dact8(const GemmKArgs& p, const f32x4_t (&acc)[8][4], in
         d.rowC = (unsigned)p.ldc * 2u;
         d.rowA = (unsigned)p.ldaux * 2u;
         d.src8a = src8a; d.src8b = src8b; d.act = p.act; d.has_c2 = p.C2 != nullptr;
-        u32x4_t fa0[8], fa1[8];        // both passes' operand pieces are requested before anything is staged (64 registers)
+        u32x4_t fa0[8], fa1[8];        // (both requests before pass 0 is staged: measured 2.29 vs 2.25 ms, not kept)
         dact8_request<0>(d, fa0);
-#if EPI_DACT_PIPE
-        dact8_request<1>(d, fa1);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         dact8_pass_full<0>(d, acc, sj, alpha4, w, cs0, cs1, fa0);
-#if !EPI_DACT_PIPE
         __builtin_amdgcn_sched_barrier(0);
         dact8_request<1>(d, fa1);
         __builtin_amdgcn_sched_barrier(0);
-#endif
         dact8_pass_full<1>(d, acc, sj, alpha4, w, cs0, cs1, fa1);
     } else {
 #pragma unroll
@@ -531,24 +518,19 @@ DEVINL void epilogue256_resid_full(const GemmKArgs& p, const f32x4_t (&acc)[8][4
     d.pC2 = HAS_C2 ? (char*)((unsigned short*)p.C2 + tile) + (d.voff >> 1) : nullptr;
     d.rowb = (unsigned)p.ldc * 4u;
     d.row_scale = HAS_SCALE ? p.row_scale + m0 + r0 : nullptr;
-    // order: request pass 0's pieces | stage pass 0 | request pass 1's pieces | copy pass 0 out | stage pass 1 | copy pass 1 out --
-    // the second request travels under the first copy-out (64 + 64 operand registers next to the 64 accumulators still to be staged)
+    // order: request pass 0's pieces | stage pass 0 | copy pass 0 out | request pass 1's pieces | stage pass 1 | copy pass 1 out.
+    // (Measured and dropped: pass 1's request under pass 0's copy-out -- 64 + 64 operand registers next to the 64 accumulators still to
+    // be staged spill ~50 registers, and every spill reload is a load in the same vmcnt queue: out forward 0.81 instead of 0.68 ms.)
     f32x4_t ra[16], rb[16];
     float sa[HAS_SCALE ? 16 : 1], sb[HAS_SCALE ? 16 : 1];
     resid_request<0, HAS_SCALE>(d, ra, sa);
     resid_stage<0>(acc, bv, sj, alpha4, w);
     __builtin_amdgcn_sched_barrier(0);
-#if EPI_RESID_PIPE
-    resid_request<1, HAS_SCALE>(d, rb, sb);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     __syncthreads();
     resid_copy_out<0, HAS_C2, HAS_SCALE>(d, ra, sa, csum);
-#if !EPI_RESID_PIPE
     __builtin_amdgcn_sched_barrier(0);
     resid_request<1, HAS_SCALE>(d, rb, sb);
     __builtin_amdgcn_sched_barrier(0);
-#endif
     __syncthreads();
     resid_stage<1>(acc, bv, sj, alpha4, w);
     __syncthreads();
@@ -774,14 +756,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
         kbeg = split * per * BK;
         kend = min(p.K, (split + 1) * per * BK);
         if (kbeg >= kend) return;
-    }
-    if (p.stag_ticks && (int)blockIdx.x < p.stag_first) {
-        // One workgroup per CU and equal tiles: without this every CU reaches its epilogue at the same moment, the epilogues' HBM
-        // traffic comes in bursts with the matrix pipes idle, and the main loops run with HBM idle.  Phase groups interleave them.
-        const unsigned ph = (blockIdx.x >> 3) % (unsigned)p.stag_p;          // blockIdx & 7 is the XCD: alternate inside an XCD
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz, independent of the shader clock
-        const unsigned long long d = (unsigned long long)ph * p.stag_ticks;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
     }
     f32x4_t acc[8][4];
 #pragma unroll
@@ -1009,36 +983,6 @@ extern "C" int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launche
     return UNIIR_OK;
 }
 
-// Tuning knobs of the 256x256 kernel's start stagger (experiments / bench sweeps; defaults below are what ships)
-static struct {
-    int phases = 0;          // 0 / 1: off
-    int ns_kstep = 1450;     // estimated main-loop time per 64-wide K step
-    int ns_epi = 6000;       // estimated epilogue time of the tile
-    int min_rounds = 6;      // only when a CU runs at least this many tiles (the stagger costs (phases - 1) / phases of a tile at the end)
-} g_tune;
-extern "C" int uniir_gemm_tune(int32_t key, int32_t value) {
-    switch (key) {
-        case 0: g_tune.phases = value; break;
-        case 1: g_tune.ns_kstep = value; break;
-        case 2: g_tune.ns_epi = value; break;
-        case 3: g_tune.min_rounds = value; break;
-        default: return UNIIR_EINVAL;
-    }
-    return UNIIR_OK;
-}
-static int device_cus() {
-    static int cus[64] = {};
-    int d = 0;
-    (void)hipGetDevice(&d);
-    d &= 63;
-    if (!cus[d]) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
-        cus[d] = v;
-    }
-    return cus[d];
-}
-
 static int gemm_impl(const uniir_gemm_desc* d, void* stream);
 extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
     const bool sample = g_gt.stride > 0 && d && (++g_gt.counter % g_gt.stride) == 0 && g_gt.n < GT_MAX;
@@ -1118,17 +1062,6 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     a.colsum = d->colsum;
     a.a_rowsum = nullptr;
     a.asm_loop = 2;
-    a.stag_first = 0; a.stag_p = 1; a.stag_ticks = 0;
-    if (g_tune.phases > 1 && d->k_splits == 1 && gemm_shape(a, d->a_tmaj, d->b_tmaj) == 1) {
-        const int cus = device_cus();
-        const long tiles = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-        if (tiles >= (long)g_tune.min_rounds * cus) {
-            const long period_ns = (long)(d->K / 64) * g_tune.ns_kstep + g_tune.ns_epi;
-            a.stag_first = cus;
-            a.stag_p = g_tune.phases;
-            a.stag_ticks = (unsigned)(period_ns / g_tune.phases / 10);
-        }
-    }
     hipStream_t st = (hipStream_t)stream;
     if (d->k_splits > 1) {
         // never leave a split empty (an empty split would leave its slab unwritten)
