@@ -110,6 +110,60 @@ DEVINL float group_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// MLP activations of the towers and their derivatives (UNIIR_ACT_*: 0 QuickGELU x sigma(1.702 x) -- openai/CLIP model.py; 1 the exact
+// erf-GELU of BLIP's ViT / MED BERT -- vit.py:24-42, med.py:298; 2 ReLU -- T5), evaluated on bf16-rounded inputs, results rounded to
+// bf16 by the callers.
+//  * Contraction is switched off and the one fused multiply-add per formula is written out: the same source then gives the same bits in
+//    every epilogue instantiation it is inlined into (the DACT copy-out exists with and without the act(f) output as two template
+//    instances, and "dx is bitwise the same either way" is a tested property).
+//  * erf-GELU (round 5): Phi(x) = 0.5 erfc(-x / sqrt 2) from Abramowitz-Stegun 7.1.26 on |x| (|error| < 1.5e-7 on erf, i.e. 2^-23 of
+//    the cdf's range: far below the bf16 rounding that follows) -- one v_rcp, one v_exp shared with the density term of the
+//    derivative, seven fma, no branch.  libm's erff is two branchy polynomial ranges + its own exp: the c_proj dgrad epilogue of
+//    BLIP's MLPs took 3.05 ms with it against 2.24 ms for QuickGELU at 263 k x 4096 (tools/r5/epi_forms.py).  The fp32 reference path
+//    (fp32_path.hip) keeps erff.
+// ------------------------------------------------------------------------------------------------------------
+DEVINL float gelu_cdf(float x, float& E) {          // Phi(x); E = exp(-x^2 / 2)
+#pragma clang fp contract(off)
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.23164189f, 1.0f));        // 0.3275911 / sqrt 2
+    const float h = -0.5f * x;
+    E = __expf(h * x);
+    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 1.421413741f);
+    poly = __builtin_fmaf(t, poly, -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.254829592f);
+    const float q = (0.5f * t) * (poly * E);          // 0.5 erfc(|x| / sqrt 2)
+    return x >= 0.0f ? 1.0f - q : q;
+}
+DEVINL float act_fwd(float x, int act) {
+#pragma clang fp contract(off)
+    // __builtin_amdgcn_rcpf: 1 ulp, one instruction (an IEEE division is ~10); the results are rounded to bf16
+    if (act == 0) {
+        const float t = 1.702f * x;
+        return x * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+    }
+    if (act == 1) {
+        float E;
+        return x * gelu_cdf(x, E);
+    }
+    return fmaxf(x, 0.0f);
+}
+DEVINL float act_bwd(float x, int act) {
+#pragma clang fp contract(off)
+    if (act == 0) {
+        const float t = 1.702f * x;
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+        return s * __builtin_fmaf(t, 1.0f - s, 1.0f);
+    }
+    if (act == 1) {
+        float E;
+        const float cdf = gelu_cdf(x, E);
+        return __builtin_fmaf(x * 0.3989422804014327f, E, cdf);
+    }
+    return x > 0.0f ? 1.0f : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Dropout masks: counter-based (no state): element idx of a call with seed s is kept iff fmix32(idx * golden ^ s) >= p * 2^32.
 // The same (seed, idx) regenerates the mask in backward.  keep_scale = 1 / (1 - p) for kept elements, 0 otherwise.
 // ------------------------------------------------------------------------------------------------------------

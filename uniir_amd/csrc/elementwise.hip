@@ -325,11 +325,7 @@ extern "C" int uniir_scatter_rows(const float* dout, const int32_t* idx, float* 
 }
 
 // ---------------------------------------------------------------------------------------------------
-DEVINL float act_fwd_e(float x, int act) {
-    if (act == UNIIR_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
-    if (act == UNIIR_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    return fmaxf(x, 0.0f);
-}
+DEVINL float act_fwd_e(float x, int act) { return act_fwd(x, act); }      // common.h: the GEMM epilogues' function, bit for bit
 __global__ __launch_bounds__(256) void act_fwd_kernel(const u32x4_t* __restrict__ f, u32x4_t* __restrict__ g,
                                                       long nvec, int act) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {

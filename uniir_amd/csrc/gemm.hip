@@ -40,34 +40,7 @@ struct GemmKArgs {
     float* a_rowsum;            // optional [M]: += sum_k A^T[m][k] (transposed-A ping-pong kernel only, see gemm_core_pp.h)
 };
 
-// Contraction is switched off inside these two and the one fused multiply-add is written out: the same source then gives the same
-// bits in every epilogue instantiation they are inlined into (round 5: the DACT copy-out exists with and without the act(f) output as
-// two template instances, and "dx is bitwise the same either way" is a tested property -- with contraction left to the compiler the
-// instance that also computes act(f) shared subexpressions differently and moved dx by an ulp).
-DEVINL float act_fwd(float x, int act) {
-#pragma clang fp contract(off)
-    // __builtin_amdgcn_rcpf: 1 ulp, one instruction (an IEEE division is ~10); the results are rounded to bf16
-    if (act == UNIIR_ACT_QUICKGELU) {
-        const float t = 1.702f * x;
-        return x * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-    }
-    if (act == UNIIR_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    return fmaxf(x, 0.0f);
-}
-DEVINL float act_bwd(float x, int act) {
-#pragma clang fp contract(off)
-    if (act == UNIIR_ACT_QUICKGELU) {
-        const float t = 1.702f * x;
-        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-        return s * __builtin_fmaf(t, 1.0f - s, 1.0f);
-    }
-    if (act == UNIIR_ACT_GELU_ERF) {
-        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-        const float h = -0.5f * x;
-        return __builtin_fmaf(x * 0.3989422804014327f, __expf(h * x), cdf);
-    }
-    return x > 0.0f ? 1.0f : 0.0f;
-}
+// act_fwd / act_bwd: common.h (shared with the stand-alone activation pass of elementwise.hip)
 
 template <int EPI, int MT, int NT>
 DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[MT][NT], int m0, int n0, int wm, int wn) {
@@ -467,7 +440,7 @@ struct ResidFull {
     char *pC, *pC2;              // this thread's first element of the outputs
     unsigned voff, rowb;
     const char* src;
-    const float* row_scale;      // + first row of the thread
+    const float* row_scale;      // + first row of the wave (wave-uniform)
 };
 template <int H, bool HAS_SCALE>
 DEVINL void resid_request(const ResidFull& d, f32x4_t (&r)[16], float (&sc)[HAS_SCALE ? 16 : 1]) {
@@ -517,7 +490,7 @@ DEVINL void epilogue256_resid_full(const GemmKArgs& p, const f32x4_t (&acc)[8][4
     d.pC = (char*)((float*)p.C + tile) + d.voff;
     d.pC2 = HAS_C2 ? (char*)((unsigned short*)p.C2 + tile) + (d.voff >> 1) : nullptr;
     d.rowb = (unsigned)p.ldc * 4u;
-    d.row_scale = HAS_SCALE ? p.row_scale + m0 + r0 : nullptr;
+    d.row_scale = HAS_SCALE ? p.row_scale + m0 + w : nullptr;     // r0 == w: the row is wave-uniform -> scalar loads, no VGPRs
     // order: request pass 0's pieces | stage pass 0 | copy pass 0 out | request pass 1's pieces | stage pass 1 | copy pass 1 out.
     // (Measured and dropped: pass 1's request under pass 0's copy-out -- 64 + 64 operand registers next to the 64 accumulators still to
     // be staged spill ~50 registers, and every spill reload is a load in the same vmcnt queue: out forward 0.81 instead of 0.68 ms.)
@@ -620,11 +593,15 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
     const bool colok = n0 + ch * 4 < p.N;
     const long rstep = 8L * p.ldc, rstep_aux = 8L * p.ldaux;
     f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
-    // (DropPath's row_scale keeps the generic loop: 32 more registers do not fit next to the two passes' operand pieces)
-    const bool resid_fast = PP && epi == UNIIR_EPI_RESID_F32 && full && p.resid != nullptr && p.row_scale == nullptr;
+    const bool resid_fast = PP && epi == UNIIR_EPI_RESID_F32 && full && p.resid != nullptr;
     if (resid_fast) {
-        if (p.C2) epilogue256_resid_full<true, false>(p, acc, bv, sj, m0, n0, lds, csum);
-        else epilogue256_resid_full<false, false>(p, acc, bv, sj, m0, n0, lds, csum);
+        if (p.C2) {
+            if (p.row_scale) epilogue256_resid_full<true, true>(p, acc, bv, sj, m0, n0, lds, csum);
+            else epilogue256_resid_full<true, false>(p, acc, bv, sj, m0, n0, lds, csum);
+        } else {
+            if (p.row_scale) epilogue256_resid_full<false, true>(p, acc, bv, sj, m0, n0, lds, csum);
+            else epilogue256_resid_full<false, false>(p, acc, bv, sj, m0, n0, lds, csum);
+        }
     }
     // (EPI_DACT's operand loads sit in the copy-out loop, four rows at a time: their round trip is the larger half of this
     // epilogue's cost -- c_proj dgrad at ViT-L/14 x 1024 items 2.99 ms against 1.91 plain for 2.2 GB more.  Requesting a pass's 16
