@@ -436,6 +436,28 @@ def _rank_max_seconds(dist, dev, fn, iters):
     return float(t)
 
 
+def _all_ranks_ok(dist, dev, err):
+    """Rank-consistent failure for the N > 1 blocks: every rank reports whether its LOCAL part (allocations, single-device kernels)
+    went through -- err is None or the exception -- and all of them leave the block together before its next collective if one
+    failed.  (A rank that raised on its own would move on to the next block while the others wait in a collective.)"""
+    flag = torch.tensor([0.0 if err is None else 1.0], device=dev if dist.get_backend() != "gloo" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if float(flag) > 0:
+        raise RuntimeError(f"local setup failed on {'this' if err is not None else 'another'} rank"
+                           + (f": {type(err).__name__}: {err}" if err is not None else ""))
+
+
+def _local(dist, dev, fn):
+    """run the rank-local part fn(); agree with the other ranks on success before returning its result"""
+    err, res = None, None
+    try:
+        res = fn()
+    except Exception as e:
+        err = e
+    _all_ranks_ok(dist, dev, err)
+    return res
+
+
 def bench_retrieval_sharded(dist, dev, rank, world, rows=700_000, d=768, k=10, qcounts=(64, 1024, 100_000), check=False):
     """configs[3] across the ranks (mbeir_retriever.py:96-100, co.shard = True): every rank holds a `rows` x 768 fp16 shard of the
     pool resident in HBM (ids disjoint), the job's queries are split contiguously over the ranks, and
@@ -444,25 +466,31 @@ def bench_retrieval_sharded(dist, dev, rank, world, rows=700_000, d=768, k=10, q
     and the three exchange / merge pieces timed alone on the same shapes.  check=True (tests): the distributed result must equal
     one search over the concatenated pool."""
     from uniir_amd import comm, retrieval
-    g = torch.Generator(device=dev).manual_seed(2023 + rank)
-    pool = torch.randn(rows, d, generator=g, device=dev).half()
-    ids = torch.arange(rows, device=dev, dtype=torch.int64) + rank * rows
-    shard = retrieval.PoolShard(pool, ids)
+    def build():
+        g = torch.Generator(device=dev).manual_seed(2023 + rank)
+        pool = torch.randn(rows, d, generator=g, device=dev).half()
+        ids = torch.arange(rows, device=dev, dtype=torch.int64) + rank * rows
+        return pool, ids, retrieval.PoolShard(pool, ids)
+
+    pool, ids, shard = _local(dist, dev, build)
     n_total = rows * world
     seen = torch.ones(1, device=dev)
     comm.allreduce_sum_(seen)
     out = {"ranks_seen": int(seen.item()), "rows_per_rank": rows, "pool_rows": n_total, "dim": d, "k": k}
     for nq in qcounts:
-        gq = torch.Generator(device=dev).manual_seed(7 + nq)          # the same global query set on every rank; each keeps its slice
-        allq = torch.randn(nq, d, generator=gq, device=dev).half()
         lo, hi = comm.contiguous_shard(nq, world, rank)
-        myq = allq[lo:hi].contiguous()
+
+        def queries():
+            gq = torch.Generator(device=dev).manual_seed(7 + nq)      # the same global query set on every rank; each keeps its slice
+            allq = torch.randn(nq, d, generator=gq, device=dev).half()
+            return allq, allq[lo:hi].contiguous(), retrieval.search_shard(shard, allq, k)     # (+ the local search: it allocates)
+
+        allq, myq, (loc_s, loc_i) = _local(dist, dev, queries)
         res = retrieval.search_resident(shard, myq, k)                  # warm-up (workspace, attributes)
         iters = 5 if nq <= 1024 else 1
         t = _rank_max_seconds(dist, dev, lambda: retrieval.search_resident(shard, myq, k), iters)
         # the pieces, alone, on this search's shapes
         t_q = _rank_max_seconds(dist, dev, lambda: comm.all_gather_varlen(myq), 3)
-        loc_s, loc_i = retrieval.search_shard(shard, allq, k)
         t_g = _rank_max_seconds(dist, dev, lambda: comm.gather_topk(loc_s, loc_i), 3)
         gs, gi = comm.gather_topk(loc_s, loc_i)
         t_m = _rank_max_seconds(dist, dev, lambda: retrieval.merge_shards(gs, gi), 3)
@@ -490,10 +518,17 @@ def bench_embed_sharded(dist, dev, world, model_name, items=2048, steps=3):
     every rank encodes `items` synthetic items per batch forward-only; items/s summed over the ranks = world x items / max time"""
     from models.uniir_clip.clip_scorefusion.clip_sf import CLIPScoreFusion
     from uniir_amd.clip_model import CLIP_CONFIGS
-    model = CLIPScoreFusion(model_name=model_name, device=dev).float().eval()
     cfg = CLIP_CONFIGS[model_name]
-    batch = synth_batch(cfg, items // 2, 2023, dev)
-    batch["did_list"] = list(range(items))
+
+    def build():
+        m = CLIPScoreFusion(model_name=model_name, device=dev).float().eval()
+        b = synth_batch(cfg, items // 2, 2023, dev)
+        b["did_list"] = list(range(items))
+        with torch.no_grad():
+            m(b, encode_mbeir_batch=True)            # the first pass allocates the workspace
+        return m, b
+
+    model, batch = _local(dist, dev, build)
     host_tok = batch["txt_batched"].cpu()
     attach_caption_lengths(batch["txt_batched"], host_tok)
     executed = VISION_FLOP_PER_ITEM_FWD[model_name] + (text_flop_per_item_fwd(cfg, host_tok) if model.clip_model.pack_text
@@ -885,6 +920,7 @@ def main():
                        "final_loss": round(loss, 4),
                        "mlp_stash": (None if args.dry_run else
                                      {k: ("f + act(f)" if v else "f") for k, v in model.clip_model.last_stash_act.items()}),
+                       "mlp_stash_decisions": (None if args.dry_run else list(model.clip_model.stash_log)),
                        "peak_mem_GB": (round(torch.cuda.max_memory_allocated(dev) / 1e9, 1) if dev.type == "cuda" else None),
                        "batch": (f"{ROTATE} synthetic caption batches per rank (distinct token tensors; captions [SOT, L ids, EOT] with "
                                  "L ~ U{5..60}, 7..62 live positions of 77) rotated through the timed steps over ONE shared image "

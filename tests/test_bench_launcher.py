@@ -105,3 +105,28 @@ def test_bench_two_ranks_sharing_the_gpu():
     em = r["embed"]
     assert "error" not in em, em
     assert em["items_per_batch_per_rank"] == 64 and em["out_shape"] == [64, 512] and em["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """Round 5: the first box that shows two GPUs runs the multi-rank bench over RCCL (backend "nccl", one rank per device) UNDER A
+    CHECKER before any 8-GPU measurement does: ranks seen, replicas identical after the timed steps, the sharded search equal to the
+    single-shard search, every collective timed.  Skipped on the one-GPU boxes of this environment (the shared-GPU gloo test above
+    covers the same code path there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (RCCL puts one rank on each)")
+    p, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "16", "--model", "ViT-B/32", "--no-cpu-baseline",
+                     "--shard-rows", "40030", "--shard-queries", "64,300", "--embed-items", "64", "--check-sharded"],
+                    {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, (lines, p.stderr[-2000:])
+    r = json.loads(lines[0])
+    rc = r["rccl"]
+    assert r["n_gpus"] == 2 and rc["backend"] == "nccl" and rc["ranks_seen"] == 2 and rc["replicas_identical"] is True
+    for k in ("all_gather_p_ms", "reduce_scatter_dp_ms", "all_reduce_grads_ms"):
+        assert rc[k] > 0
+    rt = r["retrieval"]
+    assert "error" not in rt and rt["ranks_seen"] == 2
+    assert all(rt[key]["equals_single_shard_search"] is True for key in ("q64", "q300"))
+    assert "error" not in r["embed"] and r["embed"]["value"] > 0

@@ -76,10 +76,11 @@ def test_topk_full_shard_properties(nq, n):
 @pytest.mark.parametrize("nq", [64, 1024])
 def test_topk_whole_mbeir_pool_on_one_gpu(nq):
     """BASELINE configs[3] as written on ONE GPU (mbeir_retriever.py:196-206 with a single visible device; README.md:126: 5.6 M
-    candidates): a 5.6 M x 768 fp16 pool (8.6 GB) resident as ONE PoolShard.  retrieval.search_shard searches it as 5 logical
-    sub-shards (each below the 2-GiB buffer bound, on the streaming scans) + uniir_topk_merge; checked by the size-independent
-    properties (order, valid unique ids, planted neighbours at rank 1, the C oracle's exact scores on the returned rows) and
-    against the merge of 8 x 700 k searches (the 8-GPU partitioning of the same pool), bit for bit"""
+    candidates): a 5.6 M x 768 fp16 pool (8.6 GB) resident as ONE PoolShard.  retrieval.search_shard searches it as 8 logical
+    sub-shards of 700 000 rows (below the 2-GiB buffer bound and within the fused tail's rows: round 5) + uniir_topk_merge; checked
+    by the size-independent properties (order, valid unique ids, planted neighbours at rank 1, the C oracle's exact scores on the
+    returned rows) and against the merge of 5 x 1.12 M-row searches (another partitioning of the same pool, which runs the UNFUSED
+    tail: separate selection and re-score kernels), bit for bit"""
     from oracle import c_oracle
     from uniir_amd import retrieval
     n, d, k = 5_600_000, 768, 10
@@ -93,7 +94,7 @@ def test_topk_whole_mbeir_pool_on_one_gpu(nq):
     ids = torch.arange(n, device=DEV, dtype=torch.int64) * 3 + 7
     shard = retrieval.PoolShard(pool, ids)
     bounds = retrieval.subshard_bounds(n, d)
-    assert len(bounds) == 5 and all((hi - lo) * d * 2 < 2 ** 31 and lo % 16 == 0 for lo, hi in bounds) and bounds[-1][1] == n
+    assert len(bounds) == 8 and all((hi - lo) * d * 2 < 2 ** 31 and lo % 32 == 0 for lo, hi in bounds) and bounds[-1][1] == n
     s, i = retrieval.search_shard(shard, queries, k)
     sc, ic = s.cpu().numpy(), i.cpu().numpy()
     assert (np.diff(sc, axis=1) <= 0).all()
@@ -104,7 +105,7 @@ def test_topk_whole_mbeir_pool_on_one_gpu(nq):
         rows = (i[qi] - 7) // 3
         ws, wi = c_oracle.topk(pool[rows].cpu().numpy(), ids[rows].cpu().numpy(), queries[qi:qi + 1].cpu().numpy(), k)
         assert np.array_equal(wi[0], ic[qi]) and np.array_equal(ws[0], sc[qi])
-    parts = [retrieval.search_shard(retrieval._shard_view(shard, lo, lo + 700_000), queries, k) for lo in range(0, n, 700_000)]
+    parts = [retrieval.search_shard(retrieval._shard_view(shard, lo, lo + 1_120_000), queries, k) for lo in range(0, n, 1_120_000)]
     ms, mi = retrieval.merge_shards(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(ms, s) and torch.equal(mi, i)
 
@@ -142,7 +143,7 @@ def test_topk_700k_pool_of_clip_base_width():
 
 def test_topk_c_abi_refuses_shards_of_2_gib():
     """uniir_topk_ip addresses a shard through 31-bit buffer offsets: rows * dim * 2 >= 2 GiB is UNIIR_ESHAPE at the C ABI (never
-    a silent slower path); 1 398 096 rows x 768 (the largest sub-shard retrieval.subshard_bounds produces) is accepted"""
+    a silent slower path); 1 398 096 rows x 768 (the largest single shard retrieval.subshard_bounds leaves whole) is accepted"""
     from uniir_amd import _lib, retrieval
     lib = _lib.load()
     d, k, nq = 768, 10, 8

@@ -464,10 +464,11 @@ def test_config_loader_takes_the_full_key_set_of_the_reference_yamls(tmp_path):
 
 
 def test_logical_sub_shards_of_a_resident_pool():
-    """retrieval.subshard_bounds (round 4): the row ranges a resident shard is searched in.  uniir_topk_ip addresses a shard through
-    31-bit buffer offsets, so every range stays below 2 GiB, starts on a 16-row boundary (aligned inverse norms, whole scan groups),
-    the ranges are equal (the last one shorter) and cover the shard exactly; the 5.6 M x 768 M-BEIR pool on one GPU
-    (mbeir_retriever.py:196-206 with a single visible device) is 5 of them"""
+    """retrieval.subshard_bounds (round 4 / 5): the row ranges a resident shard is searched in.  uniir_topk_ip addresses a shard through
+    31-bit buffer offsets, so every range stays below 2 GiB, starts on a 32-row boundary (aligned inverse norms, an even number of
+    whole scan groups) and -- round 5 -- holds at most the 786 432 rows the fused tail's register-resident selection takes; the
+    ranges are equal (the last one shorter) and cover the shard exactly; the 5.6 M x 768 M-BEIR pool on one GPU
+    (mbeir_retriever.py:196-206 with a single visible device) is 8 ranges of 700 000 rows"""
     from uniir_amd import retrieval
     assert retrieval.subshard_bounds(700_000, 768) == [(0, 700_000)]
     assert retrieval.subshard_bounds(1_398_096, 768) == [(0, 1_398_096)]          # 2^31 - 4 608 bytes
@@ -475,10 +476,11 @@ def test_logical_sub_shards_of_a_resident_pool():
     for n, d in ((5_600_000, 768), (5_600_001, 768), (1_398_112, 768), (9_000_000, 512), (2_100_000, 1024), (40_000_000, 64)):
         b = retrieval.subshard_bounds(n, d)
         assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
-        assert all(lo % 16 == 0 and 0 < (hi - lo) * d * 2 < 2 ** 31 for lo, hi in b)
+        assert all(lo % 32 == 0 and 0 < (hi - lo) * d * 2 < 2 ** 31 and hi - lo <= retrieval.FUSED_TAIL_ROWS for lo, hi in b)
         assert len({hi - lo for lo, hi in b[:-1]}) <= 1 and b[-1][1] - b[-1][0] <= b[0][1] - b[0][0]
-        assert len(b) == -(-n // (((2 ** 31 - 1) // (d * 2)) // 16 * 16)) or len(b) == -(-n * d * 2 // (2 ** 31 - 1))
-    assert len(retrieval.subshard_bounds(5_600_000, 768)) == 5
+        cap = min(((2 ** 31 - 1) // (d * 2)) // 32 * 32, retrieval.FUSED_TAIL_ROWS)
+        assert len(b) == -(-n // cap)                   # as few ranges as the two bounds allow
+    assert retrieval.subshard_bounds(5_600_000, 768) == [(lo, lo + 700_000) for lo in range(0, 5_600_000, 700_000)]
 
 
 def test_text_row_offsets_of_a_token_batch():

@@ -153,8 +153,16 @@ class CLIP(nn.Module):
         self.pack_text = True
         # act(f) of every MLP kept per layer by the forward (uniir_clip_tower.stash_act) instead of being re-materialised by the c_proj
         # dgrad epilogue: +2 B x rows x 4 width per layer of workspace (52 GB at ViT-L/14 x 1024 items), bitwise the same results.
-        # None = when the workspace still fits the device's free memory with 16 GiB to spare, True / False = forced.
+        # None = automatic, True / False = forced.  Automatic: decided ONCE per tower -- at the first training forward, from
+        # the device's free memory with stash_margin_bytes to spare -- and then kept (the choice moves weight-gradient bits by fp32
+        # summation order, so a run must not flip it from step to step or differ between ranks: see review_stash for W > 1);
+        # an out-of-memory error on the stash allocation re-plans that tower without it; review_stash() revisits the choice after the
+        # first complete step, when collectives' buffers and the optimizer state exist.
         self.stash_act = None
+        self.stash_margin_bytes = 16 << 30
+        self.stash_review_headroom_bytes = 6 << 30
+        self._stash_choice = {}           # tower -> bool: the automatic decision, made once (at the first training batch)
+        self.stash_log = []               # human-readable record of every decision (bench.py prints it)
         self.last_stash_act = {}          # tower -> what the last training forward chose
         self.last_text_rows = None      # (live rows, dense rows) of the last packed text-tower call (bench: executed FLOPs)
 
@@ -308,6 +316,33 @@ class CLIP(nn.Module):
                     p.grad = self.grad_view(n)
         else:
             super().zero_grad(set_to_none=set_to_none)
+
+    def review_stash(self, all_reduce_min=None):
+        """Call after the first COMPLETE training step (trainer.NativeTrainer does): the automatic act(f) stash was sized before the
+        first backward, i.e. before RCCL's channel buffers, the reducer's in-flight buckets and the optimizer state existed.  If the
+        step's measured peak (torch's peak + what lives outside torch's allocator on this device) leaves less than
+        stash_review_headroom_bytes of the device, the stash is switched off for the following steps -- on EVERY rank when
+        all_reduce_min (a callable reducing a python float with MIN over the ranks) is given, so that replicas keep computing bitwise
+        the same gradients.  Returns the headroom in bytes (None when nothing was decided automatically)."""
+        if self.stash_act is not None or not any(self._stash_choice.values()) or self._flat is None:
+            return None
+        dev = self._flat["dev"]
+        free, total = torch.cuda.mem_get_info(dev)
+        outside = total - free - torch.cuda.memory_reserved(dev)          # other processes / RCCL / HIP runtime on this device
+        headroom = float(total - outside - torch.cuda.max_memory_allocated(dev))
+        agreed = 1.0 if all(self._stash_choice.values()) else 0.0
+        if all_reduce_min is not None:          # one mode on every rank from here on
+            headroom = float(all_reduce_min(headroom))
+            agreed = float(all_reduce_min(agreed))
+        if headroom < self.stash_review_headroom_bytes or agreed == 0.0:
+            for k in self._stash_choice:
+                self._stash_choice[k] = False
+            self.stash_log.append(f"act(f) stash switched off after the first step: measured headroom {headroom / 2**30:.1f} GiB "
+                                  f"(floor {self.stash_review_headroom_bytes / 2**30:.0f} GiB), ranks agreed on the stash: {bool(agreed)}")
+        else:
+            self.stash_log.append(f"act(f) stash kept after the first step: measured headroom {headroom / 2**30:.1f} GiB "
+                                  f"(peak {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB in torch, {outside / 2**30:.1f} GiB outside)")
+        return headroom
 
     # ---- public encoder API (upstream names) ---------------------------------------------------------------------
     @property
@@ -561,31 +596,57 @@ class _TowerFn(torch.autograd.Function):
                 return lib.uniir_clip_tower_workspace_bytes(C.byref(desc), M, int(need_grad))
 
             stash = False
+            auto = False
             if need_grad and model.stash_act is not False:
                 stash = True
-                if model.stash_act is None:        # automatic: only where the larger stash leaves 16 GiB of the device free
-                    free, _ = torch.cuda.mem_get_info(dev)
-                    avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-                    stash = ws_bytes(True) + (16 << 30) <= avail
+                if model.stash_act is None:        # automatic: decided once per (tower, batch), see CLIP.__init__
+                    auto = True
+                    key = which
+                    if key not in model._stash_choice:
+                        free, _ = torch.cuda.mem_get_info(dev)
+                        avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                        need_stash = ws_bytes(True)
+                        model._stash_choice[key] = need_stash + model.stash_margin_bytes <= avail
+                        model.stash_log.append(f"{which} tower, {M} items: act(f) stash {'ON' if model._stash_choice[key] else 'off'} "
+                                               f"(workspace {need_stash / 2**30:.1f} GiB, {avail / 2**30:.1f} GiB available, margin "
+                                               f"{model.stash_margin_bytes / 2**30:.0f} GiB)")
+                    stash = model._stash_choice[key]
             desc.stash_act = int(stash)
             model.last_stash_act[which] = bool(stash)
+
+            def alloc_ws(nbytes_of):
+                """the tower workspace; when the automatic act(f) stash does not fit after all, re-plan this tower without it"""
+                nonlocal stash
+                try:
+                    n = nbytes_of()
+                    return n, (torch.empty(n, device=dev, dtype=torch.uint8) if n >= 0 else None)
+                except torch.OutOfMemoryError:
+                    if not (auto and stash):
+                        raise
+                    torch.cuda.empty_cache()
+                    stash = False
+                    model._stash_choice[which] = False
+                    model.last_stash_act[which] = False
+                    desc.stash_act = 0
+                    model.stash_log.append(f"{which} tower, {M} items: act(f) stash dropped after an out-of-memory error on its allocation")
+                    n = nbytes_of()
+                    return n, (torch.empty(n, device=dev, dtype=torch.uint8) if n >= 0 else None)
+
             if which == "text" and model.pack_text:
                 # exact packing: only the tokens up to each caption's EOT are rows of the text tower (text_row_offsets)
                 row_off, live = text_row_offsets(inp)
-                need = lib.uniir_clip_tower_workspace_bytes_packed(C.byref(desc), M, live, int(need_grad))
+                need, ws = alloc_ws(lambda: lib.uniir_clip_tower_workspace_bytes_packed(C.byref(desc), M, live, int(need_grad)))
                 if need < 0:
                     raise RuntimeError("uniir_clip_tower: unsupported tower geometry")
-                ws = torch.empty(need, device=dev, dtype=torch.uint8)
                 _lib.check(lib.uniir_clip_tower_fwd_packed(C.byref(desc), inp.data_ptr(), M, row_off.data_ptr(), live, emb.data_ptr(),
                                                            ws.data_ptr(), need, int(need_grad), ops._stream()), "clip_tower_fwd_packed")
                 model.last_text_rows = (live, M * cfg["context_length"])
                 if need_grad:
                     ctx.stash = dict(ws=ws, inp=inp, ctower=True, row_off=row_off, live=live, stash_act=int(stash))
                 return emb
-            need = lib.uniir_clip_tower_workspace_bytes(C.byref(desc), M, int(need_grad))
+            need, ws = alloc_ws(lambda: lib.uniir_clip_tower_workspace_bytes(C.byref(desc), M, int(need_grad)))
             if need < 0:
                 raise RuntimeError("uniir_clip_tower: unsupported tower geometry")
-            ws = torch.empty(need, device=dev, dtype=torch.uint8)
             inp = inp.float().contiguous() if which == "image" else inp
             _lib.check(lib.uniir_clip_tower_fwd(C.byref(desc), inp.data_ptr(), M, emb.data_ptr(), ws.data_ptr(), need,
                                                 int(need_grad), ops._stream()), "clip_tower_fwd")

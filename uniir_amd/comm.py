@@ -20,6 +20,17 @@ def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
+def all_reduce_min_float(x, device=None):
+    """MIN of a python float over the ranks (a rank-consistent decision from per-rank measurements)"""
+    if world() == 1:
+        return float(x)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
 def all_gather_rows(p):
     """[b, E] on every rank -> [W*b, E], rank-major (== torch.cat(all_gather(p), dim=0))."""
     W = world()

@@ -53,30 +53,50 @@ def _shard_view(shard, lo, hi):
 
 
 SUBSHARD_BYTES = 1 << 31     # the streaming scans and the fused tail address a shard's rows through 31-bit buffer offsets
+FUSED_TAIL_ROWS = 1024 * 2 * 24 * 16     # csrc/topk_select.h: the register-resident selection of the fused tail holds 1024 x 2 x
+                                         # TK_SELREG group maxima = 49 152 groups of 16 rows = 786 432 rows
 
 
 def subshard_bounds(n, dim):
     """Row ranges of the LOGICAL sub-shards a resident shard is searched in: one range while n * dim * 2 < 2 GiB, else equal ranges
-    (starting on 16-row boundaries: aligned inverse norms, whole scan groups) that each stay below it -- 1 398 096 rows at dim 768.
-    The 5.6 M x 768 M-BEIR pool on ONE GPU (8.6 GB, mbeir_retriever.py:196-206 with a single visible device) is 5 such ranges."""
+    (on 32-row boundaries: aligned inverse norms, an even number of whole scan groups) that each stay below it AND within the fused
+    tail's 786 432 rows.  Round 5: the ranges used to be as large as the 2-GiB bound allows (1.12 M rows at dim 768), which put every
+    sub-shard search on the unfused tail (separate selection + re-score launches, strided passes over the group maxima) -- the
+    16-19 % per-row penalty of the 256-query sweeps on the 5.6 M pool (12.3 ms for 1024 queries against 8 x 1.29).  The 5.6 M x 768
+    M-BEIR pool on ONE GPU (8.6 GB, mbeir_retriever.py:196-206 with a single visible device) is 8 ranges of 700 000 rows -- the shards
+    of the 8-GPU layout."""
     if n * dim * 2 < SUBSHARD_BYTES:
         return [(0, n)]
-    max_rows = ((SUBSHARD_BYTES - 1) // (dim * 2)) // 16 * 16
+    max_rows = min(((SUBSHARD_BYTES - 1) // (dim * 2)) // 32 * 32, FUSED_TAIL_ROWS)
     parts = -(-n // max_rows)
-    per = -(-(-(-n // parts)) // 16) * 16
+    per = -(-(-(-n // parts)) // 32) * 32
     return [(lo, min(lo + per, n)) for lo in range(0, n, per)]
 
 
-_WS_CACHE = {}     # device index -> workspace tensor (grown on demand): a search allocates nothing in steady state
+# (device index, stream handle) -> workspace tensor, grown on demand: a search allocates nothing in steady state.  Keyed by the
+# stream the search runs on: two searches on different streams of one device get different scratch (group maxima, candidates), and a
+# grown buffer replaces one that only its own stream has used -- the caching allocator re-issues the old block in stream order.
+# Scratch above WS_CACHE_MAX_BYTES (a 100 000-query bulk search asks for more) is a plain per-call allocation and goes back to the
+# allocator with the call; release_workspaces() drops everything (long-lived processes that search once).
+_WS_CACHE = {}
+WS_CACHE_MAX_BYTES = 1 << 30
 
 
 def _workspace(dev, need):
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if need > WS_CACHE_MAX_BYTES:
+        return torch.empty(need, device=dev, dtype=torch.uint8)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=dev, dtype=torch.uint8)
         _WS_CACHE[key] = ws
     return ws
+
+
+def release_workspaces():
+    """drop the cached search scratch of every device / stream"""
+    _WS_CACHE.clear()
 
 
 def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None, workspace=None):

@@ -156,6 +156,7 @@ class NativeTrainer:
         self.sched = CosineLR(self.opt, t_total)
         self.accum = accumulation_steps
         self.micro = 0
+        self._stash_reviewed = False
 
     def train_step(self, batch):
         """one micro-batch: returns the reference's outputs dict (loss un-scaled, as logged by engine.py:48)."""
@@ -170,4 +171,9 @@ class NativeTrainer:
             self.opt.step()
             self.sched.step()
             self.micro = 0
+            if not self._stash_reviewed:          # once, after the first complete step (clip_model.CLIP.review_stash)
+                self._stash_reviewed = True
+                clip = getattr(self.model, "clip_model", None)
+                if clip is not None and hasattr(clip, "review_stash"):
+                    clip.review_stash(comm.all_reduce_min_float if comm.world() > 1 else None)
         return out
