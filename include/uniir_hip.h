@@ -446,6 +446,15 @@ int64_t uniir_topk_ip_workspace_bytes_ex(int32_t nq, int32_t k, int64_t rows, in
 int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
                   int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
                   int64_t* out_ids, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same for ONE resident shard of any size (round 5) -- the whole 5.6 M x 768 M-BEIR pool on one GPU: equal logical sub-shards of
+ * uniir_topk_subshard_rows(rows, dim) rows (a multiple of 32, below the 2-GiB buffer bound and within the fused tail's 786 432 rows;
+ * = rows when the shard needs no cut), per sweep one scan launch per sub-shard, then ONE fused tail, ONE sort and ONE merge launch
+ * for all of them; identical to the merge of per-sub-shard uniir_topk_ip searches, bit for bit.  pool_ids must be given (unique). */
+int64_t uniir_topk_subshard_rows(int64_t rows, int32_t dim);
+int64_t uniir_topk_ip_multi_workspace_bytes(int32_t nq, int32_t k, int64_t rows, int32_t dim);
+int uniir_topk_ip_multi(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
+                        int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
+                        int64_t* out_ids, void* workspace, int64_t workspace_bytes, void* stream);
 /* queries per sweep inside uniir_topk_ip: 0 (default) = automatic -- 256 where the streaming scan applies (dim 768, >= 32768 rows,
  * shard < 2 GiB), else 1024 = the maximum.  Results never depend on it: the hook exists so that tests can drive the sweep loop with
  * small inputs, and for tuning.  Process-wide host setting.  uniir_topk_ip_sweep_queries: the value a search of this shape uses. */

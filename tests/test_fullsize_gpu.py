@@ -295,3 +295,36 @@ def test_config1_vit_b32_step_against_the_oracle():
     bad = {n: r for n, r in ratio.items() if r[2] > 4.0}
     assert not bad, bad
     assert sorted(r[2] for r in ratio.values())[len(ratio) // 2] < 1.5
+
+
+@pytest.mark.parametrize("n", [1_500_032, 1_500_016])
+def test_topk_ip_multi_equals_the_merge_of_sub_shard_searches(n):
+    """uniir_topk_ip_multi (round 5): one resident shard above the 2-GiB buffer bound is searched in ONE C call -- a scan per logical
+    sub-shard, then one batched tail, one sort, one merge launch -- and must equal the merge of stand-alone searches of the same row
+    ranges bit for bit; 64 queries (interactive scan) and 300 (two 256-query sweeps).  n = 1 500 016 leaves a last sub-shard with an
+    odd number of 16-row groups, which the batched tail does not take: the entry point's per-sub-shard fallback loop runs instead."""
+    from uniir_amd import _lib, retrieval
+    d, k = 768, 10
+    lib = _lib.load()
+    per = int(lib.uniir_topk_subshard_rows(n, d))
+    bounds = retrieval.subshard_bounds(n, d)
+    assert len(bounds) == 2 and bounds[0] == (0, per) and per % 32 == 0
+    assert ((n - per + 15) // 16) % 2 == (0 if n == 1_500_032 else 1)
+    assert int(lib.uniir_topk_subshard_rows(5_600_000, d)) == 700_000 and int(lib.uniir_topk_subshard_rows(700_000, d)) == 700_000
+    g = torch.Generator(device=DEV).manual_seed(n % 1000)
+    pool = torch.empty(n, d, device=DEV, dtype=torch.float16)
+    for lo in range(0, n, 500_000):
+        m = min(500_000, n - lo)
+        pool[lo:lo + m] = torch.randn(m, d, device=DEV, generator=g).half()
+    ids = torch.randperm(n, device=DEV, generator=g).to(torch.int64) * 5 + 1
+    shard = retrieval.PoolShard(pool, ids)
+    for nq in (64, 300):
+        queries = torch.randn(nq, d, device=DEV, generator=g).half()
+        where = torch.randperm(n, device=DEV, generator=g)[:nq]
+        pool[where] = (queries.float() * 2.0).half()
+        shard = retrieval.PoolShard(pool, ids)
+        s, i = retrieval.search_shard(shard, queries, k)
+        parts = [retrieval.search_shard(retrieval._shard_view(shard, lo, hi), queries, k) for lo, hi in bounds]
+        ms, mi = retrieval.merge_shards(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+        assert torch.equal(s, ms) and torch.equal(i, mi), nq
+        assert torch.equal(i[:, 0], ids[where])

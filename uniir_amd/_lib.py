@@ -137,6 +137,9 @@ SIGNATURES = {
     "uniir_topk_set_chunk": (c_int, [c_int]),
     "uniir_topk_ip_sweep_queries": (c_int, [c_int, c_i64]),
     "uniir_topk_ip": (c_int, [P, P, P, c_i64, c_int, P, c_int, c_int, P, P, P, c_i64, S]),
+    "uniir_topk_subshard_rows": (c_i64, [c_i64, c_int]),
+    "uniir_topk_ip_multi_workspace_bytes": (c_i64, [c_int, c_int, c_i64, c_int]),
+    "uniir_topk_ip_multi": (c_int, [P, P, P, c_i64, c_int, P, c_int, c_int, P, P, P, c_i64, S]),
 }
 
 _lib = None

@@ -28,7 +28,20 @@ DEVINL void tkr_wait_vm() {
 
 // topk_tail.hip: can the fused tail (selection + query norm + exact re-score | sort) serve this search / launch it behind a finished
 // scan (dense gmax [+ wave maxima]); false when the shape does not fit the fused kernels
+// Batched tail (round 5, uniir_topk_ip_multi): ONE tail launch + ONE sort launch serve the scans of all sub-shards of a resident pool
+// that is larger than the 31-bit buffer bound -- workgroup (query, part, z) works on sub-shard z = rows [z per, min((z + 1) per,
+// rows_total)) with its own descriptors (every sub-shard stays below 2 GiB), its own group / wave maxima and candidate regions; the
+// sort writes one k-list per (sub-shard, query) and uniir_topk_merge's kernel combines them.  per == 0: a plain single-shard tail.
+struct TkMulti {
+    long per;          // rows per sub-shard (a multiple of 32)
+    long rows_total;
+    long g_stride;     // floats between the sub-shards' group-maxima regions  [nq][ngroups of a full sub-shard]
+    long w_stride;     // floats between their wave-maxima regions
+    long c_stride;     // entries between their cand / exact regions           [nq][gcap * 16]
+    long o_stride;     // entries between their output lists                   [nq][k]
+};
 bool fused_tail_ok(int64_t rows, int32_t dim, int32_t kc);
 bool launch_fused_tail(const void* pool_f16, const float* pinv, const int64_t* pool_ids, int64_t rows, int32_t dim,
                        const void* queries_f16, int32_t nq, int32_t kc, int32_t k, const float* gmax, int32_t* cand,
-                       float* exact, float* out_scores, int64_t* out_ids, hipStream_t st, const float* wmax, int nw);
+                       float* exact, float* out_scores, int64_t* out_ids, hipStream_t st, const float* wmax, int nw,
+                       const TkMulti* mu = nullptr, int nsub = 1);

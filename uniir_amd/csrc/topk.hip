@@ -1380,3 +1380,124 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
     }
     return UNIIR_OK;
 }
+
+// -------------------------------------------------------------------------------------------------------------
+// uniir_topk_ip_multi (round 5): the search of ONE resident shard of any size -- the whole 5.6 M x 768 M-BEIR pool on one GPU
+// (mbeir_retriever.py:196-206 with a single visible device; README.md:126).  The streaming scans and the gather address rows through
+// 31-bit buffer offsets and the fused tail selects from at most 786 432 rows, so the shard is cut into equal LOGICAL sub-shards
+// (uniir_topk_subshard_rows: a multiple of 32 rows, below both bounds; nothing is copied) and per sweep of queries
+//   one scan launch PER sub-shard (its own 64-bit base, its own group / wave maxima region)  -- the pool is still read exactly once,
+//   ONE fused tail launch for all sub-shards (workgroup (query, part, sub-shard), TkMulti),
+//   ONE sort launch (a k-list per (sub-shard, query)),
+//   ONE merge launch on (score desc, id asc) -- uniir_topk_merge's kernel; ids are unique, so this IS the search of the whole shard.
+// Round 4 ran the three launches of uniir_topk_ip per sub-shard from the host and merged at the end: 5 x (27 + 8) us of latency-bound
+// tails behind 5 scans (64 queries: 1.88 ms = 0.571 of 8 TB/s over the 8.6-GB pool); here the tails of all sub-shards run side by side.
+// A shape the batched tail does not take (a last sub-shard with an odd number of groups, k + 8 > 64 ...) falls back to exactly that
+// loop -- same results.  A shard below both bounds is one uniir_topk_ip call.
+// -------------------------------------------------------------------------------------------------------------
+extern "C" int64_t uniir_topk_subshard_rows(int64_t rows, int32_t dim) {
+    if (rows <= 0 || dim <= 0) return 0;
+    if (rows * (int64_t)dim * 2 < ((int64_t)1 << 31)) return rows;
+    const int64_t fused = 1024L * 2 * TK_SELREG * TK_G;                       // the fused tail's register-resident selection
+    int64_t cap = ((((int64_t)1 << 31) - 1) / ((int64_t)dim * 2)) / 32 * 32;
+    if (cap > fused) cap = fused;
+    const int64_t parts = (rows + cap - 1) / cap;
+    return ((rows + parts - 1) / parts + 31) / 32 * 32;
+}
+static int64_t tkm_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
+struct TkmPlan {
+    int64_t per; int nsub; int chunk; int kc; int ncand;
+    int64_t g_bytes, w_bytes, c_bytes, o_bytes, inner_bytes;     // per sub-shard regions (aligned); inner = one uniir_topk_ip call's scratch
+};
+static void tkm_plan(int32_t nq, int32_t k, int64_t rows, int32_t dim, TkmPlan* p) {
+    p->per = uniir_topk_subshard_rows(rows, dim);
+    p->nsub = (int)((rows + p->per - 1) / p->per);
+    const int chunk_max = uniir_topk_ip_sweep_queries(dim, p->per);
+    p->chunk = nq < chunk_max ? nq : chunk_max;
+    p->kc = k + 8;
+    p->ncand = uniir_topk_ncand(p->chunk, p->kc);
+    const int64_t ngr = (p->per + TK_G - 1) / TK_G;
+    p->g_bytes = tkm_align((int64_t)p->chunk * ngr * 4);
+    p->w_bytes = tkm_align(TK_WMAX_BYTES(p->chunk <= 256 ? p->chunk : 64));
+    p->c_bytes = tkm_align((int64_t)p->chunk * p->ncand * 4);
+    p->o_bytes = tkm_align((int64_t)p->chunk * k * 8);
+    p->inner_bytes = tkm_align(uniir_topk_ip_workspace_bytes_ex(nq, k, p->per, dim));
+}
+extern "C" int64_t uniir_topk_ip_multi_workspace_bytes(int32_t nq, int32_t k, int64_t rows, int32_t dim) {
+    if (nq <= 0 || k <= 0 || rows <= 0 || dim <= 0) return 0;
+    if (rows * (int64_t)dim * 2 < ((int64_t)1 << 31)) return uniir_topk_ip_workspace_bytes_ex(nq, k, rows, dim);
+    TkmPlan p;
+    tkm_plan(nq, k, rows, dim, &p);
+    const int64_t batched = p.nsub * (p.g_bytes + p.w_bytes + 2 * p.c_bytes + 2 * p.o_bytes);
+    const int64_t fallback = p.inner_bytes + 2 * p.nsub * tkm_align((int64_t)nq * k * 8);       // per-sub-shard lists of all queries
+    return (batched > fallback ? batched : fallback) + 256;
+}
+extern "C" int uniir_topk_ip_multi(const void* pool_f16, const float* pool_inv_norm, const int64_t* pool_ids, int64_t rows,
+                                   int32_t dim, const void* queries_f16, int32_t nq, int32_t k, float* out_scores,
+                                   int64_t* out_ids, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!pool_f16 || !pool_inv_norm || !queries_f16 || !out_scores || !out_ids || !workspace) return UNIIR_EINVAL;
+    if (rows <= 0 || nq <= 0 || k <= 0) return UNIIR_EINVAL;
+    if (rows * (int64_t)dim * 2 < ((int64_t)1 << 31))
+        return uniir_topk_ip(pool_f16, pool_inv_norm, pool_ids, rows, dim, queries_f16, nq, k, out_scores, out_ids, workspace,
+                             workspace_bytes, stream);
+    if (k + 8 > TK_MAXKC || dim % 64 || dim <= 0 || rows > 0x7fffffffL) return UNIIR_ESHAPE;
+    if (((uintptr_t)pool_f16 & 15) || ((uintptr_t)queries_f16 & 15) || ((uintptr_t)pool_inv_norm & 15) || ((uintptr_t)workspace & 255))
+        return UNIIR_EALIGN;
+    if (workspace_bytes < uniir_topk_ip_multi_workspace_bytes(nq, k, rows, dim)) return UNIIR_EINVAL;
+    TkmPlan p;
+    tkm_plan(nq, k, rows, dim, &p);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t last_rows = rows - (int64_t)(p.nsub - 1) * p.per;
+    const int64_t last_groups = (last_rows + TK_G - 1) / TK_G;
+    // the batched tail wants every sub-shard on a streaming scan with wave maxima and on the fused tail (<= 256 queries per sweep)
+    const bool big = (dim == 768 || dim == 512) && last_groups >= 2048 && last_groups % 2 == 0 && p.chunk <= 256 &&
+                     (p.chunk <= 64 || stream_shared_ok(dim, p.per, p.chunk)) && (p.chunk <= 64 || stream_shared_ok(dim, last_rows, p.chunk)) &&
+                     fused_tail_ok(p.per, dim, p.kc) && fused_tail_ok(last_rows, dim, p.kc) && p.nsub <= 64;
+    if (!pool_ids) return UNIIR_EINVAL;          // (local row numbers of different sub-shards cannot be merged)
+    char* ws = (char*)workspace;
+    if (!big) {      // the per-sub-shard loop of round 4, on the device side of the ABI: lists [nsub][nq][k], one merge
+        float* ls = (float*)(ws + p.inner_bytes);
+        int64_t* li = (int64_t*)(ws + p.inner_bytes + p.nsub * tkm_align((int64_t)nq * k * 8));
+        for (int z = 0; z < p.nsub; ++z) {
+            const int64_t lo = (int64_t)z * p.per, n = z == p.nsub - 1 ? last_rows : p.per;
+            const int rc = uniir_topk_ip((const unsigned short*)pool_f16 + lo * dim, pool_inv_norm + lo, pool_ids ? pool_ids + lo : nullptr, n,
+                                         dim, queries_f16, nq, k, ls + (int64_t)z * nq * k, li + (int64_t)z * nq * k, ws, p.inner_bytes, stream);
+            if (rc) return rc;
+        }
+        return uniir_topk_merge(ls, li, p.nsub, nq, k, out_scores, out_ids, stream);
+    }
+    float* gmax = (float*)ws;
+    float* wmax = (float*)(ws + p.nsub * p.g_bytes);
+    int32_t* cand = (int32_t*)(ws + p.nsub * (p.g_bytes + p.w_bytes));
+    float* exact = (float*)((char*)cand + p.nsub * p.c_bytes);
+    float* ls = (float*)((char*)exact + p.nsub * p.c_bytes);
+    int64_t* li = (int64_t*)((char*)ls + p.nsub * p.o_bytes);
+    TkMulti mu;
+    mu.per = p.per;
+    mu.rows_total = rows;
+    mu.g_stride = p.g_bytes / 4;
+    mu.w_stride = p.w_bytes / 4;
+    mu.c_stride = p.c_bytes / 4;
+    for (int lo = 0; lo < nq; lo += p.chunk) {
+        const int n = nq - lo < p.chunk ? nq - lo : p.chunk;
+        const unsigned short* qp = (const unsigned short*)queries_f16 + (long)lo * dim;
+        int nw = 0;
+        for (int z = 0; z < p.nsub; ++z) {
+            const int64_t r0 = (int64_t)z * p.per, nr = z == p.nsub - 1 ? last_rows : p.per;
+            int nwz = 0;
+            const int sel = launch_gmax_scan((const unsigned short*)pool_f16 + r0 * dim, pool_inv_norm + r0, nr, dim, qp, n,
+                                             gmax + z * mu.g_stride, st, wmax + z * mu.w_stride, &nwz);
+            if (sel < 1) return sel < 0 ? sel : UNIIR_EUNSUPPORTED;
+            if (z == 0) nw = nwz;
+            else if (nwz != nw) return UNIIR_EUNSUPPORTED;        // (cannot happen: one rule, one device)
+        }
+        mu.o_stride = (long)n * k;
+        if (!launch_fused_tail(pool_f16, pool_inv_norm, pool_ids, p.per, dim, qp, n, p.kc, k, gmax, cand, exact, ls, li, st, wmax, nw, &mu,
+                               p.nsub))
+            return UNIIR_EUNSUPPORTED;
+        HIP_LAUNCH_CHECK();
+        const int rc = uniir_topk_merge(ls, li, p.nsub, n, k, out_scores + (long)lo * k, out_ids + (long)lo * k, stream);
+        if (rc) return rc;
+    }
+    return UNIIR_OK;
+}

@@ -242,6 +242,45 @@ extern "C" int uniir_topk_rescore(const void* pool_f16, const float* pool_inv_no
 }
 
 // k-way merge of per-shard final results (score desc, id asc); ids are unique across shards.
+// merge_rank_kernel (round 5): one 256-thread workgroup per query, the nshard * kin entries in LDS, every live entry counts the
+// entries that beat it; rank < k is its place.  The chain kernel below (one THREAD per query walking all lists k times, every step a
+// dependent global load) took 194 us for 64 queries x 8 lists of 10 and 279 us for 256 -- a quarter of a 256-query sweep over
+// eight sub-shards; it remains for merges of more than MERGE_CAP entries per query.
+#define MERGE_CAP 4096
+__global__ __launch_bounds__(256) void merge_rank_kernel(const float* __restrict__ s, const long long* __restrict__ ids, int nshard,
+                                                         int nq, int kin, int k, float* __restrict__ os, long long* __restrict__ oi) {
+    __shared__ float ls[MERGE_CAP];
+    __shared__ long long li[MERGE_CAP];
+    __shared__ int nlive;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = nshard * kin;
+    if (tid == 0) nlive = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int e = tid; e < n; e += 256) {
+        const int sh = e / kin, c = e - sh * kin;
+        const long o = ((long)sh * nq + q) * kin + c;
+        const long long id = ids[o];
+        ls[e] = id >= 0 ? s[o] : -INFINITY;
+        li[e] = id;
+        mine += id >= 0 ? 1 : 0;
+    }
+    if (mine) atomicAdd(&nlive, mine);
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {
+        const long long id = li[e];
+        if (id < 0) continue;
+        const float v = ls[e];
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            const long long oid = li[t];
+            const float ov = ls[t];
+            rank += (oid >= 0 && (ov > v || (ov == v && oid < id))) ? 1 : 0;
+        }
+        if (rank < k) { os[(long)q * k + rank] = v; oi[(long)q * k + rank] = id; }
+    }
+    for (int t = nlive + tid; t < k; t += 256) { os[(long)q * k + t] = -INFINITY; oi[(long)q * k + t] = -1; }      // FAISS padding
+}
 __global__ __launch_bounds__(256) void merge_shards_kernel(const float* __restrict__ s, const long long* __restrict__ ids,
                                                            int nshard, int nq, int kin, int k, float* __restrict__ os,
                                                            long long* __restrict__ oi) {
@@ -264,11 +303,19 @@ __global__ __launch_bounds__(256) void merge_shards_kernel(const float* __restri
         else { os[(long)q * k + j] = -INFINITY; oi[(long)q * k + j] = -1; last_s = -INFINITY; last_id = 0x7fffffffffffffffLL; }
     }
 }
+static void launch_merge(const float* scores, const int64_t* ids, int nshard, int nq, int kin, int k, float* out_scores,
+                         int64_t* out_ids, hipStream_t st) {
+    if ((long)nshard * kin <= MERGE_CAP)
+        hipLaunchKernelGGL(merge_rank_kernel, dim3(nq), dim3(256), 0, st, scores, (const long long*)ids, nshard, nq, kin, k, out_scores,
+                           (long long*)out_ids);
+    else
+        hipLaunchKernelGGL(merge_shards_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, scores, (const long long*)ids, nshard, nq,
+                           kin, k, out_scores, (long long*)out_ids);
+}
 extern "C" int uniir_topk_merge(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k,
                                 float* out_scores, int64_t* out_ids, void* stream) {
     if (!scores || !ids || !out_scores || !out_ids || nshard <= 0 || nq <= 0 || k <= 0) return UNIIR_EINVAL;
-    hipLaunchKernelGGL(merge_shards_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores,
-                       (const long long*)ids, nshard, nq, k, k, out_scores, (long long*)out_ids);
+    launch_merge(scores, ids, nshard, nq, k, k, out_scores, out_ids, (hipStream_t)stream);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -277,8 +324,7 @@ extern "C" int uniir_topk_merge(const float* scores, const int64_t* ids, int32_t
 extern "C" int uniir_topk_merge_ex(const float* scores, const int64_t* ids, int32_t nshard, int32_t nq, int32_t k_in,
                                    int32_t k_out, float* out_scores, int64_t* out_ids, void* stream) {
     if (!scores || !ids || !out_scores || !out_ids || nshard <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0) return UNIIR_EINVAL;
-    hipLaunchKernelGGL(merge_shards_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores,
-                       (const long long*)ids, nshard, nq, k_in, k_out, out_scores, (long long*)out_ids);
+    launch_merge(scores, ids, nshard, nq, k_in, k_out, out_scores, out_ids, (hipStream_t)stream);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -414,7 +460,18 @@ template <int PARTS, int RW, int DEPTH>
 __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     const unsigned short* __restrict__ pool, const float* __restrict__ pinv, long rows, int dim,
     const unsigned short* __restrict__ queries, const float* __restrict__ gmax, long ngroups, int kc, int gcap,
-    int* __restrict__ cand, float* __restrict__ exact, const float* __restrict__ wmax, int nw) {
+    int* __restrict__ cand, float* __restrict__ exact, const float* __restrict__ wmax, int nw, TkMulti mu) {
+    if (mu.per > 0) {        // batched tail: blockIdx.z = sub-shard (rows [z per, ..) of one resident pool), everything re-based onto it
+        const long z = blockIdx.z;
+        pool += z * mu.per * dim;
+        pinv += z * mu.per;
+        rows = min(mu.per, mu.rows_total - z * mu.per);
+        ngroups = (rows + TK_G - 1) / TK_G;
+        gmax += z * mu.g_stride;
+        if (wmax) wmax += z * mu.w_stride;
+        cand += z * mu.c_stride;
+        exact += z * mu.c_stride;
+    }
     extern __shared__ __attribute__((aligned(16))) char dyn[];       // the gather rings
     __shared__ int sel[2 * TK_MAXKC * TK_G];                         // the selection's output: gcap * 16 row indices, -1 = empty
     __shared__ __attribute__((aligned(16))) unsigned short qrow[4096];
@@ -502,7 +559,15 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
 #define TKT_SORTCAP (2 * TK_MAXKC * TK_G)     // 2048 slots at most (gcap <= 128 groups)
 __global__ __launch_bounds__(1024) void topk_tail_sort_kernel(const float* __restrict__ exact, const int* __restrict__ cand,
                                                              const long long* __restrict__ ids, int ncand, int k,
-                                                             float* __restrict__ out_s, long long* __restrict__ out_i) {
+                                                             float* __restrict__ out_s, long long* __restrict__ out_i, TkMulti mu) {
+    if (mu.per > 0) {        // batched tail: blockIdx.y = sub-shard; its list goes to out[y][q][k]
+        const long z = blockIdx.y;
+        exact += z * mu.c_stride;
+        cand += z * mu.c_stride;
+        if (ids) ids += z * mu.per;
+        out_s += z * mu.o_stride;
+        out_i += z * mu.o_stride;
+    }
     __shared__ __attribute__((aligned(16))) float ls[TKT_SORTCAP + 16];
     __shared__ int lrow[TKT_SORTCAP];
     __shared__ int nlive;
@@ -574,12 +639,18 @@ bool fused_tail_ok(int64_t rows, int32_t dim, int32_t kc) {
 // fused kernels
 bool launch_fused_tail(const void* pool_f16, const float* pinv, const int64_t* pool_ids, int64_t rows, int32_t dim,
                               const void* queries_f16, int32_t nq, int32_t kc, int32_t k, const float* gmax, int32_t* cand,
-                              float* exact, float* out_scores, int64_t* out_ids, hipStream_t st, const float* wmax, int nw) {
+                              float* exact, float* out_scores, int64_t* out_ids, hipStream_t st, const float* wmax, int nw,
+                              const TkMulti* mu, int nsub) {
+    // rows: of the (first) sub-shard -- in a batched tail every sub-shard but the last has this many (the caller checked the last one)
     const long ngroups = (rows + TK_G - 1) / TK_G;
     const int gcap = TK_GMULT * kc;
     if (!fused_tail_ok(rows, dim, kc)) return false;
-    const int parts = nq <= 64 ? 4 : nq <= 128 ? 2 : 1;
-    const dim3 g(nq, parts), b(TKT_THREADS);
+    TkMulti one = {};
+    if (!mu) { mu = &one; nsub = 1; }
+    // one workgroup per (query, part, sub-shard): the interactive regime spreads a query's re-score over PARTS workgroups; with
+    // several sub-shards in one launch the sub-shards already fill the chip
+    const int parts = nq * nsub <= 64 ? 4 : nq * nsub <= 128 ? 2 : 1;
+    const dim3 g(nq, parts, nsub), b(TKT_THREADS);
 #define TKT_LAUNCH(P, RW, DEPTH)                                                                                       \
     do {                                                                                                               \
         static PerDeviceOnce attr;                                                                                     \
@@ -588,15 +659,14 @@ bool launch_fused_tail(const void* pool_f16, const float* pinv, const int64_t* p
                                       hipFuncAttributeMaxDynamicSharedMemorySize, RW * DEPTH * 8192);                  \
         hipLaunchKernelGGL((topk_tail_select_rescore_kernel<P, RW, DEPTH>), g, b, RW * DEPTH * 8192, st,               \
                            (const unsigned short*)pool_f16, pinv, (long)rows, dim, (const unsigned short*)queries_f16, \
-                           gmax, ngroups, kc, gcap, cand, exact, nw > 0 ? wmax : nullptr, nw);                         \
+                           gmax, ngroups, kc, gcap, cand, exact, nw > 0 ? wmax : nullptr, nw, *mu);                    \
     } while (0)
     // rings: 3 waves x 4 slices (the interactive regime: 144 slots per workgroup at k = 10) or 5 waves x 2 slices = 96 / 80 KiB
     if (parts == 4) TKT_LAUNCH(4, 3, 4);
     else if (parts == 2) TKT_LAUNCH(2, 5, 2);
     else TKT_LAUNCH(1, 5, 2);
 #undef TKT_LAUNCH
-    hipLaunchKernelGGL(topk_tail_sort_kernel, dim3(nq), dim3(1024), 0, st, exact, cand, (const long long*)pool_ids,
-                       gcap * TK_G, k, out_scores, (long long*)out_ids);
+    hipLaunchKernelGGL(topk_tail_sort_kernel, dim3(nq, nsub), dim3(1024), 0, st, exact, cand, (const long long*)pool_ids,
+                       gcap * TK_G, k, out_scores, (long long*)out_ids, *mu);
     return true;
 }
-

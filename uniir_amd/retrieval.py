@@ -101,9 +101,9 @@ def release_workspaces():
 
 def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None, workspace=None):
     """Exact top-k of `queries` against one shard -> (scores f32 [q,k] desc, ids int64 [q,k], -1 padded).
-    One C call per logical sub-shard (uniir_topk_ip: query norms, one sweep of the rows per 256 / 1024 queries, fused select +
-    exact re-score + sort); a shard of >= 2 GiB is searched as equal sub-shards and merged on (score desc, id asc), which is the
-    search of the whole shard (ids are unique).
+    One C call (uniir_topk_ip: query norms, one sweep of the rows per 256 / 1024 queries, fused select + exact re-score + sort);
+    a shard of >= 2 GiB goes to uniir_topk_ip_multi, which searches it as the equal sub-shards of subshard_bounds and merges on
+    (score desc, id asc) -- the search of the whole shard (ids are unique).
     k > 56 (FAISS Flat accepts up to 2048; Recall@100, larger hard-negative mining depths): assembled from row slices of the
     shard, see _search_large_k."""
     from . import _lib
@@ -115,17 +115,17 @@ def search_shard(shard: PoolShard, queries_f16: torch.Tensor, k: int, q_inv=None
                 torch.full((nq, k), -1, device=dev, dtype=torch.int64))
     if k > MAX_K_DIRECT:
         return _search_large_k(shard, queries_f16, k)
-    bounds = subshard_bounds(shard.n, shard.dim)
-    if len(bounds) > 1:
-        res = [search_shard(_shard_view(shard, lo, hi), queries_f16, k, workspace=workspace) for lo, hi in bounds]
-        return merge_shards(torch.stack([r[0] for r in res]), torch.stack([r[1] for r in res]))
     out_s = torch.empty(nq, k, device=dev, dtype=torch.float32)       # every slot is written by the final sort (padding included)
     out_i = torch.empty(nq, k, device=dev, dtype=torch.int64)
-    need = _lib.load().uniir_topk_ip_workspace_bytes_ex(nq, k, shard.n, shard.dim)
+    # one C call either way: uniir_topk_ip_multi cuts a shard of >= 2 GiB into the logical sub-shards of subshard_bounds itself
+    # (one scan per sub-shard, then ONE tail, ONE sort and ONE merge launch for all of them) and is uniir_topk_ip below that
+    multi = shard.n * shard.dim * 2 >= SUBSHARD_BYTES
+    need = (_lib.load().uniir_topk_ip_multi_workspace_bytes(nq, k, shard.n, shard.dim) if multi
+            else _lib.load().uniir_topk_ip_workspace_bytes_ex(nq, k, shard.n, shard.dim))
     if workspace is None or workspace.numel() < need or workspace.data_ptr() % 256:
         workspace = _workspace(dev, need)
-    ops.call("uniir_topk_ip", shard.emb, shard.inv_norm, shard.ids, shard.n, shard.dim, queries_f16, nq, k, out_s, out_i,
-             workspace, workspace.numel())
+    ops.call("uniir_topk_ip_multi" if multi else "uniir_topk_ip", shard.emb, shard.inv_norm, shard.ids, shard.n, shard.dim,
+             queries_f16, nq, k, out_s, out_i, workspace, workspace.numel())
     return out_s, out_i
 
 
