@@ -294,6 +294,9 @@ def bench_embed(dev, model_name="ViT-L/14", items=2048, steps=3):
     from uniir_amd.clip_model import CLIP_CONFIGS
     cfg = CLIP_CONFIGS[model_name]
     model = CLIPScoreFusion(model_name=model_name, device=dev).float().eval()
+    # the reference embedder runs under autocast(fp16) (mbeir_embedder.py:52-56, embed_config.use_fp16): the towers' fp16 forward,
+    # as the embedder mirror selects it; the pair mode is also timed in bf16 (the training towers' precision)
+    model.clip_model.precision = "fp16"
     batch = synth_batch(cfg, items // 2, 2023, dev)
     batch["did_list"] = list(range(items))
     host_tok = batch["txt_batched"].cpu()
@@ -302,10 +305,11 @@ def bench_embed(dev, model_name="ViT-L/14", items=2048, steps=3):
     # the empty caption of an image-only candidate: [SOT, EOT, 0, ...]
     empty = torch.zeros_like(host_tok)
     empty[:, 0], empty[:, 1] = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1
-    modes = {"pair": (1, 1), "image_only": (0, 1), "text_only": (1, 0)}
+    modes = {"pair": (1, 1), "image_only": (0, 1), "text_only": (1, 0), "pair_bf16": (1, 1)}
     out = {}
     ones = torch.ones(items, dtype=torch.int64)
     for mode, (tm, im) in modes.items():
+        model.clip_model.precision = "bf16" if mode.endswith("_bf16") else "fp16"
         b = dict(batch)
         b["txt_mask_batched"] = (ones * tm).to(dev)
         b["image_mask_batched"] = (ones * im).to(dev)
@@ -334,7 +338,7 @@ def bench_embed(dev, model_name="ViT-L/14", items=2048, steps=3):
            "ms_per_batch": out["pair"]["ms_per_batch"], "items_per_batch": items, "out_shape": list(half.shape),
            "mfma_frac": out["pair"]["mfma_frac"],
            "mfma_frac_note": "pair mode, executed FLOPs (vision 162.03 GFLOP + the packed text tower at the captions' live lengths)",
-           "modes": out, "precision": getattr(model.clip_model, "precision", "bf16"),
+           "modes": out, "precision": "fp16 (operands and activations; fp32 residual stream, LayerNorm and accumulation)",
            "masked_rows": "compacted (each tower runs on its mask-1 rows only)" if model.compact_masked else "dense"}
     return res
 

@@ -177,10 +177,13 @@ int uniir_act_fwd(const void* f_bf16, void* g_bf16, int64_t count, int32_t act, 
 /* out[n] += sum_m x[m][n]  (x bf16 [rows][ld]) */
 int uniir_colsum_bf16(const void* x, int64_t ld, float* out, int32_t rows, int32_t cols, void* stream);
 int uniir_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);
+int uniir_cast_f32_to_f16(const float* src, void* dst, int64_t count, void* stream);     /* the fp16 forward's weight copies */
 int uniir_cast_bf16_to_f32(const void* src, float* dst, int64_t count, void* stream);
 /* dst bf16 [rows][ld_dst] (zero padded) = src f32 [rows][cols] */
 int uniir_cast_pad_rows(const float* src, void* dst, int32_t rows, int32_t cols, int32_t ld_dst,
                         void* stream);
+int uniir_cast_pad_rows_f16(const float* src, void* dst, int32_t rows, int32_t cols, int32_t ld_dst,
+                            void* stream);      /* the same into fp16 (the fp16 forward's patch-embedding weight) */
 /* dst f32 [rows][cols] += src f32 [rows][ld_src][:cols]  (un-pad a wgrad result) */
 int uniir_unpad_add(const float* src, float* dst, int32_t rows, int32_t cols, int32_t ld_src,
                     void* stream);
@@ -283,7 +286,10 @@ typedef struct {
                                                  1024 items).  Same forward bit for bit; the c_proj weight gradient reads the forward's
                                                  act(f) instead of the backward's recomputation (equal up to rare one-ulp differences).
                                                  Part of the workspace layout: every call on one workspace must see the same value */
-    int32_t reserved_;
+    int32_t dtype16;                          /* 0 = bf16 (training and the default forward); 1 = fp16, FORWARD ONLY: wqkv16 .. proj16 /
+                                                 conv16 then point at fp16 copies of the weights (uniir_cast_f32_to_f16) and every
+                                                 16-bit activation is fp16 -- the reference embedder's autocast(fp16),
+                                                 mbeir_embedder.py:52-56; save_for_backward with it is UNIIR_EUNSUPPORTED */
 } uniir_clip_tower;
 
 int64_t uniir_clip_tower_workspace_bytes(const uniir_clip_tower* t, int32_t batch, int32_t save_for_backward);

@@ -44,7 +44,7 @@ class ClipTower(C.Structure):
         ("g_conv", c_void_p), ("g_class", c_void_p), ("g_pos", c_void_p), ("g_ln_pre_w", c_void_p), ("g_ln_pre_b", c_void_p),
         ("g_token", c_void_p), ("g_ln_post_w", c_void_p), ("g_ln_post_b", c_void_p), ("g_proj", c_void_p),
         ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_i64),
-        ("stash_act", c_int), ("reserved_", c_int),
+        ("stash_act", c_int), ("dtype16", c_int),
     ]
 
 
@@ -79,8 +79,10 @@ SIGNATURES = {
     "uniir_act_fwd": (c_int, [P, P, c_i64, c_int, S]),
     "uniir_colsum_bf16": (c_int, [P, c_i64, P, c_int, c_int, S]),
     "uniir_cast_f32_to_bf16": (c_int, [P, P, c_i64, S]),
+    "uniir_cast_f32_to_f16": (c_int, [P, P, c_i64, S]),
     "uniir_cast_bf16_to_f32": (c_int, [P, P, c_i64, S]),
     "uniir_cast_pad_rows": (c_int, [P, P, c_int, c_int, c_int, S]),
+    "uniir_cast_pad_rows_f16": (c_int, [P, P, c_int, c_int, c_int, S]),
     "uniir_unpad_add": (c_int, [P, P, c_int, c_int, c_int, S]),
     "uniir_fuse_embeddings": (c_int, [P, P, P, P, P, c_int, c_int, S]),
     "uniir_select_normalize": (c_int, [P, P, P, P, c_int, c_int, S]),

@@ -144,7 +144,10 @@ class CLIP(nn.Module):
         # flat storage (built lazily on the device)
         self._flat = None
         self.kpad = (3 * P * P + 63) // 64 * 64
-        # "bf16": MFMA towers, forward + backward (training / fast extraction).  "fp32": the reference's model.float()
+        # "bf16": MFMA towers, forward + backward (training / fast extraction).  "fp16": the same MFMA towers with fp16 operands and
+        # activations, FORWARD ONLY -- the reference embedder's precision (mbeir_embedder.py:52-56: autocast(fp16) then .half()),
+        # same speed as bf16 (the fp16 MFMA rate is the bf16 rate), 3 more mantissa bits: embeddings 1e-3 instead of 6e-3 from the
+        # fp32 path; weights are read from an fp16 shadow that is refreshed with the bf16 one.  "fp32": the reference's model.float()
         # forward in exact-fp32 MFMA GEMMs + fp32 attention (csrc/fp32_path.hip): reference-precision embeddings, no backward
         self.precision = "bf16"
         # exact text-row packing (csrc/tower.hip *_packed): the text tower runs on the tokens up to each caption's EOT only.  Rows
@@ -207,6 +210,21 @@ class CLIP(nn.Module):
         ops.call("uniir_cast_f32_to_bf16", fl["p32"], fl["w16"], fl["total"])
         self._refresh_conv()
         fl["version"] = self._param_version()
+        fl["h16_version"] = None            # the fp16 shadow (precision = "fp16") is rebuilt on demand
+
+    def _sync_half_shadow(self):
+        """fp16 copies of the master weights for the fp16 forward: built on first use, rebuilt when the parameters moved"""
+        fl = self._sync_shadow()
+        ver = self._param_version()
+        if fl.get("h16") is None:
+            fl["h16"] = torch.empty(fl["total"], device=fl["dev"], dtype=torch.float16)
+            self._conv16h = torch.zeros(self.cfg["vision_width"], self.kpad, device=fl["dev"], dtype=torch.float16)
+        if fl.get("h16_version") != ver:
+            ops.call("uniir_cast_f32_to_f16", fl["p32"], fl["h16"], fl["total"])
+            vw, P = self.cfg["vision_width"], self.cfg["vision_patch_size"]
+            ops.call("uniir_cast_pad_rows_f16", self.visual.conv1.weight.data, self._conv16h, vw, 3 * P * P, self.kpad)
+            fl["h16_version"] = ver
+        return fl
 
     def _refresh_conv(self):
         vw, P = self.cfg["vision_width"], self.cfg["vision_patch_size"]
@@ -231,13 +249,14 @@ class CLIP(nn.Module):
         o = fl["off"][name]
         return fl["g32"][o:o + math.prod(fl["shapes"][name])].view(fl["shapes"][name])
 
-    def tower_desc(self, which):
+    def tower_desc(self, which, half=False):
         """the POD description uniir_clip_tower_{fwd,bwd} take (include/uniir_hip.h [TOWER]): raw device pointers into the flat
-        fp32 / bf16-shadow / gradient buffers; cached until the flat storage is rebuilt"""
+        fp32 / bf16-shadow / gradient buffers; cached until the flat storage is rebuilt.  half: the fp16 forward's description
+        (dtype16 = 1, 16-bit weights from the fp16 shadow)"""
         import ctypes as C
         from ._lib import ClipBlock, ClipTower
         fl = self._flat
-        key = (which, fl["p32"].data_ptr())
+        key = (which, fl["p32"].data_ptr(), bool(half))
         cache = fl.setdefault("tower_desc", {})
         if key in cache:
             return cache[key][0]
@@ -247,7 +266,7 @@ class CLIP(nn.Module):
             return fl["p32"].data_ptr() + 4 * fl["off"][name]
 
         def h(name):
-            return fl["w16"].data_ptr() + 2 * fl["off"][name]
+            return (fl["h16"] if half else fl["w16"]).data_ptr() + 2 * fl["off"][name]
 
         def g(name):
             return fl["g32"].data_ptr() + 4 * fl["off"][name]
@@ -270,6 +289,7 @@ class CLIP(nn.Module):
             b.g_wfc, b.g_bfc = g(f"{r}.mlp.c_fc.weight"), g(f"{r}.mlp.c_fc.bias")
             b.g_wproj, b.g_bproj = g(f"{r}.mlp.c_proj.weight"), g(f"{r}.mlp.c_proj.bias")
         t = ClipTower()
+        t.dtype16 = int(bool(half))
         t.is_text, t.layers, t.width, t.embed_dim = int(not image), L, W, cfg["embed_dim"]
         t.blocks = C.cast(blocks, C.POINTER(ClipBlock))
         # split-K slabs: one scratch buffer PER TOWER (the two towers may run on two streams at the same time)
@@ -279,7 +299,7 @@ class CLIP(nn.Module):
             P = cfg["vision_patch_size"]
             t.heads, t.tokens = W // 64, (cfg["image_resolution"] // P) ** 2 + 1
             t.resolution, t.patch, t.kpad = cfg["image_resolution"], P, self.kpad
-            t.conv16 = self._conv16.data_ptr()
+            t.conv16 = (self._conv16h if half else self._conv16).data_ptr()
             t.class_emb, t.pos_emb = p("visual.class_embedding"), p("visual.positional_embedding")
             t.ln_pre_w, t.ln_pre_b = p("visual.ln_pre.weight"), p("visual.ln_pre.bias")
             t.ln_post_w, t.ln_post_b, t.proj16 = p("visual.ln_post.weight"), p("visual.ln_post.bias"), h("visual.proj")
@@ -581,12 +601,18 @@ class _TowerFn(torch.autograd.Function):
                 raise RuntimeError("precision='fp32' is a forward-only path (embedding extraction / parity); run it under "
                                    "torch.no_grad() or switch back to precision='bf16' for training")
             return _encode_fp32(model, which, inp, p32)
-        if model.precision != "bf16":
+        half = model.precision == "fp16"
+        if half:
+            if need_grad:
+                raise RuntimeError("precision='fp16' is the embedder's forward-only path; run it under torch.no_grad() or switch "
+                                   "back to precision='bf16' for training")
+            model._sync_half_shadow()
+        elif model.precision != "bf16":
             raise RuntimeError(f"unknown precision {model.precision!r}")
-        if not _PY_TOWERS:
+        if not _PY_TOWERS or half:
             # the whole tower in one C call (csrc/tower.hip); the workspace is the activation stash of the backward
             lib = _lib.load()
-            desc = model.tower_desc(which)
+            desc = model.tower_desc(which, half=half)
             emb = torch.empty(M, E, device=dev, dtype=torch.float32)
 
             def ws_bytes(stash):

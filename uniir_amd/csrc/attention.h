@@ -130,15 +130,27 @@ DEVINL bf16x8_t pack8(const f32x4_t a, const f32x4_t b) {
 DEVINL f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// the fp16 forward (attn_fwd_kernel<.., F16 = true>): the same fragments, the 16 bits read as fp16
+template <bool F16>
+DEVINL f32x4_t mfma16x(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+DEVINL bf16x8_t pack8x(const f32x4_t a, const f32x4_t b) {
+    const u32x4_t r = {pack16x2<F16>(a[0], a[1]), pack16x2<F16>(a[2], a[3]), pack16x2<F16>(b[0], b[1]), pack16x2<F16>(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8_t, r);
+}
 // 16 rows x 64 columns of gradients (lane = row li, registers: column 16 dt + 4 g + r) -> bf16, 64 contiguous bytes per row and
 // store: v_permlane16_swap exchanges the 8-byte pieces of column tiles (0,1) / (2,3) between the lane rows g = (0,1) / (2,3), so
 // that every lane ends up with 8 consecutive columns starting at 32 p + {0, 16, 8, 24}[g].
+template <bool F16 = false>
 DEVINL void att_store_tile(const f32x4_t (&acc)[4], float scale, unsigned short* rowp, bool valid, int g) {
     u32x2_t pk[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
         const f32x4_t x = acc[dt] * scale;
-        pk[dt] = u32x2_t{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+        pk[dt] = u32x2_t{pack16x2<F16>(x[0], x[1]), pack16x2<F16>(x[2], x[3])};
     }
     const int dstart = ((g & 1) << 4) | ((g & 2) << 2);      // {0, 16, 8, 24}[g]
 #pragma unroll

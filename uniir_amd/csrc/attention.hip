@@ -17,7 +17,9 @@ int g_att_exp = 0;
 extern "C" void uniir_exp_attn_set(void* stamps, int mode) { g_att_stamps = (unsigned long long*)stamps; g_att_exp = mode; }
 #endif
 
-template <bool REL, bool DROP>
+// F16: q / k / v / out are fp16 instead of bf16 (plain or causal forward of the fp16 embedding towers; P <= 2^8 by the deferred
+// maximum, well inside fp16's range)
+template <bool REL, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int H = a.H, causal = a.causal;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
             for (int kt = 0; kt < 2; ++kt) {
                 sx[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) sx[kt] = mfma16(frag_rows(ldsK, kb * 32 + kt * 16, s, lane), qf[s], sx[kt]);
+                for (int s = 0; s < 2; ++s) sx[kt] = mfma16x<F16>(frag_rows(ldsK, kb * 32 + kt * 16, s, lane), qf[s], sx[kt]);
             }
         };
         auto softmax_pv = [&](int kb, f32x4_t (&st)[2]) {
@@ -155,9 +157,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
                     for (int r = 0; r < 4; ++r)
                         st[kt][r] *= drop_scale(rowbase + (unsigned)(kb * 32 + kt * 16 + 4 * g + r), a.drop_seed, dth, dks);
             }
-            const bf16x8_t pf = pack8(st[0], st[1]);
+            const bf16x8_t pf = pack8x<F16>(st[0], st[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_cols_tr(ldsV, kb * 32, dt, lane), pf, o[dt]);
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16x<F16>(frag_cols_tr(ldsV, kb * 32, dt, lane), pf, o[dt]);
         };
         f32x4_t sa[2], sb[2];
         s_block(0, sa);
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         // rows leave as 16-byte pieces, 64 contiguous bytes per row and store (att_store_tile; round 4: the 8-byte stores at a
         // row stride cost the 257-token forward 0.14 of its 0.70 ms)
         const bool live = q < Tq && !ATT_EXP(16);
-        att_store_tile(o, 1.0f / l_run, a.out + (qr0 + min(q, Tq - 1)) * a.out_ld + h * ATT_D, live, g);
+        att_store_tile<F16>(o, 1.0f / l_run, a.out + (qr0 + min(q, Tq - 1)) * a.out_ld + h * ATT_D, live, g);
         if (live && g == 0) a.lse[((long)m * H + h) * a.Tq + q] = m_run * LN2F + __logf(l_run);
     }
     ATT_STAMP(3);
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
 //   forward : 257 tokens 0.783 -> 0.760 ms, 197: 0.488 -> 0.487, 77 causal: 0.146 -> 0.132, 50: 0.116 -> 0.095   => always batched
 //   backward: 257 tokens 2.026 -> 2.021 ms, 197: 1.399 -> 1.446 (worse), 77: 0.388 -> 0.359, 50: 0.336 -> 0.294   => batched up to 128 tokens
 static int attn_legacy_stage(bool backward, int tmax) { return backward && tmax > 128; }
-static int launch_attn_fwd(const AttnArgs& a0, int batch, hipStream_t st) {
+static int launch_attn_fwd(const AttnArgs& a0, int batch, hipStream_t st, bool f16 = false) {
     AttnArgs a = a0;
 #ifdef UNIIR_EXP_BUILD
     a.stamps = g_att_stamps; a.exp = g_att_exp;
@@ -483,6 +485,16 @@ static int launch_attn_fwd(const AttnArgs& a0, int batch, hipStream_t st) {
     }
     const dim3 g(batch * a.H), b(ATT_THREADS);
     const bool drop = a.drop_p > 0.f;
+    if (f16) {          // the fp16 forward of the embedding towers: plain / causal / packed rows only
+        if (a.rel_emb || drop) return UNIIR_EUNSUPPORTED;
+        static PerDeviceOnce attr16;
+        if (attr16.first())
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      2 * 512 * 128 + 1024 * 4);
+        hipLaunchKernelGGL((attn_fwd_kernel<false, false, true>), g, b, sm, st, a);
+        HIP_LAUNCH_CHECK();
+        return UNIIR_OK;
+    }
     if (a.rel_emb && drop) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), g, b, sm, st, a);
     else if (a.rel_emb) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), g, b, sm, st, a);
     else if (drop) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), g, b, sm, st, a);
@@ -534,6 +546,21 @@ static int launch_attn_bwd(const AttnArgs& a0, int batch, hipStream_t st) {
     return six ? launch_attn_bwd_nt<384>(a, batch, sm, st) : launch_attn_bwd_nt<512>(a, batch, sm, st);
 }
 
+// tower.hip's forward: row_off = nullptr for dense rows; f16 = the 16-bit tensors are fp16
+int attention_fwd_impl(const void* qkv, void* out, float* lse, const int32_t* row_off, int32_t batch, int32_t seq, int32_t heads,
+                       int32_t causal, int f16, void* stream) {
+    if (!qkv || !out || !lse || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (seq < 1 || seq > 512) return UNIIR_ESHAPE;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return UNIIR_EALIGN;
+    const long W = (long)heads * ATT_D;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)qkv; a.k = a.q + W; a.v = a.q + 2 * W;
+    a.q_ld = a.kv_ld = 3 * W;
+    a.out = (unsigned short*)out; a.out_ld = W; a.lse = lse; a.klen = nullptr; a.row_off = row_off;
+    a.Tq = a.Tk = seq; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
+    return launch_attn_fwd(a, batch, (hipStream_t)stream, f16 != 0);
+}
 extern "C" int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32_t batch, int32_t seq,
                                    int32_t heads, int32_t causal, void* stream) {
     if (!qkv || !out || !lse || batch < 0 || heads <= 0) return UNIIR_EINVAL;

@@ -34,6 +34,22 @@ DEVINL unsigned pack_bf16x2(float lo, float hi) {
 }
 DEVINL float f16_to_f32(f16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 DEVINL f16_t f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+// The 16-bit storage type of a forward pass: bf16 (training and the default extraction) or fp16 (the reference embedder's
+// autocast(fp16), mbeir_embedder.py:52-56: 3 more mantissa bits for the forward-only towers).  Round-to-nearest-even both ways.
+DEVINL unsigned pack_f16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    const h2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+template <bool F16>
+DEVINL unsigned pack16x2(float lo, float hi) { return F16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
+DEVINL unsigned pack16x2(float lo, float hi, bool f16) { return f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
+template <bool F16>
+DEVINL float unpack16_lo(unsigned u) { return F16 ? f16_to_f32((unsigned short)(u & 0xffffu)) : __uint_as_float(u << 16); }
+template <bool F16>
+DEVINL float unpack16_hi(unsigned u) { return F16 ? f16_to_f32((unsigned short)(u >> 16)) : __uint_as_float(u & 0xffff0000u); }
+DEVINL float unpack16_lo(unsigned u, bool f16) { return f16 ? f16_to_f32((unsigned short)(u & 0xffffu)) : __uint_as_float(u << 16); }
+DEVINL float unpack16_hi(unsigned u, bool f16) { return f16 ? f16_to_f32((unsigned short)(u >> 16)) : __uint_as_float(u & 0xffff0000u); }
 
 DEVINL float wave_sum(float v) {
 #pragma unroll

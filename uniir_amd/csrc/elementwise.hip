@@ -17,7 +17,7 @@ static inline int grid_for(long work, int per_block, int cap = 8192) {
 // one thread produces 8 consecutive k (16 B store); reads are P-contiguous runs of a pixel row.
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img,
                                                        unsigned short* __restrict__ out, int n, int res,
-                                                       int P, int kpad) {
+                                                       int P, int kpad, int f16) {
     const int g = res / P, kreal = 3 * P * P, chunks = kpad >> 3;
     const long total = (long)n * g * g * chunks;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
@@ -36,21 +36,25 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
             }
             v[e] = val;
         }
-        u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                     pack_bf16x2(v[6], v[7])};
+        u32x4_t o = {pack16x2(v[0], v[1], f16 != 0), pack16x2(v[2], v[3], f16 != 0), pack16x2(v[4], v[5], f16 != 0),
+                     pack16x2(v[6], v[7], f16 != 0)};
         *reinterpret_cast<u32x4_t*>(out + row * kpad + ch * 8) = o;
     }
 }
 
+int patchify_impl(const float* images, void* patches, int32_t n, int32_t res, int32_t patch, int32_t kpad, int f16, void* stream);
 extern "C" int uniir_patchify(const float* images, void* patches, int32_t n, int32_t res, int32_t patch,
                               int32_t kpad, void* stream) {
+    return patchify_impl(images, patches, n, res, patch, kpad, 0, stream);
+}
+int patchify_impl(const float* images, void* patches, int32_t n, int32_t res, int32_t patch, int32_t kpad, int f16, void* stream) {
     if (!images || !patches || n < 0) return UNIIR_EINVAL;
     if (n == 0) return UNIIR_OK;
     if (patch <= 0 || res % patch || kpad % 8 || kpad < 3 * patch * patch) return UNIIR_ESHAPE;
     const int g = res / patch;
     const long total = (long)n * g * g * (kpad / 8);
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
-                       images, (unsigned short*)patches, n, res, patch, kpad);
+                       images, (unsigned short*)patches, n, res, patch, kpad, f16);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -60,7 +64,7 @@ extern "C" int uniir_patchify(const float* images, void* patches, int32_t n, int
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const unsigned short* __restrict__ po,
                                                            const float* __restrict__ cls,
                                                            const float* __restrict__ pos,
-                                                           float* __restrict__ x, int n, int T, int w) {
+                                                           float* __restrict__ x, int n, int T, int w, int f16) {
     const int wc = w >> 2;
     const long total = (long)n * T * wc;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -74,23 +78,29 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const unsigned short*
         } else {
             const u32x2_t pk =
                 *reinterpret_cast<const u32x2_t*>(po + (im * (T - 1) + (t - 1)) * (long)w + 4 * c);
-            v = f32x4_t{__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
-                        __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+            v = f32x4_t{unpack16_lo(pk[0], f16 != 0), unpack16_hi(pk[0], f16 != 0), unpack16_lo(pk[1], f16 != 0),
+                        unpack16_hi(pk[1], f16 != 0)};
         }
         v += *reinterpret_cast<const f32x4_t*>(pos + (long)t * w + 4 * c);
         *reinterpret_cast<f32x4_t*>(x + row * w + 4 * c) = v;
     }
 }
 
+int vit_assemble_impl(const void* patch_out, const float* class_emb, const float* pos_emb, float* x, int32_t n, int32_t tokens,
+                      int32_t width, int f16, void* stream);
 extern "C" int uniir_vit_assemble(const void* patch_out, const float* class_emb, const float* pos_emb,
                                   float* x, int32_t n, int32_t tokens, int32_t width, void* stream) {
+    return vit_assemble_impl(patch_out, class_emb, pos_emb, x, n, tokens, width, 0, stream);
+}
+int vit_assemble_impl(const void* patch_out, const float* class_emb, const float* pos_emb, float* x, int32_t n, int32_t tokens,
+                      int32_t width, int f16, void* stream) {
     if (!patch_out || !class_emb || !pos_emb || !x || n < 0) return UNIIR_EINVAL;
     if (n == 0) return UNIIR_OK;
     if (width % 4 || tokens < 2) return UNIIR_ESHAPE;
     const long total = (long)n * tokens * (width / 4);
     hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
                        (hipStream_t)stream, (const unsigned short*)patch_out, class_emb, pos_emb, x, n, tokens,
-                       width);
+                       width, f16);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -397,14 +407,17 @@ extern "C" int uniir_colsum_bf16(const void* x, int64_t ld, float* out, int32_t 
 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ s,
-                                                            unsigned short* __restrict__ d, long n) {
+                                                            unsigned short* __restrict__ d, long n, int f16 = 0) {
     const long nv = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
         const f32x4_t v = *reinterpret_cast<const f32x4_t*>(s + 4 * i);
-        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        u32x2_t o = {pack16x2(v[0], v[1], f16 != 0), pack16x2(v[2], v[3], f16 != 0)};
         *reinterpret_cast<u32x2_t*>(d + 4 * i) = o;
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) d[(nv << 2) + threadIdx.x] = f32_to_bf16(s[(nv << 2) + threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float x = s[(nv << 2) + threadIdx.x];
+        d[(nv << 2) + threadIdx.x] = f16 ? f32_to_f16(x) : f32_to_bf16(x);
+    }
 }
 __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const unsigned short* __restrict__ s,
                                                             float* __restrict__ d, long n) {
@@ -415,7 +428,17 @@ extern "C" int uniir_cast_f32_to_bf16(const float* src, void* dst, int64_t count
     if (count == 0) return UNIIR_OK;
     if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return UNIIR_EALIGN;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(count / 4 + 1, 256, 16384)), dim3(256), 0,
-                       (hipStream_t)stream, src, (unsigned short*)dst, (long)count);
+                       (hipStream_t)stream, src, (unsigned short*)dst, (long)count, 0);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+// fp16 shadow of the master weights for the fp16 forward (uniir_clip_tower.dtype16 = 1)
+extern "C" int uniir_cast_f32_to_f16(const float* src, void* dst, int64_t count, void* stream) {
+    if (!src || !dst || count < 0) return UNIIR_EINVAL;
+    if (count == 0) return UNIIR_OK;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return UNIIR_EALIGN;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(count / 4 + 1, 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, src, (unsigned short*)dst, (long)count, 1);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -429,22 +452,30 @@ extern "C" int uniir_cast_bf16_to_f32(const void* src, float* dst, int64_t count
 }
 __global__ __launch_bounds__(256) void cast_pad_rows_kernel(const float* __restrict__ s,
                                                             unsigned short* __restrict__ d, int rows, int cols,
-                                                            int ld) {
+                                                            int ld, int f16) {
     const long total = (long)rows * ld;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % ld);
         const long r = i / ld;
-        d[i] = c < cols ? f32_to_bf16(s[r * cols + c]) : (unsigned short)0;
+        const float x = c < cols ? s[r * cols + c] : 0.0f;
+        d[i] = f16 ? f32_to_f16(x) : f32_to_bf16(x);
     }
 }
-extern "C" int uniir_cast_pad_rows(const float* src, void* dst, int32_t rows, int32_t cols, int32_t ld_dst,
-                                   void* stream) {
+static int cast_pad_rows_impl(const float* src, void* dst, int32_t rows, int32_t cols, int32_t ld_dst, int f16, void* stream) {
     if (!src || !dst || rows < 0 || cols <= 0 || ld_dst < cols) return UNIIR_EINVAL;
     if (rows == 0) return UNIIR_OK;
     hipLaunchKernelGGL(cast_pad_rows_kernel, dim3(grid_for((long)rows * ld_dst, 256)), dim3(256), 0,
-                       (hipStream_t)stream, src, (unsigned short*)dst, rows, cols, ld_dst);
+                       (hipStream_t)stream, src, (unsigned short*)dst, rows, cols, ld_dst, f16);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
+}
+extern "C" int uniir_cast_pad_rows(const float* src, void* dst, int32_t rows, int32_t cols, int32_t ld_dst,
+                                   void* stream) {
+    return cast_pad_rows_impl(src, dst, rows, cols, ld_dst, 0, stream);
+}
+extern "C" int uniir_cast_pad_rows_f16(const float* src, void* dst, int32_t rows, int32_t cols, int32_t ld_dst,
+                                       void* stream) {
+    return cast_pad_rows_impl(src, dst, rows, cols, ld_dst, 1, stream);
 }
 __global__ __launch_bounds__(256) void unpad_add_kernel(const float* __restrict__ s, float* __restrict__ d,
                                                         int rows, int cols, int ld) {

@@ -42,7 +42,7 @@ struct GemmKArgs {
 
 // act_fwd / act_bwd: common.h (shared with the stand-alone activation pass of elementwise.hip)
 
-template <int EPI, int MT, int NT>
+template <int EPI, int MT, int NT, bool F16 = false>
 DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[MT][NT], int m0, int n0, int wm, int wn) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -56,16 +56,16 @@ DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[MT][NT], int 
                 if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
                 const long off = (long)m * p.ldc + n;
                 if (EPI == UNIIR_EPI_BF16) {
-                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    u32x2_t o = {pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
                     *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
                 } else if (EPI == UNIIR_EPI_BIAS_ACT) {
-                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    u32x2_t o = {pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
                     if (!p.skip_f) *reinterpret_cast<u32x2_t*>((unsigned short*)p.C + off) = o;
-                    const float g0 = act_fwd(__uint_as_float(o[0] << 16), p.act);
-                    const float g1 = act_fwd(__uint_as_float(o[0] & 0xffff0000u), p.act);
-                    const float g2 = act_fwd(__uint_as_float(o[1] << 16), p.act);
-                    const float g3 = act_fwd(__uint_as_float(o[1] & 0xffff0000u), p.act);
-                    u32x2_t o2 = {pack_bf16x2(g0, g1), pack_bf16x2(g2, g3)};
+                    const float g0 = act_fwd(unpack16_lo<F16>(o[0]), p.act);
+                    const float g1 = act_fwd(unpack16_hi<F16>(o[0]), p.act);
+                    const float g2 = act_fwd(unpack16_lo<F16>(o[1]), p.act);
+                    const float g3 = act_fwd(unpack16_hi<F16>(o[1]), p.act);
+                    u32x2_t o2 = {pack16x2<F16>(g0, g1), pack16x2<F16>(g2, g3)};
                     *reinterpret_cast<u32x2_t*>((unsigned short*)p.C2 + off) = o2;
                 } else if (EPI == UNIIR_EPI_RESID_F32) {
                     if (p.row_scale) v *= p.row_scale[m];
@@ -96,11 +96,11 @@ DEVINL void gemm_epilogue(const GemmKArgs& p, const f32x4_t (&acc)[MT][NT], int 
     }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool F16 = false>
 DEVINL void gemm_epilogue_dispatch(const GemmKArgs& p, const f32x4_t (&acc)[MT][NT], int m0, int n0, int wm, int wn) {
     switch (p.epilogue) {
-        case UNIIR_EPI_BF16: gemm_epilogue<UNIIR_EPI_BF16, MT, NT>(p, acc, m0, n0, wm, wn); break;
-        case UNIIR_EPI_BIAS_ACT: gemm_epilogue<UNIIR_EPI_BIAS_ACT, MT, NT>(p, acc, m0, n0, wm, wn); break;
+        case UNIIR_EPI_BF16: gemm_epilogue<UNIIR_EPI_BF16, MT, NT, F16>(p, acc, m0, n0, wm, wn); break;
+        case UNIIR_EPI_BIAS_ACT: gemm_epilogue<UNIIR_EPI_BIAS_ACT, MT, NT, F16>(p, acc, m0, n0, wm, wn); break;
         case UNIIR_EPI_RESID_F32: gemm_epilogue<UNIIR_EPI_RESID_F32, MT, NT>(p, acc, m0, n0, wm, wn); break;
         case UNIIR_EPI_DACT: gemm_epilogue<UNIIR_EPI_DACT, MT, NT>(p, acc, m0, n0, wm, wn); break;
         case UNIIR_EPI_F32: gemm_epilogue<UNIIR_EPI_F32, MT, NT>(p, acc, m0, n0, wm, wn); break;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKArgs p) {
         gemm_epilogue<UNIIR_EPI_F32, 4, 4>(q, acc, m0, n0, (w >> 1) * 64, (w & 1) * 64);
         return;
     }
-    gemm_epilogue_dispatch<4, 4>(p, acc, m0, n0, (w >> 1) * 64, (w & 1) * 64);
+    gemm_epilogue_dispatch<4, 4, Elem::F16>(p, acc, m0, n0, (w >> 1) * 64, (w & 1) * 64);
 }
 
 // Epilogue of the 256x256 (8-wave) tile staged through LDS so that every global access is a full 16-B-per-lane,
@@ -410,7 +410,7 @@ DEVINL void epilogue256_dact8(const GemmKArgs& p, const f32x4_t (&acc)[8][4], in
 }
 
 // bf16 copy-out with the activation copy (EPI_BIAS_ACT): C <- f, C2 <- act(f)
-template <int ACT, int SRCSTEP = 8192>
+template <int ACT, bool F16 = false, int SRCSTEP = 8192>
 DEVINL void epi_bf16_copy_act(const char* src, unsigned short* c1, unsigned short* c2, long rstep, bool full, bool colok,
                               int rows_left, bool skip_f) {
 #pragma unroll 2
@@ -421,7 +421,7 @@ DEVINL void epi_bf16_copy_act(const char* src, unsigned short* c1, unsigned shor
             u32x4_t g;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                g[e] = pack_bf16x2(act_fwd(__uint_as_float(v[e] << 16), ACT), act_fwd(__uint_as_float(v[e] & 0xffff0000u), ACT));
+                g[e] = pack16x2<F16>(act_fwd(unpack16_lo<F16>(v[e]), ACT), act_fwd(unpack16_hi<F16>(v[e]), ACT));
             *reinterpret_cast<u32x4_t*>(c2) = g;
         }
         c1 += rstep;
@@ -510,7 +510,7 @@ DEVINL void epilogue256_resid_full(const GemmKArgs& p, const f32x4_t (&acc)[8][4
     resid_copy_out<1, HAS_C2, HAS_SCALE>(d, rb, sb, csum);
 }
 
-template <bool PP>
+template <bool PP, bool F16 = false>
 DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], int m0, int n0, int wm, int wn,
                                char* lds, int epi) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -538,7 +538,7 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4_t v = acc[i][j] * alpha4 + bv[j];     // two v_pk_fma_f32 (alpha == 1 is exact)
-                const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                const u32x2_t o = {pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
                 *reinterpret_cast<u32x2_t*>(sj[j] + rb) = o;
             }
         }
@@ -572,11 +572,11 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
                 c1 += rstep;
             }
         } else if (p.act == UNIIR_ACT_QUICKGELU) {
-            epi_bf16_copy_act<UNIIR_ACT_QUICKGELU>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
+            epi_bf16_copy_act<UNIIR_ACT_QUICKGELU, F16>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
         } else if (p.act == UNIIR_ACT_GELU_ERF) {
-            epi_bf16_copy_act<UNIIR_ACT_GELU_ERF>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
+            epi_bf16_copy_act<UNIIR_ACT_GELU_ERF, F16>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
         } else {
-            epi_bf16_copy_act<UNIIR_ACT_RELU>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
+            epi_bf16_copy_act<UNIIR_ACT_RELU, F16>(src, c1, c2, rstep, full, colok, rows_left, p.skip_f != 0);
         }
         return;
     }
@@ -762,12 +762,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
             q.C = p.slab + (long)split * p.M * p.N;
             q.ldc = p.N;
             q.bias = nullptr;
-            epilogue256_staged<PP>(q, acc, m0, n0, wm, wn, lds, UNIIR_EPI_F32);
+            epilogue256_staged<PP, Elem::F16>(q, acc, m0, n0, wm, wn, lds, UNIIR_EPI_F32);
         } else if (p.epilogue == UNIIR_EPI_ATOMIC_F32) {
             if (PP) epilogue_atomic_pp(p, acc, m0, n0);
             else gemm_epilogue<UNIIR_EPI_ATOMIC_F32, 8, 4>(p, acc, m0, n0, wm, wn);
         } else {
-            epilogue256_staged<PP>(p, acc, m0, n0, wm, wn, lds, p.epilogue);
+            epilogue256_staged<PP, Elem::F16>(p, acc, m0, n0, wm, wn, lds, p.epilogue);
         }
         PP_STAMP(2);
         return;
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
         gemm_epilogue<UNIIR_EPI_F32, 8, 4>(q, acc, m0, n0, wm, wn);
         return;
     }
-    gemm_epilogue_dispatch<8, 4>(p, acc, m0, n0, wm, wn);
+    gemm_epilogue_dispatch<8, 4, Elem::F16>(p, acc, m0, n0, wm, wn);
 }
 
 template <typename Elem, int WM, int WN, int BK, int ASM>
@@ -987,6 +987,9 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     // column sums of the result ride the fp32 copy-out passes only (DACT / RESID_F32 / F32 epilogues)
     if (d->colsum && d->epilogue != UNIIR_EPI_DACT && d->epilogue != UNIIR_EPI_RESID_F32 && d->epilogue != UNIIR_EPI_F32)
         return UNIIR_EUNSUPPORTED;
+    // fp16 operands (the forward-only embedding towers): the 16-bit outputs of EPI_BF16 / BIAS_ACT / ACT_ONLY are fp16 as well; the
+    // backward-side epilogues (activation gradient, the bf16 copy of a residual output) exist for bf16 only
+    if (d->dtype == UNIIR_DT_F16 && (d->epilogue == UNIIR_EPI_DACT || (d->epilogue == UNIIR_EPI_RESID_F32 && d->C2))) return UNIIR_EUNSUPPORTED;
     if (d->N % 8) return UNIIR_ESHAPE;
     if (!d->a_tmaj && (d->K % 8)) return UNIIR_ESHAPE;
     if (!d->b_tmaj && (d->K % 8)) return UNIIR_ESHAPE;

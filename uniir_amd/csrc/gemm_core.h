@@ -20,12 +20,14 @@
 #define GEMM_LDS_BYTES (4 * GEMM_OPBYTES)      // 2 stages x 2 operands
 
 struct ElemBF16 {
+    static constexpr bool F16 = false;
     static DEVINL f32x4_t mfma(u32x4_t a, u32x4_t b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                        __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
 };
 struct ElemF16 {
+    static constexpr bool F16 = true;       // 16-bit OUTPUTS of the epilogues are fp16 too (EPI_BF16 / BIAS_ACT / ACT_ONLY)
     static DEVINL f32x4_t mfma(u32x4_t a, u32x4_t b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
                                                       __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);

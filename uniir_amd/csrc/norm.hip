@@ -21,8 +21,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta,
                                                      unsigned short* __restrict__ y_bf16,
                                                      float* __restrict__ y_f32, int rows, int width,
-                                                     float eps, int rms) {
-    // rms != 0: T5 / RMS norm (y = gamma * x * rsqrt(mean(x^2) + eps)): no mean subtraction, no beta
+                                                     float eps, int flags) {
+    // flags bit 0: T5 / RMS norm (y = gamma * x * rsqrt(mean(x^2) + eps)): no mean subtraction, no beta;  bit 1: the 16-bit output is
+    // fp16 instead of bf16 (the fp16 forward of the embedder, uniir_clip_tower.dtype16)
+    const int rms = flags & 1;
+    const bool f16 = (flags & 2) != 0;
     const int lane = threadIdx.x & 63;
     const int nchunk = width >> 2;
     const float inv_w = 1.0f / (float)width;
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 const f32x4_t b = rms ? f32x4_t{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4_t*>(beta + 4 * c);
                 const f32x4_t o = (v[i] - mean) * rstd * g + b;
                 if (y_bf16) {
-                    u32x2_t pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    u32x2_t pk = {pack16x2(o[0], o[1], f16), pack16x2(o[2], o[3], f16)};
                     *reinterpret_cast<u32x2_t*>(y_bf16 + row * width + 4 * c) = pk;
                 }
                 if (y_f32) *reinterpret_cast<f32x4_t*>(y_f32 + row * width + 4 * c) = o;
@@ -228,22 +231,28 @@ static inline int ln_nc(int width) {
     return c <= 2 ? 2 : (c == 3 ? 3 : (c == 4 ? 4 : 8));
 }
 
-extern "C" int uniir_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta,
-                                   void* y_bf16, float* y_f32, int32_t rows, int32_t width, float eps,
-                                   void* stream) {
-    if (!x || !gamma || !beta || (!y_bf16 && !y_f32) || rows < 0) return UNIIR_EINVAL;
+// f16: the 16-bit output as fp16 (tower.hip's fp16 forward; the extern "C" entry point writes bf16)
+int layernorm_fwd_impl(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* y_16, float* y_f32,
+                       int32_t rows, int32_t width, float eps, int f16, void* stream) {
+    if (!x || !gamma || !beta || (!y_16 && !y_f32) || rows < 0) return UNIIR_EINVAL;
     if (rows == 0) return UNIIR_OK;
     if (width % 4 || width > 64 * 4 * LN_MAXC || width <= 0 || x_stride % 4) return UNIIR_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-    unsigned short* yb = (unsigned short*)y_bf16;
+    unsigned short* yb = (unsigned short*)y_16;
+    const int flags = f16 ? 2 : 0;
     switch (ln_nc(width)) {
-        case 2: launch_ln_fwd<2>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st); break;
-        case 3: launch_ln_fwd<3>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st); break;
-        case 4: launch_ln_fwd<4>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st); break;
-        default: launch_ln_fwd<8>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st); break;
+        case 2: launch_ln_fwd<2>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st, flags); break;
+        case 3: launch_ln_fwd<3>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st, flags); break;
+        case 4: launch_ln_fwd<4>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st, flags); break;
+        default: launch_ln_fwd<8>(x, x_stride, gamma, beta, yb, y_f32, rows, width, eps, st, flags); break;
     }
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
+}
+extern "C" int uniir_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta,
+                                   void* y_bf16, float* y_f32, int32_t rows, int32_t width, float eps,
+                                   void* stream) {
+    return layernorm_fwd_impl(x, x_stride, gamma, beta, y_bf16, y_f32, rows, width, eps, 0, stream);
 }
 
 static int layernorm_bwd_impl(const float* x, int64_t x_stride, const float* gamma, const void* dy, int32_t dy_is_f32,

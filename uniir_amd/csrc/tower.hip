@@ -9,6 +9,15 @@
 #include "../../include/uniir_hip.h"
 #include <string.h>
 
+// the forward's ops with the 16-bit storage type as a parameter (defined next to their extern "C" bf16 entry points)
+int patchify_impl(const float* images, void* patches, int32_t n, int32_t res, int32_t patch, int32_t kpad, int f16, void* stream);
+int vit_assemble_impl(const void* patch_out, const float* class_emb, const float* pos_emb, float* x, int32_t n, int32_t tokens,
+                      int32_t width, int f16, void* stream);
+int layernorm_fwd_impl(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* y_16, float* y_f32,
+                       int32_t rows, int32_t width, float eps, int f16, void* stream);
+int attention_fwd_impl(const void* qkv, void* out, float* lse, const int32_t* row_off, int32_t batch, int32_t seq, int32_t heads,
+                       int32_t causal, int f16, void* stream);
+
 namespace {
 
 inline int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -123,9 +132,10 @@ void base_desc(uniir_gemm_desc& d) {
 
 // y[M,N] = x[M,K] @ w[N,K]^T (+ epilogue)
 int linear_fwd(const void* x, const void* w, void* out, int M, int N, int K, int epi, const float* bias, const float* resid,
-               void* C2, void* st) {
+               void* C2, void* st, int f16 = 0) {
     uniir_gemm_desc d;
     base_desc(d);
+    if (f16) d.dtype = UNIIR_DT_F16;
     d.A = x; d.B = w; d.C = out; d.C2 = C2; d.bias = bias; d.resid = resid;
     d.M = M; d.N = N; d.K = K; d.lda = K; d.ldb = K; d.ldc = N; d.epilogue = epi;
     return uniir_gemm(&d, st);
@@ -200,24 +210,24 @@ float* stream_in(const Plan& p, char* ws, int i) {
 
 int blocks_fwd(const uniir_clip_tower* t, const Plan& p, char* ws, void* st) {
     const int R = p.R, W = p.W;
+    const int f16 = t->dtype16 != 0;            // forward-only (tower_fwd refuses save_for_backward with it)
     for (int i = 0; i < p.L; ++i) {
         const uniir_clip_block& b = t->blocks[i];
         Lay l = layer_bufs(p, ws, i);
         float* x = stream_in(p, ws, i);
         float* xn = (!p.save && i + 1 == p.L) ? ((i & 1) ? (float*)(ws + p.lay0 + p.o_x) : (float*)(ws + p.x_last))
                                                : stream_in(p, ws, i + 1);
-        TRY(uniir_layernorm_fwd(x, W, b.ln1_w, b.ln1_b, l.h1, nullptr, R, W, 1e-5f, st));
-        TRY(linear_fwd(l.h1, b.wqkv16, l.qkv, R, 3 * W, W, UNIIR_EPI_BF16, b.bqkv, nullptr, nullptr, st));
-        if (p.row_off) TRY(uniir_attention_fwd_packed(l.qkv, l.ao, l.lse, p.row_off, p.M, p.T, p.H, t->is_text ? 1 : 0, st));
-        else TRY(uniir_attention_fwd(l.qkv, l.ao, l.lse, p.M, p.T, p.H, t->is_text ? 1 : 0, st));
-        TRY(linear_fwd(l.ao, b.wo16, l.x2, R, W, W, UNIIR_EPI_RESID_F32, b.bo, x, nullptr, st));
-        TRY(uniir_layernorm_fwd(l.x2, W, b.ln2_w, b.ln2_b, l.h2, nullptr, R, W, 1e-5f, st));
+        TRY(layernorm_fwd_impl(x, W, b.ln1_w, b.ln1_b, l.h1, nullptr, R, W, 1e-5f, f16, st));
+        TRY(linear_fwd(l.h1, b.wqkv16, l.qkv, R, 3 * W, W, UNIIR_EPI_BF16, b.bqkv, nullptr, nullptr, st, f16));
+        TRY(attention_fwd_impl(l.qkv, l.ao, l.lse, p.row_off, p.M, p.T, p.H, t->is_text ? 1 : 0, f16, st));
+        TRY(linear_fwd(l.ao, b.wo16, l.x2, R, W, W, UNIIR_EPI_RESID_F32, b.bo, x, nullptr, st, f16));
+        TRY(layernorm_fwd_impl(l.x2, W, b.ln2_w, b.ln2_b, l.h2, nullptr, R, W, 1e-5f, f16, st));
         void* g = p.stash_act ? l.g : (void*)(ws + p.g);
         if (p.save)       // f (pre-activation) is stashed for the backward; a forward-only pass writes act(f) alone
-            TRY(linear_fwd(l.h2, b.wfc16, l.f, R, 4 * W, W, UNIIR_EPI_BIAS_ACT, b.bfc, nullptr, g, st));
+            TRY(linear_fwd(l.h2, b.wfc16, l.f, R, 4 * W, W, UNIIR_EPI_BIAS_ACT, b.bfc, nullptr, g, st, f16));
         else
-            TRY(linear_fwd(l.h2, b.wfc16, g, R, 4 * W, W, UNIIR_EPI_ACT_ONLY, b.bfc, nullptr, nullptr, st));
-        TRY(linear_fwd(g, b.wproj16, xn, R, W, 4 * W, UNIIR_EPI_RESID_F32, b.bproj, l.x2, nullptr, st));
+            TRY(linear_fwd(l.h2, b.wfc16, g, R, 4 * W, W, UNIIR_EPI_ACT_ONLY, b.bfc, nullptr, nullptr, st, f16));
+        TRY(linear_fwd(g, b.wproj16, xn, R, W, 4 * W, UNIIR_EPI_RESID_F32, b.bproj, l.x2, nullptr, st, f16));
     }
     return UNIIR_OK;
 }
@@ -241,6 +251,8 @@ int tower_fwd(const uniir_clip_tower* t, const void* input, int32_t batch, const
     if (!input || !emb_out || !workspace) return UNIIR_EINVAL;
     if (batch == 0) return UNIIR_OK;
     if ((uintptr_t)workspace & 255) return UNIIR_EALIGN;
+    const int f16 = t->dtype16 != 0;
+    if (f16 && save_for_backward) return UNIIR_EUNSUPPORTED;       // the fp16 towers are the embedder's forward; training is bf16
     const Plan p = plan(t, batch, save_for_backward != 0, rows, row_off);
     if (workspace_bytes < p.total) return UNIIR_EINVAL;
     char* ws = (char*)workspace;
@@ -248,9 +260,9 @@ int tower_fwd(const uniir_clip_tower* t, const void* input, int32_t batch, const
     float* x_in = stream_in(p, ws, 0);
     const int32_t* eot = nullptr;
     if (!t->is_text) {
-        TRY(uniir_patchify((const float*)input, ws + p.patches, M, t->resolution, t->patch, t->kpad, stream));
-        TRY(linear_fwd(ws + p.patches, t->conv16, ws + p.po, M * p.G, W, t->kpad, UNIIR_EPI_BF16, nullptr, nullptr, nullptr, stream));
-        TRY(uniir_vit_assemble(ws + p.po, t->class_emb, t->pos_emb, (float*)(ws + p.x0), M, T, W, stream));
+        TRY(patchify_impl((const float*)input, ws + p.patches, M, t->resolution, t->patch, t->kpad, f16, stream));
+        TRY(linear_fwd(ws + p.patches, t->conv16, ws + p.po, M * p.G, W, t->kpad, UNIIR_EPI_BF16, nullptr, nullptr, nullptr, stream, f16));
+        TRY(vit_assemble_impl(ws + p.po, t->class_emb, t->pos_emb, (float*)(ws + p.x0), M, T, W, f16, stream));
         TRY(uniir_layernorm_fwd((float*)(ws + p.x0), W, t->ln_pre_w, t->ln_pre_b, nullptr, x_in, R, W, 1e-5f, stream));
     } else if (row_off) {    // packed: only the rows up to each caption's EOT exist; p.eot holds every item's last (= EOT) row
         TRY(uniir_text_embed_packed((const int32_t*)input, t->token_emb, t->pos_emb, row_off, x_in, (int32_t*)(ws + p.eot), M, T, W,
@@ -264,9 +276,10 @@ int tower_fwd(const uniir_clip_tower* t, const void* input, int32_t batch, const
     TRY(blocks_fwd(t, p, ws, stream));
     float* x_out = p.save ? (float*)(ws + p.x_last) : stream_out(p, ws);
     TRY(uniir_gather_rows(x_out, eot, (float*)(ws + p.rows), M, row_off ? 0 : T, W, stream));     // (packed: absolute row indices)
-    TRY(uniir_layernorm_fwd((float*)(ws + p.rows), W, t->ln_post_w, t->ln_post_b, ws + p.pooled, nullptr, M, W, 1e-5f, stream));
+    TRY(layernorm_fwd_impl((float*)(ws + p.rows), W, t->ln_post_w, t->ln_post_b, ws + p.pooled, nullptr, M, W, 1e-5f, f16, stream));
     uniir_gemm_desc d;
     base_desc(d);
+    if (f16) d.dtype = UNIIR_DT_F16;
     d.A = ws + p.pooled; d.B = t->proj16; d.C = emb_out;
     d.M = M; d.N = p.E; d.K = W; d.lda = W; d.ldb = p.E; d.ldc = p.E; d.b_tmaj = 1; d.epilogue = UNIIR_EPI_F32;
     return uniir_gemm(&d, stream);

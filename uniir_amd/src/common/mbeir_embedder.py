@@ -32,8 +32,29 @@ from dist_utils import ContiguousDistributedSampler
 from utils import build_model_from_config, set_seed
 
 
+def _clip_towers(model):
+    """the uniir_amd CLIP module behind a CLIP_SF / CLIP_FF model (DDP-wrapped or not), or None (BLIP)"""
+    inner = getattr(model, "module", model)
+    clip = getattr(inner, "clip_model", None)
+    return clip if hasattr(clip, "precision") else None
+
+
 @torch.no_grad()
 def generate_embeds_and_ids_for_dataset_with_gather(model, data_loader, device, use_fp16=True):
+    # the reference runs the towers under torch.cuda.amp.autocast(enabled=use_fp16) (:52-56) -- fp16 matmuls: the CLIP towers here take
+    # their fp16 forward for the extraction (clip_model.precision = "fp16") and go back to what they were set to afterwards
+    clip = _clip_towers(model)
+    restore = None
+    if clip is not None and use_fp16 and clip.precision == "bf16":
+        restore, clip.precision = clip.precision, "fp16"
+    try:
+        return _generate(model, data_loader, device)
+    finally:
+        if restore is not None:
+            clip.precision = restore
+
+
+def _generate(model, data_loader, device):
     chunks, id_list = [], []
     for batch in data_loader:
         for k, v in batch.items():
