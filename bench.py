@@ -230,9 +230,9 @@ def bench_retrieval(dev, n=700_000, d=768, k=10, full=True):
                          "mfma": {"achieved": round(2.0 * nq * n * d / t / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12,
                                   "unit": "TFLOP/s", "frac": round(2.0 * nq * n * d / t / MFMA_PEAK_BF16, 4)}}
     if n == 700_000 and d == 768:      # a citation of a committed profile of THIS shard shape, not a measurement of this run
-        out["traffic_note"] = ("cited from profiles/r03_topk_pmc.txt (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE of the scan kernel on a "
-                               "700000 x 768 shard): 1.079 GB fetched per sweep of the 1.075-GB shard (read once), 27.8 MB written at 64 "
-                               "queries, 81.3 MB at 256")
+        note = os.path.join(ROOT, "profiles", "topk_pmc_note.json")      # written with profiles/r05_topk_pmc.txt (tools/topk_pmc.sh)
+        out["traffic_note"] = (json.load(open(note))["note"] if os.path.exists(note) else
+                               "no rocprofv3 --pmc record of the scan kernels under profiles/")
     out["workload"] = (f"top-{k} of {n} x {d} fp16 candidates (one GPU's shard of the 5.6M pool), exact fp32 re-score; "
                        "recall on M-BEIR itself cannot be shown offline (no dataset / checkpoint in the image): exactness is "
                        "pinned against the C oracle instead")

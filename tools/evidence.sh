@@ -23,7 +23,8 @@ for S in $STAGES; do
     profile)
       bash tools/profile_bench.sh $TAG > $O/profile_bench.out 2>&1; tail -14 $O/profile_bench.out | cut -c1-200 ;;
     topk)
-      bash tools/topk_table.sh > /dev/null 2>&1; cp gpurun_out/topk_table.txt $O/ ; tail -30 $O/topk_table.txt | cut -c1-160 ;;
+      bash tools/topk_table.sh > /dev/null 2>&1; cp gpurun_out/topk_table.txt $O/ ; tail -30 $O/topk_table.txt | cut -c1-160
+      rm -f gpurun_out/topk_pmc/topk_pmc.txt; bash tools/topk_pmc.sh > /dev/null 2>&1; cp gpurun_out/topk_pmc/topk_pmc.txt $O/ ; tail -12 $O/topk_pmc.txt | cut -c1-160 ;;
     secondary)
       SEC_LIST="embed blip clipff" bash tools/profile_secondary.sh > $O/profile_secondary.out 2>&1; grep -E "^\{" $O/profile_secondary.out | cut -c1-200 ;;
     micro)
