@@ -234,3 +234,32 @@ def test_clip_base_width_pools_on_the_streaming_scan_equal_the_c_oracle(n, nq, k
     assert np.array_equal(i.cpu().numpy(), wi), np.argwhere(i.cpu().numpy() != wi)[:5]
     assert np.array_equal(s.cpu().numpy(), ws)
 
+
+
+@pytest.mark.parametrize("nq,spread", [(8, 0.0), (64, 3e-6), (64, 3e-5), (200, 2e-4), (8, 2e-3)])
+def test_topk_candidate_bound_against_adversarial_near_ties(nq, spread):
+    """The fused tail keeps every group whose maximum lies within the PROVEN rounding bound of the k-th best group maximum
+    (topk_select.h GselBound: 5e-4 |q| in the scan's units) instead of a fixed k + 8 groups.  Adversarial pools for it: 30 rows, each
+    alone in a different 16-row group, whose cosines with a query differ by less than the scan's rounding error (spread 0 ... 3e-5:
+    the approximate ranking among them is noise, all of them must be re-scored -- more than the old k + 8 = 18), around the bound
+    (2e-4) and clearly apart (2e-3: the rule may now drop most of them).  Distances and ids must equal the C oracle's, bit for bit."""
+    from oracle import c_oracle
+    from uniir_amd import retrieval
+    n, d, k = 40_000, 768, 10
+    g = torch.Generator(device=DEV).manual_seed(int(spread * 1e7) + nq)
+    pool = torch.randn(n, d, device=DEV, generator=g) * 0.3
+    queries = torch.randn(nq, d, device=DEV, generator=g)
+    qn = queries / queries.norm(dim=1, keepdim=True)
+    groups = torch.randperm(n // 16 - 1, device=DEV, generator=g)[:30] * 16 + 3          # 30 rows, each in its own group
+    for qi in range(min(nq, 8)):                       # near-tie clusters for the first queries
+        rows = (groups + qi) % n
+        noise = torch.randn(30, d, device=DEV, generator=g)
+        noise = noise - (noise @ qn[qi])[:, None] * qn[qi][None, :]
+        noise = noise / noise.norm(dim=1, keepdim=True)
+        cos = 0.9 - spread * torch.arange(30, device=DEV).float()              # cosines 0.9, 0.9 - spread, ...
+        pool[rows] = (cos[:, None] * qn[qi][None, :] + (1 - cos * cos).sqrt()[:, None] * noise) * (1.0 + 0.1 * qi)
+    pool16, q16 = pool.half(), queries.half()
+    ids = torch.randperm(n, device=DEV, generator=g).to(torch.int64) + 11
+    s, i = retrieval.search_shard(retrieval.PoolShard(pool16, ids), q16, k)
+    ws, wi = c_oracle.topk(pool16.cpu().numpy(), ids.cpu().numpy(), q16.cpu().numpy(), k)
+    assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(s.cpu().numpy(), ws)

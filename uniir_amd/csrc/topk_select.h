@@ -9,6 +9,21 @@
 //           largest group value: that many distinct groups reach it)
 //   pass 2: groups >= tau0 are collected in LDS (a few dozen), ranked exactly, the best gcap kept.
 // If the collection overflows (massive exact ties) the kernel falls back to one-extraction-per-round selection.
+// The rigorous candidate rule of the fused tail (round 5).  The scan's group maxima are APPROXIMATE scores (fp16 x fp16 products are
+// exact in fp32, the MFMA chain and the scaling by the row's inverse norm round: |approx - true| <= d_a = 793 x 2^-23 of |q| in the
+// scan's units, which leave the query un-normalised); the tail's re-score is the oracle's fp32 chain (|exact - true| <= d_e = 771 x
+// 2^-24 in cosine units).  Let tau_k be the k-th largest group maximum: k distinct rows reach it, so the k-th best EXACT score is at
+// least tau_k - (d_a + d_e), and a row of the exact top-k has an approximate score -- hence a group maximum -- of at least
+// tau_k - 2 (d_a + d_e) = tau_k - 2.8e-4 |q|.  Every group within TK_SLACK_COS = 5e-4 (x |q|) of tau_k becomes a candidate, nothing
+// else: ~11 groups at k = 10 on random data instead of the fixed k + 8 = 18 (which is no bound at all: nine near-ties within the
+// rounding error would defeat it) -- 40 % fewer rows gathered and re-scored.  More than gcap = 2 (k + 8) qualifying groups (massive
+// near-ties: duplicated rows) keep the best gcap, as before.  The kept groups occupy a PREFIX of the slots; *nkept is their number.
+#define TK_SLACK_COS 5.0e-4f
+struct GselBound {
+    int k;              // entries wanted
+    const float* iq;    // LDS: the query's inverse norm, written by the caller's mid() (read after the barrier that follows it)
+    int* nkept;         // LDS: groups kept
+};
 #define TK_SELCAP 1024
 #define TK_SELREG 24    // float2 loads per thread of the register-resident variant: ngroups <= 1024 * 2 * 24
 // REG (the interactive <= 64-query path, one 1024-thread block per query): the query's group maxima are read ONCE, as
@@ -17,7 +32,9 @@
 // `out` (gcap * TK_G row indices, -1 = empty) may be global memory (topk_gsel_kernel) or LDS (the fused tail kernel); every
 // thread of the block returns from this function (no early exit: the fused kernel goes on to the re-score).
 template <int BS, bool REG, class F>
-DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int kc, int gcap, int* out, F&& mid) {
+DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int kc, int gcap, int* out, F&& mid,
+                      const GselBound* gb = nullptr) {
+    const int kk = gb ? gb->k : kc;          // the rank whose value anchors the thresholds
     __shared__ float tmax[BS];
     __shared__ float bval[TK_SELCAP];
     __shared__ int bgrp[TK_SELCAP];
@@ -44,7 +61,7 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
         mid();
         for (long e = tid; e < ngroups; e += BS) mx = fmaxf(mx, g[e]);
     }
-    if (tid == 0) { bcnt = 0; tau0 = -INFINITY; tau = -INFINITY; }
+    if (tid == 0) { bcnt = 0; tau0 = -INFINITY; tau = -INFINITY; if (gb) *gb->nkept = 0; }
     if (BS == 1024) {
         // threshold = the kc-th largest of the 64 quarter-wave maxima (disjoint subsets, so at least kc entries reach it;
         // ~20-30 entries do at kc = 18).  Ranking all 1024 thread maxima against each other was 1 M compares per block
@@ -59,7 +76,7 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
                 const float o = tmax[t];
                 rank += (o > v || (o == v && t < tid)) ? 1 : 0;
             }
-            if (rank == min(kc, 64) - 1) tau0 = v;
+            if (rank == min(kk, 64) - 1) tau0 = v;
         }
     } else {
         tmax[tid] = mx;
@@ -69,10 +86,12 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
             const float o = tmax[t];
             rank += (o > mx || (o == mx && t < tid)) ? 1 : 0;
         }
-        if (rank == kc - 1) tau0 = mx;   // exactly one thread has this rank
+        if (rank == kk - 1) tau0 = mx;   // exactly one thread has this rank
     }
     __syncthreads();
-    const float t0 = tau0;
+    // (the barrier above also publishes *gb->iq, written inside mid())
+    const float slack = (gb && *gb->iq > 0.f) ? TK_SLACK_COS / *gb->iq : 0.f;      // in the scan's units (scores x |q|)
+    const float t0 = tau0 - slack;
     if (REG) {
 #pragma unroll
         for (int it = 0; it < TK_SELREG; ++it)
@@ -106,10 +125,10 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
                 const int og = bgrp[t];
                 rank += (o > v || (o == v && og < gi)) ? 1 : 0;
             }
-            if (rank == min(kc, n) - 1) tau = v;
+            if (rank == min(kk, n) - 1) tau = v;
         }
         __syncthreads();
-        const float tt = tau;
+        const float tt = tau - slack;
         for (int e = tid; e < n; e += BS) {
             const float v = bval[e];
             const int gi = bgrp[e];
@@ -124,6 +143,7 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
                     const long row = (long)gi * TK_G + m;
                     out[rank * TK_G + m] = row < rows ? (int)row : -1;
                 }
+                if (gb) atomicMax(gb->nkept, rank + 1);
             }
         }
     } else {
@@ -155,12 +175,13 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
         last_s = wsel; last_g = isel;
         __syncthreads();
         if (last_g == 0x7fffffffffffffffLL || last_s == -INFINITY) break;
-        if (j == kc - 1) tk = last_s;
-        if (j >= kc && last_s < tk) break;
+        if (j == kk - 1) tk = last_s - slack;
+        if (j >= kk && last_s < tk) break;
         if (tid < TK_G) {
             const long row = last_g * TK_G + tid;
             out[j * TK_G + tid] = row < rows ? (int)row : -1;
         }
+        if (gb && tid == 0) *gb->nkept = j + 1;
     }
     }
     __syncthreads();
@@ -175,7 +196,8 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
 #define TK_HWAVES 128        // candidate waves kept
 template <int BS, class F>
 DEVINL bool gsel_hier(const float* __restrict__ g, const float* __restrict__ wm, int nw, long ngroups, long rows, int kc, int gcap,
-                      int* out, F&& mid) {
+                      int* out, F&& mid, const GselBound* gb = nullptr) {
+    const int kk = gb ? gb->k : kc;
     __shared__ float qmax[64];
     __shared__ int cwave[TK_HWAVES];
     __shared__ float hval[TK_SELCAP];
@@ -186,7 +208,7 @@ DEVINL bool gsel_hier(const float* __restrict__ g, const float* __restrict__ wm,
     for (int e = tid; e < gcap * TK_G; e += BS) out[e] = -1;
     const float v = tid < nw ? wm[tid] : -INFINITY;
     mid();
-    if (tid == 0) { ccnt = 0; hcnt = 0; htau0 = -INFINITY; htau = -INFINITY; }
+    if (tid == 0) { ccnt = 0; hcnt = 0; htau0 = -INFINITY; htau = -INFINITY; if (gb) *gb->nkept = 0; }
     const float qm = row16_max(v);
     if ((tid & 15) == 0) qmax[tid >> 4] = qm;
     __syncthreads();
@@ -197,10 +219,11 @@ DEVINL bool gsel_hier(const float* __restrict__ g, const float* __restrict__ wm,
             const float o = qmax[t];
             rank += (o > x || (o == x && t < tid)) ? 1 : 0;
         }
-        if (rank == min(kc, 64) - 1) htau0 = x;
+        if (rank == min(kk, 64) - 1) htau0 = x;
     }
     __syncthreads();
-    const float t0 = htau0;
+    const float slack = (gb && *gb->iq > 0.f) ? TK_SLACK_COS / *gb->iq : 0.f;      // (*gb->iq: published by the barriers above)
+    const float t0 = htau0 - slack;
     if (v >= t0 && v > -INFINITY) {
         const int pos = atomicAdd(&ccnt, 1);
         if (pos < TK_HWAVES) cwave[pos] = tid;
@@ -236,10 +259,10 @@ DEVINL bool gsel_hier(const float* __restrict__ g, const float* __restrict__ wm,
             const int og = hgrp[t];
             rank += (o > x || (o == x && og < gi)) ? 1 : 0;
         }
-        if (rank == min(kc, n) - 1) htau = x;
+        if (rank == min(kk, n) - 1) htau = x;
     }
     __syncthreads();
-    const float tt = htau;
+    const float tt = htau - slack;
     for (int e = tid; e < n; e += BS) {
         const float x = hval[e];
         const int gi = hgrp[e];
@@ -254,6 +277,7 @@ DEVINL bool gsel_hier(const float* __restrict__ g, const float* __restrict__ wm,
                 const long row = (long)gi * TK_G + m;
                 out[rank * TK_G + m] = row < rows ? (int)row : -1;
             }
+            if (gb) atomicMax(gb->nkept, rank + 1);
         }
     }
     __syncthreads();

@@ -460,7 +460,7 @@ template <int PARTS, int RW, int DEPTH>
 __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     const unsigned short* __restrict__ pool, const float* __restrict__ pinv, long rows, int dim,
     const unsigned short* __restrict__ queries, const float* __restrict__ gmax, long ngroups, int kc, int gcap,
-    int* __restrict__ cand, float* __restrict__ exact, const float* __restrict__ wmax, int nw, TkMulti mu) {
+    int* __restrict__ cand, float* __restrict__ exact, const float* __restrict__ wmax, int nw, TkMulti mu, int k) {
     if (mu.per > 0) {        // batched tail: blockIdx.z = sub-shard (rows [z per, ..) of one resident pool), everything re-based onto it
         const long z = blockIdx.z;
         pool += z * mu.per * dim;
@@ -477,6 +477,7 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     __shared__ __attribute__((aligned(16))) unsigned short qrow[4096];
     __shared__ __attribute__((aligned(16))) float qn[4096];
     __shared__ float s_iq;
+    __shared__ int s_nkept;
     const int q = blockIdx.x, part = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned short* qr = queries + (long)q * dim;
@@ -523,9 +524,17 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
         }
     };
     // the selection ends with a barrier; behind the streaming scans it starts from the per-wave maxima (gsel_hier)
-    if (!(wmax && gsel_hier<TKT_THREADS>(gmax + (long)q * ngroups, wmax + (long)q * nw, nw, ngroups, rows, kc, gcap, sel, qnorm)))
-        gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm);
-    const int ngrp = (gcap - part + PARTS - 1) / PARTS;      // this workgroup's share: groups of rank part, part + PARTS, ...
+    // candidates: every group within the proven rounding bound of the k-th best group maximum (GselBound, topk_select.h); they fill a
+    // prefix of the slots
+    GselBound gb;
+    gb.k = k;
+    gb.iq = &s_iq;
+    gb.nkept = &s_nkept;
+    if (!(wmax && gsel_hier<TKT_THREADS>(gmax + (long)q * ngroups, wmax + (long)q * nw, nw, ngroups, rows, kc, gcap, sel, qnorm, &gb)))
+        gsel_body<TKT_THREADS, true>(gmax + (long)q * ngroups, ngroups, rows, kc, gcap, sel, qnorm, &gb);
+    const int nkept = s_nkept;
+    // the slots behind the kept groups stay empty for the sort (this workgroup writes the -1 / -inf of its share of them below)
+    const int ngrp = (nkept - part + PARTS - 1) / PARTS;     // this workgroup's share: groups of rank part, part + PARTS, ...
     const int nth = ngrp * TK_G;                             // thread t -> member t % 16 of its (t / 16)-th group
     {
         const float iq = s_iq;                 // the normalised query, once per workgroup (the oracle's qn[j])
@@ -535,6 +544,11 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
         }
     }
     __syncthreads();
+    if (part == 0)                            // the slots no group was kept for: empty for the sort
+        for (int e = nkept * TK_G + tid; e < gcap * TK_G; e += TKT_THREADS) {
+            cand[(long)q * gcap * TK_G + e] = -1;
+            exact[(long)q * gcap * TK_G + e] = -INFINITY;
+        }
     if (w >= RW) return;                                              // no barrier follows
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)pool, 0, (int)(rows * dim * 2), 0x00020000);
     const unsigned qn32 = lds_addr32(reinterpret_cast<const char*>(qn));
@@ -659,7 +673,7 @@ bool launch_fused_tail(const void* pool_f16, const float* pinv, const int64_t* p
                                       hipFuncAttributeMaxDynamicSharedMemorySize, RW * DEPTH * 8192);                  \
         hipLaunchKernelGGL((topk_tail_select_rescore_kernel<P, RW, DEPTH>), g, b, RW * DEPTH * 8192, st,               \
                            (const unsigned short*)pool_f16, pinv, (long)rows, dim, (const unsigned short*)queries_f16, \
-                           gmax, ngroups, kc, gcap, cand, exact, nw > 0 ? wmax : nullptr, nw, *mu);                    \
+                           gmax, ngroups, kc, gcap, cand, exact, nw > 0 ? wmax : nullptr, nw, *mu, k);                 \
     } while (0)
     // rings: 3 waves x 4 slices (the interactive regime: 144 slots per workgroup at k = 10) or 5 waves x 2 slices = 96 / 80 KiB
     if (parts == 4) TKT_LAUNCH(4, 3, 4);
