@@ -67,6 +67,11 @@ class CLIPScoreFusion(nn.Module):
         live_host = self._live_rows(mask)
         if live_host is None:
             return encode(inp)
+        if live_host.numel() == 0 and torch.is_grad_enabled():
+            # training: every rank must run every tower's backward (the overlapped gradient reducer announces a block's range from
+            # it, and the ranks' collective sequences have to match) -- a batch with NO live row for this tower takes the dense path;
+            # its outputs are multiplied by the zero masks as in the reference
+            return encode(inp)
         live = live_host.to(inp.device, non_blocking=True)
         sub = inp.index_select(0, live)
         lens = getattr(inp, "_uniir_lens", None)                        # caption lengths travel with the rows (packed text tower)
