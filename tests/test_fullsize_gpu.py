@@ -105,6 +105,26 @@ def test_topk_whole_mbeir_pool_on_one_gpu(nq):
         rows = (i[qi] - 7) // 3
         ws, wi = c_oracle.topk(pool[rows].cpu().numpy(), ids[rows].cpu().numpy(), queries[qi:qi + 1].cpu().numpy(), k)
         assert np.array_equal(wi[0], ic[qi]) and np.array_equal(ws[0], sc[qi])
+    # no better row was missed: an independent fp32 scan of ALL 5.6 M rows (torch matmul on the device, slice by slice; not the oracle,
+    # a second opinion that can afford the whole pool) -- the 11 best cosines per query; the returned k-th score must not lie below
+    # the best score of any row that was NOT returned (up to the fp32 noise of two different summation orders)
+    qs = min(nq, 64)
+    qf = queries[:qs].float()
+    qf = qf / qf.norm(dim=1, keepdim=True).clamp_min(1e-30)
+    best_s = torch.full((qs, 0), 0.0, device=DEV)
+    best_r = torch.zeros(qs, 0, dtype=torch.int64, device=DEV)
+    for lo in range(0, n, 700_000):
+        blk = pool[lo:lo + 700_000].float()
+        blk = blk / blk.norm(dim=1, keepdim=True).clamp_min(1e-30)
+        ts, tr = torch.topk(qf @ blk.t(), k + 1, dim=1)
+        best_s, sel = torch.topk(torch.cat([best_s, ts], 1), k + 1, dim=1)
+        best_r = torch.gather(torch.cat([best_r, tr + lo], 1), 1, sel)
+        del blk
+    ret_rows = (i[:qs] - 7) // 3
+    for qi in range(qs):
+        missed = [(float(v), int(r)) for v, r in zip(best_s[qi], best_r[qi]) if int(r) not in set(ret_rows[qi].tolist())]
+        assert missed and missed[0][0] <= float(s[qi, k - 1]) + 2e-6, (qi, missed[0], float(s[qi, k - 1]))
+        assert abs(float(best_s[qi, 0]) - float(s[qi, 0])) < 2e-6
     parts = [retrieval.search_shard(retrieval._shard_view(shard, lo, lo + 1_120_000), queries, k) for lo in range(0, n, 1_120_000)]
     ms, mi = retrieval.merge_shards(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(ms, s) and torch.equal(mi, i)

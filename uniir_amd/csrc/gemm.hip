@@ -207,14 +207,13 @@ DEVINL void epi_f32_copy(const GemmKArgs& p, const char* src, long off0, long of
     }
 }
 
-// buffer addressing for the full-tile copy-outs: one SGPR descriptor per tensor at the TILE's first element, one 32-bit per-lane byte
-// offset shared by every row, the row advance as a scalar offset -- no 64-bit per-lane address per row (16 rows x 3 tensors of them
-// is what pushed the first version of these loops into scratch)
-// LOADS only.  Measured (round 5, tools/r5/dact_dbg.py): 16-byte buffer STORES with a scalar row offset returned corrupted dwords
+// buffer addressing for the operand LOADS of the full-tile copy-outs: one SGPR descriptor at the TILE's first element, one 32-bit
+// per-lane byte offset shared by every row, the row advance as a scalar offset -- no 64-bit per-lane address per row (16 rows x 3
+// tensors of them is what pushed the first version of these loops into scratch).
+// Loads only.  Measured (round 5, tools/r5/dact_dbg.py): 16-byte buffer STORES with a scalar row offset returned corrupted dwords
 // when the next row's VALU rewrote the data registers right behind them -- the ">64-bit VMEM store, then VALU write of its data"
 // hazard, which the compiler's hazard recogniser only pads when soffset is NOT a register -- so the outputs leave through plain
 // global stores from a per-thread pointer.
-typedef __attribute__((ext_vector_type(4))) unsigned int bufu4_t;
 DEVINL __amdgpu_buffer_rsrc_t epi_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, -1, 0x00020000);
 }
