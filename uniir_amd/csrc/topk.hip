@@ -13,14 +13,16 @@
 //   scan  : gmax[q][g] = best approximate score of the 16 pool rows of group g.  <= 64 queries: topk_stream2_kernel (queries
 //           in registers, pool streamed through wave-private LDS-DMA rings); 65..256: topk_stream5_kernel (the ring shared by
 //           2 / 4 waves of 64 register-resident queries each); more: topk_gmax_pp_kernel (ping-pong GEMM core);
-//   tail 1: topk_tail_select_rescore_kernel: the k + 8 best groups per query (hierarchically from the scan's per-wave maxima),
-//           the query's inverse norm, the exact re-score of those groups' rows (LDS-DMA gather);
+//   tail 1: topk_tail_select_rescore_kernel: the candidate groups of a query (hierarchically from the scan's per-wave maxima: every
+//           group within the proven rounding bound of the k-th best group maximum, topk_select.h GselBound -- round 5; the fixed
+//           k + 8 best groups before), the query's inverse norm, the exact re-score of those groups' rows (LDS-DMA gather);
 //   tail 2: topk_tail_sort_kernel: (score desc, id asc) by rank counting.
 // This file: inverse norms, the scans, the selection kernels, the one-call search.  topk_tail.hip: re-score, sorts, merges and the
 // fused tail; topk_select.h: the group-selection templates both use; topk.h: shared constants.
-// Exactness: an fp16-product / fp32-accumulate score differs from the oracle's only in summation order, so the true top k rows
-// lie in the k + 8 best groups (ties at the group threshold keep up to 2 (k + 8) groups); the re-score then reproduces the
-// oracle bit for bit.  No run-time switches: the variants that lost their A/B (filtered scan, one-wave rolling-register scan,
+// Exactness: an fp16-product / fp32-accumulate score differs from the oracle's only by rounding (bounded: topk_select.h), so the
+// true top k rows lie in the groups whose maximum is within that bound of the k-th best group maximum (the fused tail), a fortiori
+// in the k + 8 best groups on any non-adversarial input (the op-level selection kernels; ties at the threshold keep up to 2 (k + 8)
+// groups in both); the re-score then reproduces the oracle bit for bit.  No run-time switches: the variants that lost their A/B (filtered scan, one-wave rolling-register scan,
 // default-policy pool streams, ...) are described in experiments/topk/README.md.
 #include "topk.h"
 #include "topk_select.h"
@@ -1327,7 +1329,7 @@ extern "C" int uniir_topk_ip(const void* pool_f16, const float* pool_inv_norm, c
     if (rows <= 0 || nq <= 0 || k <= 0) return UNIIR_EINVAL;
     if (k + 8 > TK_MAXKC || dim % 64 || dim <= 0 || rows > 0x7fffffffL) return UNIIR_ESHAPE;
     // a shard is addressed through 31-bit buffer offsets: >= 2 GiB of rows is searched as equal sub-shards by the caller
-    // (retrieval.subshard_bounds: the 5.6 M x 768 pool on one GPU = 5 calls + uniir_topk_merge), never silently by a slower path
+    // (uniir_topk_ip_multi below: the 5.6 M x 768 pool on one GPU = 8 logical sub-shards), never silently by a slower path
     if (rows * (int64_t)dim * 2 >= ((int64_t)1 << 31)) return UNIIR_ESHAPE;
     if (((uintptr_t)pool_f16 & 15) || ((uintptr_t)queries_f16 & 15) || ((uintptr_t)pool_inv_norm & 15) ||
         ((uintptr_t)workspace & 255))
