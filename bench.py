@@ -526,6 +526,7 @@ def bench_embed_sharded(dist, dev, world, model_name, items=2048, steps=3):
 
     def build():
         m = CLIPScoreFusion(model_name=model_name, device=dev).float().eval()
+        m.clip_model.precision = "fp16"             # the embedder's precision (mbeir_embedder.py:52-56), as in bench_embed
         b = synth_batch(cfg, items // 2, 2023, dev)
         b["did_list"] = list(range(items))
         with torch.no_grad():
@@ -545,7 +546,7 @@ def bench_embed_sharded(dist, dev, world, model_name, items=2048, steps=3):
     with torch.no_grad():
         run()
         t = _rank_max_seconds(dist, dev, run, steps)
-    return {"metric": "embedding items/s (CLIP_SF forward only, fp16 out), summed over the ranks", "value": round(world * items / t, 1),
+    return {"metric": "embedding items/s (CLIP_SF forward only, fp16 towers, fp16 out), summed over the ranks", "value": round(world * items / t, 1),
             "unit": "items/s", "ms_per_batch": round(t * 1e3, 2), "items_per_batch_per_rank": items, "out_shape": shape,
             "mfma_frac": round(world * items / t * executed / (world * MFMA_PEAK_BF16), 4),
             "mfma_frac_note": "pair mode, executed FLOPs (packed text tower at the captions' live lengths)"}
