@@ -45,8 +45,8 @@ if ks:
             k = m.group(1).strip()
             head.append(f"#   {k:42s} {float(m.group(2)):8.2f}   (r04 {R04.get(k, float('nan')):7.2f})")
     head.append("# VERDICT r04 targets: GEMM families <= 415 ms/step (this box: see above; un-profiled the same box ran the driver-shaped bench -- steps 20, warmup 5 --")
-    head.append("#   at the ms/step of profiles/r05_bench_line.json; the round's fastest box: 540.1 ms, profiles/r05_bench_line_box1.json), attention <= 48 (not worked on")
-    head.append("#   this round: its per-head prologue / epilogue diet was priced at ~0.1 ms per launch).")
+    head.append("#   at the ms/step of profiles/r05_bench_line.json; the round's fastest box: 540.1 ms, profiles/r05_bench_line_box1.json), attention <= 48 (its prologue")
+    head.append("#   diet was built and measured this round: no difference, experiments/attention_pair/README.md).")
     open(os.path.join(P, f"{tag}_bench_kernel_stats.txt"), "w").write("\n".join(head) + "\n" + ks)
     if under:
         json.dump(under, open(os.path.join(P, f"{tag}_bench_line_profiled_box.json"), "w"))
