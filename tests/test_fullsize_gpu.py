@@ -317,20 +317,23 @@ def test_config1_vit_b32_step_against_the_oracle():
     assert sorted(r[2] for r in ratio.values())[len(ratio) // 2] < 1.5
 
 
-@pytest.mark.parametrize("n", [1_500_032, 1_500_016])
-def test_topk_ip_multi_equals_the_merge_of_sub_shard_searches(n):
+@pytest.mark.parametrize("n,d", [(1_500_032, 768), (1_500_016, 768), (2_200_000, 512)])
+def test_topk_ip_multi_equals_the_merge_of_sub_shard_searches(n, d):
     """uniir_topk_ip_multi (round 5): one resident shard above the 2-GiB buffer bound is searched in ONE C call -- a scan per logical
     sub-shard, then one batched tail, one sort, one merge launch -- and must equal the merge of stand-alone searches of the same row
     ranges bit for bit; 64 queries (interactive scan) and 300 (two 256-query sweeps).  n = 1 500 016 leaves a last sub-shard with an
-    odd number of 16-row groups, which the batched tail does not take: the entry point's per-sub-shard fallback loop runs instead."""
+    odd number of 16-row groups, which the batched tail does not take: the entry point's per-sub-shard fallback loop runs instead.
+    2.2 M x 512 (the CLIP base models' width, 3 sub-shards): batched at 64 queries, the fallback loop at 300 (no shared-ring scan at
+    this width)."""
     from uniir_amd import _lib, retrieval
-    d, k = 768, 10
+    k = 10
     lib = _lib.load()
     per = int(lib.uniir_topk_subshard_rows(n, d))
     bounds = retrieval.subshard_bounds(n, d)
-    assert len(bounds) == 2 and bounds[0] == (0, per) and per % 32 == 0
-    assert ((n - per + 15) // 16) % 2 == (0 if n == 1_500_032 else 1)
-    assert int(lib.uniir_topk_subshard_rows(5_600_000, d)) == 700_000 and int(lib.uniir_topk_subshard_rows(700_000, d)) == 700_000
+    assert len(bounds) == (2 if d == 768 else 3) and bounds[0] == (0, per) and per % 32 == 0
+    if d == 768:
+        assert ((n - per + 15) // 16) % 2 == (0 if n == 1_500_032 else 1)
+    assert int(lib.uniir_topk_subshard_rows(5_600_000, 768)) == 700_000 and int(lib.uniir_topk_subshard_rows(700_000, 768)) == 700_000
     g = torch.Generator(device=DEV).manual_seed(n % 1000)
     pool = torch.empty(n, d, device=DEV, dtype=torch.float16)
     for lo in range(0, n, 500_000):
