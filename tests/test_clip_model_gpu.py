@@ -238,3 +238,67 @@ def test_stashed_mlp_activation_changes_nothing():
     assert l1 == l0 and torch.equal(e1, e0)
     worst = max(float((g1[n] - g0[n]).norm() / g0[n].norm().clamp_min(1e-20)) for n in g0)
     assert worst < 1e-4, worst          # (act(f) from the forward's epilogue vs from the backward's: equal up to rare single-ulp flips)
+
+
+def test_automatic_stash_is_decided_once_reviewed_and_survives_an_out_of_memory_error(monkeypatch):
+    """The automatic act(f) stash (clip_model.stash_act = None, the default): (1) decided per tower at the first training batch and
+    logged, not per step; (2) review_stash() after the first step keeps it when the measured headroom is above the floor and switches
+    it off on every tower (the MIN over ranks decides: a rank that reports less flips this rank too) when not; (3) an out-of-memory
+    error on the stash-sized workspace re-plans that tower without the stash and the step still completes with the same loss."""
+    from oracle import clip_oracle as O
+    cfg = O.tiny_config(vision_width=128, vision_layers=2, transformer_width=128, transformer_heads=2, transformer_layers=2)
+
+    def step(model, dbatch):
+        model.train()
+        model.clip_model._ensure_flat()
+        model.clip_model.zero_grad()
+        out = model(dbatch)
+        out["loss"].backward()
+        return float(out["loss"].detach())
+
+    model, _, O = _build(cfg, seed=9)
+    clip = model.clip_model
+    assert clip.stash_act is None and clip.review_stash() is None          # nothing decided yet
+    batch = O.synthetic_batch(cfg, 12, seed=41)
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    l_on = step(model, dbatch)
+    assert clip._stash_choice == {"text": True, "image": True} and clip.last_stash_act == {"text": True, "image": True}
+    n_log = len(clip.stash_log)
+    assert n_log == 2 and all("stash ON" in s for s in clip.stash_log)
+    assert step(model, dbatch) == l_on and len(clip.stash_log) == n_log        # decided once: no new decision, no new log line
+    head = clip.review_stash()
+    assert head is not None and head > clip.stash_review_headroom_bytes and "kept" in clip.stash_log[-1]
+    assert clip._stash_choice == {"text": True, "image": True}
+    # another rank measured 1 GiB of headroom: every tower of this rank follows
+    seen = []
+    def fake_min(x):
+        seen.append(x)
+        return min(x, float(1 << 30)) if len(seen) == 1 else x
+    assert clip.review_stash(fake_min) == float(1 << 30) and len(seen) == 2
+    assert clip._stash_choice == {"text": False, "image": False} and "switched off" in clip.stash_log[-1]
+    assert step(model, dbatch) == l_on and clip.last_stash_act == {"text": False, "image": False}
+    assert clip.review_stash() is None                                          # nothing left to review
+
+    # (3) the allocation of the stash-sized workspace of the tower that runs second fails once
+    model, _, O = _build(cfg, seed=9)
+    clip = model.clip_model
+    real_empty, real_desc, state = torch.empty, clip.tower_desc, {"failed": 0, "armed": False}
+
+    def arming_desc(which, half=False):
+        state["armed"] = bool(clip.last_stash_act)          # one tower has been planned already
+        return real_desc(which, half=half)
+
+    def flaky_empty(*a, **kw):
+        if state["armed"] and not state["failed"] and kw.get("dtype") is torch.uint8:
+            state["failed"] += 1
+            raise torch.OutOfMemoryError("injected")
+        return real_empty(*a, **kw)
+
+    monkeypatch.setattr(clip, "tower_desc", arming_desc)
+    monkeypatch.setattr(torch, "empty", flaky_empty)
+    l_fb = step(model, dbatch)
+    monkeypatch.undo()
+    assert state["failed"] == 1
+    assert sorted(clip._stash_choice.values()) == [False, True] and sorted(clip.last_stash_act.values()) == [False, True]
+    assert any("out-of-memory" in s for s in clip.stash_log)
+    assert l_fb == l_on
