@@ -302,3 +302,63 @@ def test_automatic_stash_is_decided_once_reviewed_and_survives_an_out_of_memory_
     assert sorted(clip._stash_choice.values()) == [False, True] and sorted(clip.last_stash_act.values()) == [False, True]
     assert any("out-of-memory" in s for s in clip.stash_log)
     assert l_fb == l_on
+
+
+def test_two_stream_towers_equal_the_one_stream_order():
+    """clip_model.CLIP.overlap_towers: the text leg of the model forward (compaction gathers, packed text tower, scatter) and its
+    backward run on the model's second stream.  No kernel differs, so what could differ is a missing wait.
+    (a) Fixed weights, six batches with dead rows in both modalities, each run in both orders: losses bitwise equal (the forward is
+        deterministic), gradients equal within the run-to-run noise of the one-stream order itself (bias / LayerNorm-weight gradients
+        are fp32 atomic column sums: 3e-8 absolute between any two runs at these sizes, tools/r5/overlap_dbg.py).
+    (b) Train steps (NativeTrainer: zero_grad, forward, backward, fused AdamW, next forward reading the refreshed bf16 shadow): a lost
+        wait between the text backward and the optimizer would move EVERY text-tower weight by ~lr; the noise above moves, through
+        AdamW's normalisation, the few weights whose gradient is itself noise: the count of weights that differ by 1e-5 is held to
+        that of two one-stream runs (x4) or 2 %."""
+    from oracle import clip_oracle as O
+    from uniir_amd.trainer import NativeTrainer
+    cfg = O.tiny_config(vision_width=128, vision_layers=3, transformer_width=128, transformer_heads=2, transformer_layers=3)
+
+    def make_batch(it):
+        batch = O.synthetic_batch(cfg, 24, seed=100 + it)
+        dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        g = torch.Generator().manual_seed(it)
+        for key in ("txt_mask_batched", "image_mask_batched"):          # about a third of the rows dead in each modality
+            m = (torch.rand(dbatch[key].shape[0], generator=g) > 0.33).to(dbatch[key].dtype)
+            dbatch[key] = m.view(dbatch[key].shape).cuda()
+        return dbatch
+
+    model, _, O = _build(cfg, seed=5)
+    clip = model.clip_model
+    model.train()
+    clip._ensure_flat()
+    for it in range(6):
+        dbatch = make_batch(it)
+        res = {}
+        for overlap in (True, False):
+            clip.overlap_towers = overlap
+            clip.zero_grad()
+            out = model(dbatch)
+            out["loss"].backward()
+            res[overlap] = (float(out["loss"].detach()), clip._flat["g32"].clone())
+        assert res[True][0] == res[False][0]
+        g1, g0 = res[True][1], res[False][1]
+        assert float(g0.abs().max()) > 0
+        assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max()), it
+    assert clip._side_streams
+
+    runs = {}
+    for tag, overlap in (("two", True), ("one", False), ("one again", False)):
+        model, _, O = _build(cfg, seed=5)
+        model.clip_model.overlap_towers = overlap
+        tr = NativeTrainer(model, lr=1e-3, t_total=10)
+        rec = []
+        for it in range(4):
+            out = tr.train_step(make_batch(it))
+            rec.append((float(out["loss"].detach()), model.clip_model._flat["p32"].clone()))
+        torch.cuda.synchronize()
+        runs[tag] = rec
+    for (l2, w2), (l1, w1), (l0, w0) in zip(runs["two"], runs["one again"], runs["one"]):
+        assert abs(l2 - l0) <= 1e-4 * max(1.0, abs(l0))
+        moved = int(((w2 - w0).abs() > 1e-5).sum())
+        floor = int(((w1 - w0).abs() > 1e-5).sum())          # what two one-stream runs differ by (observed ~1 % by the 4th step)
+        assert moved <= max(4 * floor, 0.02 * w0.numel()), (moved, floor)          # a lost wait: ~50 % (every text-tower weight)

@@ -8,6 +8,7 @@ fp32 LayerNorm, fused attention, fp32 residual stream.  This file is host plumbi
 (one flat fp32 master buffer + flat grad buffer + bf16 shadow), the per-layer launch sequence of forward and
 backward, and the activation stash.  There is no torch fallback.
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -168,6 +169,15 @@ class CLIP(nn.Module):
         self.stash_log = []               # human-readable record of every decision (bench.py prints it)
         self.last_stash_act = {}          # tower -> what the last training forward chose
         self.last_text_rows = None      # (live rows, dense rows) of the last packed text-tower call (bench: executed FLOPs)
+        # The two towers of a batch are independent until the fusion: with overlap_towers the TEXT leg of a model forward (side_leg()
+        # in clip_sf.encode_multimodal_input) is enqueued on a second HIP stream and joined before the fusion; autograd runs the
+        # leg's backward on that stream again (nodes run on the stream of their forward) and the tower backward joins it to the
+        # stream the leg forked from.  The text tower's small GEMMs (1.6 rounds of 256-tiles at 35 k rows) then run on the compute
+        # units the image tower's kernels leave idle in their last round of tiles and between launches.  Results are bitwise those
+        # of the one-stream order (no kernel changes, disjoint buffers: split-K slabs and workspaces are per tower).
+        self.overlap_towers = os.environ.get("UNIIR_OVERLAP_TOWERS", "1") != "0"
+        self._side_streams = {}
+        self._leg_main = None           # inside side_leg(): the stream the leg forked from
 
     # ---- flat parameter / gradient / bf16-shadow storage -----------------------------------------------------
     def _ensure_flat(self):
@@ -363,6 +373,44 @@ class CLIP(nn.Module):
             self.stash_log.append(f"act(f) stash kept after the first step: measured headroom {headroom / 2**30:.1f} GiB "
                                   f"(peak {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB in torch, {outside / 2**30:.1f} GiB outside)")
         return headroom
+
+    # ---- two-stream towers -------------------------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def side_leg(self, dev):
+        """with model.side_leg(dev) as leg: everything enqueued inside (one tower call and the torch ops around it) goes to this
+        model's second stream of `dev`, ordered after all work enqueued so far on the current stream; leg is None when the overlap is
+        off (CPU tensors, overlap_towers False, the Python tower sequences) and the body then runs on the current stream as before.
+        The caller hands the tensors the leg produced to join_leg() before the current stream reads them."""
+        dev = torch.device(dev)
+        if not self.overlap_towers or dev.type != "cuda" or _PY_TOWERS or self.precision == "fp32" or self._leg_main is not None:
+            yield None
+            return
+        # every lazily built shared buffer (flat storage, 16-bit shadows of the weights) is brought up to date on the forking stream,
+        # BEFORE the fork: both towers read them
+        (self._sync_half_shadow if self.precision == "fp16" else self._sync_shadow)()
+        main = torch.cuda.current_stream(dev)
+        side = self._side_streams.get(dev.index)
+        if side is None:
+            side = self._side_streams[dev.index] = torch.cuda.Stream(dev)
+        side.wait_stream(main)
+        self._leg_main = main
+        try:
+            with torch.cuda.stream(side):
+                yield side
+        finally:
+            self._leg_main = None
+
+    @staticmethod
+    def join_leg(leg, *tensors):
+        """the current stream waits for everything side_leg() enqueued; `tensors` (allocated inside the leg) are about to be read on
+        the current stream"""
+        if leg is None:
+            return
+        main = torch.cuda.current_stream(leg.device)
+        main.wait_stream(leg)
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)
 
     # ---- public encoder API (upstream names) ---------------------------------------------------------------------
     @property
@@ -579,6 +627,20 @@ def _encode_fp32(model, which, inp, p32):
     return emb
 
 
+def _join_backward(st, demb):
+    """a tower backward that ran on the side stream of CLIP.side_leg(): its parameter gradients went straight into the flat gradient
+    buffer (no AccumulateGrad node the autograd engine could synchronise on), so the stream the leg forked from -- where the optimizer,
+    the gradient reducer's finish() and the next step's zero_grad run -- waits for it here.  Autograd runs the later-built image tower
+    backward first, so at this point the whole image backward is already enqueued on that stream and nothing of it is delayed."""
+    main = st.get("join_to")
+    if main is None:
+        return
+    cur = torch.cuda.current_stream(demb.device)
+    if cur != main:
+        demb.record_stream(cur)
+        main.wait_stream(cur)
+
+
 class _TowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, which, inp, anchor):
@@ -668,7 +730,7 @@ class _TowerFn(torch.autograd.Function):
                                                            ws.data_ptr(), need, int(need_grad), ops._stream()), "clip_tower_fwd_packed")
                 model.last_text_rows = (live, M * cfg["context_length"])
                 if need_grad:
-                    ctx.stash = dict(ws=ws, inp=inp, ctower=True, row_off=row_off, live=live, stash_act=int(stash))
+                    ctx.stash = dict(ws=ws, inp=inp, ctower=True, row_off=row_off, live=live, stash_act=int(stash), join_to=model._leg_main)
                 return emb
             need, ws = alloc_ws(lambda: lib.uniir_clip_tower_workspace_bytes(C.byref(desc), M, int(need_grad)))
             if need < 0:
@@ -677,7 +739,7 @@ class _TowerFn(torch.autograd.Function):
             _lib.check(lib.uniir_clip_tower_fwd(C.byref(desc), inp.data_ptr(), M, emb.data_ptr(), ws.data_ptr(), need,
                                                 int(need_grad), ops._stream()), "clip_tower_fwd")
             if need_grad:
-                ctx.stash = dict(ws=ws, inp=inp, ctower=True, stash_act=int(stash))
+                ctx.stash = dict(ws=ws, inp=inp, ctower=True, stash_act=int(stash), join_to=model._leg_main)
             return emb
         if which == "image":
             W, P, L = cfg["vision_width"], cfg["vision_patch_size"], cfg["vision_layers"]
@@ -749,6 +811,7 @@ class _TowerFn(torch.autograd.Function):
                         reducer.ready(*model.layer_grad_range(prefix, lo))
                 _lib.check(lib.uniir_clip_tower_bwd_stem_packed(C.byref(desc), inp.data_ptr(), M, ro, live, ws.data_ptr(), need, stream),
                            "tower_bwd_stem_packed")
+                _join_backward(st, demb)
                 return None, None, None, None
             _lib.check(lib.uniir_clip_tower_bwd_head(C.byref(desc), demb.data_ptr(), M, ws.data_ptr(), need, stream), "tower_bwd_head")
             if reducer is None:
@@ -759,6 +822,7 @@ class _TowerFn(torch.autograd.Function):
                                "tower_bwd_blocks")
                     reducer.ready(*model.layer_grad_range(prefix, i))
             _lib.check(lib.uniir_clip_tower_bwd_stem(C.byref(desc), inp.data_ptr(), M, ws.data_ptr(), need, stream), "tower_bwd_stem")
+            _join_backward(st, demb)
             return None, None, None, None
         cfg = model.cfg
         fl = model._flat

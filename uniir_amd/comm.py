@@ -150,6 +150,7 @@ class GradReducer:
         self.announced = []           # every range of this step, sorted: a repeat is refused in ready(), not discovered at finish()
         self.extra_done = set()       # data_ptr of further flat buffers reduced through reduce_extra() this step
         self.n_collectives = 0
+        self._stream = None           # the compute stream the pending ranges were announced on (device buffers only)
 
     def reset(self):
         """forget the state of an armed backward whose step() never came (an exception, a skipped step): called by
@@ -158,6 +159,7 @@ class GradReducer:
             w.wait()
         self.pending, self.launched, self.works, self.announced, self.n_collectives = [], [], [], [], 0
         self.extra_done = set()
+        self._stream = None
 
     def _sync_backend(self):
         # tests only (two gloo ranks sharing one GPU): gloo cannot reduce device memory -> staged through the host
@@ -176,6 +178,15 @@ class GradReducer:
                                "in this step, or the previous armed backward was never followed by step()); use arm_overlap(False) "
                                "for such steps")
         self.announced.insert(i, (lo, hi))
+        if self.flat.is_cuda:
+            # a collective is ordered after the CURRENT stream's position only.  The towers' backwards may run on two streams
+            # (clip_model.CLIP.side_leg): ranges announced from another stream go out first, from that stream, so that no bucket mixes
+            # producers
+            cur = torch.cuda.current_stream(self.flat.device)
+            if self._stream is not None and self._stream != cur and self.pending:
+                with torch.cuda.stream(self._stream):
+                    self.flush()
+            self._stream = cur
         self.pending.append((lo, hi))
         if sum(h - l for l, h in self.pending) >= self.bucket_elems:
             self.flush()
@@ -239,6 +250,7 @@ class GradReducer:
         n = self.n_collectives
         self.pending, self.launched, self.works, self.announced, self.n_collectives = [], [], [], [], 0
         self.extra_done = set()
+        self._stream = None
         return n, extra
 
 

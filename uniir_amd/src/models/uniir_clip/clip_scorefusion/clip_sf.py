@@ -84,12 +84,18 @@ class CLIPScoreFusion(nn.Module):
         return full.index_copy(0, live, emb_live)                       # differentiable scatter: dead rows stay exact zeros
 
     def encode_multimodal_input(self, txt_tensor, img_tensor, txt_mask, img_mask):
+        # the towers are independent up to the fusion: the text leg goes to the model's second stream (clip_model.CLIP.side_leg) and is
+        # joined before FuseFn reads it; same kernels, same results
+        with self.clip_model.side_leg(txt_tensor.device) as leg:
+            if self.compact_masked:
+                txt_emb = self._encode_live(self.encode_text, txt_tensor, txt_mask)
+            else:
+                txt_emb = self.encode_text(txt_tensor)
         if self.compact_masked:
-            txt_emb = self._encode_live(self.encode_text, txt_tensor, txt_mask)
             img_emb = self._encode_live(self.encode_image, img_tensor, img_mask)
         else:
-            txt_emb = self.encode_text(txt_tensor)
             img_emb = self.encode_image(img_tensor)
+        self.clip_model.join_leg(leg, txt_emb)
         return FuseFn.apply(txt_emb, img_emb, txt_mask, img_mask)  # txt*mask + img*mask, [batch, embed_dim]
 
     def get_logit_scale(self):
