@@ -816,7 +816,8 @@ def main():
     barrier()
     board = BoardSampler(local_rank) if (ops is not None and rank == 0) else None
     if ops is not None and rank == 0:
-        ops.gemm_timing_start()
+        # the towers run on two streams (clip_model.CLIP.side_leg): follow the one that carries the image tower, the fusion and the loss
+        ops.gemm_timing_start(stream=torch.cuda.current_stream(dev))
         board.start()
     t0 = time.perf_counter()
     timed_from = step_no
@@ -898,8 +899,11 @@ def main():
                     "achieved": round(gflop / gtime / 1e12, 2) if gtime > 0 else None, "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(gflop / gtime / MFMA_PEAK_BF16, 4) if gtime > 0 else None,
                     "traffic": traffic, "traffic_note": traffic_note, "launches_timed": nsamp,
-                    "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} uniir_gemm calls of the timed region bracketed by HIP events on the "
-                                "launch stream inside the library (uniir_gemm_timing; 2 event records per sampled launch)",
+                    "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} uniir_gemm calls of the timed region on the image tower's stream, "
+                                "bracketed by HIP events on that stream inside the library (uniir_gemm_timing_on; 2 event records "
+                                "per sampled launch).  The text tower's GEMMs run on the model's second stream at the same time "
+                                "(overlap_towers), where an event pair would measure shared, not kernel, time: they are not sampled, "
+                                "and a sampled image-tower GEMM that shares the device with them counts with its full elapsed time",
                     "end_to_end_frac": round(value * flop_pair / (world * MFMA_PEAK_BF16), 4),
                     "end_to_end_note": ("value x EXECUTED FLOPs per pair / peak: the text tower runs on the rows up to each caption's "
                                         "EOT only (exact: rows behind the EOT never reach the pooled feature under the causal mask); "

@@ -930,6 +930,8 @@ static struct {
     long counter = 0;
     int n = 0;
     bool created = false;
+    bool filter = false;          // sample the launches on `only` alone (uniir_gemm_timing_on)
+    hipStream_t only = nullptr;
     hipEvent_t ev[2 * GT_MAX];
     double flop[GT_MAX];
 } g_gt;
@@ -943,7 +945,19 @@ extern "C" int uniir_gemm_timing(int32_t stride) {
     g_gt.stride = stride;
     g_gt.counter = 0;
     g_gt.n = 0;
+    g_gt.filter = false;
     return UNIIR_OK;
+}
+// the same, counting and sampling the launches on ONE stream only: an event pair measures the time between two points of its stream,
+// which is the kernel's own duration only while no other stream shares the device -- with the two towers on two streams
+// (clip_model.CLIP.side_leg) the measuring run follows the stream that carries the image tower
+extern "C" int uniir_gemm_timing_on(int32_t stride, void* stream) {
+    const int rc = uniir_gemm_timing(stride);
+    if (rc == UNIIR_OK && stride > 0) {
+        g_gt.filter = true;
+        g_gt.only = (hipStream_t)stream;
+    }
+    return rc;
 }
 // sums over the sampled launches (call after synchronising the stream): algorithmic 2 M N K, elapsed milliseconds, count
 extern "C" int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launches) {
@@ -961,7 +975,8 @@ extern "C" int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launche
 
 static int gemm_impl(const uniir_gemm_desc* d, void* stream);
 extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
-    const bool sample = g_gt.stride > 0 && d && (++g_gt.counter % g_gt.stride) == 0 && g_gt.n < GT_MAX;
+    const bool sample = g_gt.stride > 0 && d && (!g_gt.filter || g_gt.only == (hipStream_t)stream) &&
+                        (++g_gt.counter % g_gt.stride) == 0 && g_gt.n < GT_MAX;
     if (!sample) return gemm_impl(d, stream);
     const int i = g_gt.n;
     (void)hipEventRecord(g_gt.ev[2 * i], (hipStream_t)stream);

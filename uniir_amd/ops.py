@@ -15,8 +15,13 @@ GEMM_TIMING_STRIDE = 29   # bench.py: every 29th uniir_gemm call is bracketed by
 # 441 GEMM launches per step and 441 % 29 = 6, so the sampled positions walk through every shape within a few steps
 
 
-def gemm_timing_start(stride=GEMM_TIMING_STRIDE):
-    check(_lib.load().uniir_gemm_timing(int(stride)), "gemm_timing")
+def gemm_timing_start(stride=GEMM_TIMING_STRIDE, stream=None):
+    """stream: a torch.cuda.Stream -- sample the launches on that stream only (the other tower's stream shares the device: an event
+    pair there would measure shared time, see uniir_gemm_timing_on)"""
+    if stream is None:
+        check(_lib.load().uniir_gemm_timing(int(stride)), "gemm_timing")
+    else:
+        check(_lib.load().uniir_gemm_timing_on(int(stride), C.c_void_p(stream.cuda_stream)), "gemm_timing_on")
 
 
 def gemm_timing_stop():
