@@ -770,7 +770,7 @@ def main():
     if args.dry_run:
         E = 64
         trainer = _DryRunTrainer(args.pairs, E)
-        batch, timing, model, ops = None, (0.0, 0.0, 0), None, None
+        batch, timing, model, ops = None, (0.0, 0.0, 0, 0), None, None
         flat = trainer.g32
     else:
         from types import SimpleNamespace
@@ -828,7 +828,11 @@ def main():
     dt = time.perf_counter() - t0
     board_rec = board.stop() if board is not None else None
     if ops is not None and rank == 0:
-        timing = ops.gemm_timing_stop()          # (flop, seconds, launches) of the sampled GEMM launches
+        try:
+            timing = ops.gemm_timing_stop(with_shared=True)          # (flop, seconds, launches, left out) of the sampled GEMM launches
+        except RuntimeError as e:          # the measurement hook must never cost the bench line
+            print(f"bench: GEMM sampling failed ({e}); roofline.achieved is null", file=sys.stderr)
+            timing = (0.0, 0.0, 0, 0)
     loss = float(out["loss"].detach())
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -887,7 +891,7 @@ def main():
                 flop_pair, live_rows, dense_rows = (sum(x[j] for x in per) / len(per) for j in range(3))
             else:
                 flop_pair, live_rows, dense_rows = FLOP_PER_PAIR[args.model], 0, 0
-            gflop, gtime, nsamp = timing
+            gflop, gtime, nsamp, nshared = timing
             traffic, traffic_note = None, "no rocprofv3 --pmc record for this configuration under profiles/"
             if os.path.exists(PMC_FILE):
                 rec = json.load(open(PMC_FILE))
@@ -898,12 +902,13 @@ def main():
                               "forward, dgrad and wgrad of the towers' linear layers)",
                     "achieved": round(gflop / gtime / 1e12, 2) if gtime > 0 else None, "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(gflop / gtime / MFMA_PEAK_BF16, 4) if gtime > 0 else None,
-                    "traffic": traffic, "traffic_note": traffic_note, "launches_timed": nsamp,
+                    "traffic": traffic, "traffic_note": traffic_note, "launches_timed": nsamp, "samples_left_out_device_shared": nshared,
                     "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} uniir_gemm calls of the timed region on the image tower's stream, "
                                 "bracketed by HIP events on that stream inside the library (uniir_gemm_timing_on; 2 event records "
                                 "per sampled launch).  The text tower's GEMMs run on the model's second stream at the same time "
-                                "(overlap_towers), where an event pair would measure shared, not kernel, time: they are not sampled, "
-                                "and a sampled image-tower GEMM that shares the device with them counts with its full elapsed time",
+                                "(overlap_towers): an event pair measures a kernel's own duration only while the device is not "
+                                "shared, so those calls are bracketed as 'device shared' windows instead and the samples that "
+                                "intersect a window are left out (samples_left_out_device_shared); end_to_end_frac has everything",
                     "end_to_end_frac": round(value * flop_pair / (world * MFMA_PEAK_BF16), 4),
                     "end_to_end_note": ("value x EXECUTED FLOPs per pair / peak: the text tower runs on the rows up to each caption's "
                                         "EOT only (exact: rows behind the EOT never reach the pooled feature under the causal mask); "

@@ -87,11 +87,14 @@ int uniir_gemm(const uniir_gemm_desc* d, void* stream);
 /* measurement hook (bench.py): stride > 0 brackets every stride-th uniir_gemm call -- from any caller, the tower entry
  * points included -- with HIP events on its launch stream; 0 switches it off.  uniir_gemm_timing_read (after a stream
  * synchronise) returns the sums over the sampled launches: 2 M N K, elapsed ms, count.  Single measuring thread.
- * uniir_gemm_timing_on: the same, counting and sampling only the calls launched on `stream` (an event pair measures a kernel's own
- * duration only while no other stream shares the device: with the towers on two streams the measurement follows one of them). */
+ * uniir_gemm_timing_on: the same, counting and sampling only the calls launched on `stream`.  An event pair measures a kernel's own
+ * duration only while no other stream shares the device: with the towers on two streams the measurement follows one of them, the
+ * uniir_gemm calls on other streams are bracketed as "device shared" windows, and the read functions leave out the samples that
+ * intersect a window (uniir_gemm_timing_read_ex also returns their count in *shared; shared may be NULL). */
 int uniir_gemm_timing(int32_t stride);
 int uniir_gemm_timing_on(int32_t stride, void* stream);
 int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launches);
+int uniir_gemm_timing_read_ex(double* flop, double* ms, int32_t* launches, int32_t* shared);
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] building block 2: LayerNorm over the last dim (fp32 statistics, CLIP eps 1e-5).

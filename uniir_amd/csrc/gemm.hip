@@ -925,15 +925,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // it is launched on, whoever the caller is (the C towers of tower.hip or a host-language loop).  Host-side bookkeeping only;
 // not thread-safe (one measuring thread), off by default.
 #define GT_MAX 4096
+#define GT_FMAX 8192
 static struct {
     int stride = 0;
     long counter = 0;
     int n = 0;
     bool created = false;
     bool filter = false;          // sample the launches on `only` alone (uniir_gemm_timing_on)
+    bool fcreated = false;
     hipStream_t only = nullptr;
+    int nf = 0;                   // uniir_gemm calls seen on OTHER streams while filtering: the windows in which the device was shared
     hipEvent_t ev[2 * GT_MAX];
     double flop[GT_MAX];
+    hipEvent_t base;
+    hipEvent_t fev[2 * GT_FMAX];
 } g_gt;
 extern "C" int uniir_gemm_timing(int32_t stride) {
     if (stride < 0) return UNIIR_EINVAL;
@@ -945,38 +950,92 @@ extern "C" int uniir_gemm_timing(int32_t stride) {
     g_gt.stride = stride;
     g_gt.counter = 0;
     g_gt.n = 0;
+    g_gt.nf = 0;
     g_gt.filter = false;
     return UNIIR_OK;
 }
-// the same, counting and sampling the launches on ONE stream only: an event pair measures the time between two points of its stream,
-// which is the kernel's own duration only while no other stream shares the device -- with the two towers on two streams
-// (clip_model.CLIP.side_leg) the measuring run follows the stream that carries the image tower
+// The same, counting and sampling the launches on ONE stream only.  An event pair measures the time between two points of its
+// stream, which is the kernel's own duration only while no other stream shares the device.  With the two towers on two streams
+// (clip_model.CLIP.side_leg) the measuring run follows the stream that carries the image tower, and every uniir_gemm call on another
+// stream is bracketed too -- not as a sample but as a record of WHEN the device was shared: uniir_gemm_timing_read leaves out the
+// samples that intersect those windows (windows closer than GT_MERGE_MS are one window: the LayerNorm / attention kernels between two
+// GEMMs of the other tower share the device just the same) and uniir_gemm_timing_read_ex also returns how many it left out.
+#define GT_MERGE_MS 3.0f
 extern "C" int uniir_gemm_timing_on(int32_t stride, void* stream) {
     const int rc = uniir_gemm_timing(stride);
-    if (rc == UNIIR_OK && stride > 0) {
-        g_gt.filter = true;
-        g_gt.only = (hipStream_t)stream;
+    if (rc != UNIIR_OK || stride == 0) return rc;
+    if (!g_gt.fcreated) {
+        if (hipEventCreate(&g_gt.base) != hipSuccess) return UNIIR_ELAUNCH;
+        for (int i = 0; i < 2 * GT_FMAX; ++i)
+            if (hipEventCreate(&g_gt.fev[i]) != hipSuccess) return UNIIR_ELAUNCH;
+        g_gt.fcreated = true;
     }
-    return rc;
+    g_gt.filter = true;
+    g_gt.only = (hipStream_t)stream;
+    if (hipEventRecord(g_gt.base, g_gt.only) != hipSuccess) return UNIIR_ELAUNCH;
+    return UNIIR_OK;
 }
-// sums over the sampled launches (call after synchronising the stream): algorithmic 2 M N K, elapsed milliseconds, count
-extern "C" int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launches) {
+// sums over the sampled launches (call after synchronising the device): algorithmic 2 M N K, elapsed milliseconds, count; shared
+// (may be NULL): samples left out because another stream's GEMMs shared the device with them (uniir_gemm_timing_on)
+extern "C" int uniir_gemm_timing_read_ex(double* flop, double* ms, int32_t* launches, int32_t* shared) {
     if (!flop || !ms || !launches) return UNIIR_EINVAL;
+    // the other streams' windows on the time axis of `base`, merged
+    int nw = 0;
+    float (*win)[2] = nullptr;
+    if (g_gt.filter && g_gt.nf > 0) {
+        win = (float (*)[2])malloc(sizeof(float[2]) * g_gt.nf);
+        if (!win) return UNIIR_EINVAL;
+        for (int i = 0; i < g_gt.nf; ++i) {
+            float a = 0.f, b = 0.f;
+            if (hipEventElapsedTime(&a, g_gt.base, g_gt.fev[2 * i]) != hipSuccess ||
+                hipEventElapsedTime(&b, g_gt.base, g_gt.fev[2 * i + 1]) != hipSuccess) { free(win); return UNIIR_ELAUNCH; }
+            win[i][0] = a; win[i][1] = b;
+        }
+        qsort(win, g_gt.nf, sizeof(float[2]), [](const void* x, const void* y) {
+            const float a = ((const float*)x)[0], b = ((const float*)y)[0];
+            return a < b ? -1 : a > b ? 1 : 0;
+        });
+        for (int i = 0; i < g_gt.nf; ++i) {
+            if (nw > 0 && win[i][0] <= win[nw - 1][1] + GT_MERGE_MS) win[nw - 1][1] = fmaxf(win[nw - 1][1], win[i][1]);
+            else { win[nw][0] = win[i][0]; win[nw][1] = win[i][1]; ++nw; }
+        }
+    }
     double f = 0.0, t = 0.0;
+    int kept = 0, left_out = 0;
     for (int i = 0; i < g_gt.n; ++i) {
         float e = 0.f;
-        if (hipEventElapsedTime(&e, g_gt.ev[2 * i], g_gt.ev[2 * i + 1]) != hipSuccess) return UNIIR_ELAUNCH;
+        if (hipEventElapsedTime(&e, g_gt.ev[2 * i], g_gt.ev[2 * i + 1]) != hipSuccess) { free(win); return UNIIR_ELAUNCH; }
+        if (nw > 0) {
+            float a = 0.f;
+            if (hipEventElapsedTime(&a, g_gt.base, g_gt.ev[2 * i]) != hipSuccess) { free(win); return UNIIR_ELAUNCH; }
+            bool hit = false;
+            for (int w = 0; w < nw && !hit; ++w) hit = a < win[w][1] && a + e > win[w][0];
+            if (hit) { ++left_out; continue; }
+        }
         f += g_gt.flop[i];
         t += e;
+        ++kept;
     }
-    *flop = f; *ms = t; *launches = g_gt.n;
+    free(win);
+    *flop = f; *ms = t; *launches = kept;
+    if (shared) *shared = left_out;
     return UNIIR_OK;
+}
+extern "C" int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launches) {
+    return uniir_gemm_timing_read_ex(flop, ms, launches, nullptr);
 }
 
 static int gemm_impl(const uniir_gemm_desc* d, void* stream);
 extern "C" int uniir_gemm(const uniir_gemm_desc* d, void* stream) {
-    const bool sample = g_gt.stride > 0 && d && (!g_gt.filter || g_gt.only == (hipStream_t)stream) &&
-                        (++g_gt.counter % g_gt.stride) == 0 && g_gt.n < GT_MAX;
+    if (g_gt.stride > 0 && d && g_gt.filter && g_gt.only != (hipStream_t)stream) {          // another stream while one is measured
+        if (g_gt.nf >= GT_FMAX) return gemm_impl(d, stream);
+        const int i = g_gt.nf++;
+        (void)hipEventRecord(g_gt.fev[2 * i], (hipStream_t)stream);
+        const int rc = gemm_impl(d, stream);
+        (void)hipEventRecord(g_gt.fev[2 * i + 1], (hipStream_t)stream);
+        return rc;
+    }
+    const bool sample = g_gt.stride > 0 && d && (++g_gt.counter % g_gt.stride) == 0 && g_gt.n < GT_MAX;
     if (!sample) return gemm_impl(d, stream);
     const int i = g_gt.n;
     (void)hipEventRecord(g_gt.ev[2 * i], (hipStream_t)stream);

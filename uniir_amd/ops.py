@@ -24,11 +24,14 @@ def gemm_timing_start(stride=GEMM_TIMING_STRIDE, stream=None):
         check(_lib.load().uniir_gemm_timing_on(int(stride), C.c_void_p(stream.cuda_stream)), "gemm_timing_on")
 
 
-def gemm_timing_stop():
-    """-> (sum of 2 M N K, seconds, launches) over the sampled GEMM launches; synchronise the stream first"""
-    f, ms, n = C.c_double(), C.c_double(), C.c_int32()
-    check(_lib.load().uniir_gemm_timing_read(C.byref(f), C.byref(ms), C.byref(n)), "gemm_timing_read")
+def gemm_timing_stop(with_shared=False):
+    """-> (sum of 2 M N K, seconds, launches) over the sampled GEMM launches [, samples left out because another stream's GEMMs
+    shared the device with them: gemm_timing_start(stream=...)]; synchronise the device first"""
+    f, ms, n, sh = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+    check(_lib.load().uniir_gemm_timing_read_ex(C.byref(f), C.byref(ms), C.byref(n), C.byref(sh)), "gemm_timing_read")
     check(_lib.load().uniir_gemm_timing(0), "gemm_timing")
+    if with_shared:
+        return f.value, ms.value * 1e-3, n.value, sh.value
     return f.value, ms.value * 1e-3, n.value
 
 
