@@ -9,6 +9,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 ARGS="--no-cpu-baseline --no-secondary --no-retrieval --no-unpacked"
+# per-kernel accounting: both towers on ONE stream (kernel durations add up to the step only when nothing overlaps; the two-stream
+# order runs the same kernel binaries -- its effect on the step is an A/B, tools/r5/overlap_ab.sh).  UNIIR_OVERLAP_TOWERS=1 tools/profile_bench.sh
+# profiles the default order instead.
+export UNIIR_OVERLAP_TOWERS=${UNIIR_OVERLAP_TOWERS:-0}
 rm -rf /tmp/pb_stats /tmp/pb_fetch /tmp/pb_write
 rocprofv3 --kernel-trace --stats -d /tmp/pb_stats -o s -- python $R/bench.py --steps 4 --warmup 1 $ARGS > $O/bench_under_rocprof.json 2> $O/stats.err
 DB=$(find /tmp/pb_stats -name "*_results.db" | head -1)
