@@ -173,8 +173,9 @@ class CLIP(nn.Module):
         # in clip_sf.encode_multimodal_input) is enqueued on a second HIP stream and joined before the fusion; autograd runs the
         # leg's backward on that stream again (nodes run on the stream of their forward) and the tower backward joins it to the
         # stream the leg forked from.  The text tower's small GEMMs (1.6 rounds of 256-tiles at 35 k rows) then run on the compute
-        # units the image tower's kernels leave idle in their last round of tiles and between launches.  Results are bitwise those
-        # of the one-stream order (no kernel changes, disjoint buffers: split-K slabs and workspaces are per tower).
+        # units the image tower's kernels leave idle in their last round of tiles and between launches.  No kernel changes and the
+        # towers' buffers are disjoint (split-K slabs and workspaces are per tower): losses and embeddings are bitwise those of the
+        # one-stream order, gradients equal up to the order of the fp32 atomic column sums, which neither order fixes.
         self.overlap_towers = os.environ.get("UNIIR_OVERLAP_TOWERS", "1") != "0"
         self._side_streams = {}
         self._leg_main = None           # inside side_leg(): the stream the leg forked from
