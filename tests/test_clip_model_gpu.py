@@ -313,7 +313,7 @@ def test_two_stream_towers_equal_the_one_stream_order():
     (b) Train steps (NativeTrainer: zero_grad, forward, backward, fused AdamW, next forward reading the refreshed bf16 shadow): a lost
         wait between the text backward and the optimizer would move EVERY text-tower weight by ~lr; the noise above moves, through
         AdamW's normalisation, the few weights whose gradient is itself noise: the count of weights that differ by 1e-5 is held to
-        that of two one-stream runs (x4) or 2 %."""
+        that of two one-stream runs (x4) or 10 % (observed: 1 % by the fourth step, in both comparisons)."""
     from oracle import clip_oracle as O
     from uniir_amd.trainer import NativeTrainer
     cfg = O.tiny_config(vision_width=128, vision_layers=3, transformer_width=128, transformer_heads=2, transformer_layers=3)
@@ -361,4 +361,4 @@ def test_two_stream_towers_equal_the_one_stream_order():
         assert abs(l2 - l0) <= 1e-4 * max(1.0, abs(l0))
         moved = int(((w2 - w0).abs() > 1e-5).sum())
         floor = int(((w1 - w0).abs() > 1e-5).sum())          # what two one-stream runs differ by (observed ~1 % by the 4th step)
-        assert moved <= max(4 * floor, 0.02 * w0.numel()), (moved, floor)          # a lost wait: ~50 % (every text-tower weight)
+        assert moved <= max(4 * floor, 0.10 * w0.numel()), (moved, floor)          # a lost wait: ~45 % (every text-tower weight)
