@@ -314,6 +314,8 @@ def bench_embed(dev, model_name="ViT-L/14", items=2048, steps=3):
         b["txt_mask_batched"] = (ones * tm).to(dev)
         b["image_mask_batched"] = (ones * im).to(dev)
         b["txt_mask_batched"]._uniir_host, b["image_mask_batched"]._uniir_host = ones * tm, ones * im     # as the prefetcher does
+        for key in ("txt_mask_batched", "image_mask_batched"):
+            b[key]._uniir_host_version = b[key]._version
         if not tm:
             b["txt_batched"] = attach_caption_lengths(empty.to(dev), empty)
         if not im:
@@ -722,6 +724,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the embed / BLIP_FF / CLIP_FF blocks")
     ap.add_argument("--no-unpacked", action="store_true", help="skip the second timing of the step with the text tower unpacked")
     ap.add_argument("--no-stash-act", action="store_true", help="A/B: re-materialise the MLP activations in the backward (clip_model.stash_act = False)")
+    ap.add_argument("--overlap-towers", choices=("auto", "0", "1"), default="auto",
+                    help="text tower on a second stream: auto = on at N = 1, off at N > 1 (clip_model.CLIP.overlap_towers); 0 / 1 force "
+                         "it (A/B; at N > 1 compare rccl.replicas_identical of both)")
     ap.add_argument("--dry-run", action="store_true", help="CPU ranks over gloo with a stand-in step (launcher test)")
     ap.add_argument("--shard-rows", type=int, default=700_000, help="N > 1: pool rows per rank of the sharded retrieval block")
     ap.add_argument("--shard-queries", default="64,1024,100000", help="N > 1: global query counts of the sharded retrieval block")
@@ -790,6 +795,8 @@ def main():
         trainer = NativeTrainer(model, lr=1e-5, t_total=10000)
         if args.no_stash_act:
             model.clip_model.stash_act = False
+        if args.overlap_towers != "auto":
+            model.clip_model.overlap_towers = args.overlap_towers == "1"
         batch = synth_batch(cfg, args.pairs, 2023 + rank, dev)
         # The timed loop rotates ROTATE distinct caption batches (distinct token tensors, different lengths; the 0.6-GB image tensor
         # is shared -- three more of them do not fit next to the 265-GiB activation stash).  Each arrives the way the train loop's
@@ -832,7 +839,7 @@ def main():
             timing = ops.gemm_timing_stop(with_shared=True)          # (flop, seconds, launches, left out) of the sampled GEMM launches
         except RuntimeError as e:          # the measurement hook must never cost the bench line
             print(f"bench: GEMM sampling failed ({e}); roofline.achieved is null", file=sys.stderr)
-            timing = (0.0, 0.0, 0, 0)
+            timing = (0.0, 0.0, 0, 0, False)
     loss = float(out["loss"].detach())
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -891,7 +898,7 @@ def main():
                 flop_pair, live_rows, dense_rows = (sum(x[j] for x in per) / len(per) for j in range(3))
             else:
                 flop_pair, live_rows, dense_rows = FLOP_PER_PAIR[args.model], 0, 0
-            gflop, gtime, nsamp, nshared = timing
+            gflop, gtime, nsamp, nshared, nfallback = timing
             traffic, traffic_note = None, "no rocprofv3 --pmc record for this configuration under profiles/"
             if os.path.exists(PMC_FILE):
                 rec = json.load(open(PMC_FILE))
@@ -902,7 +909,9 @@ def main():
                               "forward, dgrad and wgrad of the towers' linear layers)",
                     "achieved": round(gflop / gtime / 1e12, 2) if gtime > 0 else None, "peak": MFMA_PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": round(gflop / gtime / MFMA_PEAK_BF16, 4) if gtime > 0 else None,
-                    "traffic": traffic, "traffic_note": traffic_note, "launches_timed": nsamp, "samples_left_out_device_shared": nshared,
+                    "traffic": traffic, "traffic_note": traffic_note, "launches_timed": nsamp, "samples_left_out_device_shared": 0 if nfallback else nshared,
+                    "sampling_fallback": (f"{nshared} of {nsamp} samples overlapped the other stream's GEMMs, fewer than 8 would have "
+                                          "been left: every sample is kept (shared time included)") if nfallback else None,
                     "sampling": f"1 in {ops.GEMM_TIMING_STRIDE} uniir_gemm calls of the timed region on the image tower's stream, "
                                 "bracketed by HIP events on that stream inside the library (uniir_gemm_timing_on; 2 event records "
                                 "per sampled launch).  The text tower's GEMMs run on the model's second stream at the same time "
@@ -935,6 +944,9 @@ def main():
                        "mlp_stash": (None if args.dry_run else
                                      {k: ("f + act(f)" if v else "f") for k, v in model.clip_model.last_stash_act.items()}),
                        "mlp_stash_decisions": (None if args.dry_run else list(model.clip_model.stash_log)),
+                       "towers": (None if args.dry_run else
+                                  ("two streams (text leg on the model's second stream)" if model.clip_model.overlap_on()
+                                   else "one stream") + f" [--overlap-towers {args.overlap_towers}]"),
                        "peak_mem_GB": (round(torch.cuda.max_memory_allocated(dev) / 1e9, 1) if dev.type == "cuda" else None),
                        "batch": (f"{ROTATE} synthetic caption batches per rank (distinct token tensors; captions [SOT, L ids, EOT] with "
                                  "L ~ U{5..60}, 7..62 live positions of 77) rotated through the timed steps over ONE shared image "

@@ -90,11 +90,18 @@ int uniir_gemm(const uniir_gemm_desc* d, void* stream);
  * uniir_gemm_timing_on: the same, counting and sampling only the calls launched on `stream`.  An event pair measures a kernel's own
  * duration only while no other stream shares the device: with the towers on two streams the measurement follows one of them, the
  * uniir_gemm calls on other streams are bracketed as "device shared" windows, and the read functions leave out the samples that
- * intersect a window (uniir_gemm_timing_read_ex also returns their count in *shared; shared may be NULL). */
+ * intersect a window (uniir_gemm_timing_read_ex also returns their count in *shared; shared may be NULL).  Windows closer than two
+ * mean sample durations (at most 3 ms) count as one; when fewer than 8 samples (or than all, if fewer were taken) would be left the
+ * sums cover ALL samples and *fallback (may be NULL) is 1 -- a read after at least one sampled launch never returns zero launches.
+ * uniir_gemm_timing_filter is that rule alone on caller-supplied times, no device involved: windows = nwin x (begin, end) ms,
+ * samples = n x (begin, duration) ms on the same axis, merge_ms < 0 = the automatic gap; writes keep[n] (1 = counts) and returns the
+ * number kept (negative UNIIR_E* on bad arguments). */
 int uniir_gemm_timing(int32_t stride);
 int uniir_gemm_timing_on(int32_t stride, void* stream);
 int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launches);
-int uniir_gemm_timing_read_ex(double* flop, double* ms, int32_t* launches, int32_t* shared);
+int uniir_gemm_timing_read_ex(double* flop, double* ms, int32_t* launches, int32_t* shared, int32_t* fallback);
+int uniir_gemm_timing_filter(const float* windows, int32_t nwin, const float* samples, int32_t n, float merge_ms, uint8_t* keep,
+                             int32_t* fallback);
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] building block 2: LayerNorm over the last dim (fp32 statistics, CLIP eps 1e-5).

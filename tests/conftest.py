@@ -12,7 +12,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order.  The driver runs `pytest tests -x -q -m gpu`: the FIRST failure ends the record.  The oracle / golden comparisons
+# are the parity claim, the bench-harness tests only check measurement plumbing -- so the harness runs LAST, where a regression in a
+# measurement hook can no longer blank every parity result (round 5: test_bench_launcher.py sorted first, failed, 0 of 218 ran).
+_ORDER_FIRST = ("test_parity_exact_gpu", "test_kernels_gpu", "test_topk_gpu", "test_fp32_parity_gpu", "test_clip_model_gpu",
+                "test_blip_gpu", "test_clipff_gpu", "test_fullsize_gpu", "test_pipeline_gpu", "test_bench_paths_gpu",
+                "test_dist_device_gpu")
+_ORDER_LAST = ("test_bench_launcher",)
+
+
+def _file_rank(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if name in _ORDER_FIRST:
+        return _ORDER_FIRST.index(name)
+    if name in _ORDER_LAST:
+        return 10_000 + _ORDER_LAST.index(name)
+    return 1_000          # everything else (CPU suites, new files) between the two, in pytest's own order
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_file_rank)          # stable: the order inside a file is kept
     try:
         import torch
         has_gpu = torch.cuda.is_available()

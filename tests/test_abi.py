@@ -116,3 +116,41 @@ def test_search_host_logic_sweep_size_and_workspace_sizes():
     assert lib.uniir_sgemm_splitk_workspace_bytes(0, 768, 64) == 0
     assert lib.uniir_sgemm_splitk(None, 1, 1, None, 1, 1, None, 1, 4, 4, 16, 1.0, 0, None, 0, None) < 0
     assert lib.uniir_topk_ip(None, None, None, 10, 768, None, 1, 10, None, None, None, 0, None) < 0
+
+
+def test_gemm_sampling_rule_never_returns_an_empty_set():
+    """uniir_gemm_timing_filter = the rule uniir_gemm_timing_read_ex applies to the sampled launches (timing_filter.h), on plain
+    numbers.  Round 5's driver GPU record went red on exactly the first case below: a millisecond-long step whose samples ALL sit
+    inside the other stream's merged windows returned zero launches (roofline.achieved null)."""
+    from uniir_amd import ops
+    # (1) tiny configuration: both towers busy for the whole 4-ms region -> every sample shared -> fall back to all, flagged
+    windows = [(0.05 * i, 0.05 * i + 0.04) for i in range(80)]                 # 4 ms of back-to-back text-tower GEMMs
+    samples = [(0.4 * i + 0.01, 0.03) for i in range(10)]
+    keep, fb = ops.gemm_timing_filter(windows, samples)
+    assert fb is True and all(keep) and len(keep) == 10
+    # (2) headline shape: 1.3-ms samples, the text tower busy during 15 % of the step -> those samples go, the rest stay, no fallback
+    windows = [(100.0 + 0.3 * i, 100.0 + 0.3 * i + 0.25) for i in range(200)]   # 100 .. 160 ms, gaps 0.05 ms
+    samples = [(10.0 * i, 1.3) for i in range(40)]                              # 0, 10, .. 390 ms
+    keep, fb = ops.gemm_timing_filter(windows, samples)
+    assert fb is False
+    assert [i for i, k in enumerate(keep) if not k] == [10, 11, 12, 13, 14, 15]          # the samples that begin inside 100 .. 160 ms
+    # (3) the gap follows the samples' own duration: two windows 1 ms apart are ONE window for 1.3-ms samples (gap 2.6 ms) and TWO
+    #     for 0.1-ms samples (gap 0.2 ms); a sample sitting between them is left out in the first case only
+    windows = [(10.0, 11.0), (12.0, 13.0)]
+    long_s = [(11.2, 0.5)] + [(100.0 + 5 * i, 1.3 + 0.01 * i) for i in range(20)]
+    short_s = [(11.2, 0.5)] + [(100.0 + 5 * i, 0.1) for i in range(20)]
+    assert ops.gemm_timing_filter(windows, long_s)[0][0] is False
+    assert ops.gemm_timing_filter(windows, short_s)[0][0] is True
+    assert ops.gemm_timing_filter(windows, long_s, merge_ms=0.0)[0][0] is True          # an explicit gap overrides the automatic one
+    # (4) the automatic gap is capped at 3 ms however long the samples are
+    windows = [(10.0, 11.0), (15.0, 16.0)]
+    s = [(12.5, 0.5)] + [(100.0 + 50 * i, 20.0) for i in range(20)]
+    assert ops.gemm_timing_filter(windows, s)[0][0] is True
+    # (5) no windows / no samples / unsorted windows
+    assert ops.gemm_timing_filter([], [(0.0, 1.0)]) == ([True], False)
+    assert ops.gemm_timing_filter([(0.0, 1.0)], []) == ([], False)
+    keep, fb = ops.gemm_timing_filter([(50.0, 51.0), (0.0, 1.0)], [(0.5, 0.1)] + [(10.0 + i, 0.1) for i in range(9)])
+    assert keep[0] is False and all(keep[1:]) and fb is False
+    # (6) fewer than 8 samples taken, one survives: not a statistic -> all kept
+    keep, fb = ops.gemm_timing_filter([(0.0, 10.0)], [(1.0, 0.1), (2.0, 0.1), (20.0, 0.1)])
+    assert fb is True and all(keep)

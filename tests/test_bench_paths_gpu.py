@@ -219,6 +219,7 @@ def test_mask_compacted_towers_equal_the_dense_towers_forward_and_backward():
             t._uniir_lens = (b["txt_batched"].argmax(dim=-1) + 1).to(torch.int32)
             t._uniir_lens_version = t._version
             tm._uniir_host, im._uniir_host = tmask.clone(), imask.clone()
+            tm._uniir_host_version, im._uniir_host_version = tm._version, im._version
         batch = {"txt_batched": t, "image_batched": img, "txt_mask_batched": tm, "image_mask_batched": im,
                  "index_mapping": b["index_mapping"]}
         emb = model.encode_multimodal_input(t, img, tm, im)
@@ -254,3 +255,16 @@ def test_mask_compacted_towers_equal_the_dense_towers_forward_and_backward():
     t2._uniir_lens = torch.zeros(16, dtype=torch.int32)               # out of range: ignored
     t2._uniir_lens_version = t2._version
     assert text_row_offsets(t2)[1] == int((txt.argmax(dim=-1) + 1).sum())
+    # a stale host copy of a modality mask (device mask edited in place after the hand-over) is ignored as well: the rows the towers
+    # run on are the rows FuseFn's DEVICE mask keeps
+    tm = tmask.to(DEV)
+    tm._uniir_host, tm._uniir_host_version = tmask.clone(), tm._version
+    assert torch.equal(CLIPScoreFusion._live_rows(tm), torch.nonzero(tmask).flatten())
+    tm[1] = 1                                                          # now live on the device; the host copy still says dead
+    want = tmask.clone()
+    want[1] = 1
+    assert torch.equal(CLIPScoreFusion._live_rows(tm), torch.nonzero(want).flatten())
+    tm2 = tmask.to(DEV)
+    tm2._uniir_host = tmask.clone()                                    # a hint without a version is not trusted either
+    lt, li = CLIPScoreFusion._live_rows(tm2, imask.to(DEV))            # both read back in one transfer
+    assert torch.equal(lt, torch.nonzero(tmask).flatten()) and torch.equal(li, torch.nonzero(imask).flatten())

@@ -241,3 +241,48 @@ def test_reducer_rejects_overlapping_ranges():
     with pytest.raises(RuntimeError):
         comm.GradReducer._coalesce([(0, 10), (5, 20)])
     assert comm.GradReducer._coalesce([(10, 20), (0, 10), (30, 40)]) == [(0, 20), (30, 40)]
+
+
+def _stash_review_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import clip_oracle as O
+    from uniir_amd import clip_model, comm
+    model = clip_model.CLIP(O.tiny_config(), seed=5)
+    model._flat = {"dev": torch.device("cpu")}                      # "a training step has run" (review_stash never reads the buffers)
+    model._measured_headroom = lambda: (float(40 << 30), float(200 << 30), float(2 << 30))
+    # rank 0 chose the stash for both towers; rank 1 had less free memory and chose it for NEITHER (its old early return skipped
+    # the two MIN all-reduces, so rank 0's reductions paired with rank 1's next gradient bucket)
+    model._stash_choice = {"text": rank == 0, "image": rank == 0}
+    calls = []
+    def counted_min(x):
+        calls.append(x)
+        return comm.all_reduce_min_float(x)
+    ret = model.review_stash(counted_min)
+    # the collective that follows on every rank (a gradient bucket): must still pair up and sum correctly
+    g = torch.full((1000,), float(rank + 1))
+    dist.all_reduce(g)
+    q.put((rank, len(calls), ret, dict(model._stash_choice), bool((g == 3.0).all()), list(model.stash_log)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stash_review_runs_the_same_collectives_on_a_rank_that_chose_no_stash():
+    """clip_model.CLIP.review_stash returned before its two MIN all-reduces on a rank whose automatic choice was
+    'off' for every tower -- a per-rank condition.  Both ranks must issue both reductions, end with the stash off everywhere, and the
+    next all-reduce must pair up."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stash_review_worker, args=(r, 2, 29547, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    (_, n0, ret0, ch0, ok0, log0), (_, n1, ret1, ch1, ok1, log1) = res
+    assert n0 == 2 and n1 == 2                                      # the same collective sequence on both ranks
+    assert ok0 and ok1                                              # ... so the gradient bucket after it summed 1 + 2 everywhere
+    assert ch0 == {"text": False, "image": False} == ch1            # one mode on every rank: rank 0 followed rank 1
+    assert ret0 == float(40 << 30) and "ranks agreed on the stash: False" in log0[-1]
+    assert ret1 is None and "took part" in log1[-1]

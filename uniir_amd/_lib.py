@@ -57,7 +57,10 @@ SIGNATURES = {
     "uniir_gemm_timing": (c_int, [c_int]),
     "uniir_gemm_timing_on": (c_int, [c_int, c_void_p]),
     "uniir_gemm_timing_read": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
-    "uniir_gemm_timing_read_ex": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int), C.POINTER(c_int)]),
+    "uniir_gemm_timing_read_ex": (c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int), C.POINTER(c_int),
+                                          C.POINTER(c_int)]),
+    "uniir_gemm_timing_filter": (c_int, [C.POINTER(c_float), c_int, C.POINTER(c_float), c_int, c_float, C.POINTER(C.c_uint8),
+                                         C.POINTER(c_int)]),
     "uniir_layernorm_fwd": (c_int, [P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
     "uniir_layernorm_bwd": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, P, c_int, c_int, c_float, S]),
     "uniir_layernorm_bwd_ex": (c_int, [P, c_i64, P, P, c_int, P, P, c_i64, P, P, P, P, P, c_int, c_int, c_float, S]),

@@ -176,7 +176,13 @@ class CLIP(nn.Module):
         # units the image tower's kernels leave idle in their last round of tiles and between launches.  No kernel changes and the
         # towers' buffers are disjoint (split-K slabs and workspaces are per tower): losses and embeddings are bitwise those of the
         # one-stream order, gradients equal up to the order of the fp32 atomic column sums, which neither order fixes.
-        self.overlap_towers = os.environ.get("UNIIR_OVERLAP_TOWERS", "1") != "0"
+        # True / False = forced (UNIIR_OVERLAP_TOWERS=1 / 0); None = automatic: ON in a single-rank job, OFF when a process group
+        # with more than one rank exists.  With W > 1 the overlapped gradient reducer (comm.GradReducer) hands ranges to the
+        # collective library from whichever stream announces them, and RCCL's async all-reduce orders against the CURRENT stream only:
+        # that ordering has run over gloo (host copies, synchronous) but never over RCCL -- no two-GPU box in this environment -- so
+        # a multi-rank job keeps the one-stream order until it has (bench.py --overlap-towers forces it for an A/B).
+        env = os.environ.get("UNIIR_OVERLAP_TOWERS")
+        self.overlap_towers = None if env is None else env != "0"
         self._side_streams = {}
         self._leg_main = None           # inside side_leg(): the stream the leg forked from
 
@@ -355,16 +361,23 @@ class CLIP(nn.Module):
         stash_review_headroom_bytes of the device, the stash is switched off for the following steps -- on EVERY rank when
         all_reduce_min (a callable reducing a python float with MIN over the ranks) is given, so that replicas keep computing bitwise
         the same gradients.  Returns the headroom in bytes (None when nothing was decided automatically)."""
-        if self.stash_act is not None or not any(self._stash_choice.values()) or self._flat is None:
+        # Only RANK-UNIFORM conditions may return before the collectives: the automatic decision itself is per rank (each rank's own
+        # free memory, an out-of-memory re-plan), so a rank that chose "off" for every tower must still take part in both reductions
+        # -- skipping them would leave its peers' MIN all-reduces to pair with this rank's next gradient bucket.
+        if self.stash_act is not None or self._flat is None:
             return None
-        dev = self._flat["dev"]
-        free, total = torch.cuda.mem_get_info(dev)
-        outside = total - free - torch.cuda.memory_reserved(dev)          # other processes / RCCL / HIP runtime on this device
-        headroom = float(total - outside - torch.cuda.max_memory_allocated(dev))
-        agreed = 1.0 if all(self._stash_choice.values()) else 0.0
+        mine = any(self._stash_choice.values())
+        if all_reduce_min is None and not mine:
+            return None
+        headroom, peak, outside = self._measured_headroom() if mine else (float("inf"), 0.0, 0.0)
+        agreed = 1.0 if (mine and all(self._stash_choice.values())) else 0.0
         if all_reduce_min is not None:          # one mode on every rank from here on
             headroom = float(all_reduce_min(headroom))
             agreed = float(all_reduce_min(agreed))
+        if not mine:
+            if self._stash_choice:
+                self.stash_log.append("act(f) stash was off on this rank already; took part in the ranks' review")
+            return None
         if headroom < self.stash_review_headroom_bytes or agreed == 0.0:
             for k in self._stash_choice:
                 self._stash_choice[k] = False
@@ -372,10 +385,25 @@ class CLIP(nn.Module):
                                   f"(floor {self.stash_review_headroom_bytes / 2**30:.0f} GiB), ranks agreed on the stash: {bool(agreed)}")
         else:
             self.stash_log.append(f"act(f) stash kept after the first step: measured headroom {headroom / 2**30:.1f} GiB "
-                                  f"(peak {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB in torch, {outside / 2**30:.1f} GiB outside)")
+                                  f"(peak {peak / 2**30:.1f} GiB in torch, {outside / 2**30:.1f} GiB outside)")
         return headroom
 
+    def _measured_headroom(self):
+        """(bytes of the device the finished step left unused at its peak, torch's peak, bytes held outside torch's allocator)"""
+        dev = self._flat["dev"]
+        free, total = torch.cuda.mem_get_info(dev)
+        outside = total - free - torch.cuda.memory_reserved(dev)          # other processes / RCCL / HIP runtime on this device
+        peak = torch.cuda.max_memory_allocated(dev)
+        return float(total - outside - peak), float(peak), float(outside)
+
     # ---- two-stream towers -------------------------------------------------------------------------------------------
+    def overlap_on(self):
+        """overlap_towers resolved: forced value, or (automatic) on exactly when this is a single-rank job"""
+        if self.overlap_towers is not None:
+            return bool(self.overlap_towers)
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
     @contextlib.contextmanager
     def side_leg(self, dev):
         """with model.side_leg(dev) as leg: everything enqueued inside (one tower call and the torch ops around it) goes to this
@@ -383,7 +411,7 @@ class CLIP(nn.Module):
         off (CPU tensors, overlap_towers False, the Python tower sequences) and the body then runs on the current stream as before.
         The caller hands the tensors the leg produced to join_leg() before the current stream reads them."""
         dev = torch.device(dev)
-        if not self.overlap_towers or dev.type != "cuda" or _PY_TOWERS or self.precision == "fp32" or self._leg_main is not None:
+        if not self.overlap_on() or dev.type != "cuda" or _PY_TOWERS or self.precision == "fp32" or self._leg_main is not None:
             yield None
             return
         # every lazily built shared buffer (flat storage, 16-bit shadows of the weights) is brought up to date on the forking stream,

@@ -5,7 +5,9 @@
 #include "gemm_core256.h"
 #include "gemm_core_pp.h"
 #include "../../include/uniir_hip.h"
+#include "timing_filter.h"
 #include <stdlib.h>
+#include <vector>
 
 // per-row epilogue operands (residual stream, stashed pre-activation) are read exactly once: loaded with the nt policy.
 // MEASURED (round 3, same box, interleaved twice, ViT-L/14 512-pair step): 634.5 / 635.6 ms with plain loads, 632.9 / 631.9 ms with
@@ -958,9 +960,9 @@ extern "C" int uniir_gemm_timing(int32_t stride) {
 // stream, which is the kernel's own duration only while no other stream shares the device.  With the two towers on two streams
 // (clip_model.CLIP.side_leg) the measuring run follows the stream that carries the image tower, and every uniir_gemm call on another
 // stream is bracketed too -- not as a sample but as a record of WHEN the device was shared: uniir_gemm_timing_read leaves out the
-// samples that intersect those windows (windows closer than GT_MERGE_MS are one window: the LayerNorm / attention kernels between two
-// GEMMs of the other tower share the device just the same) and uniir_gemm_timing_read_ex also returns how many it left out.
-#define GT_MERGE_MS 3.0f
+// samples that intersect those windows (windows closer than two mean sample durations are one window: the LayerNorm / attention
+// kernels between two GEMMs of the other tower share the device just the same; the rule is host arithmetic in timing_filter.h) and
+// uniir_gemm_timing_read_ex also returns how many it left out -- or that it kept them all because too few would have been left.
 extern "C" int uniir_gemm_timing_on(int32_t stride, void* stream) {
     const int rc = uniir_gemm_timing(stride);
     if (rc != UNIIR_OK || stride == 0) return rc;
@@ -976,53 +978,47 @@ extern "C" int uniir_gemm_timing_on(int32_t stride, void* stream) {
     return UNIIR_OK;
 }
 // sums over the sampled launches (call after synchronising the device): algorithmic 2 M N K, elapsed milliseconds, count; shared
-// (may be NULL): samples left out because another stream's GEMMs shared the device with them (uniir_gemm_timing_on)
-extern "C" int uniir_gemm_timing_read_ex(double* flop, double* ms, int32_t* launches, int32_t* shared) {
+// (may be NULL): samples left out because another stream's GEMMs shared the device with them (uniir_gemm_timing_on); fallback (may be
+// NULL): 1 when the rule would have left fewer than GT_MIN_KEEP samples and the sums are over ALL samples instead (shared then counts
+// what the rule wanted to drop).  The rule itself is host arithmetic in timing_filter.h.
+extern "C" int uniir_gemm_timing_read_ex(double* flop, double* ms, int32_t* launches, int32_t* shared, int32_t* fallback) {
     if (!flop || !ms || !launches) return UNIIR_EINVAL;
-    // the other streams' windows on the time axis of `base`, merged
-    int nw = 0;
-    float (*win)[2] = nullptr;
-    if (g_gt.filter && g_gt.nf > 0) {
-        win = (float (*)[2])malloc(sizeof(float[2]) * g_gt.nf);
-        if (!win) return UNIIR_EINVAL;
-        for (int i = 0; i < g_gt.nf; ++i) {
-            float a = 0.f, b = 0.f;
-            if (hipEventElapsedTime(&a, g_gt.base, g_gt.fev[2 * i]) != hipSuccess ||
-                hipEventElapsedTime(&b, g_gt.base, g_gt.fev[2 * i + 1]) != hipSuccess) { free(win); return UNIIR_ELAUNCH; }
-            win[i][0] = a; win[i][1] = b;
+    const int n = g_gt.n, nwin = g_gt.filter ? g_gt.nf : 0;
+    std::vector<float> dur(n), samples(2 * (size_t)n), windows(2 * (size_t)nwin);
+    std::vector<uint8_t> keep(n ? n : 1, 1);
+    for (int i = 0; i < n; ++i)
+        if (hipEventElapsedTime(&dur[i], g_gt.ev[2 * i], g_gt.ev[2 * i + 1]) != hipSuccess) return UNIIR_ELAUNCH;
+    int fb = 0, left_out = 0;
+    if (nwin > 0 && n > 0) {          // everything on the time axis of `base`
+        for (int i = 0; i < nwin; ++i)
+            if (hipEventElapsedTime(&windows[2 * i], g_gt.base, g_gt.fev[2 * i]) != hipSuccess ||
+                hipEventElapsedTime(&windows[2 * i + 1], g_gt.base, g_gt.fev[2 * i + 1]) != hipSuccess) return UNIIR_ELAUNCH;
+        for (int i = 0; i < n; ++i) {
+            if (hipEventElapsedTime(&samples[2 * i], g_gt.base, g_gt.ev[2 * i]) != hipSuccess) return UNIIR_ELAUNCH;
+            samples[2 * i + 1] = dur[i];
         }
-        qsort(win, g_gt.nf, sizeof(float[2]), [](const void* x, const void* y) {
-            const float a = ((const float*)x)[0], b = ((const float*)y)[0];
-            return a < b ? -1 : a > b ? 1 : 0;
-        });
-        for (int i = 0; i < g_gt.nf; ++i) {
-            if (nw > 0 && win[i][0] <= win[nw - 1][1] + GT_MERGE_MS) win[nw - 1][1] = fmaxf(win[nw - 1][1], win[i][1]);
-            else { win[nw][0] = win[i][0]; win[nw][1] = win[i][1]; ++nw; }
-        }
+        gt_filter_samples(windows.data(), nwin, samples.data(), n, -1.f, keep.data(), &fb, &left_out);
     }
     double f = 0.0, t = 0.0;
-    int kept = 0, left_out = 0;
-    for (int i = 0; i < g_gt.n; ++i) {
-        float e = 0.f;
-        if (hipEventElapsedTime(&e, g_gt.ev[2 * i], g_gt.ev[2 * i + 1]) != hipSuccess) { free(win); return UNIIR_ELAUNCH; }
-        if (nw > 0) {
-            float a = 0.f;
-            if (hipEventElapsedTime(&a, g_gt.base, g_gt.ev[2 * i]) != hipSuccess) { free(win); return UNIIR_ELAUNCH; }
-            bool hit = false;
-            for (int w = 0; w < nw && !hit; ++w) hit = a < win[w][1] && a + e > win[w][0];
-            if (hit) { ++left_out; continue; }
-        }
-        f += g_gt.flop[i];
-        t += e;
-        ++kept;
-    }
-    free(win);
+    int kept = 0;
+    for (int i = 0; i < n; ++i)
+        if (keep[i]) { f += g_gt.flop[i]; t += dur[i]; ++kept; }
     *flop = f; *ms = t; *launches = kept;
     if (shared) *shared = left_out;
+    if (fallback) *fallback = fb;
     return UNIIR_OK;
 }
 extern "C" int uniir_gemm_timing_read(double* flop, double* ms, int32_t* launches) {
-    return uniir_gemm_timing_read_ex(flop, ms, launches, nullptr);
+    return uniir_gemm_timing_read_ex(flop, ms, launches, nullptr, nullptr);
+}
+// the rule alone, on caller-supplied times (no device needed): tests, and a host-language caller that keeps its own event log
+extern "C" int uniir_gemm_timing_filter(const float* windows, int32_t nwin, const float* samples, int32_t n, float merge_ms,
+                                        uint8_t* keep, int32_t* fallback) {
+    if (nwin < 0 || n < 0 || (nwin && !windows) || (n && (!samples || !keep))) return UNIIR_EINVAL;
+    int fb = 0;
+    const int kept = gt_filter_samples(windows, nwin, samples, n, merge_ms, keep, &fb, nullptr);
+    if (fallback) *fallback = fb;
+    return kept;
 }
 
 static int gemm_impl(const uniir_gemm_desc* d, void* stream);

@@ -1457,7 +1457,9 @@ extern "C" int uniir_topk_ip_multi(const void* pool_f16, const float* pool_inv_n
                      fused_tail_ok(p.per, dim, p.kc) && fused_tail_ok(last_rows, dim, p.kc) && p.nsub <= 64;
     if (!pool_ids) return UNIIR_EINVAL;          // (local row numbers of different sub-shards cannot be merged)
     char* ws = (char*)workspace;
-    if (!big) {      // the per-sub-shard loop of round 4, on the device side of the ABI: lists [nsub][nq][k], one merge
+    // the per-sub-shard loop of round 4, on the device side of the ABI: lists [nsub][nq][k], one merge.  Also the way out when the
+    // batched path refuses a shape (same results: both end in the exact re-score and the same merge rule)
+    auto per_sub_shard = [&]() -> int {
         float* ls = (float*)(ws + p.inner_bytes);
         int64_t* li = (int64_t*)(ws + p.inner_bytes + p.nsub * tkm_align((int64_t)nq * k * 8));
         for (int z = 0; z < p.nsub; ++z) {
@@ -1467,7 +1469,14 @@ extern "C" int uniir_topk_ip_multi(const void* pool_f16, const float* pool_inv_n
             if (rc) return rc;
         }
         return uniir_topk_merge(ls, li, p.nsub, nq, k, out_scores, out_ids, stream);
-    }
+    };
+    if (!big) return per_sub_shard();
+    // the per-wave maxima (hierarchical selection) exist only when EVERY sub-shard's scan writes them: the rule depends on the
+    // sub-shard's group count and the device's CU count, and the shorter last sub-shard may disagree with the full ones
+    const int ncu = tk_cu_count();
+    if (ncu < 0) return UNIIR_ELAUNCH;
+    auto waves_ok = [&](int64_t r) { const long ng = (r + TK_G - 1) / TK_G; return ncu * 4 <= 1024 && (ng + ncu * 4 - 1) / (ncu * 4) <= 64; };
+    const bool use_wmax = waves_ok(p.per) && waves_ok(last_rows);
     float* gmax = (float*)ws;
     float* wmax = (float*)(ws + p.nsub * p.g_bytes);
     int32_t* cand = (int32_t*)(ws + p.nsub * (p.g_bytes + p.w_bytes));
@@ -1488,15 +1497,15 @@ extern "C" int uniir_topk_ip_multi(const void* pool_f16, const float* pool_inv_n
             const int64_t r0 = (int64_t)z * p.per, nr = z == p.nsub - 1 ? last_rows : p.per;
             int nwz = 0;
             const int sel = launch_gmax_scan((const unsigned short*)pool_f16 + r0 * dim, pool_inv_norm + r0, nr, dim, qp, n,
-                                             gmax + z * mu.g_stride, st, wmax + z * mu.w_stride, &nwz);
-            if (sel < 1) return sel < 0 ? sel : UNIIR_EUNSUPPORTED;
+                                             gmax + z * mu.g_stride, st, use_wmax ? wmax + z * mu.w_stride : nullptr, &nwz);
+            if (sel < 0) return sel;
+            if (sel < 1 || (z > 0 && nwz != nw)) return per_sub_shard();       // a scan the batched tail cannot follow: start over
             if (z == 0) nw = nwz;
-            else if (nwz != nw) return UNIIR_EUNSUPPORTED;        // (cannot happen: one rule, one device)
         }
         mu.o_stride = (long)n * k;
-        if (!launch_fused_tail(pool_f16, pool_inv_norm, pool_ids, p.per, dim, qp, n, p.kc, k, gmax, cand, exact, ls, li, st, wmax, nw, &mu,
-                               p.nsub))
-            return UNIIR_EUNSUPPORTED;
+        if (!launch_fused_tail(pool_f16, pool_inv_norm, pool_ids, p.per, dim, qp, n, p.kc, k, gmax, cand, exact, ls, li, st,
+                               nw > 0 ? wmax : nullptr, nw, &mu, p.nsub))
+            return per_sub_shard();
         HIP_LAUNCH_CHECK();
         const int rc = uniir_topk_merge(ls, li, p.nsub, n, k, out_scores + (long)lo * k, out_ids + (long)lo * k, stream);
         if (rc) return rc;

@@ -18,9 +18,18 @@
 // else: ~11 groups at k = 10 on random data instead of the fixed k + 8 = 18 (which is no bound at all: nine near-ties within the
 // rounding error would defeat it) -- 40 % fewer rows gathered and re-scored.  More than gcap = 2 (k + 8) qualifying groups (massive
 // near-ties: duplicated rows) keep the best gcap, as before.  The kept groups occupy a PREFIX of the slots; *nkept is their number.
+// Both error bounds grow with the length of the fp32 chain: d_a = (dim + 25) x 2^-23, d_e = (dim + 3) x 2^-24.  The slack follows dim
+// (a constant 5e-4 stops being a proven bound above dim ~ 1300 while the fused tail accepts dim <= 4096): 1.78 x the bound
+// 2 (d_a + d_e) -- the margin 5e-4 / 2.81e-4 of the 768 case -- and never below the 5e-4 that dims <= 768 were measured with.
 #define TK_SLACK_COS 5.0e-4f
+static inline __host__ __device__ float tk_slack_cos(int dim) {
+    const float bound = 2.f * ((float)(dim + 25) * 1.1920929e-7f + (float)(dim + 3) * 5.9604645e-8f);
+    const float s = 1.78f * bound;
+    return s > TK_SLACK_COS ? s : TK_SLACK_COS;
+}
 struct GselBound {
     int k;              // entries wanted
+    float slack_cos;    // tk_slack_cos(dim)
     const float* iq;    // LDS: the query's inverse norm, written by the caller's mid() (read after the barrier that follows it)
     int* nkept;         // LDS: groups kept
 };
@@ -90,7 +99,7 @@ DEVINL void gsel_body(const float* __restrict__ g, long ngroups, long rows, int 
     }
     __syncthreads();
     // (the barrier above also publishes *gb->iq, written inside mid())
-    const float slack = (gb && *gb->iq > 0.f) ? TK_SLACK_COS / *gb->iq : 0.f;      // in the scan's units (scores x |q|)
+    const float slack = (gb && *gb->iq > 0.f) ? gb->slack_cos / *gb->iq : 0.f;      // in the scan's units (scores x |q|)
     const float t0 = tau0 - slack;
     if (REG) {
 #pragma unroll
@@ -222,7 +231,7 @@ DEVINL bool gsel_hier(const float* __restrict__ g, const float* __restrict__ wm,
         if (rank == min(kk, 64) - 1) htau0 = x;
     }
     __syncthreads();
-    const float slack = (gb && *gb->iq > 0.f) ? TK_SLACK_COS / *gb->iq : 0.f;      // (*gb->iq: published by the barriers above)
+    const float slack = (gb && *gb->iq > 0.f) ? gb->slack_cos / *gb->iq : 0.f;      // (*gb->iq: published by the barriers above)
     const float t0 = htau0 - slack;
     if (v >= t0 && v > -INFINITY) {
         const int pos = atomicAdd(&ccnt, 1);

@@ -528,6 +528,7 @@ __global__ __launch_bounds__(TKT_THREADS) void topk_tail_select_rescore_kernel(
     // prefix of the slots
     GselBound gb;
     gb.k = k;
+    gb.slack_cos = tk_slack_cos(dim);
     gb.iq = &s_iq;
     gb.nkept = &s_nkept;
     if (!(wmax && gsel_hier<TKT_THREADS>(gmax + (long)q * ngroups, wmax + (long)q * nw, nw, ngroups, rows, kc, gcap, sel, qnorm, &gb)))

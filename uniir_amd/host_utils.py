@@ -264,6 +264,11 @@ def batch_to_device(batch, gpu_id):
     for key, value in batch.items():
         if isinstance(value, torch.Tensor):
             batch[key] = value.to(gpu_id, non_blocking=True)
+            if key in ("txt_mask_batched", "image_mask_batched") and not value.is_cuda and batch[key] is not value:
+                # the modality masks stay readable on the host (as DevicePrefetcher leaves them): CLIP_SF sizes each tower's launch
+                # from the live rows and would otherwise read the mask back from the device
+                batch[key]._uniir_host = value
+                batch[key]._uniir_host_version = batch[key]._version
         elif hasattr(value, "to_device"):                                   # clip_front.RawImageBatch: transform on the GPU
             batch[key] = value.to_device(torch.device("cuda", gpu_id) if isinstance(gpu_id, int) else torch.device(gpu_id))
         elif hasattr(value, "input_ids") and hasattr(value, "items"):      # transformers BatchEncoding (BLIP tokenizer)
@@ -309,6 +314,7 @@ class DevicePrefetcher:
                         # the modality masks stay readable on the host: CLIP_SF runs each tower on its live rows only
                         # (clip_sf.encode_multimodal_input) and needs their number to size the launch
                         batch[key]._uniir_host = host_mask
+                        batch[key]._uniir_host_version = batch[key]._version     # dies with an in-place edit of the device mask
                 elif hasattr(value, "to_device"):                                   # clip_front.RawImageBatch
                     batch[key] = value.pin_memory().to_device(self.dev)
                 elif hasattr(value, "input_ids") and hasattr(value, "items"):      # transformers BatchEncoding (BLIP)

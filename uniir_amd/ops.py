@@ -26,13 +26,27 @@ def gemm_timing_start(stride=GEMM_TIMING_STRIDE, stream=None):
 
 def gemm_timing_stop(with_shared=False):
     """-> (sum of 2 M N K, seconds, launches) over the sampled GEMM launches [, samples left out because another stream's GEMMs
-    shared the device with them: gemm_timing_start(stream=...)]; synchronise the device first"""
-    f, ms, n, sh = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
-    check(_lib.load().uniir_gemm_timing_read_ex(C.byref(f), C.byref(ms), C.byref(n), C.byref(sh)), "gemm_timing_read")
+    shared the device with them: gemm_timing_start(stream=...), and whether the rule fell back to all samples because fewer than 8
+    would have been left]; synchronise the device first"""
+    f, ms, n, sh, fb = C.c_double(), C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(_lib.load().uniir_gemm_timing_read_ex(C.byref(f), C.byref(ms), C.byref(n), C.byref(sh), C.byref(fb)), "gemm_timing_read")
     check(_lib.load().uniir_gemm_timing(0), "gemm_timing")
     if with_shared:
-        return f.value, ms.value * 1e-3, n.value, sh.value
+        return f.value, ms.value * 1e-3, n.value, sh.value, bool(fb.value)
     return f.value, ms.value * 1e-3, n.value
+
+
+def gemm_timing_filter(windows, samples, merge_ms=-1.0):
+    """the sampling rule alone (host arithmetic, no device): windows [(begin, end) ms], samples [(begin, duration) ms] ->
+    (keep flags, fell back to all samples?)"""
+    nw, n = len(windows), len(samples)
+    w = (C.c_float * max(1, 2 * nw))(*[x for p in windows for x in p])
+    s = (C.c_float * max(1, 2 * n))(*[x for p in samples for x in p])
+    keep, fb = (C.c_uint8 * max(1, n))(), C.c_int32()
+    kept = _lib.load().uniir_gemm_timing_filter(w, nw, s, n, float(merge_ms), keep, C.byref(fb))
+    if kept < 0:
+        check(kept, "gemm_timing_filter")
+    return [bool(keep[i]) for i in range(n)], bool(fb.value)
 
 
 

@@ -54,17 +54,41 @@ class CLIPScoreFusion(nn.Module):
     compact_masked = True
 
     @staticmethod
-    def _live_rows(mask):
-        """(None if every row is live, else the int64 HOST index tensor of the live rows).  The host copy of the mask comes from
-        the prefetcher (`mask._uniir_host`, host_utils.DevicePrefetcher) when there is one; otherwise one device -> host read."""
+    def _host_hint(mask):
+        """the host copy of a modality mask that travelled with it (`mask._uniir_host`: host_utils.DevicePrefetcher /
+        batch_to_device), or None.  Like the caption-length hint it is tied to the tensor's version: an in-place edit of the device
+        mask after the hand-over invalidates it (the rows kept here must be the rows FuseFn's mask keeps)."""
         host = getattr(mask, "_uniir_host", None)
+        ver = _tensor_version(mask)
         if not isinstance(host, torch.Tensor) or host.is_cuda or host.shape != mask.shape:
-            host = mask.detach().to("cpu")
-        live = torch.nonzero(host != 0).flatten()
-        return None if live.numel() == host.numel() else live
+            return None
+        if ver is None or getattr(mask, "_uniir_host_version", None) != ver:
+            return None
+        return host
 
-    def _encode_live(self, encode, inp, mask):
-        live_host = self._live_rows(mask)
+    @classmethod
+    def _live_rows(cls, *masks):
+        """per mask: None if every row is live, else the int64 HOST index tensor of the live rows.  Masks without a valid host
+        hint are read back together, in ONE device -> host transfer on the current stream (before the text leg forks)."""
+        hosts = [cls._host_hint(m) for m in masks]
+        missing = [i for i, h in enumerate(hosts) if h is None]
+        if len(missing) == 1:
+            hosts[missing[0]] = masks[missing[0]].detach().to("cpu")
+        elif missing:
+            if all(masks[i].shape == masks[missing[0]].shape and masks[i].dtype == masks[missing[0]].dtype for i in missing):
+                both = torch.stack([masks[i].detach() for i in missing]).to("cpu")
+                for j, i in enumerate(missing):
+                    hosts[i] = both[j]
+            else:
+                for i in missing:
+                    hosts[i] = masks[i].detach().to("cpu")
+        out = []
+        for host in hosts:
+            live = torch.nonzero(host != 0).flatten()
+            out.append(None if live.numel() == host.numel() else live)
+        return out[0] if len(masks) == 1 else out
+
+    def _encode_live(self, encode, inp, live_host):
         if live_host is None:
             return encode(inp)
         if live_host.numel() == 0 and torch.is_grad_enabled():
@@ -85,14 +109,17 @@ class CLIPScoreFusion(nn.Module):
 
     def encode_multimodal_input(self, txt_tensor, img_tensor, txt_mask, img_mask):
         # the towers are independent up to the fusion: the text leg goes to the model's second stream (clip_model.CLIP.side_leg) and is
-        # joined before FuseFn reads it; same kernels, same results
+        # joined before FuseFn reads it; same kernels, same results.  Both masks' live rows are settled BEFORE the fork (a blocking
+        # read inside the leg would stall the host while the image tower's launches wait behind it).
+        if self.compact_masked:
+            live_txt, live_img = self._live_rows(txt_mask, img_mask)
         with self.clip_model.side_leg(txt_tensor.device) as leg:
             if self.compact_masked:
-                txt_emb = self._encode_live(self.encode_text, txt_tensor, txt_mask)
+                txt_emb = self._encode_live(self.encode_text, txt_tensor, live_txt)
             else:
                 txt_emb = self.encode_text(txt_tensor)
         if self.compact_masked:
-            img_emb = self._encode_live(self.encode_image, img_tensor, img_mask)
+            img_emb = self._encode_live(self.encode_image, img_tensor, live_img)
         else:
             img_emb = self.encode_image(img_tensor)
         self.clip_model.join_leg(leg, txt_emb)
