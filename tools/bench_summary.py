@@ -23,7 +23,7 @@ if isinstance(rt, dict):
 em = d.get("embed")
 if isinstance(em, dict) and "modes" in em:
     for k, v in em["modes"].items():
-        print("embed", k, v["value"], "items/s", v["mfma_frac"], "(dense count", v["mfma_frac_dense_count"], ")")
+        print("embed", k, v["value"], "items/s", v["mfma_frac"], "(dense count", v.get("mfma_frac_dense_count"), ")")
 for k in ("blip_ff_large", "clip_ff"):
     if isinstance(d.get(k), dict):
         print(k, d[k].get("value"), d[k].get("mfma_frac"), d[k].get("ms_per_step"))
