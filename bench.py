@@ -356,9 +356,22 @@ def _blip_synth(pairs, L, vocab, seed, device):
     mask = (torch.arange(L).unsqueeze(0) < valid.unsqueeze(1)).long()
     ids = ids * mask
     img = torch.randn(M, 3, 224, 224, generator=torch.Generator(device=device).manual_seed(seed), device=device)
-    return {"txt_batched": types.SimpleNamespace(input_ids=ids.to(device), attention_mask=mask.to(device)),
+    dmask = mask.to(device)
+    dmask._uniir_lens, dmask._uniir_lens_version = valid.to(torch.int32), dmask._version       # as host_utils.DevicePrefetcher does
+    return {"txt_batched": types.SimpleNamespace(input_ids=ids.to(device), attention_mask=dmask), "valid_host": valid,
             "image_batched": img, "p_did_list": torch.arange(pairs) + 1000 * seed,
             "index_mapping": {"query": [[2 * i] for i in range(pairs)], "pos_cand": [[2 * i + 1] for i in range(pairs)]}}
+
+
+def blip_ff_executed_flop_per_pair(valid, L, Ti=197, W=768, I=3072, Ew=1024, layers=12, vit_fwd=123.1e9):
+    """FLOPs (2 x MACs, SURVEY 8(d) conventions) of one BLIP_FF pair -- 2 items x (online fwd + 2 x bwd + momentum fwd) -- with BERT on
+    each caption's valid rows: per layer the row-wise GEMMs (qkv, the three output dense layers, cross-attention query, FFN) and the
+    cross-attention scores scale with the length, self-attention with its square, the K / V projection of the 197 image tokens does
+    not.  At len = L this is SURVEY's 28.35 GFLOP per item and BLIP_FF_FLOP_PER_PAIR."""
+    n = valid.double()
+    per_row = 2 * W * 3 * W + 3 * 2 * W * W + 4 * Ti * W + 4 * W * I             # per text row and layer
+    item = layers * (per_row * n + 4 * W * n * n + 2 * Ti * Ew * 2 * W) + 2 * W * W          # + the pooler
+    return float((vit_fwd + item).mean()) * 8.0
 
 
 def bench_blip_ff(dev, pairs=256, steps=3, warmup=1, queue=57344, length=100):
@@ -374,24 +387,48 @@ def bench_blip_ff(dev, pairs=256, steps=3, warmup=1, queue=57344, length=100):
     batches = [_blip_synth(pairs, length, 30524, s, dev) for s in range(2)]
 
     def step(i):
+        b = batches[i % 2]
+        m = b["txt_batched"].attention_mask
+        if hasattr(m, "_uniir_pack"):           # the per-batch host work of the packed BERT (prefix sums, row map, two small copies)
+            del m._uniir_pack                   # belongs to every step: a train loop never sees the same batch object twice
         opt.zero_grad()
-        out = model(batches[i % 2], alpha=0.4)
+        out = model(b, alpha=0.4)
         out["loss"].backward()
         opt.step()
         return out
 
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        out = step(i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"metric": "query+cand pairs/sec in-batch contrastive (BLIP_FF large)", "value": round(pairs / dt, 1),
-            "unit": "pairs/s", "ms_per_step": round(dt * 1e3, 2), "pairs_per_gpu": pairs, "queue_size": queue,
-            "text_len": length, "dropout": "train mode (BERT 0.1, DropPath <= 0.1)",
-            "mfma_frac": round(pairs / dt * BLIP_FF_FLOP_PER_PAIR / MFMA_PEAK_BF16, 4), "final_loss": round(float(out["loss"]), 4)}
+    def timed(n):
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            o = step(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, o
+
+    dt, out = timed(steps)
+    executed = sum(blip_ff_executed_flop_per_pair(batches[i % 2]["valid_host"], length) for i in range(steps)) / steps
+    rows = model.last_text_rows
+    rec = {"metric": "query+cand pairs/sec in-batch contrastive (BLIP_FF large)", "value": round(pairs / dt, 1),
+           "unit": "pairs/s", "ms_per_step": round(dt * 1e3, 2), "pairs_per_gpu": pairs, "queue_size": queue,
+           "text_len": length, "dropout": "train mode (BERT 0.1, DropPath <= 0.1)",
+           "mfma_frac": round(pairs / dt * executed / MFMA_PEAK_BF16, 4),
+           "mfma_frac_note": (f"value x EXECUTED FLOPs per pair / peak: BERT runs on the rows up to each caption's valid length only "
+                              f"(blip_model.TextPack; exact: padded keys are masked to an exact 0 and only token 0 is pooled, "
+                              f"med.py:687-688, blip_ff.py:82-116); {executed / 1e12:.4f} TFLOP per pair executed vs "
+                              f"{BLIP_FF_FLOP_PER_PAIR / 1e12:.3f} with {length} positions per caption; BERT rows {rows[0]} of {rows[1]} "
+                              "in the last batch; the per-batch host work of the packing is inside the timed steps"),
+           "mfma_frac_dense_count": round(pairs / dt * BLIP_FF_FLOP_PER_PAIR / MFMA_PEAK_BF16, 4),
+           "final_loss": round(float(out["loss"]), 4)}
+    # the same step on the padded rows of the reference (pack_text = False): what earlier rounds measured
+    model.pack_text = False
+    torch.cuda.empty_cache()
+    dtp, _ = timed(max(2, steps // 2))
+    model.pack_text = True
+    rec["padded_rows"] = {"value": round(pairs / dtp, 1), "ms_per_step": round(dtp * 1e3, 2),
+                          "mfma_frac": round(pairs / dtp * BLIP_FF_FLOP_PER_PAIR / MFMA_PEAK_BF16, 4)}
+    return rec
 
 
 def bench_clip_ff(dev, pairs=256, steps=3, warmup=1):

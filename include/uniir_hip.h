@@ -155,6 +155,20 @@ int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k, const voi
                            uint32_t drop_seed, void* stream);
 /* drop_p > 0 (BERT attention_probs_dropout_prob in train mode): P V uses P * mask / (1 - drop_p), mask regenerated from
  * (drop_seed, ((item * heads + head) * tq + query) * tk + key); backward must get the same pair. */
+/* The general form on PACKED QUERY ROWS (BLIP's MED BERT on the tokens up to each caption's valid length only; replaces the padded
+ * rows of backbone/med.py:160-232, whose keys are masked by (1 - m) * -10000, :687-688): item m owns the rows q_row_off[m] ..
+ * q_row_off[m + 1] - 1 of q / out / dout / dq (length <= tq).  kv_packed != 0: self-attention -- k / v / dk / dv are rows of the same
+ * packed numbering, the item's key count is its own length (what key_len is in the padded call; key_len must be NULL, tq == tk);
+ * kv_packed == 0: cross-attention -- k / v / dk / dv stay dense [batch][tk] rows, key_len optional.  lse keeps the dense
+ * [batch][heads][tq] layout; the dropout mask is drawn at the dense coordinates above, so every live row equals the padded call's
+ * bit for bit, train mode included. */
+int uniir_attention_fwd_rows(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld, void* out, int64_t out_ld,
+                             float* lse, const int32_t* q_row_off, int32_t kv_packed, const int32_t* key_len, int32_t batch,
+                             int32_t tq, int32_t tk, int32_t heads, float drop_p, uint32_t drop_seed, void* stream);
+int uniir_attention_bwd_rows(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld, const void* out,
+                             const void* dout, int64_t out_ld, const float* lse, const int32_t* q_row_off, int32_t kv_packed,
+                             const int32_t* key_len, void* dq, int64_t dq_ld, void* dk, void* dv, int64_t dkv_ld, int32_t batch,
+                             int32_t tq, int32_t tk, int32_t heads, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] small fused pieces of the towers.
@@ -403,6 +417,12 @@ int uniir_dropout_f32(const float* x, const float* resid, float* y_f32, void* y_
 int uniir_dropout_bf16(const void* x, void* y, int64_t rows, int32_t cols, int64_t ld, float p, uint32_t seed,
                        const float* rowscale, int32_t rows_per_scale, void* stream);
 int uniir_dropout_mask(float* out, int64_t count, float p, uint32_t seed, void* stream);
+/* the same on PACKED rows (no rowscale): row r of x / resid / y is row row_map[r] of the logical tensor, idx = row_map[r] * cols + col
+ * -- a BERT that runs on the live rows of its captions only draws the mask elements those rows have in the padded batch */
+int uniir_dropout_f32_rows(const float* x, const float* resid, float* y_f32, void* y_bf16, int64_t rows, int32_t cols, float p,
+                           uint32_t seed, const int32_t* row_map, void* stream);
+int uniir_dropout_bf16_rows(const void* x, void* y, int64_t rows, int32_t cols, int64_t ld, float p, uint32_t seed,
+                            const int32_t* row_map, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [CLIP_FF] pieces of the feature-fusion stack of src/models/uniir_clip/clip_featurefusion/clip_ff.py:80-96,161-192

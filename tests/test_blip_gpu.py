@@ -383,3 +383,63 @@ def test_blip_ff_large_two_pairs_against_the_oracle():
         ref = bo.encode_multimodal_input({k: v.detach() for k, v in sd.items()}, ids, mask, img, model.vit_cfg, model.med_cfg)
     print("OBS blip-large emb rel", rel(emb, ref))
     assert rel(emb, ref) < 2e-2
+
+
+@pytest.mark.parametrize("score_fusion", [False, True])
+def test_packed_bert_rows_equal_the_padded_rows(score_fusion):
+    """BERT on the rows up to each caption's valid length only (blip_model.TextPack; reference: padded rows with
+    masked keys, med.py:160-232,687-688, only token 0 pooled, blip_ff.py:82-116).  Against pack_text = False on the same weights,
+    tokens, images and dropout seeds: the embedding is BITWISE equal in eval mode and in train mode (hidden dropout, attention
+    dropout -- masks drawn at the dense coordinates -- and DropPath), every parameter gradient equal up to the order of the fp32
+    additions in the weight-gradient reductions (the reduction runs over fewer rows, so the split-K chunks differ).  BERT-base width
+    (768, 12 heads, 100 positions, 2 layers) over a small ViT; lengths include a full caption, a one-token caption and ragged ones;
+    BLIP_SF: mode "text" (no cross-attention), class-token output."""
+    from uniir_amd.blip_model import BLIPFeatureFusion, BLIPScoreFusion
+    L, M = 100, 8
+    med = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=2, vocab_size=30524,
+               max_position_embeddings=512, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    vit = dict(img_size=64, patch_size=16, embed_dim=256, depth=2, num_heads=4, drop_path_rate=0.1)
+    cls = BLIPScoreFusion if score_fusion else BLIPFeatureFusion
+    model = cls(med_config=med, vit_config=vit, embed_dim=768 if not score_fusion else 256, queue_size=16,
+                config=types.SimpleNamespace(tokenizer_max_length=L), seed=11).cuda()
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1000, 30000, (M, L), generator=g)
+    ids[:, 0] = 101
+    valid = torch.tensor([L, 1, 37, 5, 64, 99, 2, 50])
+    mask = (torch.arange(L).unsqueeze(0) < valid.unsqueeze(1)).long()
+    ids = ids * mask
+    img = torch.randn(M, 3, 64, 64, generator=g).cuda()
+    w = torch.randn(M, model.embed_dim, generator=g).cuda()
+
+    def run(pack, train):
+        model.pack_text = pack
+        model.train(train)
+        model.zero_grad()
+        txt = types.SimpleNamespace(input_ids=ids.cuda(), attention_mask=mask.cuda())     # fresh tensors: no remembered pack
+        torch.manual_seed(21)                                                              # the dropout seeds of this pass
+        emb = model.encode_multimodal_input(txt, img)
+        rows = model.last_text_rows
+        (emb * w).sum().backward()
+        grads = {n: p.grad.detach().clone() for n, p in model._online_params() if n not in model._frozen and n != "temp"}
+        with torch.no_grad():
+            torch.manual_seed(22)
+            emb_m = model.encode_multimodal_input(txt, img, use_momentum=True)
+        return emb.detach().clone(), emb_m.clone(), grads, rows
+
+    for train in (False, True):
+        e_d, m_d, g_d, rows_d = run(False, train)
+        e_p, m_p, g_p, rows_p = run(True, train)
+        assert rows_d == (M * L, M * L) and rows_p == (int(valid.sum()), M * L)
+        assert torch.equal(e_p, e_d), (train, (e_p - e_d).abs().max().item())
+        assert torch.equal(m_p, m_d), train                                     # the momentum encoder (no grad) packs the same way
+        worst = max((float((g_p[n] - g_d[n]).abs().max()) / (float(g_d[n].abs().max()) + 1e-12), n) for n in g_d)
+        assert worst[0] <= 2e-5, (train, worst)
+        live = [n for n in g_d if float(g_d[n].abs().max()) > 0]
+        assert len(live) >= len(g_d) - (4 if score_fusion else 0)               # (BLIP_SF: nothing else is dead)
+    # a batch of full-length captions has nothing to drop: no pack is built
+    full = types.SimpleNamespace(input_ids=ids.cuda(), attention_mask=torch.ones(M, L, dtype=torch.long).cuda())
+    model.pack_text = True
+    model.eval()
+    with torch.no_grad():
+        model.encode_multimodal_input(full, img)
+    assert model.last_text_rows == (M * L, M * L)

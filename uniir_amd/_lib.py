@@ -72,6 +72,10 @@ SIGNATURES = {
                                        C.c_uint32, S]),
     "uniir_attention_bwd_ex": (c_int, [P, c_i64, P, P, c_i64, P, P, c_i64, P, P, P, c_i64, P, P, c_i64, c_int, c_int,
                                        c_int, c_int, c_int, c_float, C.c_uint32, S]),
+    "uniir_attention_fwd_rows": (c_int, [P, c_i64, P, P, c_i64, P, c_i64, P, P, c_int, P, c_int, c_int, c_int, c_int, c_float,
+                                         C.c_uint32, S]),
+    "uniir_attention_bwd_rows": (c_int, [P, c_i64, P, P, c_i64, P, P, c_i64, P, P, c_int, P, P, c_i64, P, P, c_i64, c_int, c_int,
+                                         c_int, c_int, c_float, C.c_uint32, S]),
     "uniir_patchify": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "uniir_vit_assemble": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
     "uniir_vit_assemble_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, S]),
@@ -109,6 +113,8 @@ SIGNATURES = {
     "uniir_dropout_f32": (c_int, [P, P, P, P, c_i64, c_int, c_float, C.c_uint32, P, c_int, S]),
     "uniir_dropout_bf16": (c_int, [P, P, c_i64, c_int, c_i64, c_float, C.c_uint32, P, c_int, S]),
     "uniir_dropout_mask": (c_int, [P, c_i64, c_float, C.c_uint32, S]),
+    "uniir_dropout_f32_rows": (c_int, [P, P, P, P, c_i64, c_int, c_float, C.c_uint32, P, S]),
+    "uniir_dropout_bf16_rows": (c_int, [P, P, c_i64, c_int, c_i64, c_float, C.c_uint32, P, S]),
     "uniir_tanh_fwd": (c_int, [P, P, c_i64, S]),
     "uniir_tanh_bwd": (c_int, [P, P, P, c_i64, S]),
     "uniir_ema_update": (c_int, [P, P, P, c_i64, c_float, S]),

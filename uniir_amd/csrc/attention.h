@@ -191,7 +191,8 @@ struct AttnArgs {
     unsigned drop_seed;
     int legacy_stage;             // 1 = one slice at a time, statistics before it (see launch_attn_bwd for when)
     const int* row_off;           // optional [batch + 1]: packed rows -- item m = rows row_off[m] .. row_off[m + 1] - 1 (Tq = Tk = its
-                                  // length <= the Tq given, which stays the stride of lse); self-attention without bias / dropout only
+                                  // length <= the Tq given, which stays the stride of lse); no relative-position bias
+    int row_off_q_only;           // with row_off: only the QUERY side is packed (cross-attention; K / V dense [batch][Tk], klen allowed)
 #ifdef UNIIR_EXP_BUILD
     unsigned long long* stamps;   // timing build: [64 workgroups][8 waves][8] s_memtime stamps
     int exp;                      // knock-out bits: 1 phase 1 / compute, 2 phase 2, 4 stage A, 8 stage B, 16 stores

@@ -29,8 +29,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     int Tq = a.Tq, Tk = a.Tk;
     long qr0 = (long)m * Tq, kr0 = (long)m * Tk;
     if (a.row_off) {
-        qr0 = kr0 = a.row_off[m];
-        Tq = Tk = a.row_off[m + 1] - a.row_off[m];
+        qr0 = a.row_off[m];
+        Tq = a.row_off[m + 1] - a.row_off[m];
+        if (!a.row_off_q_only) { kr0 = qr0; Tk = Tq; }      // (q_only: rectangular cross-attention, K / V stay dense per item)
     }
     const int Tkp = (Tk + 31) & ~31;
     char* ldsK = lds;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
                 l4 = l4 + st[kt];
             }
             if (DROP) {
-                const unsigned rowbase = (unsigned)((((long)m * H + h) * Tq + q) * Tk);
+                const unsigned rowbase = (unsigned)((((long)m * H + h) * a.Tq + q) * a.Tk);      // dense coordinates: packed rows draw the dense call's mask
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -196,8 +197,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
     int Tq = a.Tq, Tk = a.Tk;              // packed rows: see attn_fwd_kernel
     long qr0 = (long)m * Tq, kr0 = (long)m * Tk;
     if (a.row_off) {
-        qr0 = kr0 = a.row_off[m];
-        Tq = Tk = a.row_off[m + 1] - a.row_off[m];
+        qr0 = a.row_off[m];
+        Tq = a.row_off[m + 1] - a.row_off[m];
+        if (!a.row_off_q_only) { kr0 = qr0; Tk = Tq; }
     }
     const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
     const int Tmax = max(Tqp, Tkp);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
     const unsigned dth = DROP ? drop_threshold(a.drop_p) : 0u;
     const float dks = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar loop control
-    const unsigned headbase = (unsigned)((((long)m * H + h) * Tq) * Tk);
+    const unsigned headbase = (unsigned)((((long)m * H + h) * a.Tq) * a.Tk);      // dense coordinates (see attn_fwd_kernel)
     const unsigned short* qbase = a.q + qr0 * a.q_ld + h * ATT_D;
     const unsigned short* kbase = a.k + kr0 * a.kv_ld + h * ATT_D;
     const unsigned short* vbase = a.v + kr0 * a.kv_ld + h * ATT_D;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
                     const int q = qv + r;
                     const int dg = min(max(key - q + Tq - 1, 0), Tq + Tk - 2);
                     const float p = pt[qt][r];
-                    const float mk = DROP ? drop_scale(headbase + (unsigned)q * (unsigned)Tk + (unsigned)key, a.drop_seed, dth, dks) : 1.0f;
+                    const float mk = DROP ? drop_scale(headbase + (unsigned)q * (unsigned)a.Tk + (unsigned)key, a.drop_seed, dth, dks) : 1.0f;
                     pt[qt][r] = DROP ? p * mk : p;
                     dst[qt][r] = p * ((DROP ? dp[r] * mk : dp[r]) - d4[r]);
                 }
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb * 32 + kt * 16 + 4 * g + r;
-                    const float mk = DROP ? drop_scale(headbase + (unsigned)q * (unsigned)Tk + (unsigned)key, a.drop_seed, dth, dks) : 1.0f;
+                    const float mk = DROP ? drop_scale(headbase + (unsigned)q * (unsigned)a.Tk + (unsigned)key, a.drop_seed, dth, dks) : 1.0f;
                     dst[kt][r] = dst[kt][r] * ((DROP ? dp[r] * mk : dp[r]) - my_D);
                 }
             }
@@ -672,6 +674,56 @@ extern "C" int uniir_attention_bwd_ex(const void* q, int64_t q_ld, const void* k
     a.dq = (unsigned short*)dq; a.dk = (unsigned short*)dk; a.dv = (unsigned short*)dv;
     a.dq_ld = dq_ld; a.dkv_ld = dkv_ld;
     if (drop_p < 0.f || drop_p >= 1.f) return UNIIR_EINVAL;
+    a.drop_p = drop_p; a.drop_seed = drop_seed;
+    return launch_attn_bwd(a, batch, (hipStream_t)stream);
+}
+
+// The general form on PACKED QUERY ROWS (the BLIP MED BERT on the tokens up to each caption's valid length only): item m owns the rows
+// q_row_off[m] .. q_row_off[m + 1] - 1 of q / out / dout / dq (its length <= tq).  kv_packed != 0: self-attention, K / V (and dk /
+// dv) are rows of the same packed numbering and the item's key count is its own length (the dense call's key_len); kv_packed == 0:
+// cross-attention, K / V stay dense ([batch][tk] rows, optional key_len).  lse keeps the dense [batch][heads][tq] layout and the
+// dropout mask is drawn at the DENSE coordinates ((m H + h) tq + q) tk + key, so every live row's result -- train mode included -- is
+// bitwise that of uniir_attention_fwd_ex / _bwd_ex on the padded batch (masked keys contribute exactly 0 there, med.py:687-688).
+extern "C" int uniir_attention_fwd_rows(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld, void* out,
+                                        int64_t out_ld, float* lse, const int32_t* q_row_off, int32_t kv_packed,
+                                        const int32_t* key_len, int32_t batch, int32_t tq, int32_t tk, int32_t heads, float drop_p,
+                                        uint32_t drop_seed, void* stream) {
+    if (!q || !k || !v || !out || !lse || !q_row_off || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (tq < 1 || tk < 1 || tq > 512 || tk > 512) return UNIIR_ESHAPE;
+    if (kv_packed && (tq != tk || key_len)) return UNIIR_EINVAL;
+    if ((q_ld % 8) || (kv_ld % 8) || (out_ld % 8)) return UNIIR_EALIGN;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15)) return UNIIR_EALIGN;
+    if (drop_p < 0.f || drop_p >= 1.f) return UNIIR_EINVAL;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
+    a.q_ld = q_ld; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = out_ld; a.lse = lse; a.klen = key_len;
+    a.Tq = tq; a.Tk = tk; a.H = heads; a.causal = 0; a.scale = ATT_SCALE;
+    a.row_off = q_row_off; a.row_off_q_only = kv_packed ? 0 : 1;
+    a.drop_p = drop_p; a.drop_seed = drop_seed;
+    return launch_attn_fwd(a, batch, (hipStream_t)stream);
+}
+extern "C" int uniir_attention_bwd_rows(const void* q, int64_t q_ld, const void* k, const void* v, int64_t kv_ld, const void* out,
+                                        const void* dout, int64_t out_ld, const float* lse, const int32_t* q_row_off,
+                                        int32_t kv_packed, const int32_t* key_len, void* dq, int64_t dq_ld, void* dk, void* dv,
+                                        int64_t dkv_ld, int32_t batch, int32_t tq, int32_t tk, int32_t heads, float drop_p,
+                                        uint32_t drop_seed, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !q_row_off || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (tq < 1 || tk < 1 || tq > 512 || tk > 512) return UNIIR_ESHAPE;
+    if (kv_packed && (tq != tk || key_len)) return UNIIR_EINVAL;
+    if ((q_ld % 8) || (kv_ld % 8) || (out_ld % 8) || (dq_ld % 8) || (dkv_ld % 8)) return UNIIR_EALIGN;
+    if (((uintptr_t)dq & 15) || ((uintptr_t)dk & 15) || ((uintptr_t)dv & 15)) return UNIIR_EALIGN;
+    if (drop_p < 0.f || drop_p >= 1.f) return UNIIR_EINVAL;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
+    a.q_ld = q_ld; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = out_ld;
+    a.lse = const_cast<float*>(lse); a.klen = key_len;
+    a.Tq = tq; a.Tk = tk; a.H = heads; a.causal = 0; a.scale = ATT_SCALE;
+    a.row_off = q_row_off; a.row_off_q_only = kv_packed ? 0 : 1;
+    a.dout = (const unsigned short*)dout;
+    a.dq = (unsigned short*)dq; a.dk = (unsigned short*)dk; a.dv = (unsigned short*)dv;
+    a.dq_ld = dq_ld; a.dkv_ld = dkv_ld;
     a.drop_p = drop_p; a.drop_seed = drop_seed;
     return launch_attn_bwd(a, batch, (hipStream_t)stream);
 }

@@ -854,7 +854,8 @@ extern "C" int uniir_meanpool_bwd(const float* dout, float* dx, int32_t n, int32
 __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                           float* __restrict__ y32, unsigned short* __restrict__ y16,
                                                           long rows, int cols, float p, unsigned seed,
-                                                          const float* __restrict__ rowscale, int div) {
+                                                          const float* __restrict__ rowscale, int div,
+                                                          const int* __restrict__ row_map) {
     const unsigned th = drop_threshold(p);
     const float ks = 1.0f / (1.0f - p);
     const long nv = rows * (cols / 4);
@@ -862,10 +863,11 @@ __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restric
         const long row = i / (cols / 4);
         const int c = (int)(i - row * (cols / 4)) * 4;
         const long e = row * cols + c;
+        const long me = row_map ? (long)row_map[row] * cols + c : e;      // the mask's element index: the LOGICAL (dense) row
         f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + e);
         const float rs = rowscale ? rowscale[row / div] : 1.0f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= (p > 0.f ? drop_scale((unsigned)(e + k), seed, th, ks) : 1.0f) * rs;
+        for (int k = 0; k < 4; ++k) v[k] *= (p > 0.f ? drop_scale((unsigned)(me + k), seed, th, ks) : 1.0f) * rs;
         if (resid) v += *reinterpret_cast<const f32x4_t*>(resid + e);
         if (y32) *reinterpret_cast<f32x4_t*>(y32 + e) = v;
         if (y16) {
@@ -876,14 +878,15 @@ __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void dropout_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                                            long rows, int cols, long ld, float p, unsigned seed,
-                                                           const float* __restrict__ rowscale, int div) {
+                                                           const float* __restrict__ rowscale, int div,
+                                                           const int* __restrict__ row_map) {
     const unsigned th = drop_threshold(p);
     const float ks = 1.0f / (1.0f - p);
     const long nv = rows * (cols / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
         const long row = i / (cols / 4);
         const int c = (int)(i - row * (cols / 4)) * 4;
-        const long e = row * cols + c;
+        const long e = (row_map ? (long)row_map[row] : row) * cols + c;
         const u32x2_t a = *reinterpret_cast<const u32x2_t*>(x + row * ld + c);
         float v[4] = {__uint_as_float(a[0] << 16), __uint_as_float(a[0] & 0xffff0000u), __uint_as_float(a[1] << 16),
                       __uint_as_float(a[1] & 0xffff0000u)};
@@ -906,7 +909,29 @@ extern "C" int uniir_dropout_f32(const float* x, const float* resid, float* y_f3
     if (rowscale && rows_per_scale <= 0) return UNIIR_EINVAL;
     if (rows == 0) return UNIIR_OK;
     hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid_for(rows * (cols / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, x,
-                       resid, y_f32, (unsigned short*)y_bf16, (long)rows, cols, p, seed, rowscale, rows_per_scale > 0 ? rows_per_scale : 1);
+                       resid, y_f32, (unsigned short*)y_bf16, (long)rows, cols, p, seed, rowscale, rows_per_scale > 0 ? rows_per_scale : 1,
+                       (const int*)nullptr);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+// the same on PACKED rows: row r of x / resid / y is row row_map[r] of the logical (dense) tensor the mask is defined on, so a packed
+// BERT draws exactly the mask elements its live rows have in the padded batch
+extern "C" int uniir_dropout_f32_rows(const float* x, const float* resid, float* y_f32, void* y_bf16, int64_t rows, int32_t cols,
+                                      float p, uint32_t seed, const int32_t* row_map, void* stream) {
+    if (!x || (!y_f32 && !y_bf16) || !row_map || rows < 0 || cols <= 0 || cols % 4 || p < 0.f || p >= 1.f) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid_for(rows * (cols / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                       resid, y_f32, (unsigned short*)y_bf16, (long)rows, cols, p, seed, (const float*)nullptr, 1, row_map);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+extern "C" int uniir_dropout_bf16_rows(const void* x, void* y, int64_t rows, int32_t cols, int64_t ld, float p, uint32_t seed,
+                                       const int32_t* row_map, void* stream) {
+    if (!x || !y || !row_map || rows < 0 || cols <= 0 || cols % 4 || ld % 4 || p < 0.f || p >= 1.f) return UNIIR_EINVAL;
+    if (rows == 0) return UNIIR_OK;
+    hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid_for(rows * (cols / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, (unsigned short*)y, (long)rows, cols, (long)ld, p, seed, (const float*)nullptr, 1,
+                       row_map);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
@@ -917,7 +942,7 @@ extern "C" int uniir_dropout_bf16(const void* x, void* y, int64_t rows, int32_t 
     if (rows == 0) return UNIIR_OK;
     hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid_for(rows * (cols / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)x, (unsigned short*)y, (long)rows, cols, (long)ld, p, seed, rowscale,
-                       rows_per_scale > 0 ? rows_per_scale : 1);
+                       rows_per_scale > 0 ? rows_per_scale : 1, (const int*)nullptr);
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }

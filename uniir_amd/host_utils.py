@@ -320,6 +320,11 @@ class DevicePrefetcher:
                 elif hasattr(value, "input_ids") and hasattr(value, "items"):      # transformers BatchEncoding (BLIP)
                     for k, v in value.items():
                         value[k] = self._move(v)
+                        if k == "attention_mask" and not v.is_cuda and v.dim() == 2:
+                            # the captions' valid lengths stay readable on the host: BLIP's BERT runs on the rows up to them only
+                            # (blip_model.TextPack) and sizes its launches from their sum
+                            value[k]._uniir_lens = v.sum(1).to(torch.int32)
+                            value[k]._uniir_lens_version = value[k]._version
             done = torch.cuda.Event()
             done.record(self.stream)
         return batch, done

@@ -216,21 +216,38 @@ def attention_bwd(qkv, out, dout, lse, batch, seq, heads, causal, *, dqkv=None):
     return dqkv
 
 
-def attention_fwd_ex(q, q_ld, k, v, kv_ld, batch, tq, tk, heads, *, key_len=None, causal=False, drop_p=0.0, drop_seed=0):
-    """separate Q / K / V views (head h at column h*64 of rows with the given leading dimension); out [batch*tq, heads*64]"""
-    out = torch.empty(batch * tq, heads * 64, device=q.device, dtype=torch.bfloat16)
+def attention_fwd_ex(q, q_ld, k, v, kv_ld, batch, tq, tk, heads, *, key_len=None, causal=False, drop_p=0.0, drop_seed=0,
+                     row_off=None, kv_packed=False, rows=None):
+    """separate Q / K / V views (head h at column h*64 of rows with the given leading dimension); out [batch*tq, heads*64].
+    row_off (int32 [batch + 1], with rows = its total): the query rows are PACKED (item m = rows row_off[m] .. row_off[m + 1] - 1,
+    uniir_attention_fwd_rows); kv_packed: K / V are rows of the same numbering (self-attention), else dense [batch][tk]"""
+    nrow = batch * tq if row_off is None else int(rows)
+    out = torch.empty(nrow, heads * 64, device=q.device, dtype=torch.bfloat16)
     lse = torch.empty(batch, heads, tq, device=q.device, dtype=torch.float32)
-    check(_lib.load().uniir_attention_fwd_ex(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), heads * 64, _p(lse), _p(key_len),
-                                             batch, tq, tk, heads, int(causal), float(drop_p), int(drop_seed), _stream()),
-          "attention_fwd_ex")
+    if row_off is None:
+        check(_lib.load().uniir_attention_fwd_ex(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), heads * 64, _p(lse), _p(key_len),
+                                                 batch, tq, tk, heads, int(causal), float(drop_p), int(drop_seed), _stream()),
+              "attention_fwd_ex")
+    else:
+        if causal:
+            raise ValueError("packed query rows: non-causal attention only (the causal packed form is uniir_attention_fwd_packed)")
+        check(_lib.load().uniir_attention_fwd_rows(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), heads * 64, _p(lse), _p(row_off),
+                                                   int(bool(kv_packed)), _p(key_len), batch, tq, tk, heads, float(drop_p),
+                                                   int(drop_seed), _stream()), "attention_fwd_rows")
     return out, lse
 
 
 def attention_bwd_ex(q, q_ld, k, v, kv_ld, out, dout, lse, dq, dq_ld, dk, dv, dkv_ld, batch, tq, tk, heads, *,
-                     key_len=None, causal=False, drop_p=0.0, drop_seed=0):
-    check(_lib.load().uniir_attention_bwd_ex(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), _p(dout), heads * 64, _p(lse),
-                                             _p(key_len), _p(dq), dq_ld, _p(dk), _p(dv), dkv_ld, batch, tq, tk, heads,
-                                             int(causal), float(drop_p), int(drop_seed), _stream()), "attention_bwd_ex")
+                     key_len=None, causal=False, drop_p=0.0, drop_seed=0, row_off=None, kv_packed=False):
+    if row_off is None:
+        check(_lib.load().uniir_attention_bwd_ex(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), _p(dout), heads * 64, _p(lse),
+                                                 _p(key_len), _p(dq), dq_ld, _p(dk), _p(dv), dkv_ld, batch, tq, tk, heads,
+                                                 int(causal), float(drop_p), int(drop_seed), _stream()), "attention_bwd_ex")
+    else:
+        check(_lib.load().uniir_attention_bwd_rows(_p(q), q_ld, _p(k), _p(v), kv_ld, _p(out), _p(dout), heads * 64, _p(lse),
+                                                   _p(row_off), int(bool(kv_packed)), _p(key_len), _p(dq), dq_ld, _p(dk), _p(dv),
+                                                   dkv_ld, batch, tq, tk, heads, float(drop_p), int(drop_seed), _stream()),
+              "attention_bwd_rows")
 
 
 class DropSeeds:
@@ -247,16 +264,25 @@ class DropSeeds:
         return (self.base + self.n * 0x9E3779B1) & 0xFFFFFFFF
 
 
-def dropout_f32(x, p, seed, *, resid=None, out_f32=None, out_bf16=None, rowscale=None, rows_per_scale=0):
-    """(resid +) x * mask [* rowscale[row // rows_per_scale]] of an fp32 [rows, cols] tensor -> fp32 and / or bf16"""
+def dropout_f32(x, p, seed, *, resid=None, out_f32=None, out_bf16=None, rowscale=None, rows_per_scale=0, row_map=None):
+    """(resid +) x * mask [* rowscale[row // rows_per_scale]] of an fp32 [rows, cols] tensor -> fp32 and / or bf16.
+    row_map (int32 [rows]): x holds PACKED rows, row r being row row_map[r] of the logical tensor the mask is defined on"""
     rows, cols = x.shape
+    if row_map is not None:
+        check(_lib.load().uniir_dropout_f32_rows(_p(x), _p(resid), _p(out_f32), _p(out_bf16), rows, cols, float(p), int(seed),
+                                                 _p(row_map), _stream()), "dropout_f32_rows")
+        return
     check(_lib.load().uniir_dropout_f32(_p(x), _p(resid), _p(out_f32), _p(out_bf16), rows, cols, float(p), int(seed),
                                         _p(rowscale), int(rows_per_scale), _stream()), "dropout_f32")
 
 
-def dropout_bf16_(x, p, seed, *, rowscale=None, rows_per_scale=0):
-    """in place x *= mask [* rowscale[row // rows_per_scale]] of a contiguous bf16 [rows, cols] gradient"""
+def dropout_bf16_(x, p, seed, *, rowscale=None, rows_per_scale=0, row_map=None):
+    """in place x *= mask [* rowscale[row // rows_per_scale]] of a contiguous bf16 [rows, cols] gradient (row_map: see dropout_f32)"""
     rows, cols = x.shape
+    if row_map is not None:
+        check(_lib.load().uniir_dropout_bf16_rows(_p(x), _p(x), rows, cols, cols, float(p), int(seed), _p(row_map), _stream()),
+              "dropout_bf16_rows")
+        return
     check(_lib.load().uniir_dropout_bf16(_p(x), _p(x), rows, cols, cols, float(p), int(seed), _p(rowscale),
                                          int(rows_per_scale), _stream()), "dropout_bf16")
 
