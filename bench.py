@@ -37,17 +37,27 @@ ROTATE = 4          # distinct caption batches rotated through the timed train s
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_gemm_traffic.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes
 
 
-def executed_flop_per_pair(cfg, txt, dense_flop_per_pair):
-    """FLOPs per pair the step actually executes when the text tower runs on packed rows (clip_model.pack_text): SURVEY 8(d)'s
-    count (2 MACs, dense attention incl. the causal half, backward = 2 x forward) with every caption's 77 positions replaced by its
-    live length L = argmax + 1: text forward = layers x (24 W^2 L + 4 L^2 W) + 2 W E; the vision tower is unchanged.  At L = 77 this
-    is SURVEY's 13.30 GFLOP per text item."""
+def pooled_last_block_saving(W, T):
+    """forward FLOPs one item's LAST residual block does NOT execute under clip_model.pool_last_block (csrc/tower.hip): the block's
+    24 W^2 T + 4 T^2 W become 4 W^2 T (K | V of every row) + 20 W^2 (Q, out_proj, c_fc, c_proj of the pooled row) + 4 T W (one query)"""
+    return 20.0 * W * W * (T - 1) + 4.0 * T * W * (T - 1)
+
+
+def executed_flop_per_pair(cfg, txt, dense_flop_per_pair, pack_text=True, pool_last=False):
+    """FLOPs per pair the step actually executes: SURVEY 8(d)'s count (2 MACs, dense attention incl. the causal half, backward = 2 x
+    forward) with (pack_text) every caption's 77 positions replaced by its live length L = argmax + 1 -- text forward = layers x
+    (24 W^2 L + 4 L^2 W) + 2 W E, 13.30 GFLOP per text item at L = 77 -- and (pool_last) the last block of each tower on its pooled
+    row (pooled_last_block_saving).  -> (FLOPs per pair, text rows run, text rows of the padded batch)"""
     W, Lyr, E, ctx = cfg["transformer_width"], cfg["transformer_layers"], cfg["embed_dim"], cfg["context_length"]
-    text_fwd = lambda L: Lyr * (24.0 * W * W * L + 4.0 * L * L * W) + 2.0 * W * E
-    lens = (txt.argmax(dim=-1) + 1).double().cpu()
+    text_fwd = lambda L: Lyr * (24.0 * W * W * L + 4.0 * L * L * W) + 2.0 * W * E - (pooled_last_block_saving(W, L) if pool_last else 0.0)
+    lens = (txt.argmax(dim=-1) + 1).double().cpu() if pack_text else torch.full((txt.shape[0],), float(ctx), dtype=torch.float64)
     live = float(sum(text_fwd(float(L)) for L in lens)) / (txt.shape[0] / 2)          # per pair (2 items), forward
-    dense = 2.0 * text_fwd(float(ctx))
-    return dense_flop_per_pair - 3.0 * (dense - live), float(lens.sum()), txt.shape[0] * ctx
+    dense = 2.0 * (Lyr * (24.0 * W * W * ctx + 4.0 * ctx * ctx * W) + 2.0 * W * E)
+    vis = 0.0
+    if pool_last:
+        Tv = (cfg["image_resolution"] // cfg["vision_patch_size"]) ** 2 + 1
+        vis = 2.0 * pooled_last_block_saving(cfg["vision_width"], Tv)
+    return dense_flop_per_pair - 3.0 * (dense - live) - 3.0 * vis, float(lens.sum()), txt.shape[0] * ctx
 
 
 def synth_tokens(cfg, M, g):
@@ -276,11 +286,17 @@ def bench_retrieval_full_pool(dev, n=5_600_000, d=768, k=10):
 VISION_FLOP_PER_ITEM_FWD = {"ViT-L/14": 162.03e9, "ViT-B/32": 8.82e9}       # the image tower's share of the item
 
 
-def text_flop_per_item_fwd(cfg, txt):
+def text_flop_per_item_fwd(cfg, txt, pool_last=False):
     """executed forward FLOPs of the packed text tower, mean per caption (the formula of executed_flop_per_pair)"""
     W, Lyr, E = cfg["transformer_width"], cfg["transformer_layers"], cfg["embed_dim"]
     lens = (txt.argmax(dim=-1) + 1).double().cpu()
-    return float(sum(Lyr * (24.0 * W * W * L + 4.0 * L * L * W) + 2.0 * W * E for L in lens.tolist())) / max(1, txt.shape[0])
+    return float(sum(Lyr * (24.0 * W * W * L + 4.0 * L * L * W) + 2.0 * W * E - (pooled_last_block_saving(W, L) if pool_last else 0.0)
+                     for L in lens.tolist())) / max(1, txt.shape[0])
+
+
+def vision_flop_per_item_fwd(cfg, model_name, pool_last=False):
+    Tv = (cfg["image_resolution"] // cfg["vision_patch_size"]) ** 2 + 1
+    return VISION_FLOP_PER_ITEM_FWD[model_name] - (pooled_last_block_saving(cfg["vision_width"], Tv) if pool_last else 0.0)
 
 
 def bench_embed(dev, model_name="ViT-L/14", items=2048, steps=3):
@@ -301,7 +317,9 @@ def bench_embed(dev, model_name="ViT-L/14", items=2048, steps=3):
     batch["did_list"] = list(range(items))
     host_tok = batch["txt_batched"].cpu()
     attach_caption_lengths(batch["txt_batched"], host_tok)
-    text_flop = text_flop_per_item_fwd(cfg, host_tok) if model.clip_model.pack_text else FLOP_PER_ITEM_FWD[model_name] - VISION_FLOP_PER_ITEM_FWD[model_name]
+    pl = bool(getattr(model.clip_model, "pool_last_block", False))
+    text_flop = (text_flop_per_item_fwd(cfg, host_tok, pl) if model.clip_model.pack_text
+                 else FLOP_PER_ITEM_FWD[model_name] - VISION_FLOP_PER_ITEM_FWD[model_name])
     # the empty caption of an image-only candidate: [SOT, EOT, 0, ...]
     empty = torch.zeros_like(host_tok)
     empty[:, 0], empty[:, 1] = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1
@@ -321,19 +339,25 @@ def bench_embed(dev, model_name="ViT-L/14", items=2048, steps=3):
         if not im:
             b["image_batched"] = torch.zeros_like(batch["image_batched"])
         n = steps if mode != "text_only" else 4 * steps
+        board = BoardSampler(dev.index or 0) if mode in ("pair", "pair_bf16") else None
         with torch.no_grad():
             model(b, encode_mbeir_batch=True)
             torch.cuda.synchronize()
+            if board is not None:
+                board.start()
             t0 = time.perf_counter()
             for _ in range(n):
                 emb, _ids = model(b, encode_mbeir_batch=True)
                 half = emb.half()
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        executed = (VISION_FLOP_PER_ITEM_FWD[model_name] if im else 0.0) + (text_flop if tm else 0.0)
+        brec = board.stop() if board is not None else None
+        executed = (vision_flop_per_item_fwd(cfg, model_name, pl) if im else 0.0) + (text_flop if tm else 0.0)
         out[mode] = {"value": round(items / dt, 1), "unit": "items/s", "ms_per_batch": round(dt * 1e3, 2),
                      "executed_gflop_per_item": round(executed / 1e9, 2),
                      "mfma_frac": round(items / dt * executed / MFMA_PEAK_BF16, 4)}
+        if brec:            # fp16 vs bf16 on identical FLOPs: the sustained clock under the power cap is the difference
+            out[mode]["board"] = {k: brec[k] for k in ("sclk_mhz_mean", "power_w_mean") if k in brec}
         if tm and im:       # the reference's count (both towers, 77 positions) describes work only where both towers ran
             out[mode]["mfma_frac_dense_count"] = round(items / dt * FLOP_PER_ITEM_FWD[model_name] / MFMA_PEAK_BF16, 4)
         del b
@@ -576,8 +600,9 @@ def bench_embed_sharded(dist, dev, world, model_name, items=2048, steps=3):
     model, batch = _local(dist, dev, build)
     host_tok = batch["txt_batched"].cpu()
     attach_caption_lengths(batch["txt_batched"], host_tok)
-    executed = VISION_FLOP_PER_ITEM_FWD[model_name] + (text_flop_per_item_fwd(cfg, host_tok) if model.clip_model.pack_text
-                                                        else FLOP_PER_ITEM_FWD[model_name] - VISION_FLOP_PER_ITEM_FWD[model_name])
+    pl = bool(getattr(model.clip_model, "pool_last_block", False))
+    executed = vision_flop_per_item_fwd(cfg, model_name, pl) + (text_flop_per_item_fwd(cfg, host_tok, pl) if model.clip_model.pack_text
+                                                                else FLOP_PER_ITEM_FWD[model_name] - VISION_FLOP_PER_ITEM_FWD[model_name])
     shape = []
 
     def run():
@@ -760,7 +785,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-retrieval", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the embed / BLIP_FF / CLIP_FF blocks")
-    ap.add_argument("--no-unpacked", action="store_true", help="skip the second timing of the step with the text tower unpacked")
+    ap.add_argument("--no-unpacked", action="store_true", help="skip the second timing of the step in the reference's shape (77 text "
+                    "positions, every row through every block)")
+    ap.add_argument("--no-pool-last", action="store_true", help="A/B: every row through the last block too (clip_model.pool_last_block = False)")
     ap.add_argument("--no-stash-act", action="store_true", help="A/B: re-materialise the MLP activations in the backward (clip_model.stash_act = False)")
     ap.add_argument("--overlap-towers", choices=("auto", "0", "1"), default="auto",
                     help="text tower on a second stream: auto = on at N = 1, off at N > 1 (clip_model.CLIP.overlap_towers); 0 / 1 force "
@@ -835,6 +862,8 @@ def main():
             model.clip_model.stash_act = False
         if args.overlap_towers != "auto":
             model.clip_model.overlap_towers = args.overlap_towers == "1"
+        if args.no_pool_last:
+            model.clip_model.pool_last_block = False
         batch = synth_batch(cfg, args.pairs, 2023 + rank, dev)
         # The timed loop rotates ROTATE distinct caption batches (distinct token tensors, different lengths; the 0.6-GB image tensor
         # is shared -- three more of them do not fit next to the 265-GiB activation stash).  Each arrives the way the train loop's
@@ -885,11 +914,12 @@ def main():
     dt = float(tmax)
     global_pairs = args.pairs * world
     value = global_pairs * args.steps / dt
-    # the same step with the text tower on all 77 positions of every caption (clip_model.pack_text = False): what earlier rounds
-    # measured, and the line the SURVEY 8(d) FLOP count (77 positions per caption) prices
+    # the same step in the REFERENCE'S shape -- the text tower on all 77 positions of every caption (clip_model.pack_text = False) and
+    # every row through every block (pool_last_block = False): exactly the work the SURVEY 8(d) FLOP count prices
     unpacked = None
     if not args.dry_run and getattr(model.clip_model, "pack_text", False) and not args.no_unpacked:
-        model.clip_model.pack_text = False
+        pool_was = model.clip_model.pool_last_block
+        model.clip_model.pack_text, model.clip_model.pool_last_block = False, False
         out = None
         torch.cuda.empty_cache()     # the text workspace changes size: let the 182 GiB vision stash be re-cut from a clean pool
         for i in range(max(1, args.warmup)):
@@ -903,7 +933,7 @@ def main():
         if world > 1:
             dist.all_reduce(tu, op=dist.ReduceOp.MAX)
         unpacked = float(tu)
-        model.clip_model.pack_text = True
+        model.clip_model.pack_text, model.clip_model.pool_last_block = True, pool_was
         torch.cuda.empty_cache()
 
     rccl = None
@@ -931,8 +961,10 @@ def main():
             roof = None
         else:
             packed_on = bool(getattr(model.clip_model, "pack_text", False))
-            if packed_on:       # executed FLOPs: mean over the caption batches of the timed steps
-                per = [executed_flop_per_pair(cfg, tok_hosts[(timed_from + i) % ROTATE], FLOP_PER_PAIR[args.model]) for i in range(args.steps)]
+            pool_on = bool(getattr(model.clip_model, "pool_last_block", False))
+            if packed_on or pool_on:       # executed FLOPs: mean over the caption batches of the timed steps
+                per = [executed_flop_per_pair(cfg, tok_hosts[(timed_from + i) % ROTATE], FLOP_PER_PAIR[args.model], packed_on, pool_on)
+                       for i in range(args.steps)]
                 flop_pair, live_rows, dense_rows = (sum(x[j] for x in per) / len(per) for j in range(3))
             else:
                 flop_pair, live_rows, dense_rows = FLOP_PER_PAIR[args.model], 0, 0
@@ -957,12 +989,16 @@ def main():
                                 "shared, so those calls are bracketed as 'device shared' windows instead and the samples that "
                                 "intersect a window are left out (samples_left_out_device_shared); end_to_end_frac has everything",
                     "end_to_end_frac": round(value * flop_pair / (world * MFMA_PEAK_BF16), 4),
-                    "end_to_end_note": ("value x EXECUTED FLOPs per pair / peak: the text tower runs on the rows up to each caption's "
-                                        "EOT only (exact: rows behind the EOT never reach the pooled feature under the causal mask); "
-                                        f"{flop_pair / 1e12:.4f} TFLOP per pair executed vs {FLOP_PER_PAIR[args.model] / 1e12:.3f} "
-                                        f"with 77 positions per caption; text rows {int(live_rows)} of {int(dense_rows)} (mean over the "
-                                        "timed steps' caption batches)")
-                    if packed_on else "value x SURVEY 8(d) FLOPs per pair / peak",
+                    "end_to_end_note": ("value x EXECUTED FLOPs per pair / peak"
+                                        + (": the text tower runs on the rows up to each caption's EOT only (exact: rows behind the EOT "
+                                           "never reach the pooled feature under the causal mask)" if packed_on else "")
+                                        + ("; the last block of each tower runs Q / attention / out_proj / MLP on its pooled row only "
+                                           "(exact: upstream pools x[:, 0] / x[arange, argmax] and discards the block's other rows; "
+                                           "ln_1 and K | V still see every row)" if pool_on else "")
+                                        + f"; {flop_pair / 1e12:.4f} TFLOP per pair executed vs {FLOP_PER_PAIR[args.model] / 1e12:.3f} "
+                                        f"in SURVEY 8(d)'s count (77 positions per caption, every row through every block); text rows "
+                                        f"{int(live_rows)} of {int(dense_rows)} (mean over the timed steps' caption batches)")
+                    if (packed_on or pool_on) else "value x SURVEY 8(d) FLOPs per pair / peak",
                     "end_to_end_frac_unpacked": (round(global_pairs * args.steps / unpacked * FLOP_PER_PAIR[args.model]
                                                        / (world * MFMA_PEAK_BF16), 4) if unpacked else None),
                     "board": board_rec}
@@ -982,6 +1018,9 @@ def main():
                        "mlp_stash": (None if args.dry_run else
                                      {k: ("f + act(f)" if v else "f") for k, v in model.clip_model.last_stash_act.items()}),
                        "mlp_stash_decisions": (None if args.dry_run else list(model.clip_model.stash_log)),
+                       "last_block": (None if args.dry_run else
+                                      ("Q / attention / out_proj / MLP on the pooled row of every item (pool_last_block)"
+                                       if model.clip_model.pool_last_block else "every row (reference shape)")),
                        "towers": (None if args.dry_run else
                                   ("two streams (text leg on the model's second stream)" if model.clip_model.overlap_on()
                                    else "one stream") + f" [--overlap-towers {args.overlap_towers}]"),

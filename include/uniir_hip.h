@@ -317,6 +317,13 @@ typedef struct {
                                                  conv16 then point at fp16 copies of the weights (uniir_cast_f32_to_f16) and every
                                                  16-bit activation is fp16 -- the reference embedder's autocast(fp16),
                                                  mbeir_embedder.py:52-56; save_for_backward with it is UNIIR_EUNSUPPORTED */
+    int32_t pool_last_block;                  /* 1 = the LAST residual block runs its Q projection, attention, out_proj, ln_2 and MLP on
+                                                 the one pooled row of every item only (class token / EOT row; ln_1 and the K | V
+                                                 projection still see every row): the reference computes the other rows' outputs of
+                                                 that block and discards them (VisionTransformer.forward: ln_post(x[:, 0, :]);
+                                                 CLIP.encode_text: x[arange, text.argmax(-1)]).  Same embedding, same gradients without
+                                                 their exact-zero terms; 10 of the block's 12 WxW GEMM units leave the step.  Part of the
+                                                 workspace layout like stash_act.  0 = every row through every sublayer */
 } uniir_clip_tower;
 
 int64_t uniir_clip_tower_workspace_bytes(const uniir_clip_tower* t, int32_t batch, int32_t save_for_backward);

@@ -362,3 +362,54 @@ def test_two_stream_towers_equal_the_one_stream_order():
         moved = int(((w2 - w0).abs() > 1e-5).sum())
         floor = int(((w1 - w0).abs() > 1e-5).sum())          # what two one-stream runs differ by (observed ~1 % by the 4th step)
         assert moved <= max(4 * floor, 0.10 * w0.numel()), (moved, floor)          # a lost wait: ~45 % (every text-tower weight)
+
+
+@pytest.mark.parametrize("pack_text", [True, False])
+def test_pooled_last_block_equals_the_full_last_block(pack_text):
+    """clip_model.pool_last_block (uniir_clip_tower.pool_last_block, default on): the last residual block of each tower runs its Q
+    projection, attention, out_proj, ln_2 and MLP on the ONE pooled row of every item (class token / EOT row) -- the reference
+    computes the other rows' outputs of that block and discards them (upstream VisionTransformer.forward: ln_post(x[:, 0, :]);
+    CLIP.encode_text: x[arange, text.argmax(-1)]; called from clip_sf.py:44,47).  Against pool_last_block = False on the same
+    weights and batch: image and text embeddings BITWISE equal (train, no-grad and the fp16 embedder forward), the loss bitwise
+    equal, every parameter gradient equal up to the order of the fp32 additions of the weight-gradient reductions (the pooled form
+    sums the non-zero rows only).  Both text forms (packed rows / dense rows with the EOT key count), a caption that fills the
+    context, a ViT with 3 layers and a text tower with 3.  256 items, so that the pooled rows fill a 256-row GEMM tile like the full
+    rows do: below 256 rows uniir_gemm sums a bias gradient from the ROUNDED bf16 result in a separate pass instead of from the fp32
+    accumulators in the epilogue -- a 3e-3 difference between kernel classes that has nothing to do with the pooling (the bench's
+    1024 items are far above it)."""
+    from oracle import clip_oracle as O
+    cfg = O.tiny_config(vision_width=128, vision_layers=3, transformer_width=128, transformer_heads=2, transformer_layers=3)
+    res = {}
+    for pooled in (True, False):
+        model, _, O = _build(cfg, seed=5)
+        clip = model.clip_model
+        clip.pack_text, clip.pool_last_block = pack_text, pooled
+        batch = O.synthetic_batch(cfg, 128, seed=33)
+        txt = batch["txt_batched"]
+        ctx = txt.shape[1]
+        txt[3] = torch.randint(1, cfg["vocab_size"] - 2, (ctx,), dtype=torch.int32, generator=torch.Generator().manual_seed(7))
+        txt[3, 0], txt[3, ctx - 1] = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1          # a caption that fills the context
+        dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        model.train()
+        clip._ensure_flat()
+        clip.zero_grad()
+        temb, iemb = clip.encode_text(dbatch["txt_batched"]), clip.encode_image(dbatch["image_batched"])
+        out = model(dbatch)
+        out["loss"].backward()
+        with torch.no_grad():
+            temb_ng, iemb_ng = clip.encode_text(dbatch["txt_batched"]), clip.encode_image(dbatch["image_batched"])
+            clip.precision = "fp16"
+            temb_h, iemb_h = clip.encode_text(dbatch["txt_batched"]), clip.encode_image(dbatch["image_batched"])
+            clip.precision = "bf16"
+        grads = {n: p.grad.detach().clone() for n, p in clip.named_parameters() if p.grad is not None}
+        res[pooled] = (temb.detach().clone(), iemb.detach().clone(), temb_ng, iemb_ng, temb_h, iemb_h, float(out["loss"].detach()), grads)
+    p, f = res[True], res[False]
+    for k, name in enumerate(("text", "image", "text no-grad", "image no-grad", "text fp16", "image fp16")):
+        assert torch.equal(p[k], f[k]), (name, float((p[k] - f[k]).abs().max()))
+    assert torch.equal(p[0], p[2]) and torch.equal(p[1], p[3])
+    assert p[6] == f[6]
+    g_p, g_f = p[7], f[7]
+    assert set(g_p) == set(g_f)
+    for n in g_f:
+        den = g_f[n].norm().clamp_min(1e-20)
+        assert float((g_p[n] - g_f[n]).norm() / den) < 1e-5, (n, float((g_p[n] - g_f[n]).norm() / den))

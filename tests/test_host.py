@@ -524,3 +524,28 @@ def test_executed_flops_of_the_packed_step():
     short[:, 19] = 49407                                              # 20 live rows per caption
     f2, live2, _ = bench.executed_flop_per_pair(cfg, short, bench.FLOP_PER_PAIR["ViT-L/14"])
     assert live2 == 160 and abs((f - f2) - 3 * 2 * (text_fwd(77) - text_fwd(20))) < 1.0
+
+
+def test_executed_flops_of_the_pooled_last_block():
+    """bench.pooled_last_block_saving / executed_flop_per_pair(pool_last=True): what clip_model.pool_last_block leaves out, per item and
+    forward, is the last block's 24 W^2 T + 4 T^2 W minus what still runs (K | V of every row 4 W^2 T, the pooled row's Q / out_proj /
+    MLP 20 W^2, one query's attention 4 T W): 5.64 GFLOP of the ViT-L/14 image tower's 162.03 (3.5 %)"""
+    import bench
+    from uniir_amd.clip_model import CLIP_CONFIGS
+    cfg = CLIP_CONFIGS["ViT-L/14"]
+    W, T = 1024, 257
+    full_block = 24.0 * W * W * T + 4.0 * T * T * W
+    kept = 4.0 * W * W * T + 20.0 * W * W + 4.0 * T * W
+    assert bench.pooled_last_block_saving(W, T) == full_block - kept
+    assert abs(bench.pooled_last_block_saving(W, T) - 5.64e9) < 0.01e9
+    assert abs(24 * full_block - 162.03e9) < 1.2e9            # 24 such blocks are the image tower (+ patch embedding and projection)
+    toks = torch.zeros(8, 77, dtype=torch.int32)
+    toks[:, 19] = 49407                                              # 20 live rows per caption
+    f0, _, _ = bench.executed_flop_per_pair(cfg, toks, bench.FLOP_PER_PAIR["ViT-L/14"], True, False)
+    f1, _, _ = bench.executed_flop_per_pair(cfg, toks, bench.FLOP_PER_PAIR["ViT-L/14"], True, True)
+    Wt = cfg["transformer_width"]
+    want = 3 * 2 * (bench.pooled_last_block_saving(W, T) + bench.pooled_last_block_saving(Wt, 20))
+    assert abs((f0 - f1) - want) < 1.0
+    # the reference shape: neither packing nor pooling -> SURVEY's count whatever the captions are
+    assert bench.executed_flop_per_pair(cfg, toks, bench.FLOP_PER_PAIR["ViT-L/14"], False, False)[0] == bench.FLOP_PER_PAIR["ViT-L/14"]
+    assert bench.vision_flop_per_item_fwd(cfg, "ViT-L/14", True) == bench.VISION_FLOP_PER_ITEM_FWD["ViT-L/14"] - bench.pooled_last_block_saving(W, T)

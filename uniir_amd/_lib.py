@@ -44,7 +44,7 @@ class ClipTower(C.Structure):
         ("g_conv", c_void_p), ("g_class", c_void_p), ("g_pos", c_void_p), ("g_ln_pre_w", c_void_p), ("g_ln_pre_b", c_void_p),
         ("g_token", c_void_p), ("g_ln_post_w", c_void_p), ("g_ln_post_b", c_void_p), ("g_proj", c_void_p),
         ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_i64),
-        ("stash_act", c_int), ("dtype16", c_int),
+        ("stash_act", c_int), ("dtype16", c_int), ("pool_last_block", c_int),
     ]
 
 

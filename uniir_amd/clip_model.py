@@ -163,6 +163,11 @@ class CLIP(nn.Module):
         # an out-of-memory error on the stash allocation re-plans that tower without it; review_stash() revisits the choice after the
         # first complete step, when collectives' buffers and the optimizer state exist.
         self.stash_act = None
+        # The last residual block of a POOLING tower on the pooled rows only (uniir_clip_tower.pool_last_block, csrc/tower.hip): the
+        # class token / the EOT row is all that leaves the tower (clip_sf.py:44,47 -> upstream ln_post(x[:, 0, :]) /
+        # x[arange, text.argmax(-1)]), so in the last block only ln_1 and the K | V projection need every row.  Exact: the same
+        # embedding, the same parameter gradients without their zero terms.  False = every row through every sublayer (A/B, tests).
+        self.pool_last_block = os.environ.get("UNIIR_POOL_LAST_BLOCK", "1") != "0"
         self.stash_margin_bytes = 16 << 30
         self.stash_review_headroom_bytes = 6 << 30
         self._stash_choice = {}           # tower -> bool: the automatic decision, made once (at the first training batch)
@@ -704,6 +709,7 @@ class _TowerFn(torch.autograd.Function):
             # the whole tower in one C call (csrc/tower.hip); the workspace is the activation stash of the backward
             lib = _lib.load()
             desc = model.tower_desc(which, half=half)
+            desc.pool_last_block = int(bool(model.pool_last_block))
             emb = torch.empty(M, E, device=dev, dtype=torch.float32)
 
             def ws_bytes(stash):
@@ -759,7 +765,8 @@ class _TowerFn(torch.autograd.Function):
                                                            ws.data_ptr(), need, int(need_grad), ops._stream()), "clip_tower_fwd_packed")
                 model.last_text_rows = (live, M * cfg["context_length"])
                 if need_grad:
-                    ctx.stash = dict(ws=ws, inp=inp, ctower=True, row_off=row_off, live=live, stash_act=int(stash), join_to=model._leg_main)
+                    ctx.stash = dict(ws=ws, inp=inp, ctower=True, row_off=row_off, live=live, stash_act=int(stash), join_to=model._leg_main,
+                                     pool_last=int(desc.pool_last_block))
                 return emb
             need, ws = alloc_ws(lambda: lib.uniir_clip_tower_workspace_bytes(C.byref(desc), M, int(need_grad)))
             if need < 0:
@@ -768,7 +775,8 @@ class _TowerFn(torch.autograd.Function):
             _lib.check(lib.uniir_clip_tower_fwd(C.byref(desc), inp.data_ptr(), M, emb.data_ptr(), ws.data_ptr(), need,
                                                 int(need_grad), ops._stream()), "clip_tower_fwd")
             if need_grad:
-                ctx.stash = dict(ws=ws, inp=inp, ctower=True, stash_act=int(stash), join_to=model._leg_main)
+                ctx.stash = dict(ws=ws, inp=inp, ctower=True, stash_act=int(stash), join_to=model._leg_main,
+                                 pool_last=int(desc.pool_last_block))
             return emb
         if which == "image":
             W, P, L = cfg["vision_width"], cfg["vision_patch_size"], cfg["vision_layers"]
@@ -823,6 +831,7 @@ class _TowerFn(torch.autograd.Function):
             lib = _lib.load()
             desc = model.tower_desc(which)
             desc.stash_act = st["stash_act"]        # part of the workspace layout: the value the forward ran with
+            desc.pool_last_block = st["pool_last"]
             ws, inp, stream = st["ws"], st["inp"], ops._stream()
             demb = demb.contiguous().float()
             need = ws.numel()

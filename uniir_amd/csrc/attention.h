@@ -193,6 +193,9 @@ struct AttnArgs {
     const int* row_off;           // optional [batch + 1]: packed rows -- item m = rows row_off[m] .. row_off[m + 1] - 1 (Tq = Tk = its
                                   // length <= the Tq given, which stays the stride of lse); no relative-position bias
     int row_off_q_only;           // with row_off: only the QUERY side is packed (cross-attention; K / V dense [batch][Tk], klen allowed)
+    const int* kv_row_off;        // optional [batch + 1]: the KEY / VALUE side alone is packed (item m = rows kv_row_off[m] ..): the
+                                  // pooled-row attention of a packed text tower's last block (tower.hip): one dense query row per item
+    int klen_add;                 // added to klen[m] (the EOT index + 1 = the key count of a pooled causal query)
 #ifdef UNIIR_EXP_BUILD
     unsigned long long* stamps;   // timing build: [64 workgroups][8 waves][8] s_memtime stamps
     int exp;                      // knock-out bits: 1 phase 1 / compute, 2 phase 2, 4 stage A, 8 stage B, 16 stores

@@ -33,6 +33,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         Tq = a.row_off[m + 1] - a.row_off[m];
         if (!a.row_off_q_only) { kr0 = qr0; Tk = Tq; }      // (q_only: rectangular cross-attention, K / V stay dense per item)
     }
+    if (a.kv_row_off) {
+        kr0 = a.kv_row_off[m];
+        Tk = a.kv_row_off[m + 1] - a.kv_row_off[m];
+    }
     const int Tkp = (Tk + 31) & ~31;
     char* ldsK = lds;
     char* ldsV = lds + Tkp * 128;
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     const unsigned short* qbase = a.q + qr0 * a.q_ld + h * ATT_D;
     const unsigned short* kbase = a.k + kr0 * a.kv_ld + h * ATT_D;
     const unsigned short* vbase = a.v + kr0 * a.kv_ld + h * ATT_D;
-    const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
+    const int kvalid = a.klen ? min(Tk, a.klen[m] + a.klen_add) : Tk;
     const float sl2 = REL ? a.scale * LOG2EF : SCALE_LOG2E;
     const unsigned dth = DROP ? drop_threshold(a.drop_p) : 0u;
     const float dks = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
@@ -201,6 +205,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
         Tq = a.row_off[m + 1] - a.row_off[m];
         if (!a.row_off_q_only) { kr0 = qr0; Tk = Tq; }
     }
+    if (a.kv_row_off) {
+        kr0 = a.kv_row_off[m];
+        Tk = a.kv_row_off[m + 1] - a.kv_row_off[m];
+    }
     const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
     const int Tmax = max(Tqp, Tkp);
     char* bufA = lds;                 // Q, later K
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void attn_bwd_kernel(AttnArg
     unsigned short* dqbase = a.dq + qr0 * a.dq_ld + h * ATT_D;
     unsigned short* dkbase = a.dk + kr0 * a.dkv_ld + h * ATT_D;
     unsigned short* dvbase = a.dv + kr0 * a.dkv_ld + h * ATT_D;
-    const int kvalid = a.klen ? min(Tk, a.klen[m]) : Tk;
+    const int kvalid = a.klen ? min(Tk, a.klen[m] + a.klen_add) : Tk;
 
     auto row_stats = [&] {          // D[q] = dO[q] . O[q], lse2[q] = lse[q] * log2 e; the bias / gradient rows of a T5 head
         for (int r = tid; r < Tqp; r += NT) {
@@ -563,6 +571,44 @@ int attention_fwd_impl(const void* qkv, void* out, float* lse, const int32_t* ro
     a.Tq = a.Tk = seq; a.H = heads; a.causal = causal; a.scale = ATT_SCALE;
     return launch_attn_fwd(a, batch, (hipStream_t)stream, f16 != 0);
 }
+// tower.hip's last block when only one row per item is pooled (the class token / the EOT row): ONE query row per item ([batch][W],
+// dense) against the item's keys and values.  K / V are columns of the block's qkv buffer (row stride kv_ld): dense [batch][tk]
+// rows with an optional key count klen[m] + klen_add (the causal text tower: the EOT index + 1), or the item's own packed rows
+// (kv_row_off).  A query row's result does not depend on the rows that share its tile, so out equals that row of the full call.
+int attention_pooled_fwd_impl(const void* q, const void* k, const void* v, int64_t kv_ld, void* out, float* lse, const int32_t* klen,
+                              int32_t klen_add, const int32_t* kv_row_off, int32_t batch, int32_t tk, int32_t heads, int f16,
+                              void* stream) {
+    if (!q || !k || !v || !out || !lse || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (tk < 1 || tk > 512 || (kv_ld % 8)) return UNIIR_ESHAPE;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15)) return UNIIR_EALIGN;
+    const long W = (long)heads * ATT_D;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
+    a.q_ld = W; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = W; a.lse = lse;
+    a.klen = klen; a.klen_add = klen_add; a.kv_row_off = kv_row_off;
+    a.Tq = 1; a.Tk = tk; a.H = heads; a.causal = 0; a.scale = ATT_SCALE;
+    return launch_attn_fwd(a, batch, (hipStream_t)stream, f16 != 0);
+}
+int attention_pooled_bwd_impl(const void* q, const void* k, const void* v, int64_t kv_ld, const void* out, const void* dout,
+                              const float* lse, const int32_t* klen, int32_t klen_add, const int32_t* kv_row_off, void* dq,
+                              int64_t dq_ld, void* dk, void* dv, int64_t dkv_ld, int32_t batch, int32_t tk, int32_t heads, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || batch < 0 || heads <= 0) return UNIIR_EINVAL;
+    if (batch == 0) return UNIIR_OK;
+    if (tk < 1 || tk > 512 || (kv_ld % 8) || (dkv_ld % 8) || (dq_ld % 8)) return UNIIR_ESHAPE;
+    if (((uintptr_t)dq & 15) || ((uintptr_t)dk & 15) || ((uintptr_t)dv & 15)) return UNIIR_EALIGN;
+    const long W = (long)heads * ATT_D;
+    AttnArgs a = {};
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
+    a.q_ld = W; a.kv_ld = kv_ld; a.out = (unsigned short*)out; a.out_ld = W; a.lse = const_cast<float*>(lse);
+    a.klen = klen; a.klen_add = klen_add; a.kv_row_off = kv_row_off;
+    a.Tq = 1; a.Tk = tk; a.H = heads; a.causal = 0; a.scale = ATT_SCALE;
+    a.dout = (const unsigned short*)dout;
+    a.dq = (unsigned short*)dq; a.dk = (unsigned short*)dk; a.dv = (unsigned short*)dv;
+    a.dq_ld = dq_ld; a.dkv_ld = dkv_ld;
+    return launch_attn_bwd(a, batch, (hipStream_t)stream);
+}
+
 extern "C" int uniir_attention_fwd(const void* qkv, void* out, float* lse, int32_t batch, int32_t seq,
                                    int32_t heads, int32_t causal, void* stream) {
     if (!qkv || !out || !lse || batch < 0 || heads <= 0) return UNIIR_EINVAL;

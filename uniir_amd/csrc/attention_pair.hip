@@ -716,7 +716,7 @@ static bool ap_geom(int T, ApGeom* gm, int* TP) {
 int launch_attn_bwd_pair(const AttnArgs& a, int batch, hipStream_t st) {      // returns 1 when the shape is not taken
     ApGeom gm;
     int TP;
-    if (a.Tq != a.Tk || a.causal || a.klen || a.row_off || a.rel_emb || a.drop_p > 0.f || !ap_geom(a.Tq, &gm, &TP)) return 1;
+    if (a.Tq != a.Tk || a.causal || a.klen || a.row_off || a.kv_row_off || a.rel_emb || a.drop_p > 0.f || !ap_geom(a.Tq, &gm, &TP)) return 1;
     if ((a.q_ld | a.kv_ld | a.out_ld | a.dq_ld | a.dkv_ld) % 8) return 1;                  // 16-byte pieces
     if ((long)a.Tq * a.q_ld * 2 >= (1L << 31) || (long)a.Tq * a.kv_ld * 2 >= (1L << 31) || (long)a.Tq * a.out_ld * 2 >= (1L << 31)) return 1;
     gm.total_heads = batch * a.H;

@@ -323,6 +323,31 @@ extern "C" int uniir_gather_rows(const float* x, const int32_t* idx, float* out,
     HIP_LAUNCH_CHECK();
     return UNIIR_OK;
 }
+// one row per item between a [n * seq]-row tensor and an [n]-row tensor, as raw 16-byte pieces (any element type): gather (dir 0:
+// small[i] = big[i * seq + idx[i]]) or scatter-overwrite (dir 1: big[i * seq + idx[i]] = small[i]); idx NULL = 0.  Row pitches in
+// bytes, row_bytes a multiple of 16.  (tower.hip: the pooled rows of the last block.)
+__global__ __launch_bounds__(256) void rows_copy_kernel(const char* __restrict__ src, const int* __restrict__ idx, char* __restrict__ dst,
+                                                        int n, int seq, int pieces, long big_pitch, long small_pitch, int dir) {
+    const long total = (long)n * pieces;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % pieces);
+        const long r = i / pieces;
+        const long big = (r * seq + (idx ? idx[r] : 0)) * big_pitch + 16L * c, small = r * small_pitch + 16L * c;
+        if (!dir) *reinterpret_cast<u32x4_t*>(dst + small) = *reinterpret_cast<const u32x4_t*>(src + big);
+        else *reinterpret_cast<u32x4_t*>(dst + big) = *reinterpret_cast<const u32x4_t*>(src + small);
+    }
+}
+int rows_copy_impl(const void* src, const int32_t* idx, void* dst, int32_t n, int32_t seq, int32_t row_bytes, int64_t big_pitch,
+                   int64_t small_pitch, int32_t scatter, void* stream) {
+    if (!src || !dst || n < 0) return UNIIR_EINVAL;
+    if (n == 0) return UNIIR_OK;
+    if (row_bytes <= 0 || (row_bytes % 16) || (big_pitch % 16) || (small_pitch % 16)) return UNIIR_ESHAPE;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return UNIIR_EALIGN;
+    hipLaunchKernelGGL(rows_copy_kernel, dim3(grid_for((long)n * (row_bytes / 16), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, idx, (char*)dst, n, seq, row_bytes / 16, (long)big_pitch, (long)small_pitch, scatter);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
 extern "C" int uniir_scatter_rows(const float* dout, const int32_t* idx, float* dx, int32_t n, int32_t seq,
                                   int32_t width, void* stream) {
     if (!dout || !dx || n < 0) return UNIIR_EINVAL;

@@ -17,6 +17,15 @@ int layernorm_fwd_impl(const float* x, int64_t x_stride, const float* gamma, con
                        int32_t rows, int32_t width, float eps, int f16, void* stream);
 int attention_fwd_impl(const void* qkv, void* out, float* lse, const int32_t* row_off, int32_t batch, int32_t seq, int32_t heads,
                        int32_t causal, int f16, void* stream);
+// one query row per item (attention.hip) and raw row gather / scatter-overwrite (elementwise.hip): the pooled last block below
+int attention_pooled_fwd_impl(const void* q, const void* k, const void* v, int64_t kv_ld, void* out, float* lse, const int32_t* klen,
+                              int32_t klen_add, const int32_t* kv_row_off, int32_t batch, int32_t tk, int32_t heads, int f16,
+                              void* stream);
+int attention_pooled_bwd_impl(const void* q, const void* k, const void* v, int64_t kv_ld, const void* out, const void* dout,
+                              const float* lse, const int32_t* klen, int32_t klen_add, const int32_t* kv_row_off, void* dq,
+                              int64_t dq_ld, void* dk, void* dv, int64_t dkv_ld, int32_t batch, int32_t tk, int32_t heads, void* stream);
+int rows_copy_impl(const void* src, const int32_t* idx, void* dst, int32_t n, int32_t seq, int32_t row_bytes, int64_t big_pitch,
+                   int64_t small_pitch, int32_t scatter, void* stream);
 
 namespace {
 
@@ -38,6 +47,12 @@ struct Plan {
     int64_t total;
     // packed text rows (uniir_clip_tower_*_packed): R = the live rows, item m = rows row_off[m] .. row_off[m + 1] - 1
     const int32_t* row_off;
+    // pool_last_block: the last block's sublayers behind the K / V projection run on the ONE pooled row of every item ([M]-row
+    // buffers): forward (kept for the backward with save) ...
+    bool pool_last;
+    int64_t pl_q, pl_h1, pl_x, pl_ao, pl_lse, pl_x2, pl_h2, pl_f, pl_g;
+    // ... and backward transients
+    int64_t pl_dxb, pl_df, pl_dh, pl_dx2, pl_dqkv, pl_dhq;
 };
 
 // rows < 0: the dense layout (batch x tokens rows)
@@ -75,6 +90,12 @@ Plan plan(const uniir_clip_tower* t, int batch, bool save, int rows = -1, const 
     p.lay_stride = save ? lc : 0;
     cur += save ? lc * p.L : lc;
     p.x_last = take(R * W * 4);          // with !save the stream ping-pongs between o_x of the single layer set and this
+    p.pool_last = t->pool_last_block != 0;
+    if (p.pool_last) {
+        p.pl_q = take(M * W * 2); p.pl_h1 = take(M * W * 2); p.pl_x = take(M * W * 4); p.pl_ao = take(M * W * 2);
+        p.pl_lse = take(M * (int64_t)p.H * 4); p.pl_x2 = take(M * W * 4); p.pl_h2 = take(M * W * 2);
+        p.pl_f = take(M * 4 * W * 2); p.pl_g = take(M * 4 * W * 2);
+    }
     // transients: forward needs g only; backward the rest
     p.tmp = cur;
     p.g = take(R * 4 * W * 2);
@@ -91,6 +112,10 @@ Plan plan(const uniir_clip_tower* t, int batch, bool save, int rows = -1, const 
     p.demb16 = take(M * (int64_t)p.E * 2);
     p.dpooled = take(M * W * 2);
     p.drows = take(M * W * 4);
+    if (p.pool_last) {
+        p.pl_dxb = take(M * W * 2); p.pl_df = take(M * 4 * W * 2); p.pl_dh = take(M * W * 2); p.pl_dx2 = take(M * W * 4);
+        p.pl_dqkv = take(M * 3 * W * 2); p.pl_dhq = take(M * W * 2);
+    }
     if (!t->is_text) {
         p.dx0 = take(R * W * 4);
         p.dpo = take((int64_t)M * p.G * W * 2);
@@ -211,7 +236,7 @@ float* stream_in(const Plan& p, char* ws, int i) {
 int blocks_fwd(const uniir_clip_tower* t, const Plan& p, char* ws, void* st) {
     const int R = p.R, W = p.W;
     const int f16 = t->dtype16 != 0;            // forward-only (tower_fwd refuses save_for_backward with it)
-    for (int i = 0; i < p.L; ++i) {
+    for (int i = 0; i < p.L - (p.pool_last ? 1 : 0); ++i) {      // (pool_last: the last block is last_block_fwd_pooled)
         const uniir_clip_block& b = t->blocks[i];
         Lay l = layer_bufs(p, ws, i);
         float* x = stream_in(p, ws, i);
@@ -230,6 +255,60 @@ int blocks_fwd(const uniir_clip_tower* t, const Plan& p, char* ws, void* st) {
         TRY(linear_fwd(g, b.wproj16, xn, R, W, 4 * W, UNIIR_EPI_RESID_F32, b.bproj, l.x2, nullptr, st, f16));
     }
     return UNIIR_OK;
+}
+
+
+// ---- the LAST block on the pooled rows (uniir_clip_tower.pool_last_block) -----------------------------------------------------
+// Only ONE row per item leaves the tower: the class token (VisionTransformer.forward: ln_post(x[:, 0, :])) or the EOT row
+// (CLIP.encode_text: x[arange, text.argmax(-1)]), clip_sf.py:44,47.  In the last residual block every other row's attention output,
+// out-projection and MLP are computed by the reference and thrown away; what the pooled row needs from the other rows is their KEYS
+// and VALUES only.  So the last block runs ln_1 and the K | V two thirds of in_proj on every row, and the Q third, the attention
+// (one query row per item), out_proj, ln_2 and the MLP on the M pooled rows: 10 of the block's 12 WxW GEMM units and nearly all of
+// its attention leave the step -- 1/24 x ~0.85 of the vision tower -- with the same embedding (the same dot products in the same
+// order on the rows that matter) and, in the backward, the same parameter gradients without their exact-zero terms.
+struct PoolIdx {
+    const int32_t* idx;       // pooled row of item m = m * seq + idx[m] (idx NULL: 0)
+    int seq;
+    const int32_t* klen;      // dense text: keys 0 .. eot (klen[m] + 1 of them)
+    int klen_add;
+    const int32_t* kv_row_off;
+};
+PoolIdx pool_idx(const uniir_clip_tower* t, const Plan& p, char* ws) {
+    PoolIdx x = {nullptr, p.T, nullptr, 0, nullptr};
+    if (t->is_text) {
+        x.idx = (const int32_t*)(ws + p.eot);
+        if (p.row_off) { x.seq = 0; x.kv_row_off = p.row_off; }          // packed: absolute EOT rows; an item's keys are its own rows
+        else { x.klen = x.idx; x.klen_add = 1; }
+    }
+    return x;
+}
+int last_block_fwd_pooled(const uniir_clip_tower* t, const Plan& p, char* ws, void* st) {
+    const int R = p.R, W = p.W, M = p.M, i = p.L - 1;
+    const int f16 = t->dtype16 != 0;
+    const uniir_clip_block& b = t->blocks[i];
+    Lay l = layer_bufs(p, ws, i);
+    float* x = stream_in(p, ws, i);
+    const PoolIdx px = pool_idx(t, p, ws);
+    TRY(layernorm_fwd_impl(x, W, b.ln1_w, b.ln1_b, l.h1, nullptr, R, W, 1e-5f, f16, st));
+    uniir_gemm_desc d;
+    base_desc(d);       // K | V of every row -> columns W .. 3W of the qkv buffer
+    if (f16) d.dtype = UNIIR_DT_F16;
+    d.A = l.h1; d.B = (const char*)b.wqkv16 + (int64_t)W * W * 2; d.C = (char*)l.qkv + (int64_t)W * 2; d.bias = b.bqkv + W;
+    d.M = R; d.N = 2 * W; d.K = W; d.lda = W; d.ldb = W; d.ldc = 3 * W; d.epilogue = UNIIR_EPI_BF16;
+    TRY(uniir_gemm(&d, st));
+    TRY(rows_copy_impl(l.h1, px.idx, ws + p.pl_h1, M, px.seq, W * 2, (int64_t)W * 2, (int64_t)W * 2, 0, st));
+    TRY(linear_fwd(ws + p.pl_h1, b.wqkv16, ws + p.pl_q, M, W, W, UNIIR_EPI_BF16, b.bqkv, nullptr, nullptr, st, f16));
+    TRY(attention_pooled_fwd_impl(ws + p.pl_q, (char*)l.qkv + (int64_t)W * 2, (char*)l.qkv + (int64_t)W * 4, 3 * W, ws + p.pl_ao,
+                                  (float*)(ws + p.pl_lse), px.klen, px.klen_add, px.kv_row_off, M, p.T, p.H, f16, st));
+    TRY(rows_copy_impl(x, px.idx, ws + p.pl_x, M, px.seq, W * 4, (int64_t)W * 4, (int64_t)W * 4, 0, st));
+    TRY(linear_fwd(ws + p.pl_ao, b.wo16, ws + p.pl_x2, M, W, W, UNIIR_EPI_RESID_F32, b.bo, (float*)(ws + p.pl_x), nullptr, st, f16));
+    TRY(layernorm_fwd_impl((float*)(ws + p.pl_x2), W, b.ln2_w, b.ln2_b, ws + p.pl_h2, nullptr, M, W, 1e-5f, f16, st));
+    if (p.save)
+        TRY(linear_fwd(ws + p.pl_h2, b.wfc16, ws + p.pl_f, M, 4 * W, W, UNIIR_EPI_BIAS_ACT, b.bfc, nullptr, ws + p.pl_g, st, f16));
+    else
+        TRY(linear_fwd(ws + p.pl_h2, b.wfc16, ws + p.pl_g, M, 4 * W, W, UNIIR_EPI_ACT_ONLY, b.bfc, nullptr, nullptr, st, f16));
+    // the block's output on the pooled rows IS the tower's pooled-row buffer
+    return linear_fwd(ws + p.pl_g, b.wproj16, ws + p.rows, M, W, 4 * W, UNIIR_EPI_RESID_F32, b.bproj, (float*)(ws + p.pl_x2), nullptr, st, f16);
 }
 
 // the tower output stream after blocks_fwd
@@ -274,8 +353,12 @@ int tower_fwd(const uniir_clip_tower* t, const void* input, int32_t batch, const
         eot = (const int32_t*)(ws + p.eot);
     }
     TRY(blocks_fwd(t, p, ws, stream));
-    float* x_out = p.save ? (float*)(ws + p.x_last) : stream_out(p, ws);
-    TRY(uniir_gather_rows(x_out, eot, (float*)(ws + p.rows), M, row_off ? 0 : T, W, stream));     // (packed: absolute row indices)
+    if (p.pool_last) {
+        TRY(last_block_fwd_pooled(t, p, ws, stream));      // writes the pooled rows itself
+    } else {
+        float* x_out = p.save ? (float*)(ws + p.x_last) : stream_out(p, ws);
+        TRY(uniir_gather_rows(x_out, eot, (float*)(ws + p.rows), M, row_off ? 0 : T, W, stream));     // (packed: absolute row indices)
+    }
     TRY(layernorm_fwd_impl((float*)(ws + p.rows), W, t->ln_post_w, t->ln_post_b, ws + p.pooled, nullptr, M, W, 1e-5f, f16, stream));
     uniir_gemm_desc d;
     base_desc(d);
@@ -307,6 +390,10 @@ int tower_bwd_head(const uniir_clip_tower* t, const float* demb, int32_t batch, 
     TRY(uniir_gemm(&d, stream));
     TRY(uniir_layernorm_bwd((float*)(ws + p.rows), W, t->ln_post_w, ws + p.dpooled, 0, nullptr, (float*)(ws + p.drows), W, nullptr,
                             t->g_ln_post_w, t->g_ln_post_b, nullptr, M, W, 1e-5f, stream));
+    if (p.pool_last) {      // the gradient stays on the pooled rows through the last block (last_block_bwd_pooled)
+        TRY(uniir_cast_f32_to_bf16((float*)(ws + p.drows), ws + p.pl_dxb, (int64_t)M * W, stream));
+        return uniir_colsum_bf16(ws + p.pl_dxb, W, t->blocks[p.L - 1].g_bproj, M, W, stream);
+    }
     if (hipMemsetAsync(ws + p.dx, 0, (size_t)R * W * 4, (hipStream_t)stream) != hipSuccess) return UNIIR_ELAUNCH;
     TRY(uniir_scatter_rows((float*)(ws + p.drows), t->is_text ? (const int32_t*)(ws + p.eot) : nullptr, (float*)(ws + p.dx), M,
                            row_off ? 0 : T, W, stream));
@@ -314,6 +401,65 @@ int tower_bwd_head(const uniir_clip_tower* t, const float* demb, int32_t batch, 
     // bias gradient of the last block's c_proj: column sums of the incoming gradient (the other blocks get theirs from the
     // LayerNorm backward that produces their incoming gradient)
     return uniir_colsum_bf16(ws + p.dxb, W, t->blocks[p.L - 1].g_bproj, R, W, stream);
+}
+
+
+// backward of last_block_fwd_pooled: the incoming gradient lives on the pooled rows (ws + p.drows fp32, p.pl_dxb bf16); leaves the
+// block's input gradient in dx / dxb like every other block
+int last_block_bwd_pooled(const uniir_clip_tower* t, const Plan& p, char* ws, void* st) {
+    const int R = p.R, W = p.W, M = p.M, i = p.L - 1;
+    const uniir_clip_block& b = t->blocks[i];
+    Lay l = layer_bufs(p, ws, i);
+    const PoolIdx px = pool_idx(t, p, ws);
+    float* dx = (float*)(ws + p.dx);
+    float* dx2 = (float*)(ws + p.dx2);
+    void *dxb = ws + p.dxb, *dh = ws + p.dh, *dqkv = ws + p.dqkv;
+    void *pdxb = ws + p.pl_dxb, *pdf = ws + p.pl_df, *pdh = ws + p.pl_dh, *pdqkv = ws + p.pl_dqkv;
+    // MLP and out_proj on the M pooled rows
+    TRY(linear_dgrad(pdxb, b.wproj16, pdf, M, W, 4 * W, ws + p.pl_f, nullptr, b.g_bfc, st));
+    TRY(linear_wgrad(t, pdxb, ws + p.pl_g, b.g_wproj, M, W, 4 * W, st));
+    TRY(linear_wgrad(t, pdf, ws + p.pl_h2, b.g_wfc, M, 4 * W, W, st));
+    TRY(linear_dgrad(pdf, b.wfc16, pdh, M, 4 * W, W, nullptr, nullptr, nullptr, st));
+    TRY(uniir_layernorm_bwd((float*)(ws + p.pl_x2), W, b.ln2_w, pdh, 0, (float*)(ws + p.drows), (float*)(ws + p.pl_dx2), W, pdxb,
+                            b.g_ln2_w, b.g_ln2_b, b.g_bo, M, W, 1e-5f, st));
+    TRY(linear_wgrad(t, pdxb, ws + p.pl_ao, b.g_wo, M, W, W, st));
+    TRY(linear_dgrad(pdxb, b.wo16, pdh, M, W, W, nullptr, nullptr, nullptr, st));
+    // one query row per item: dq -> columns 0 .. W of the pooled [M, 3W] gradient, dk | dv of EVERY row -> columns W .. 3W of dqkv
+    TRY(attention_pooled_bwd_impl(ws + p.pl_q, (char*)l.qkv + (int64_t)W * 2, (char*)l.qkv + (int64_t)W * 4, 3 * W, ws + p.pl_ao, pdh,
+                                  (float*)(ws + p.pl_lse), px.klen, px.klen_add, px.kv_row_off, pdqkv, 3 * W,
+                                  (char*)dqkv + (int64_t)W * 2, (char*)dqkv + (int64_t)W * 4, 3 * W, M, p.T, p.H, st));
+    uniir_gemm_desc d;
+    base_desc(d);       // in_proj weight / bias gradient, K | V rows: over every row
+    d.A = (char*)dqkv + (int64_t)W * 2; d.B = l.h1; d.C = b.g_wqkv + (int64_t)W * W; d.a_rowsum = b.g_bqkv + W;
+    d.M = 2 * W; d.N = W; d.K = R; d.lda = 3 * W; d.ldb = W; d.ldc = W; d.a_tmaj = 1; d.b_tmaj = 1;
+    d.epilogue = UNIIR_EPI_ATOMIC_F32;
+    d.k_splits = wgrad_splits(R, ((2 * W + 255) / 256) * ((W + 255) / 256));
+    if (d.k_splits > 1 && t->splitk_ws && t->splitk_ws_bytes >= (int64_t)4 * d.k_splits * 2 * W * W) {
+        d.splitk_ws = t->splitk_ws;
+        d.splitk_ws_bytes = t->splitk_ws_bytes;
+    }
+    TRY(uniir_gemm(&d, st));
+    base_desc(d);       // ... Q rows: over the pooled rows
+    d.A = pdqkv; d.B = ws + p.pl_h1; d.C = b.g_wqkv; d.a_rowsum = b.g_bqkv;
+    d.M = W; d.N = W; d.K = M; d.lda = 3 * W; d.ldb = W; d.ldc = W; d.a_tmaj = 1; d.b_tmaj = 1; d.epilogue = UNIIR_EPI_ATOMIC_F32;
+    TRY(uniir_gemm(&d, st));
+    base_desc(d);       // d ln_1 out of every row: its K | V part ...
+    d.A = (char*)dqkv + (int64_t)W * 2; d.B = (const char*)b.wqkv16 + (int64_t)W * W * 2; d.C = dh;
+    d.M = R; d.N = W; d.K = 2 * W; d.lda = 3 * W; d.ldb = W; d.ldc = W; d.b_tmaj = 1; d.epilogue = UNIIR_EPI_BF16;
+    TRY(uniir_gemm(&d, st));
+    // ... and, for the pooled rows, the whole K = 3W product in one accumulation (what the dense call computes for them)
+    TRY(rows_copy_impl((char*)dqkv + (int64_t)W * 2, px.idx, (char*)pdqkv + (int64_t)W * 2, M, px.seq, 2 * W * 2, (int64_t)3 * W * 2,
+                       (int64_t)3 * W * 2, 0, st));
+    base_desc(d);
+    d.A = pdqkv; d.B = b.wqkv16; d.C = ws + p.pl_dhq;
+    d.M = M; d.N = W; d.K = 3 * W; d.lda = 3 * W; d.ldb = W; d.ldc = W; d.b_tmaj = 1; d.epilogue = UNIIR_EPI_BF16;
+    TRY(uniir_gemm(&d, st));
+    TRY(rows_copy_impl(ws + p.pl_dhq, px.idx, dh, M, px.seq, W * 2, (int64_t)W * 2, (int64_t)W * 2, 1, st));
+    // the residual gradient entering ln_1's backward is zero except on the pooled rows
+    if (hipMemsetAsync(dx2, 0, (size_t)R * W * 4, (hipStream_t)st) != hipSuccess) return UNIIR_ELAUNCH;
+    TRY(uniir_scatter_rows((float*)(ws + p.pl_dx2), px.idx, dx2, M, px.seq, W, st));
+    return uniir_layernorm_bwd(l.x, W, b.ln1_w, dh, 0, dx2, dx, W, dxb, b.g_ln1_w, b.g_ln1_b,
+                               i > 0 ? t->blocks[i - 1].g_bproj : nullptr, R, W, 1e-5f, st);
 }
 
 // backward, stage 2: residual blocks layer_hi-1 ... layer_lo (call with descending ranges that cover [0, layers))
@@ -334,6 +480,10 @@ int tower_bwd_blocks(const uniir_clip_tower* t, int32_t batch, const int32_t* ro
         if (!b.g_wqkv || !b.g_bqkv || !b.g_wo || !b.g_bo || !b.g_wfc || !b.g_bfc || !b.g_wproj || !b.g_bproj || !b.g_ln1_w ||
             !b.g_ln1_b || !b.g_ln2_w || !b.g_ln2_b)
             return UNIIR_EINVAL;
+        if (p.pool_last && i == p.L - 1) {
+            TRY(last_block_bwd_pooled(t, p, ws, stream));
+            continue;
+        }
         Lay l = layer_bufs(p, ws, i);
         // d(mlp): df = (dx @ Wproj) * act'(f); the same epilogue re-materialises g = act(f) for dWproj and sums df's columns
         // into the c_fc bias gradient
