@@ -36,6 +36,15 @@ extern "C" {
 const char* uniir_strerror(int code);
 /* ABI version; bumped on any signature change. */
 int uniir_abi_version(void);
+/* Reproducible reductions (round 6).  Bias, LayerNorm-weight and token-embedding gradients are sums over every row of a batch taken by
+ * many workgroups; added with fp32 atomics they depend on the arrival order, and two runs of one training step differ in their last
+ * bits.  Register a caller-owned device buffer for a stream (256-byte aligned; 64 MiB covers ViT-L/14 at 1024 items; buf NULL removes
+ * the entry) and every such reduction launched on that stream -- uniir_gemm's colsum / a_rowsum, uniir_layernorm_bwd*, uniir_colsum_bf16,
+ * uniir_text_embed_bwd* and the tower entry points that use them -- stores per-workgroup partials there and adds them in a fixed
+ * order (one extra small launch each): same inputs, same bits.  Kernels on one stream run one after the other, so one buffer per
+ * stream is enough.  A reduction that needs more than the buffer holds keeps its atomics.  Host-side table (16 streams), not
+ * thread-safe: one training thread per process, as in the reference (train.py). */
+int uniir_reduce_scratch(void* buf, int64_t bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * [ENC] building block 1: 16-bit MFMA GEMM with fused epilogues.

@@ -154,3 +154,16 @@ def test_gemm_sampling_rule_never_returns_an_empty_set():
     # (6) fewer than 8 samples taken, one survives: not a statistic -> all kept
     keep, fb = ops.gemm_timing_filter([(0.0, 10.0)], [(1.0, 0.1), (2.0, 0.1), (20.0, 0.1)])
     assert fb is True and all(keep)
+
+
+def test_reduce_scratch_registry_validates_its_arguments():
+    """uniir_reduce_scratch is host-side bookkeeping (no device call): a 256-byte aligned buffer of positive size per stream;
+    NULL removes the entry and is harmless when there is none"""
+    from uniir_amd import _lib
+    lib = _lib.load()
+    assert lib.uniir_reduce_scratch(None, 0, None) == 0
+    assert lib.uniir_reduce_scratch(0x1001, 1 << 20, None) == -1           # unaligned
+    assert lib.uniir_reduce_scratch(0x1000, 0, None) == -1                 # no size
+    assert lib.uniir_reduce_scratch(0x10000, 1 << 20, 0x42) == 0
+    assert lib.uniir_reduce_scratch(0x20000, 2 << 20, 0x42) == 0           # re-registration replaces
+    assert lib.uniir_reduce_scratch(None, 0, 0x42) == 0

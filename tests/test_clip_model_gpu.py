@@ -306,14 +306,14 @@ def test_automatic_stash_is_decided_once_reviewed_and_survives_an_out_of_memory_
 
 def test_two_stream_towers_equal_the_one_stream_order():
     """clip_model.CLIP.overlap_towers: the text leg of the model forward (compaction gathers, packed text tower, scatter) and its
-    backward run on the model's second stream.  No kernel differs, so what could differ is a missing wait.
-    (a) Fixed weights, six batches with dead rows in both modalities, each run in both orders: losses bitwise equal (the forward is
-        deterministic), gradients equal within the run-to-run noise of the one-stream order itself (bias / LayerNorm-weight gradients
-        are fp32 atomic column sums: 3e-8 absolute between any two runs at these sizes, tools/r5/overlap_dbg.py).
-    (b) Train steps (NativeTrainer: zero_grad, forward, backward, fused AdamW, next forward reading the refreshed bf16 shadow): a lost
-        wait between the text backward and the optimizer would move EVERY text-tower weight by ~lr; the noise above moves, through
-        AdamW's normalisation, the few weights whose gradient is itself noise: the count of weights that differ by 1e-5 is held to
-        that of two one-stream runs (x4) or 10 % (observed: 1 % by the fourth step, in both comparisons)."""
+    backward run on the model's second stream.  No kernel differs, so what could differ is a missing wait -- and since round 6 every
+    cross-workgroup gradient sum is added in a fixed order (uniir_reduce_scratch: bias / LayerNorm-weight column sums, the token
+    embedding's scatter), so the comparison is EXACT:
+    (a) fixed weights, six batches with dead rows in both modalities, each run in both orders: losses and the whole flat gradient
+        buffer bitwise equal;
+    (b) train steps (NativeTrainer: zero_grad, forward, backward, fused AdamW, next forward reading the refreshed bf16 shadow): the
+        weights after every one of four steps bitwise equal between the two-stream order, the one-stream order, and a second
+        one-stream run (a lost wait between the text backward and the optimizer would move every text-tower weight)."""
     from oracle import clip_oracle as O
     from uniir_amd.trainer import NativeTrainer
     cfg = O.tiny_config(vision_width=128, vision_layers=3, transformer_width=128, transformer_heads=2, transformer_layers=3)
@@ -343,7 +343,7 @@ def test_two_stream_towers_equal_the_one_stream_order():
         assert res[True][0] == res[False][0]
         g1, g0 = res[True][1], res[False][1]
         assert float(g0.abs().max()) > 0
-        assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max()), it
+        assert torch.equal(g1, g0), (it, float((g1 - g0).abs().max()), _first_difference(clip, g1, g0))
     assert clip._side_streams
 
     runs = {}
@@ -357,11 +357,57 @@ def test_two_stream_towers_equal_the_one_stream_order():
             rec.append((float(out["loss"].detach()), model.clip_model._flat["p32"].clone()))
         torch.cuda.synchronize()
         runs[tag] = rec
-    for (l2, w2), (l1, w1), (l0, w0) in zip(runs["two"], runs["one again"], runs["one"]):
-        assert abs(l2 - l0) <= 1e-4 * max(1.0, abs(l0))
-        moved = int(((w2 - w0).abs() > 1e-5).sum())
-        floor = int(((w1 - w0).abs() > 1e-5).sum())          # what two one-stream runs differ by (observed ~1 % by the 4th step)
-        assert moved <= max(4 * floor, 0.10 * w0.numel()), (moved, floor)          # a lost wait: ~45 % (every text-tower weight)
+    for step, ((l2, w2), (l1, w1), (l0, w0)) in enumerate(zip(runs["two"], runs["one again"], runs["one"])):
+        assert l1 == l0 and torch.equal(w1, w0), ("two one-stream runs differ", step, int((w1 != w0).sum()))
+        assert l2 == l0 and torch.equal(w2, w0), ("the two-stream order differs", step, int((w2 != w0).sum()))
+
+
+def _first_difference(clip, a, b):
+    """names of the parameters whose slice of the flat buffers differs (diagnostics of the exact comparisons)"""
+    fl = clip._flat
+    bad = []
+    for n, off in fl["off"].items():
+        k = 1
+        for d in fl["shapes"][n]:
+            k *= d
+        if not torch.equal(a[off:off + k], b[off:off + k]):
+            bad.append(n)
+    return bad[:12]
+
+
+def test_training_step_is_reproducible_bit_for_bit():
+    """two runs of the same training steps from the same state give the same bits.  The gradients that
+    are sums over all rows taken by many workgroups -- bias gradients (GEMM epilogue column sums, the weight-gradient kernel's row
+    sums), LayerNorm weight / bias gradients, the token embedding's scatter-add over repeated ids -- were fp32 atomics in arrival
+    order; with a scratch buffer per stream (uniir_reduce_scratch, attached by uniir_amd.ops) they are stored per workgroup and
+    added in a fixed order.  256 items so that the 256-row GEMM kernels (fused column sums) run; captions share their SOT / EOT ids
+    (256-fold collisions) and random ids collide among 20 k tokens.  Gradients after one backward and weights after three
+    NativeTrainer steps are compared with torch.equal; the packed and the dense text tower, the pooled and the full last block."""
+    from oracle import clip_oracle as O
+    from uniir_amd.trainer import NativeTrainer
+    cfg = O.tiny_config(vision_width=128, vision_layers=2, transformer_width=128, transformer_heads=2, transformer_layers=2)
+    batch = O.synthetic_batch(cfg, 128, seed=3)
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    for pack_text, pool in ((True, True), (False, False)):
+        grads, weights = [], []
+        for run in range(2):
+            model, _, O = _build(cfg, seed=5)
+            clip = model.clip_model
+            clip.pack_text, clip.pool_last_block = pack_text, pool
+            model.train()
+            clip._ensure_flat()
+            clip.zero_grad()
+            out = model(dbatch)
+            out["loss"].backward()
+            grads.append(clip._flat["g32"].clone())
+            tr = NativeTrainer(model, lr=1e-3, t_total=10)
+            for it in range(3):
+                tr.train_step(dbatch)
+            torch.cuda.synchronize()
+            weights.append(clip._flat["p32"].clone())
+        assert float(grads[0].abs().max()) > 0
+        assert torch.equal(grads[0], grads[1]), (pack_text, pool, _first_difference(clip, grads[0], grads[1]))
+        assert torch.equal(weights[0], weights[1]), (pack_text, pool, _first_difference(clip, weights[0], weights[1]))
 
 
 @pytest.mark.parametrize("pack_text", [True, False])

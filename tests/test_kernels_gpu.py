@@ -669,3 +669,96 @@ def test_gemm_large_shape_every_epilogue_on_two_row_ranges():
     both(dx, dref, 5e-3)
     both(act_out, a * sg, 4e-3)
     assert rel_err(colsum, dref.sum(0)) < 5e-3
+
+
+def test_cross_workgroup_sums_are_reproducible():
+    """uniir_reduce_scratch (attached per stream by uniir_amd.ops): the reductions that many workgroups contribute to store their
+    partials and add them in a fixed order -- each of them, run twice on the same inputs, returns the same bits, and still matches
+    the fp32 reference: the GEMM epilogue's column sums (DACT, 40 row panels), the weight-gradient kernel's row sums (8 K splits x 3
+    column panels), LayerNorm's weight / bias gradients and dx column sums (hundreds of workgroups), uniir_colsum_bf16, and the token
+    embedding's scatter-add (dense and packed rows; every caption shares ids 1 and 2, the rest collide among 64 ids; one id has
+    more rows than the sorted-bucket limit and all-zero gradients, like the padding id of an unpacked batch)."""
+    ops = _ops()
+    from uniir_amd import _lib
+    ops._stream()
+    assert ops._DETERMINISTIC and ops._RED_SCRATCH          # this stream has its scratch buffer
+    torch.manual_seed(3)
+    M, N, K = 10240, 1024, 512
+
+    def twice(fn):
+        a, b = fn(), fn()
+        assert torch.equal(a, b), float((a - b).abs().max())
+        return a
+
+    # (1) DACT epilogue column sums
+    dy, w, f = bf(torch.randn(M, K, device=DEV)), bf(torch.randn(K, N, device=DEV) * 0.05), bf(torch.randn(M, N, device=DEV))
+
+    def dact():
+        cs = torch.zeros(N, device=DEV)
+        ops.linear_dgrad(dy, w, out=torch.empty(M, N, device=DEV, dtype=torch.bfloat16), aux=f, colsum=cs, act=ops.ACT_QUICKGELU)
+        return cs
+    cs = twice(dact)
+    ff = f.float()
+    sg = torch.sigmoid(1.702 * ff)
+    ref = ((dy.float() @ w.float()) * (sg * (1 + 1.702 * ff * (1 - sg)))).sum(0)
+    assert rel_err(cs, ref) < 2e-3, rel_err(cs, ref)
+    # (2) weight gradient + bias gradient (row sums of dy^T)
+    x = bf(torch.randn(M, K, device=DEV))
+    dy2 = bf(torch.randn(M, 768, device=DEV) + 0.25)
+
+    def wgrad():
+        dw, db = torch.zeros(768, K, device=DEV), torch.zeros(768, device=DEV)
+        ops.linear_wgrad(dy2, x, dw, dbias=db)
+        return torch.cat([dw.flatten(), db])
+    out = twice(wgrad)
+    assert rel_err(out[-768:], dy2.float().sum(0)) < 1e-5
+    # (3) LayerNorm backward
+    rows, width = 50000, 1024
+    xx, gamma = torch.randn(rows, width, device=DEV), torch.randn(width, device=DEV)
+    dyy = bf(torch.randn(rows, width, device=DEV))
+
+    def lnb():
+        dg, db, dc = (torch.zeros(width, device=DEV) for _ in range(3))
+        _lib.check(_lib.load().uniir_layernorm_bwd(xx.data_ptr(), width, gamma.data_ptr(), dyy.data_ptr(), 0, None,
+                                                    torch.empty(rows, width, device=DEV).data_ptr(), width, None, dg.data_ptr(),
+                                                    db.data_ptr(), dc.data_ptr(), rows, width, 1e-5, ops._stream()), "ln_bwd")
+        return torch.cat([dg, db, dc])
+    out = twice(lnb)
+    assert rel_err(out[width:2 * width], dyy.float().sum(0)) < 1e-5
+    # (4) column sums of a bf16 matrix
+    def colsum():
+        o = torch.zeros(1024, device=DEV)
+        ops.call("uniir_colsum_bf16", dyy, 1024, o, rows, 1024)
+        return o
+    assert rel_err(twice(colsum), dyy.float().sum(0)) < 1e-5
+    # (5) token-embedding gradient
+    n, ctx, wdt, vocab = 300, 77, 128, 4096
+    ids = torch.randint(3, 67, (n, ctx), dtype=torch.int32)
+    ids[:, 0], lens = 1, torch.randint(5, ctx + 1, (n,))
+    ids[torch.arange(n), lens - 1] = 2
+    ids = torch.where(torch.arange(ctx).unsqueeze(0) < lens.unsqueeze(1), ids, torch.zeros_like(ids))      # id 0 behind the last token
+    dx = torch.randn(n * ctx, wdt, device=DEV)
+    live = (torch.arange(ctx).unsqueeze(0) < lens.unsqueeze(1)).flatten().to(DEV)
+    dx_dense = dx * live.unsqueeze(1)                                                                      # zeros on the dead rows
+    assert int((ids == 0).sum()) > 4096                                                                    # the unsorted bucket
+    idd = ids.to(DEV)
+
+    def dense():
+        dt, dp = torch.zeros(vocab, wdt, device=DEV), torch.zeros(ctx, wdt, device=DEV)
+        ops.call("uniir_text_embed_bwd", idd, dx_dense, dt, dp, n, ctx, wdt, vocab)
+        return dt
+    ref = torch.zeros(vocab, wdt, device=DEV).index_add_(0, idd.flatten().long(), dx_dense)
+    got = twice(dense)
+    assert (got - ref).abs().max() < 2e-4 * float(ref.abs().max())
+    row_off = torch.zeros(n + 1, dtype=torch.int32)
+    row_off[1:] = torch.cumsum(lens, 0)
+    dxp = dx_dense[live].contiguous()
+    ro = row_off.to(DEV)
+
+    def packed():
+        dt, dp = torch.zeros(vocab, wdt, device=DEV), torch.zeros(ctx, wdt, device=DEV)
+        ops.call("uniir_text_embed_bwd_packed", idd, dxp, ro, dt, dp, n, ctx, wdt, vocab)
+        return dt
+    gotp = twice(packed)
+    assert torch.equal(gotp[1:], got[1:])          # every id but the padding id: the same rows in the same (row) order
+    assert (gotp - ref).abs().max() < 2e-4 * float(ref.abs().max())

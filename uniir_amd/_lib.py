@@ -53,6 +53,7 @@ P, S = c_void_p, c_void_p
 SIGNATURES = {
     "uniir_strerror": (C.c_char_p, [c_int]),
     "uniir_abi_version": (c_int, []),
+    "uniir_reduce_scratch": (c_int, [c_void_p, c_i64, c_void_p]),
     "uniir_gemm": (c_int, [C.POINTER(GemmDesc), S]),
     "uniir_gemm_timing": (c_int, [c_int]),
     "uniir_gemm_timing_on": (c_int, [c_int, c_void_p]),

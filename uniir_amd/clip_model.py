@@ -21,6 +21,7 @@ from . import _lib, ops
 # True (tests): run the CLIP towers as the per-op launch sequence below (what CLIP_FF and BLIP use for their variants) instead of
 # the single-call C towers of csrc/tower.hip -- same kernels, same order
 _PY_TOWERS = False
+_SIDE_STREAMS = {}          # device index -> the torch stream that carries the text leg of two-stream towers (CLIP.side_leg)
 
 ALIGN = 64  # elements; every parameter starts on a 256-B boundary of the flat buffers
 
@@ -188,7 +189,7 @@ class CLIP(nn.Module):
         # a multi-rank job keeps the one-stream order until it has (bench.py --overlap-towers forces it for an A/B).
         env = os.environ.get("UNIIR_OVERLAP_TOWERS")
         self.overlap_towers = None if env is None else env != "0"
-        self._side_streams = {}
+        self._side_streams = _SIDE_STREAMS          # one second stream per DEVICE, shared by every model of the process
         self._leg_main = None           # inside side_leg(): the stream the leg forked from
 
     # ---- flat parameter / gradient / bf16-shadow storage -----------------------------------------------------

@@ -90,6 +90,15 @@ struct PerDeviceOnce {
     }
 };
 
+// ---- deterministic cross-workgroup column sums (round 6) -------------------------------------------------------------------------
+// Bias / LayerNorm-weight / embedding gradients are sums over all rows of a tensor, taken by many workgroups.  Their fp32 atomic adds
+// land in arrival order, so two runs of one step differed in the last bits.  With a caller-owned scratch buffer registered for the
+// launch stream (uniir_reduce_scratch) every workgroup STORES its partial instead and one small kernel adds the partials in a fixed
+// order (reduce_partials); without one the kernels keep their atomics.  Host-side table, one measuring/training thread per process.
+float* reduce_scratch(hipStream_t st, int64_t bytes);       // the stream's scratch if it holds `bytes`, else nullptr
+// dst_k[c] += sum_j part[j * stride + k * plane + c]  (j < nparts, c < cols, up to three destinations k; NULL ones are skipped)
+int reduce_partials(const float* part, int nparts, long stride, int cols, float* d0, float* d1, float* d2, long plane, hipStream_t st);
+
 #define HIP_LAUNCH_CHECK()                                         \
     do {                                                           \
         hipError_t e__ = hipGetLastError();                        \

@@ -13,6 +13,120 @@ static inline int grid_for(long work, int per_block, int cap = 8192) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// deterministic column sums: the scratch registry and the fixed-order reduction of per-workgroup partials (common.h)
+#define RED_SLOTS 64
+static struct { hipStream_t st; int dev; float* buf; int64_t bytes; bool used; unsigned long stamp; } g_red_scratch[RED_SLOTS];
+static unsigned long g_red_clock = 0;
+static int red_device() {          // the NULL stream is every device's default stream: entries are per (device, stream)
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
+extern "C" int uniir_reduce_scratch(void* buf, int64_t bytes, void* stream) {
+    if ((buf && bytes <= 0) || ((uintptr_t)buf & 255)) return UNIIR_EINVAL;
+    int slot = -1, oldest = 0;
+    const int dev = red_device();
+    for (int i = 0; i < RED_SLOTS; ++i) {
+        if (g_red_scratch[i].used && g_red_scratch[i].st == (hipStream_t)stream && g_red_scratch[i].dev == dev) {
+            if (!buf) { g_red_scratch[i].used = false; return UNIIR_OK; }
+            g_red_scratch[i].buf = (float*)buf; g_red_scratch[i].bytes = bytes; g_red_scratch[i].stamp = ++g_red_clock;
+            return UNIIR_OK;
+        }
+        if (!g_red_scratch[i].used && slot < 0) slot = i;
+        if (g_red_scratch[i].stamp < g_red_scratch[oldest].stamp) oldest = i;
+    }
+    if (!buf) return UNIIR_OK;
+    if (slot < 0) slot = oldest;          // table full: the entry used longest ago goes (a stream that has not launched a reduction
+                                          // for 63 registrations is gone, or falls back to atomics until it registers again)
+    g_red_scratch[slot].st = (hipStream_t)stream; g_red_scratch[slot].dev = dev; g_red_scratch[slot].buf = (float*)buf;
+    g_red_scratch[slot].bytes = bytes; g_red_scratch[slot].used = true; g_red_scratch[slot].stamp = ++g_red_clock;
+    return UNIIR_OK;
+}
+float* reduce_scratch(hipStream_t st, int64_t bytes) {
+    int dev = -1;
+    for (int i = 0; i < RED_SLOTS; ++i)
+        if (g_red_scratch[i].used && g_red_scratch[i].st == st) {
+            if (dev < 0) dev = red_device();
+            if (g_red_scratch[i].dev == dev) {
+                g_red_scratch[i].stamp = ++g_red_clock;
+                return g_red_scratch[i].bytes >= bytes ? g_red_scratch[i].buf : nullptr;
+            }
+        }
+    return nullptr;
+}
+// block = 8 groups of 4 columns x 32 chunks of the parts; chunk q adds its contiguous range of parts in order (16-byte loads, all
+// independent), the 32 chunk sums are added in order: one fixed summation tree per column, whatever order the producers finished in.
+// cols and stride are multiples of 4 at every call site.
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int nparts, long stride, int cols,
+                                                             float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2,
+                                                             long plane) {
+    __shared__ f32x4_t red[32][8];
+    float* dst = blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2);
+    if (!dst) return;
+    const int cg = threadIdx.x & 7, q = threadIdx.x >> 3, c = (blockIdx.x * 8 + cg) * 4;
+    const float* p = part + (long)blockIdx.y * plane;
+    const int per = (nparts + 31) / 32, j0 = q * per, j1 = min(nparts, j0 + per);
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        // eight loads in flight per thread (a dependent load-add chain ran at one HBM latency per part: 52 us per call), added in
+        // the order of the parts
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {
+            f32x4_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4_t*>(p + (long)(j + u) * stride + c);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; j < j1; ++j) s += *reinterpret_cast<const f32x4_t*>(p + (long)j * stride + c);
+    }
+    red[q][cg] = s;
+    __syncthreads();
+    if (q == 0 && c < cols) {
+        f32x4_t t = red[0][cg];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) t += red[k][cg];
+        f32x4_t* o = reinterpret_cast<f32x4_t*>(dst + c);
+        *o = *o + t;
+    }
+}
+// the same tree, one column per thread (a destination that is not 16-byte aligned)
+__global__ __launch_bounds__(256) void partial_reduce1_kernel(const float* __restrict__ part, int nparts, long stride, int cols,
+                                                              float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2,
+                                                              long plane) {
+    __shared__ float red[32][8];
+    float* dst = blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2);
+    if (!dst) return;
+    const int cg = threadIdx.x & 7, q = threadIdx.x >> 3;
+    const float* p = part + (long)blockIdx.y * plane;
+    const int per = (nparts + 31) / 32, j0 = q * per, j1 = min(nparts, j0 + per);
+    for (int e = 0; e < 4; ++e) {          // the four columns of the group one after the other, the float4 kernel's order per column
+        const int c = (blockIdx.x * 8 + cg) * 4 + e;
+        float s = 0.f;
+        if (c < cols)
+            for (int j = j0; j < j1; ++j) s += p[(long)j * stride + c];
+        red[q][cg] = s;
+        __syncthreads();
+        if (q == 0 && c < cols) {
+            float t = red[0][cg];
+            for (int k = 1; k < 32; ++k) t += red[k][cg];
+            dst[c] += t;
+        }
+        __syncthreads();
+    }
+}
+int reduce_partials(const float* part, int nparts, long stride, int cols, float* d0, float* d1, float* d2, long plane, hipStream_t st) {
+    if (nparts <= 0 || cols <= 0) return UNIIR_OK;
+    const bool vec = !((cols | stride | plane) & 3) && !(((uintptr_t)part | (uintptr_t)d0 | (uintptr_t)d1 | (uintptr_t)d2) & 15);
+    if (vec)
+        hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 31) / 32, 3), dim3(256), 0, st, part, nparts, stride, cols, d0, d1, d2, plane);
+    else
+        hipLaunchKernelGGL(partial_reduce1_kernel, dim3((cols + 31) / 32, 3), dim3(256), 0, st, part, nparts, stride, cols, d0, d1, d2, plane);
+    HIP_LAUNCH_CHECK();
+    return UNIIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // patchify: images f32 [n][3][res][res] -> bf16 [n*g*g][kpad], k = c*P*P + py*P + px
 // one thread produces 8 consecutive k (16 B store); reads are P-contiguous runs of a pixel row.
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img,
@@ -182,6 +296,143 @@ extern "C" int uniir_text_embed(const int32_t* text, const float* token_emb, con
     return UNIIR_OK;
 }
 
+// ---- deterministic token-embedding gradient (round 6) -------------------------------------------------------------------------
+// dtok[id] += sum of the dx rows whose token is id.  Token ids repeat (every caption has the SOT / EOT or [CLS] / [SEP] ids, common
+// words collide), so the plain kernels below add with fp32 atomics in arrival order.  With a scratch buffer on the stream the rows are
+// bucketed by id instead (counting sort: integer atomics only, whose results do not depend on order), every bucket is put in ascending
+// row order, and one workgroup per id adds its rows in that order: the same bits every run.  A bucket longer than TOKD_SORT rows
+// (only the padding id of an UNPACKED batch -- rows behind the EOT / the valid length, whose gradients are exact zeros -- or the
+// special tokens of a batch of more than 4096 captions) is added in bucket order as filled.
+#define TOKD_SORT 4096
+DEVINL bool tokd_row(const int* __restrict__ text, const int* __restrict__ row_off, long row, int ctx, int vocab, int* id, long* dxrow) {
+    const int t = (int)(row % ctx), m = (int)(row / ctx);
+    if (row_off) {
+        const int r0 = row_off[m];
+        if (t >= row_off[m + 1] - r0) return false;
+        *dxrow = r0 + t;
+    } else {
+        *dxrow = row;
+    }
+    const int v = text[row];
+    *id = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+    return true;
+}
+__global__ __launch_bounds__(256) void tokd_count_kernel(const int* __restrict__ text, const int* __restrict__ row_off, long rows, int ctx,
+                                                         int vocab, int* __restrict__ counts) {
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        int id; long dxr;
+        if (tokd_row(text, row_off, r, ctx, vocab, &id, &dxr)) atomicAdd(counts + id, 1);
+    }
+}
+// one workgroup: starts = exclusive prefix sums of counts ([vocab + 1]), cursor = a copy the fill pass advances.  A thread owns
+// <= TOKD_PER consecutive ids, read with all loads in flight (vocab <= 1024 * TOKD_PER)
+#define TOKD_PER 64
+__global__ __launch_bounds__(1024) void tokd_scan_kernel(const int* __restrict__ counts, int* __restrict__ starts, int* __restrict__ cursor,
+                                                         int vocab) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, per = (vocab + 1023) / 1024, lo = tid * per;
+    int c[TOKD_PER];
+#pragma unroll
+    for (int i = 0; i < TOKD_PER; ++i) c[i] = (i < per && lo + i < vocab) ? counts[lo + i] : 0;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < TOKD_PER; ++i) s += c[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+#pragma unroll
+    for (int i = 0; i < TOKD_PER; ++i) {
+        if (i < per && lo + i < vocab) {
+            starts[lo + i] = run;
+            cursor[lo + i] = run;
+            run += c[i];
+        }
+    }
+    if (tid == 1023) starts[vocab] = part[1023];
+}
+__global__ __launch_bounds__(256) void tokd_fill_kernel(const int* __restrict__ text, const int* __restrict__ row_off, long rows, int ctx,
+                                                        int vocab, int* __restrict__ cursor, int* __restrict__ bucket) {
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        int id; long dxr;
+        if (tokd_row(text, row_off, r, ctx, vocab, &id, &dxr)) bucket[atomicAdd(cursor + id, 1)] = (int)dxr;
+    }
+}
+// one workgroup per (token id, 256-column slab): the id's bucket in ascending row order (bitonic sort in LDS), then its rows added in
+// that order -- four contiguous quarters of the bucket in parallel (eight 16-byte loads in flight per thread), the four quarter sums
+// added in order: one fixed summation tree per element
+__global__ __launch_bounds__(256) void tokd_accum_kernel(const int* __restrict__ starts, const int* __restrict__ bucket,
+                                                         const float* __restrict__ dx, float* __restrict__ dtok, int w) {
+    __shared__ int srt[TOKD_SORT];
+    __shared__ f32x4_t red[4][64];
+    const int id = blockIdx.x, tid = threadIdx.x;
+    const int b0 = starts[id], cnt = starts[id + 1] - b0;
+    if (cnt == 0) return;
+    const int* rows = bucket + b0;
+    const bool sorted = cnt <= TOKD_SORT;
+    if (sorted && cnt > 1) {
+        int np = 2;
+        while (np < cnt) np <<= 1;
+        for (int i = tid; i < np; i += 256) srt[i] = i < cnt ? rows[i] : 0x7fffffff;
+        __syncthreads();
+        for (int k = 2; k <= np; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < np; i += 256) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const int a = srt[i], b = srt[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { srt[i] = b; srt[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        rows = nullptr;
+    }
+    auto row_at = [&](int i) { return (sorted && cnt > 1) ? srt[i] : bucket[b0 + i]; };
+    const int cg = tid & 63, q = tid >> 6, col = blockIdx.y * 256 + cg * 4;
+    const int per = (cnt + 3) / 4, i0 = q * per, i1 = min(cnt, i0 + per);
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    if (col < w) {
+        int i = i0;
+        for (; i + 8 <= i1; i += 8) {
+            f32x4_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4_t*>(dx + (long)row_at(i + u) * w + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < i1; ++i) s += *reinterpret_cast<const f32x4_t*>(dx + (long)row_at(i) * w + col);
+    }
+    red[q][cg] = s;
+    __syncthreads();
+    if (q == 0 && col < w) {
+        const f32x4_t t = ((red[0][cg] + red[1][cg]) + red[2][cg]) + red[3][cg];
+        f32x4_t* o = reinterpret_cast<f32x4_t*>(dtok + (long)id * w + col);
+        *o = *o + t;
+    }
+}
+// the bucketed form when the stream has a scratch buffer; false = the caller runs the atomic kernel
+static bool tokd_run(const int* text, const float* dx, const int* row_off, float* dtok, int n, int ctx, int w, int vocab, hipStream_t st) {
+    const long rows = (long)n * ctx;
+    if (rows >= 0x7fffffffL || vocab > 1024 * TOKD_PER || (w & 3) || (((uintptr_t)dx | (uintptr_t)dtok) & 15)) return false;
+    int* ws = (int*)reduce_scratch(st, (int64_t)(3L * vocab + 4 + rows) * 4);
+    if (!ws) return false;
+    int *counts = ws, *starts = ws + vocab + 1, *cursor = starts + vocab + 1, *bucket = cursor + vocab + 1;
+    if (hipMemsetAsync(counts, 0, (size_t)(vocab + 1) * 4, st) != hipSuccess) return false;
+    const int g = grid_for(rows, 256, 4096);
+    hipLaunchKernelGGL(tokd_count_kernel, dim3(g), dim3(256), 0, st, text, row_off, rows, ctx, vocab, counts);
+    hipLaunchKernelGGL(tokd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, starts, cursor, vocab);
+    hipLaunchKernelGGL(tokd_fill_kernel, dim3(g), dim3(256), 0, st, text, row_off, rows, ctx, vocab, cursor, bucket);
+    hipLaunchKernelGGL(tokd_accum_kernel, dim3(vocab, (w + 255) / 256), dim3(256), 0, st, starts, bucket, dx, dtok, w);
+    return hipGetLastError() == hipSuccess;
+}
+
 // backward: dtok[text[n][t]] += dx[n][t] (atomics: ids repeat); dpos[t] += sum_n dx[n][t]
 __global__ __launch_bounds__(256) void text_embed_bwd_tok_kernel(const int* __restrict__ text,
                                                                  const float* __restrict__ dx,
@@ -212,8 +463,9 @@ extern "C" int uniir_text_embed_bwd(const int32_t* text, const float* dx, float*
     if (!text || !dx || !dtoken_emb || !dpos || n < 0) return UNIIR_EINVAL;
     if (n == 0) return UNIIR_OK;
     const long total = (long)n * ctx * width;
-    hipLaunchKernelGGL(text_embed_bwd_tok_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
-                       (hipStream_t)stream, text, dx, dtoken_emb, n, ctx, width, vocab);
+    if (!tokd_run(text, dx, nullptr, dtoken_emb, n, ctx, width, vocab, (hipStream_t)stream))
+        hipLaunchKernelGGL(text_embed_bwd_tok_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
+                           (hipStream_t)stream, text, dx, dtoken_emb, n, ctx, width, vocab);
     hipLaunchKernelGGL(text_embed_bwd_pos_kernel, dim3(ctx, (width + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, dx, dpos, n, ctx, width);
     HIP_LAUNCH_CHECK();
@@ -286,8 +538,9 @@ extern "C" int uniir_text_embed_bwd_packed(const int32_t* text, const float* dx,
     if (!text || !dx || !row_off || !dtoken_emb || !dpos || n < 0) return UNIIR_EINVAL;
     if (n == 0) return UNIIR_OK;
     const long total = (long)n * ctx * width;
-    hipLaunchKernelGGL(text_embed_bwd_tok_packed_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, text,
-                       dx, row_off, dtoken_emb, n, ctx, width, vocab);
+    if (!tokd_run(text, dx, row_off, dtoken_emb, n, ctx, width, vocab, (hipStream_t)stream))
+        hipLaunchKernelGGL(text_embed_bwd_tok_packed_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, text,
+                           dx, row_off, dtoken_emb, n, ctx, width, vocab);
     hipLaunchKernelGGL(text_embed_bwd_pos_packed_kernel, dim3(ctx, (width + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx,
                        row_off, dpos, n, ctx, width);
     HIP_LAUNCH_CHECK();
@@ -388,7 +641,7 @@ extern "C" int uniir_act_fwd(const void* f_bf16, void* g_bf16, int64_t count, in
 // colsum: out[c] += sum_r x[r][c].  Block = 256 threads covers 64 column-chunks of 8 (512 cols) x 4 row lanes.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ x, long ld,
                                                           float* __restrict__ out, int rows, int cols,
-                                                          int rows_per_block) {
+                                                          int rows_per_block, float* __restrict__ part) {
     __shared__ float red[4][512];
     const int cchunk = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.x * 512 + cchunk * 8;
@@ -410,7 +663,11 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* 
     __syncthreads();
     for (int c = threadIdx.x; c < 512; c += 256) {
         const int gc = blockIdx.x * 512 + c;
-        if (gc < cols) unsafeAtomicAdd(out + gc, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        if (gc < cols) {
+            const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            if (part) part[(long)blockIdx.y * cols + gc] = t;          // fixed-order reduction follows (reduce_partials)
+            else unsafeAtomicAdd(out + gc, t);
+        }
     }
 }
 extern "C" int uniir_colsum_bf16(const void* x, int64_t ld, float* out, int32_t rows, int32_t cols,
@@ -424,9 +681,12 @@ extern "C" int uniir_colsum_bf16(const void* x, int64_t ld, float* out, int32_t 
     int rpb = (rows + gy - 1) / gy;
     if (rpb < 64) rpb = 64;
     gy = (rows + rpb - 1) / rpb;
+    // several row blocks per column: their partial sums go through the stream's scratch and are added in a fixed order
+    float* part = gy > 1 ? reduce_scratch((hipStream_t)stream, (int64_t)gy * cols * 4) : nullptr;
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x, (long)ld, out, rows, cols, rpb);
+                       (const unsigned short*)x, (long)ld, out, rows, cols, rpb, part);
     HIP_LAUNCH_CHECK();
+    if (part) return reduce_partials(part, gy, cols, cols, out, nullptr, nullptr, 0, (hipStream_t)stream);
     return UNIIR_OK;
 }
 

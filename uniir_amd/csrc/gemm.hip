@@ -40,6 +40,8 @@ struct GemmKArgs {
     int skip_f;                 // EPI_BIAS_ACT without the pre-activation store (UNIIR_EPI_ACT_ONLY: forward-only passes)
     const float* row_scale;     // EPI_RESID_F32: (v + bias) * row_scale[m] + resid (DropPath factor of the row's item), or nullptr
     float* a_rowsum;            // optional [M]: += sum_k A^T[m][k] (transposed-A ping-pong kernel only, see gemm_core_pp.h)
+    float* colsum_part;         // deterministic form of colsum: row panel mt STORES its column partial at [mt][N] (gemm_impl reduces)
+    float* rowsum_part;         // ... of a_rowsum: block (split, nt) stores its row partial at [split * tiles_n + nt][M]
 };
 
 // act_fwd / act_bwd: common.h (shared with the stand-alone activation pass of elementwise.hip)
@@ -401,10 +403,14 @@ DEVINL void epilogue256_dact8(const GemmKArgs& p, const f32x4_t (&acc)[8][4], in
             for (int k = 1; k < 16; ++k) s += red[2 * ((tid >> 1) + 32 * k) + (tid & 1)];
             const int n = n0 + tid * 4;
             if (n < p.N) {
-                unsafeAtomicAdd(p.colsum + n + 0, s[0]);
-                unsafeAtomicAdd(p.colsum + n + 1, s[1]);
-                unsafeAtomicAdd(p.colsum + n + 2, s[2]);
-                unsafeAtomicAdd(p.colsum + n + 3, s[3]);
+                if (p.colsum_part) {          // this row panel's partial; added to colsum in panel order by reduce_partials
+                    *reinterpret_cast<f32x4_t*>(p.colsum_part + (long)(m0 >> 8) * p.N + n) = s;
+                } else {
+                    unsafeAtomicAdd(p.colsum + n + 0, s[0]);
+                    unsafeAtomicAdd(p.colsum + n + 1, s[1]);
+                    unsafeAtomicAdd(p.colsum + n + 2, s[2]);
+                    unsafeAtomicAdd(p.colsum + n + 3, s[3]);
+                }
             }
         }
     }
@@ -650,10 +656,14 @@ DEVINL void epilogue256_staged(const GemmKArgs& p, const f32x4_t (&acc)[8][4], i
             for (int k = 1; k < 8; ++k) s += red[tid + 64 * k];
             const int n = n0 + tid * 4;
             if (n < p.N) {
-                unsafeAtomicAdd(p.colsum + n + 0, s[0]);
-                unsafeAtomicAdd(p.colsum + n + 1, s[1]);
-                unsafeAtomicAdd(p.colsum + n + 2, s[2]);
-                unsafeAtomicAdd(p.colsum + n + 3, s[3]);
+                if (p.colsum_part) {          // this row panel's partial; added to colsum in panel order by reduce_partials
+                    *reinterpret_cast<f32x4_t*>(p.colsum_part + (long)(m0 >> 8) * p.N + n) = s;
+                } else {
+                    unsafeAtomicAdd(p.colsum + n + 0, s[0]);
+                    unsafeAtomicAdd(p.colsum + n + 1, s[1]);
+                    unsafeAtomicAdd(p.colsum + n + 2, s[2]);
+                    unsafeAtomicAdd(p.colsum + n + 3, s[3]);
+                }
             }
         }
     }
@@ -744,7 +754,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_glds_kernel(GemmKArgs p)
     constexpr bool PP = (WM == 2 && WN == 4 && BK == 64 && (LOOP == 2 || LOOP == 3 || LOOP == 4));
     if (PP)
         glds_mainloop_pp<Elem, A_TMAJ, B_TMAJ, LOOP == 3>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc,
-                                                          p.a_rowsum, nt, p.tiles_n);
+                                                          (LOOP == 3 && p.rowsum_part) ? p.rowsum_part + (long)(split * p.tiles_n + nt) * p.M
+                                                                                       : p.a_rowsum,
+                                                          nt, p.tiles_n, LOOP == 3 && p.rowsum_part != nullptr);
     else if (WM == 2 && WN == 4 && BK == 64 && LOOP == 1)
         glds_mainloop_asm<Elem, A_TMAJ, B_TMAJ>(p.A, p.lda, p.M, p.B, p.ldb, p.N, m0, n0, kbeg, kend, lds, acc);
     else
@@ -1110,6 +1122,8 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     a.slab = nullptr;
     a.colsum = d->colsum;
     a.a_rowsum = nullptr;
+    a.colsum_part = nullptr;
+    a.rowsum_part = nullptr;
     a.asm_loop = 2;
     hipStream_t st = (hipStream_t)stream;
     if (d->k_splits > 1) {
@@ -1130,7 +1144,12 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
     if (d->a_rowsum) {
         if (!d->a_tmaj || d->dtype != UNIIR_DT_BF16) return UNIIR_EUNSUPPORTED;     // (the separate pass reads bf16 too)
         rowsum_fused = d->dtype == UNIIR_DT_BF16 && d->b_tmaj && pp_eligible(a, d->a_tmaj, d->b_tmaj);
-        if (rowsum_fused) a.a_rowsum = d->a_rowsum;
+        if (rowsum_fused) {
+            a.a_rowsum = d->a_rowsum;
+            // one partial per (split, column panel) block, reduced in block order below (atomics in arrival order without a scratch)
+            // (the 256 x 256 kernel's own panel counts: launch_glds_rowsum)
+            a.rowsum_part = reduce_scratch(st, (int64_t)a.k_splits * ((d->N + 255) / 256) * d->M * 4);
+        }
     }
     int rc;
     // colsum and the DACT epilogue's second output act(aux) exist in the LDS-staged epilogue of the 256-tile kernel only; when the
@@ -1151,12 +1170,22 @@ static int gemm_impl(const uniir_gemm_desc* d, void* stream) {
             a.C2 = nullptr;
         }
     }
+    if (staged && a.colsum && (d->N % 4 == 0))       // the 256-row panels' column partials, reduced in panel order below
+        a.colsum_part = reduce_scratch(st, (int64_t)((d->M + 255) / 256) * d->N * 4);
     if (d->dtype == UNIIR_DT_BF16) rc = launch_gemm<ElemBF16>(a, d->a_tmaj, d->b_tmaj, st);
 #ifndef UNIIR_EXP_BUILD
     else if (d->dtype == UNIIR_DT_F16) rc = launch_gemm<ElemF16>(a, d->a_tmaj, d->b_tmaj, st);
 #endif
     else return UNIIR_EINVAL;
     if (rc) return rc;
+    if (a.colsum_part) {
+        rc = reduce_partials(a.colsum_part, (d->M + 255) / 256, d->N, d->N, d->colsum, nullptr, nullptr, 0, st);
+        if (rc) return rc;
+    }
+    if (a.rowsum_part) {
+        rc = reduce_partials(a.rowsum_part, a.k_splits * ((d->N + 255) / 256), d->M, d->M, d->a_rowsum, nullptr, nullptr, 0, st);
+        if (rc) return rc;
+    }
     if (colsum_after) {
         rc = uniir_colsum_bf16(d->C, d->ldc, d->colsum, d->M, d->N, stream);
         if (rc) return rc;

@@ -298,7 +298,7 @@ DEVINL void pp_main(const PPState<Elem, A_TMAJ, B_TMAJ>& st, int nk, f32x4_t (&a
 template <typename Elem, bool A_TMAJ, bool B_TMAJ, bool ROWSUM = false, bool HALFN = false, int AUXA = 0>
 DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int M, const unsigned short* __restrict__ B,
                              long ldb, int N, int m0, int n0, int kbeg, int kend, char* lds, f32x4_t (&acc)[8][4],
-                             float* a_rowsum = nullptr, int nt = 0, int tiles_n = 1) {
+                             float* a_rowsum = nullptr, int nt = 0, int tiles_n = 1, bool rs_store = false) {
     PPState<Elem, A_TMAJ, B_TMAJ> st;
     pp_setup(st, A, lda, M, B, ldb, N, m0, n0, kbeg, lds);
     st.rs_nt = (ROWSUM && a_rowsum) ? nt : -1;
@@ -315,7 +315,10 @@ DEVINL void glds_mainloop_pp(const unsigned short* __restrict__ A, long lda, int
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             const int m = m0 + h * 128 + (st.w >> 2) * 64 + 16 * (st.w & 3) + (lane & 15);
-            if (lane < 16 && m < M) unsafeAtomicAdd(a_rowsum + m, v);
+            if (lane < 16 && m < M) {
+                if (rs_store) a_rowsum[m] = v;          // a_rowsum is this block's partial row [M]; gemm_impl reduces in block order
+                else unsafeAtomicAdd(a_rowsum + m, v);
+            }
         }
     }
 }

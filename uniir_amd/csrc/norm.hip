@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, (EXACT && NC <= 4) ? 3 : 1) void ln_bwd_kernel
                                                      float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta,
                                                      float* __restrict__ dx_colsum, int rows, int width,
-                                                     float eps, int rms, const float* __restrict__ bscale) {
+                                                     float eps, int rms, const float* __restrict__ bscale,
+                                                     float* __restrict__ part) {
     __shared__ float red[4][64 * 4 * NC];  // per wave staging for the column reduction
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nchunk = width >> 2;
@@ -178,7 +179,9 @@ __global__ __launch_bounds__(256, (EXACT && NC <= 4) ? 3 : 1) void ln_bwd_kernel
         float* dst = pass == 0 ? dgamma : (pass == 1 ? dbeta : dx_colsum);
         for (int col = threadIdx.x; col < width; col += 256) {
             const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-            unsafeAtomicAdd(dst + col, t);
+            // part: this workgroup's three column partials [block][pass][width]; a fixed-order reduction follows (common.h)
+            if (part) part[((long)blockIdx.x * 3 + pass) * width + col] = t;
+            else unsafeAtomicAdd(dst + col, t);
         }
         __syncthreads();
     }
@@ -219,12 +222,16 @@ static void launch_ln_bwd(const float* x, long x_stride, const float* gamma, con
     }
     int g = (rows + 3) / 4;
     if (g > resident[exact]) g = resident[exact];
+    // more than one workgroup: the per-workgroup column partials (d gamma, d beta, column sums of dx) are stored and reduced in a
+    // fixed order when the stream has a scratch buffer (atomics in arrival order otherwise)
+    float* part = g > 1 ? reduce_scratch(st, (int64_t)g * 3 * width * 4) : nullptr;
     if (exact)
         hipLaunchKernelGGL((ln_bwd_kernel<NC, F32, true>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
-                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms, bscale);
+                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms, bscale, part);
     else
         hipLaunchKernelGGL((ln_bwd_kernel<NC, F32, false>), dim3(g), dim3(256), 0, st, x, x_stride, gamma, dy, dres, dx,
-                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms, bscale);
+                           dx_stride, dxb, dgamma, dbeta, dxsum, rows, width, eps, rms, bscale, part);
+    if (part) (void)reduce_partials(part, g, 3L * width, width, dgamma, rms ? nullptr : dbeta, dxsum, width, st);
 }
 static inline int ln_nc(int width) {
     const int c = (width / 4 + 63) / 64;

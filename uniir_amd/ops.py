@@ -2,6 +2,7 @@
 plumbing here: every function passes raw device pointers + the current HIP stream to libuniir_hip.so.
 There is no torch fallback: a CPU tensor raises."""
 import ctypes as C
+import os
 
 import torch
 
@@ -50,8 +51,28 @@ def gemm_timing_filter(windows, samples, merge_ms=-1.0):
 
 
 
+# Reproducible reductions (include/uniir_hip.h uniir_reduce_scratch): every stream this module launches on gets a scratch buffer, so
+# that bias / LayerNorm / embedding gradients are added in a fixed order and two runs of one step give the same bits.
+# UNIIR_DETERMINISTIC=0 leaves the kernels on their fp32 atomics (A/B of the extra reduce launches).
+RED_SCRATCH_BYTES = 64 << 20
+_RED_SCRATCH = {}
+_DETERMINISTIC = os.environ.get("UNIIR_DETERMINISTIC", "1") != "0"
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s = torch.cuda.current_stream()
+    if _DETERMINISTIC:
+        key = (s.device.index, s.cuda_stream)
+        if key not in _RED_SCRATCH:
+            if len(_RED_SCRATCH) >= 24:          # streams come and go (tests): forget the oldest entry, the library's table is LRU too
+                old = next(iter(_RED_SCRATCH))
+                del _RED_SCRATCH[old]
+            with torch.cuda.device(s.device):
+                buf = torch.empty(RED_SCRATCH_BYTES, dtype=torch.uint8, device=s.device)
+                check(_lib.load().uniir_reduce_scratch(C.c_void_p(buf.data_ptr()), RED_SCRATCH_BYTES, C.c_void_p(s.cuda_stream)),
+                      "reduce_scratch")
+            _RED_SCRATCH[key] = buf
+    return C.c_void_p(s.cuda_stream)
 
 
 def _p(t):
