@@ -25,6 +25,9 @@ def line_of(path):
 
 
 R04 = {"GEMMs (+ split-K reduce, small GEMMs)": 447.32, "attention": 57.25, "LayerNorm": 56.27, "AdamW + rest": 6.44, "total kernel time": 567.28}
+# round 5's accounting (profiles/r05_bench_kernel_stats.txt): what round 6 is compared with
+R05 = {"GEMMs (+ split-K reduce, small GEMMs)": 425.3, "attention": 57.9, "LayerNorm": 54.0, "AdamW + rest": 6.4, "total kernel time": 543.6}
+PREV, PREV_TAG = (R05, "r05") if tag >= "r06" else (R04, "r04")
 
 # ---- kernel stats of the step, with the accounting table
 ks = rd(os.path.join(prof, "kernel_stats.txt"))
@@ -33,20 +36,23 @@ if ks:
                             capture_output=True, text=True).stdout
     under = line_of(os.path.join(prof, "bench_under_rocprof.json"))
     head = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-retrieval --no-unpacked",
-            f"# (5 train steps of CLIP_SF ViT-L/14, 512 pairs, packed text rows, act(f) kept, rotating caption batches; 1 x MI355X, round-5 build; tools/profile_bench.sh {tag})."]
+            f"# (5 train steps of CLIP_SF ViT-L/14, 512 pairs, packed text rows, act(f) kept, rotating caption batches, both towers on ONE stream so that kernel durations add up;",
+            f"#  1 x MI355X, build of round {tag[1:]}" + (": the last block of each tower on its pooled rows, reproducible reductions (partial_reduce_kernel, tokd_*)" if tag >= "r06" else "") + f"; tools/profile_bench.sh {tag})."]
     if under:
         b = under["roofline"].get("board") or {}
         head.append(f"# Under the profiler the step ran at {under['ms_per_step']} ms ({under['value']} pairs/s), board {b.get('sclk_mhz_mean')} MHz mean at "
                     f"{b.get('power_w_mean')} W of {b.get('power_cap_w')} W; sampled GEMM rate {under['roofline'].get('achieved')} TFLOP/s.")
-    head.append("# Accounting, ms of kernel time per step (this file / round 4's profiles/r04_bench_kernel_stats.txt, a box of the same clock class):")
+    head.append(f"# Accounting, ms of kernel time per step (this file / profiles/{PREV_TAG}_bench_kernel_stats.txt, a box of the same clock class):")
     for ln in groups.splitlines():
         m = re.match(r"^(.{42}) +([\d.]+) ms / step", ln)
         if m:
             k = m.group(1).strip()
-            head.append(f"#   {k:42s} {float(m.group(2)):8.2f}   (r04 {R04.get(k, float('nan')):7.2f})")
-    head.append("# VERDICT r04 targets: GEMM families <= 415 ms/step (this box: see above; un-profiled the same box ran the driver-shaped bench -- steps 20, warmup 5 --")
-    head.append("#   at the ms/step of profiles/r05_bench_line.json; the round's fastest box: 540.1 ms, profiles/r05_bench_line_box1.json), attention <= 48 (its prologue")
-    head.append("#   diet was built and measured this round: no difference, experiments/attention_pair/README.md).")
+            head.append(f"#   {k:42s} {float(m.group(2)):8.2f}   ({PREV_TAG} {PREV.get(k, float('nan')):7.2f})")
+    if tag >= "r06":
+        head.append("# VERDICT r05 targets: step <= 528 ms (un-profiled, two streams: profiles/r06_bench_line.json), attention <= 50 ms/step.  What moved: the last block of each")
+        head.append("#   tower on its pooled rows (-1/24 of the image tower's GEMM / attention / ln_2 time, + small [1024-row] launches), section 2 of DESIGN.md.")
+    else:
+        head.append("# VERDICT r04 targets: GEMM families <= 415 ms/step, attention <= 48 (experiments/attention_pair/README.md).")
     open(os.path.join(P, f"{tag}_bench_kernel_stats.txt"), "w").write("\n".join(head) + "\n" + ks)
     if under:
         json.dump(under, open(os.path.join(P, f"{tag}_bench_line_profiled_box.json"), "w"))
@@ -56,7 +62,7 @@ pf, pw = rd(os.path.join(prof, "pmc_fetch.txt")), rd(os.path.join(prof, "pmc_wri
 if pf and pw:
     tr = line_of(os.path.join(prof, "pmc_gemm_traffic.out")) or {}
     head = ["# rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of",
-            "#   python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-retrieval --no-unpacked   (2 train steps, CLIP_SF ViT-L/14, 512 pairs, round-5 build)",
+            "#   python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-retrieval --no-unpacked   (2 train steps, CLIP_SF ViT-L/14, 512 pairs)",
             "# Counter unit: KB per dispatch, summed per kernel family (tools/pmc_summary.py).  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of the",
             "# bytes of wide (16 B/lane) reads -> doubled in tools/pmc_gemm_traffic.py; WRITE_SIZE as is.  L2<->fabric requests: MALL hits included (upper bound of HBM bytes).",
             f"# GEMM mean per launch: {json.dumps({k: tr.get(k) for k in ('bytes_per_launch', 'fetch_bytes_per_launch_corrected', 'write_bytes_per_launch', 'launches')})} -> profiles/pmc_gemm_traffic.json (bench.py roofline.traffic)"]
@@ -101,13 +107,13 @@ if ef:
         + "\n".join(l for l in ef.splitlines() if "amdgpu.ids" not in l) + "\n")
 mb = rd(os.path.join(fin, "microbench.txt"))
 if mb:
-    open(os.path.join(P, f"{tag}_microbench.txt"), "w").write("# MB_ITEMS=1024 python tools/microbench.py (round-5 build)\n" + "\n".join(l for l in mb.splitlines() if "amdgpu.ids" not in l) + "\n")
+    open(os.path.join(P, f"{tag}_microbench.txt"), "w").write(f"# MB_ITEMS=1024 python tools/microbench.py (build of round {tag[1:]})\n" + "\n".join(l for l in mb.splitlines() if "amdgpu.ids" not in l) + "\n")
 for n in ("blip", "clipff", "embed"):
     k = rd(os.path.join(sec, f"{n}_kernel_stats.txt"))
     j = line_of(os.path.join(sec, f"{n}.json"))
     if k:
         open(os.path.join(P, f"{tag}_{n}_kernel_stats.txt"), "w").write(
-            f"# rocprofv3 --kernel-trace --stats -- python tools/bench_{n}.py --steps 3 (tools/profile_secondary.sh, round-5 build); the run's own line: "
+            f"# rocprofv3 --kernel-trace --stats -- python tools/bench_{n}.py --steps 3 (tools/profile_secondary.sh); the run's own line: "
             f"{json.dumps({kk: j[kk] for kk in list(j)[:4]}) if j else 'n/a'}\n" + k)
 bl = line_of(os.path.join(fin, "bench_line.json"))
 if bl:
