@@ -549,3 +549,19 @@ def test_executed_flops_of_the_pooled_last_block():
     # the reference shape: neither packing nor pooling -> SURVEY's count whatever the captions are
     assert bench.executed_flop_per_pair(cfg, toks, bench.FLOP_PER_PAIR["ViT-L/14"], False, False)[0] == bench.FLOP_PER_PAIR["ViT-L/14"]
     assert bench.vision_flop_per_item_fwd(cfg, "ViT-L/14", True) == bench.VISION_FLOP_PER_ITEM_FWD["ViT-L/14"] - bench.pooled_last_block_saving(W, T)
+
+
+def test_text_pack_row_offsets_and_row_map():
+    """blip_model.TextPack (host arithmetic; the device tensors are plain copies): row offsets = prefix sums of the valid lengths, the
+    row map sends packed row r of item m, position t to the padded row m * L + t; build() declines batches with nothing to drop or
+    with an empty caption (the class token must exist)"""
+    from uniir_amd.blip_model import TextPack
+    lens = torch.tensor([3, 1, 5, 2], dtype=torch.int32)
+    p = TextPack(lens, 5, torch.device("cpu"))
+    assert p.R == 11 and p.M == 4 and p.L == 5
+    assert p.row_off.tolist() == [0, 3, 4, 9, 11] and p.row_off.dtype == torch.int32
+    assert p.row_map.tolist() == [0, 1, 2, 5, 10, 11, 12, 13, 14, 15, 16]
+    assert TextPack.build(lens, 5, torch.device("cpu")).R == 11
+    assert TextPack.build(torch.tensor([5, 5]), 5, torch.device("cpu")) is None          # every caption full: nothing to pack
+    assert TextPack.build(torch.tensor([2, 0, 3]), 5, torch.device("cpu")) is None       # an empty caption: padded path
+    assert TextPack.build(torch.tensor([2, 6]), 5, torch.device("cpu")) is None          # longer than the context: not a prefix mask

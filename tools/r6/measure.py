@@ -4,7 +4,7 @@
       costs against the 256-token grid (tiles are 16 query rows x 32 keys: 257 tokens run 17 x 9 of them, 256 run 16 x 8);
   (2) bulk search 100 000 (and 16 384) queries x 700 000 x 768 with 256 (streaming scan), 512 and 1024 (ping-pong GEMM-shaped scan)
       queries per sweep (uniir_topk_set_chunk; results never depend on it), and the dim-512 pool at 1024 queries.
-    python tools/r6_measure.py > gpurun_out/r06_measure.txt"""
+    python tools/r6/measure.py > gpurun_out/r06_measure.txt"""
 import os
 import sys
 
