@@ -64,8 +64,10 @@ def _stream():
     if _DETERMINISTIC:
         key = (s.device.index, s.cuda_stream)
         if key not in _RED_SCRATCH:
-            if len(_RED_SCRATCH) >= 24:          # streams come and go (tests): forget the oldest entry, the library's table is LRU too
-                old = next(iter(_RED_SCRATCH))
+            if len(_RED_SCRATCH) >= 24:          # streams come and go (tests): forget the oldest entry -- in the library's table
+                old = next(iter(_RED_SCRATCH))   # first, so that it never points at freed memory
+                with torch.cuda.device(old[0]):
+                    _lib.load().uniir_reduce_scratch(None, 0, C.c_void_p(old[1]))
                 del _RED_SCRATCH[old]
             with torch.cuda.device(s.device):
                 buf = torch.empty(RED_SCRATCH_BYTES, dtype=torch.uint8, device=s.device)
