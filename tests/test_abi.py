@@ -31,7 +31,7 @@ def test_ctypes_table_matches_header():
 def test_error_strings_and_version():
     from uniir_amd import _lib
     lib = _lib.load()
-    assert lib.uniir_abi_version() >= 1
+    assert lib.uniir_abi_version() >= _lib.ABI_VERSION == 2
     assert lib.uniir_strerror(0) == b"ok"
     assert b"aligned" in lib.uniir_strerror(-3)
 

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UNIIR_HIP_LIB") or os.path.join(_HERE, "libuniir_hip.so")   # env: kernel experiments only
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+ABI_VERSION = 2          # include/uniir_hip.h as of round 6 (uniir_clip_tower.pool_last_block, uniir_reduce_scratch, ...)
 
 
 class GemmDesc(C.Structure):
@@ -174,6 +175,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
         fn.restype = res
         fn.argtypes = args
+    if lib.uniir_abi_version() < ABI_VERSION:          # a stale build: struct layouts (ClipTower) would not match
+        raise RuntimeError(f"{LIB_PATH} is ABI version {lib.uniir_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                           "(python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
 

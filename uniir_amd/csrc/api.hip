@@ -12,4 +12,6 @@ extern "C" const char* uniir_strerror(int code) {
         default: return "unknown uniir error code";
     }
 }
-extern "C" int uniir_abi_version(void) { return 1; }
+// 2 (round 6): uniir_clip_tower grew pool_last_block; uniir_gemm_timing_read_ex returns the fallback flag; new entry points
+// uniir_reduce_scratch, uniir_attention_{fwd,bwd}_rows, uniir_dropout_{f32,bf16}_rows, uniir_gemm_timing_filter
+extern "C" int uniir_abi_version(void) { return 2; }
