@@ -3,7 +3,7 @@
 # usage (GPU box): bash tools/attn_pmc.sh   -> gpurun_out/attn_pmc.txt
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/attn_pmc.txt
+OUT=$R/gpurun_out/attn_pmc${MB_TOKENS:+_$MB_TOKENS}.txt
 : > $OUT
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
 P2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_TRANS_F32"

@@ -22,7 +22,10 @@ def timeit(fn, iters=10, warm=3):
 
 def attn_only(items):
     torch.manual_seed(0)
-    for (T, H, causal, b) in [(257, 16, 0, items), (197, 16, 0, items), (50, 12, 0, items), (77, 12, 1, items)]:
+    shapes = [(257, 16, 0, items), (197, 16, 0, items), (50, 12, 0, items), (77, 12, 1, items)]
+    if os.environ.get("MB_TOKENS"):          # one plain self-attention shape only (PMC passes per token count, tools/attn_pmc.sh)
+        shapes = [(int(os.environ["MB_TOKENS"]), 16, 0, items)]
+    for (T, H, causal, b) in shapes:
         qkv = torch.randn(b * T, 3 * H * 64, device=dev).bfloat16()
         out, lse = ops.attention_fwd(qkv, b, T, H, causal)
         t = timeit(lambda: ops.attention_fwd(qkv, b, T, H, causal, out=out, lse=lse), iters=20)
@@ -32,6 +35,8 @@ def attn_only(items):
         t2 = timeit(lambda: ops.attention_bwd(qkv, out, do, lse, b, T, H, causal, dqkv=dqkv), iters=20)
         print(f"attn T={T} H={H} b={b} causal={causal}: fwd {t*1e3:.3f} ms {fl/t/1e12:.1f} TF/s | bwd {t2*1e3:.3f} ms {2.5*fl/t2/1e12:.1f} TF/s "
               f"(legacy_stage={os.environ.get('UNIIR_ATTN_LEGACY_STAGE', '0')}) chk out {out.float().abs().sum().item():.1f} dqkv {dqkv.float().abs().sum().item():.1f}")
+    if os.environ.get("MB_TOKENS"):
+        return
     # BLIP MED cross-attention: 100 text queries x 197 image keys, 12 heads
     b, tq, tk, H = items, 100, 197, 12
     W = H * 64
