@@ -330,8 +330,11 @@ typedef struct {
                                                  the one pooled row of every item only (class token / EOT row; ln_1 and the K | V
                                                  projection still see every row): the reference computes the other rows' outputs of
                                                  that block and discards them (VisionTransformer.forward: ln_post(x[:, 0, :]);
-                                                 CLIP.encode_text: x[arange, text.argmax(-1)]).  Same embedding, same gradients without
-                                                 their exact-zero terms; 10 of the block's 12 WxW GEMM units leave the step.  Part of the
+                                                 CLIP.encode_text: x[arange, text.argmax(-1)]).  Same embedding bit for bit; the same
+                                                 gradient sums without their exact-zero terms (the one-query attention backward is the
+                                                 general kernel: at 193..288 tokens, where the full block runs the pair-tile kernel,
+                                                 upstream gradients agree to bf16 rounding, 4e-3); 10 of the block's 12 WxW GEMM units
+                                                 leave the step.  Part of the
                                                  workspace layout like stash_act.  0 = every row through every sublayer */
 } uniir_clip_tower;
 
