@@ -999,6 +999,10 @@ def main():
                                         f"in SURVEY 8(d)'s count (77 positions per caption, every row through every block); text rows "
                                         f"{int(live_rows)} of {int(dense_rows)} (mean over the timed steps' caption batches)")
                     if (packed_on or pool_on) else "value x SURVEY 8(d) FLOPs per pair / peak",
+                    "end_to_end_frac_reference_flops": round(value * FLOP_PER_PAIR[args.model] / (world * MFMA_PEAK_BF16), 4),
+                    "end_to_end_frac_reference_flops_note": ("value x SURVEY 8(d)'s FLOPs per pair / peak: the rate at which the WORK THE "
+                                                             "REFERENCE EXECUTES for these pairs (77 text positions, every row through every "
+                                                             "block) is retired; the step itself executes fewer FLOPs (end_to_end_frac)"),
                     "end_to_end_frac_unpacked": (round(global_pairs * args.steps / unpacked * FLOP_PER_PAIR[args.model]
                                                        / (world * MFMA_PEAK_BF16), 4) if unpacked else None),
                     "board": board_rec}
