@@ -443,3 +443,46 @@ def test_packed_bert_rows_equal_the_padded_rows(score_fusion):
     with torch.no_grad():
         model.encode_multimodal_input(full, img)
     assert model.last_text_rows == (M * L, M * L)
+
+
+def test_blip_ff_training_step_is_reproducible_bit_for_bit():
+    """Round 6 (uniir_reduce_scratch): BLIP_FF's gradients go through the same reductions as CLIP's -- LayerNorm weight / bias sums,
+    bias gradients out of the weight-gradient GEMMs and the dgrad epilogues, the word-embedding scatter ([CLS] / [PAD] ids shared by
+    every caption) -- so two runs of the same two training steps (train mode: hidden / attention dropout and DropPath on, seeded
+    through torch's CPU generator) from the same state give the same loss, gradients, momentum weights and queues, bit for bit."""
+    z = np.load(os.path.join(G, "g8_blipff.npz"))
+    med_cfg, vit_cfg = json.loads(str(z["med_cfg"])), json.loads(str(z["vit_cfg"]))
+    med_cfg.update(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    vit_cfg["drop_path_rate"] = 0.1
+    runs = []
+    for run in range(2):
+        model = tiny_model(med_cfg, vit_cfg, queue_size=int(z["queue_size"]), momentum=float(z["momentum"]))
+        load_sub(model, z, "sd0::", "")
+        model.copy_params()
+        model = model.cuda()
+        model.train()
+        torch.manual_seed(77)
+        rec = []
+        for step in range(2):
+            b = len(z[f"s{step}_pdid"])
+            batch = {
+                "txt_batched": types.SimpleNamespace(input_ids=torch.from_numpy(z[f"s{step}_ids"]).cuda(),
+                                                     attention_mask=torch.from_numpy(z[f"s{step}_mask"]).cuda()),
+                "image_batched": torch.from_numpy(z[f"s{step}_img"]).cuda(),
+                "p_did_list": torch.from_numpy(z[f"s{step}_pdid"]),
+                "index_mapping": {"query": [[2 * i] for i in range(b)], "pos_cand": [[2 * i + 1] for i in range(b)]},
+            }
+            model.zero_grad()
+            out = model(batch, alpha=float(z[f"s{step}_alpha"]))
+            out["loss"].backward()
+            torch.cuda.synchronize()
+            rec.append((out["loss"].detach().clone(), model._online.g32.clone(), model._mom.p32.clone(), model.query_queue.clone(),
+                        model.cand_queue.clone()))
+            with torch.no_grad():
+                for n, p in model._online_params():
+                    if n not in model._frozen:
+                        p.add_(-0.05 * p.grad)
+        runs.append(rec)
+    for step in range(2):
+        for k, (a, b) in enumerate(zip(runs[0][step], runs[1][step])):
+            assert torch.equal(a, b), (step, k, int((a != b).sum()), float((a.float() - b.float()).abs().max()))
