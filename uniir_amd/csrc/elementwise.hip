@@ -417,20 +417,21 @@ __global__ __launch_bounds__(256) void tokd_accum_kernel(const int* __restrict__
         *o = *o + t;
     }
 }
-// the bucketed form when the stream has a scratch buffer; false = the caller runs the atomic kernel
-static bool tokd_run(const int* text, const float* dx, const int* row_off, float* dtok, int n, int ctx, int w, int vocab, hipStream_t st) {
+// the bucketed form when the stream has a scratch buffer: 1 = done, 0 = not applicable (the caller runs the atomic kernel), < 0 = a
+// launch failed (nothing may be added a second time)
+static int tokd_run(const int* text, const float* dx, const int* row_off, float* dtok, int n, int ctx, int w, int vocab, hipStream_t st) {
     const long rows = (long)n * ctx;
-    if (rows >= 0x7fffffffL || vocab > 1024 * TOKD_PER || (w & 3) || (((uintptr_t)dx | (uintptr_t)dtok) & 15)) return false;
+    if (rows >= 0x7fffffffL || vocab > 1024 * TOKD_PER || (w & 3) || (((uintptr_t)dx | (uintptr_t)dtok) & 15)) return 0;
     int* ws = (int*)reduce_scratch(st, (int64_t)(3L * vocab + 4 + rows) * 4);
-    if (!ws) return false;
+    if (!ws) return 0;
     int *counts = ws, *starts = ws + vocab + 1, *cursor = starts + vocab + 1, *bucket = cursor + vocab + 1;
-    if (hipMemsetAsync(counts, 0, (size_t)(vocab + 1) * 4, st) != hipSuccess) return false;
+    if (hipMemsetAsync(counts, 0, (size_t)(vocab + 1) * 4, st) != hipSuccess) return UNIIR_ELAUNCH;
     const int g = grid_for(rows, 256, 4096);
     hipLaunchKernelGGL(tokd_count_kernel, dim3(g), dim3(256), 0, st, text, row_off, rows, ctx, vocab, counts);
     hipLaunchKernelGGL(tokd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, starts, cursor, vocab);
     hipLaunchKernelGGL(tokd_fill_kernel, dim3(g), dim3(256), 0, st, text, row_off, rows, ctx, vocab, cursor, bucket);
     hipLaunchKernelGGL(tokd_accum_kernel, dim3(vocab, (w + 255) / 256), dim3(256), 0, st, starts, bucket, dx, dtok, w);
-    return hipGetLastError() == hipSuccess;
+    return hipGetLastError() == hipSuccess ? 1 : UNIIR_ELAUNCH;
 }
 
 // backward: dtok[text[n][t]] += dx[n][t] (atomics: ids repeat); dpos[t] += sum_n dx[n][t]
@@ -463,7 +464,9 @@ extern "C" int uniir_text_embed_bwd(const int32_t* text, const float* dx, float*
     if (!text || !dx || !dtoken_emb || !dpos || n < 0) return UNIIR_EINVAL;
     if (n == 0) return UNIIR_OK;
     const long total = (long)n * ctx * width;
-    if (!tokd_run(text, dx, nullptr, dtoken_emb, n, ctx, width, vocab, (hipStream_t)stream))
+    const int det = tokd_run(text, dx, nullptr, dtoken_emb, n, ctx, width, vocab, (hipStream_t)stream);
+    if (det < 0) return det;
+    if (!det)
         hipLaunchKernelGGL(text_embed_bwd_tok_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
                            (hipStream_t)stream, text, dx, dtoken_emb, n, ctx, width, vocab);
     hipLaunchKernelGGL(text_embed_bwd_pos_kernel, dim3(ctx, (width + 255) / 256), dim3(256), 0,
@@ -538,7 +541,9 @@ extern "C" int uniir_text_embed_bwd_packed(const int32_t* text, const float* dx,
     if (!text || !dx || !row_off || !dtoken_emb || !dpos || n < 0) return UNIIR_EINVAL;
     if (n == 0) return UNIIR_OK;
     const long total = (long)n * ctx * width;
-    if (!tokd_run(text, dx, row_off, dtoken_emb, n, ctx, width, vocab, (hipStream_t)stream))
+    const int det = tokd_run(text, dx, row_off, dtoken_emb, n, ctx, width, vocab, (hipStream_t)stream);
+    if (det < 0) return det;
+    if (!det)
         hipLaunchKernelGGL(text_embed_bwd_tok_packed_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, text,
                            dx, row_off, dtoken_emb, n, ctx, width, vocab);
     hipLaunchKernelGGL(text_embed_bwd_pos_packed_kernel, dim3(ctx, (width + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx,
