@@ -167,3 +167,25 @@ def test_reduce_scratch_registry_validates_its_arguments():
     assert lib.uniir_reduce_scratch(0x10000, 1 << 20, 0x42) == 0
     assert lib.uniir_reduce_scratch(0x20000, 2 << 20, 0x42) == 0           # re-registration replaces
     assert lib.uniir_reduce_scratch(None, 0, 0x42) == 0
+
+
+def test_tower_workspace_query_sees_the_pooled_last_block_flag():
+    """uniir_clip_tower.pool_last_block is part of the workspace layout (csrc/tower.hip plan()): with it the query adds the [batch]-row
+    buffers of the pooled last block -- 9 forward buffers, 6 more with save_for_backward -- and nothing else.  Host arithmetic; also
+    pins the ctypes mirror of the struct's last fields (a shifted field would turn the sizes into garbage)."""
+    from uniir_amd import _lib
+    lib = _lib.load()
+    al = lambda x: (x + 255) & ~255
+    for image in (True, False):
+        t, blocks = _tower(image=image, layers=24 if image else 12, width=1024 if image else 768, tokens=257 if image else 77)
+        M, W, H = 1024, t.width, t.heads
+        fwd = [M * W * 2, M * W * 2, M * W * 4, M * W * 2, M * H * 4, M * W * 4, M * W * 2, M * 4 * W * 2, M * 4 * W * 2]
+        bwd = [M * W * 2, M * 4 * W * 2, M * W * 2, M * W * 4, M * 3 * W * 2, M * W * 2]
+        for save in (0, 1):
+            t.pool_last_block = 0
+            base = lib.uniir_clip_tower_workspace_bytes(ctypes.byref(t), M, save)
+            t.pool_last_block = 1
+            pooled = lib.uniir_clip_tower_workspace_bytes(ctypes.byref(t), M, save)
+            assert base > 0 and pooled - base == sum(al(x) for x in fwd + (bwd if save else [])), (image, save, pooled - base)
+        t.stash_act, t.pool_last_block = 1, 1            # the two layout flags are independent
+        assert lib.uniir_clip_tower_workspace_bytes(ctypes.byref(t), M, 1) > pooled
